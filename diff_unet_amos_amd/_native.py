@@ -1,0 +1,95 @@
+"""ctypes binding of libdua_hip.so (include/dua_hip.h).
+
+There is no CPU fallback: if the library is missing or a GPU entry point is
+called without a device, this module raises.  torch is imported first so that
+the library binds to the libamdhip64 already mapped by PyTorch-ROCm (same
+SONAME) and both share one HIP runtime, device context and stream objects.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: maps libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdua_hip.so")
+
+F32, F16 = 0, 1
+ERR_ARG = -22
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class Conv3Desc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("Cin", C.c_int), ("Cin_stride", C.c_int), ("Cin_off", C.c_int),
+                ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int), ("slope", C.c_float)]
+
+
+class MaterializeDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+                ("raw_stride", C.c_int), ("emb_stride", C.c_int), ("out_stride", C.c_int), ("out_off", C.c_int),
+                ("pool_stride", C.c_int), ("slope", C.c_float)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "dua_conv3d_k3_rows": (C.c_int, [C.POINTER(Conv3Desc)]),
+    "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_pack_conv3_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "dua_instnorm_finalize": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
+    "dua_materialize": (C.c_int, [C.POINTER(MaterializeDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "dua_pack_deconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "dua_to_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "dua_from_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, C.c_int, _P, _P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every entry point include/dua_hip.h declares (kept in step by tests/test_abi.py)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda, "libdua_hip.so entry points take device pointers"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {'invalid argument' if rc == ERR_ARG else f'hipError {rc}'}")
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float16:
+        return F16
+    if dtype == torch.float32:
+        return F32
+    raise ValueError(f"unsupported activation dtype {dtype}")

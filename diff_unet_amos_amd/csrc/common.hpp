@@ -1,0 +1,85 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the Diff-UNet hot path.
+//
+// Data layout convention used by every kernel in this directory:
+//   activations  : channels-last  [N][D][H][W][Cs]   (Cs = channel stride of the buffer; a
+//                  kernel addresses channels [c_off, c_off + C) of it, so concat buffers
+//                  are written in place by their producers -- reference torch.cat at
+//                  models/basic_unet/denoiser.py:190,298 becomes "no kernel")
+//   element type : f16 (production; MFMA 32x32x16, fp32 accumulate) or f32 (parity mode;
+//                  MFMA 32x32x2, bit-for-bit an fmaf chain)
+//   "k-group"    : 16 bytes of consecutive channels (8 x f16 or 4 x f32) -- the unit a lane
+//                  loads for one MFMA operand fragment.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dua {
+
+using f16 = _Float16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum : int { DT_F32 = 0, DT_F16 = 1 };
+
+template <typename T> struct Elem;
+template <> struct Elem<f16> {
+  static constexpr int EPG = 8;   // elements per 16-byte k-group
+  using Frag = f16x8;
+};
+template <> struct Elem<float> {
+  static constexpr int EPG = 4;
+  using Frag = f32x4;
+};
+
+// One "k-group pair" step of a 32x32 output tile.  Lane l = (r = l & 31, h = l >> 5) holds the
+// 16 bytes of row/column r for k-group (2*ks + h); both operand kinds use the same mapping, so
+// the sum over k covers every channel of the two k-groups exactly once.
+__device__ __forceinline__ void mma32(f32x16& acc, const f16x8& a, const f16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& acc, const f32x4& a, const f32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+// Row of a 32x32 MFMA accumulator held in register i (0..15) of lane-half h.
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// Blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of tiles so that
+// neighbouring tiles (which share halo voxels and all weights) hit the same L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  int q = n >> 3, r = n & 7, x = bid & 7, j = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// Input transform applied while a consumer stages its operand: the producer stored the raw
+// convolution output; y = leaky_relu(x * scale[c] + shift[c]) + add[c] is InstanceNorm3d(affine)
+// -> Dropout(0) -> LeakyReLU(0.1) (MONAI ADN "NDA") followed by the timestep-embedding bias of
+// TwoConv.forward (models/basic_unet/denoiser.py:63-67).  scale/shift come from
+// instnorm_finalize; add may be null.
+struct InXform {
+  const float* scale;  // [N][C] or null (input already materialised)
+  const float* shift;  // [N][C]
+  const float* add;    // [N][C] or null
+  float slope;
+};
+
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::Frag xform_frag(typename Elem<T>::Frag v, const float* sc,
+                                                               const float* sh, const float* ad, float slope) {
+  constexpr int E = Elem<T>::EPG;
+  typename Elem<T>::Frag o;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    float y = fmaf((float)v[j], sc[j], sh[j]);
+    y = y > 0.f ? y : y * slope;
+    o[j] = (T)(y + ad[j]);
+  }
+  return o;
+}
+
+}  // namespace dua

@@ -1,0 +1,154 @@
+// Boundary layout conversions and weight packing.
+//
+// The reference keeps every tensor NCDHW fp32 (torch default); the kernels here keep
+// activations channels-last so that the K dimension of the implicit GEMM (channels) is the
+// contiguous one.  These kernels run once per call at the API boundary
+// (Diffusion.forward, models/diffusion/diffusion.py:49-63) or once per weight update.
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+
+namespace dua {
+
+// ---- conv3 weights: [Cout][Cin_src][27] fp32 -> [ct][chunk][kd][t9][kg][64][EPG] ----
+template <typename T>
+__global__ void pack_conv3_kernel(int Cout, int Cin_src, int nchunks, const float* __restrict__ w,
+                                  const int* __restrict__ perm, T* __restrict__ out, long total) {
+  constexpr int EPG = Elem<T>::EPG;
+  constexpr int CK = 4 * EPG;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long t = i;
+    const int e = (int)(t % EPG); t /= EPG;
+    const int co_l = (int)(t % 64); t /= 64;
+    const int kg = (int)(t % 4); t /= 4;
+    const int t9 = (int)(t % 9); t /= 9;
+    const int kd = (int)(t % 3); t /= 3;
+    const int ch = (int)(t % nchunks); const int ct = (int)(t / nchunks);
+    const int co = ct * 64 + co_l;
+    const int cp = ch * CK + kg * EPG + e;            // packed input channel
+    const int ci = perm ? perm[cp] : cp;
+    float v = 0.f;
+    if (co < Cout && ci >= 0 && ci < Cin_src) v = w[((long)co * Cin_src + ci) * 27 + kd * 9 + t9];
+    out[i] = (T)v;
+  }
+}
+
+// ---- deconv k2 s2 weights: [Cin][Cout][8] fp32 -> [tap][ct][chunk][kg][64][EPG] ----
+template <typename T>
+__global__ void pack_deconv_kernel(int Cin, int Cout, int nchunks, int nct, const float* __restrict__ w,
+                                   T* __restrict__ out, long total) {
+  constexpr int EPG = Elem<T>::EPG;
+  constexpr int CK = 4 * EPG;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long t = i;
+    const int e = (int)(t % EPG); t /= EPG;
+    const int co_l = (int)(t % 64); t /= 64;
+    const int kg = (int)(t % 4); t /= 4;
+    const int ch = (int)(t % nchunks); t /= nchunks;
+    const int ct = (int)(t % nct); const int tap = (int)(t / nct);
+    const int co = ct * 64 + co_l, ci = ch * CK + kg * EPG + e;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((long)ci * Cout + co) * 8 + tap];
+    out[i] = (T)v;
+  }
+}
+
+// ---- NCDHW fp32 -> channels-last T, channel slice [c_off, c_off+C) of a buffer with stride Cs ----
+// One thread per (voxel, channel): reads are strided across lanes by voxel (coalesced along W
+// for fixed c when the inner loop walks channels), writes land in the voxel's channel run.
+template <typename T>
+__global__ void to_channels_last_kernel(const float* __restrict__ src, int C, long vox, T* __restrict__ dst, int Cs,
+                                        int c_off, int Cfill) {
+  const int n = blockIdx.y;
+  for (long v = blockIdx.x * 256L + threadIdx.x; v < vox; v += (long)gridDim.x * 256) {
+    T* o = dst + ((long)n * vox + v) * Cs + c_off;
+    for (int c = 0; c < C; ++c) o[c] = (T)src[((long)n * C + c) * vox + v];
+    for (int c = C; c < Cfill; ++c) o[c] = (T)0.f;
+  }
+}
+
+template <typename T>
+__global__ void from_channels_last_kernel(const T* __restrict__ src, int Cs, int c_off, int C, long vox,
+                                          float* __restrict__ dst) {
+  const int n = blockIdx.y;
+  for (long v = blockIdx.x * 256L + threadIdx.x; v < vox; v += (long)gridDim.x * 256) {
+    const T* i = src + ((long)n * vox + v) * Cs + c_off;
+    for (int c = 0; c < C; ++c) dst[((long)n * C + c) * vox + v] = (float)i[c];
+  }
+}
+
+static inline unsigned nblocks(long total) {
+  long b = (total + 255) / 256;
+  return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+}  // namespace dua
+
+extern "C" {
+
+long dua_pack_conv3_weights(int dtype, int Cout, int Cin_src, int Cin_packed, const float* w, const int* in_perm,
+                            void* w_packed, void* stream) {
+  const int epg = dtype == DUA_F16 ? 8 : 4, ck = 4 * epg;
+  if ((dtype != DUA_F16 && dtype != DUA_F32) || Cout <= 0 || Cin_src <= 0 || Cin_packed <= 0) return DUA_ERR_ARG;
+  const int nchunks = (Cin_packed + ck - 1) / ck, nct = (Cout + 63) / 64;
+  const long total = (long)nct * nchunks * 27 * 4 * 64 * epg;
+  const long bytes = total * (dtype == DUA_F16 ? 2 : 4);
+  if (!w_packed) return bytes;
+  if (!w) return DUA_ERR_ARG;
+  // in_perm must cover nchunks*ck entries when given
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::pack_conv3_kernel<dua::f16>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
+                       Cout, Cin_src, nchunks, w, in_perm, (dua::f16*)w_packed, total);
+  else
+    hipLaunchKernelGGL(dua::pack_conv3_kernel<float>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
+                       Cout, Cin_src, nchunks, w, in_perm, (float*)w_packed, total);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? bytes : -(long)e;
+}
+
+long dua_pack_deconv_weights(int dtype, int Cin, int Cout, const float* w, void* w_packed, void* stream) {
+  const int epg = dtype == DUA_F16 ? 8 : 4, ck = 4 * epg;
+  if ((dtype != DUA_F16 && dtype != DUA_F32) || Cout <= 0 || Cin <= 0) return DUA_ERR_ARG;
+  const int nchunks = (Cin + ck - 1) / ck, nct = (Cout + 63) / 64;
+  const long total = 8L * nct * nchunks * 4 * 64 * epg;
+  const long bytes = total * (dtype == DUA_F16 ? 2 : 4);
+  if (!w_packed) return bytes;
+  if (!w) return DUA_ERR_ARG;
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::pack_deconv_kernel<dua::f16>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
+                       Cin, Cout, nchunks, nct, w, (dua::f16*)w_packed, total);
+  else
+    hipLaunchKernelGGL(dua::pack_deconv_kernel<float>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
+                       Cin, Cout, nchunks, nct, w, (float*)w_packed, total);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? bytes : -(long)e;
+}
+
+int dua_to_channels_last(int dtype, int N, int C, long voxels, const float* src, void* dst, int Cstride, int C_off,
+                         int C_fill, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || voxels <= 0 || C_off + (C_fill > C ? C_fill : C) > Cstride) return DUA_ERR_ARG;
+  dim3 grid(dua::nblocks(voxels), N);
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::to_channels_last_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, src, C, voxels,
+                       (dua::f16*)dst, Cstride, C_off, C_fill);
+  else if (dtype == DUA_F32)
+    hipLaunchKernelGGL(dua::to_channels_last_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, C, voxels,
+                       (float*)dst, Cstride, C_off, C_fill);
+  else return DUA_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+int dua_from_channels_last(int dtype, int N, int C, long voxels, const void* src, int Cstride, int C_off, float* dst,
+                           void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || voxels <= 0 || C_off + C > Cstride) return DUA_ERR_ARG;
+  dim3 grid(dua::nblocks(voxels), N);
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::from_channels_last_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const dua::f16*)src, Cstride, C_off, C, voxels, dst);
+  else if (dtype == DUA_F32)
+    hipLaunchKernelGGL(dua::from_channels_last_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, Cstride, C_off, C, voxels, dst);
+  else return DUA_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+/* C ABI of libdua_hip.so -- the MI355X (gfx950) kernels behind the Diff-UNet hot path.
+ *
+ * The reference (aarchiiive/diff-unet-amos) is pure Python: its "FFI" for this path is the set
+ * of torch.nn / torch elementwise calls listed below.  Each entry point names the reference
+ * call site it replaces (file:line relative to the reference tree).  All entry points:
+ *   - take raw device pointers, sizes and a hipStream_t (as void*); no torch types;
+ *   - enqueue work on that stream and return immediately (no allocation, no synchronisation),
+ *     so a caller may capture them into a hipGraph;
+ *   - return 0 on success, a positive hipError_t, or DUA_ERR_ARG for a rejected argument.
+ *
+ * Activation layout everywhere: channels-last [N][D][H][W][Cstride]; a call addresses channels
+ * [C_off, C_off + C) of the buffer.  dtype selects the element type of activations and packed
+ * weights: DUA_F16 (fp16 operands, fp32 accumulate on MFMA 32x32x16) or DUA_F32 (exact fp32 on
+ * MFMA 32x32x2).  Statistics, scale/shift vectors, biases and sampler state are always fp32.
+ */
+#ifndef DUA_HIP_H
+#define DUA_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DUA_F32 0
+#define DUA_F16 1
+#define DUA_ERR_ARG (-22)
+
+/* ---- 3x3x3 convolution --------------------------------------------------------------------
+ * Replaces nn.Conv3d(k3,s1,p1,bias) built by MONAI Convolution at
+ * models/basic_unet/denoiser.py:56-59 and models/basic_unet/pretrained/basic_unet.py:60-63,
+ * fused with the producer's InstanceNorm3d+LeakyReLU(+temb add, denoiser.py:65) on the input
+ * side and with this layer's InstanceNorm statistics on the output side. */
+typedef struct {
+  int dtype;
+  int N, D, H, W;
+  int Cin, Cin_stride, Cin_off;    /* all multiples of 8 */
+  int Cout, Cout_stride, Cout_off; /* all multiples of 8 */
+  float slope;                     /* LeakyReLU negative slope of the fused input transform */
+} dua_conv3_desc;
+
+/* rows of the partial-statistics matrix the call writes per batch item */
+int dua_conv3d_k3_rows(const dua_conv3_desc* d);
+
+/* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32[ceil(Cout/64)*64].
+ * in_scale/in_shift/in_add: fp32[N][Cin] or NULL (in_scale NULL = input already materialised).
+ * y: raw output (conv + bias).  partials: fp32[N][rows][ceil(Cout/64)*64][2] = (sum, M2) per slab;
+ * counts: fp32[rows] voxels per slab. */
+int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
+                      const float* in_scale, const float* in_shift, const float* in_add, void* y,
+                      float* partials, float* counts, void* stream);
+
+/* Packs nn.Conv3d weight fp32[Cout][Cin_src][3][3][3] into the kernel's slab order
+ * [cout_tile][chunk][kd][kh*3+kw][k-group][64][16 B].  in_perm (device int32[Cin_packed], may be
+ * NULL = identity) gives for each packed input channel its source channel, or -1 for a zero pad
+ * channel.  Returns bytes needed when w_packed is NULL. */
+long dua_pack_conv3_weights(int dtype, int Cout, int Cin_src, int Cin_packed, const float* w, const int* in_perm,
+                            void* w_packed, void* stream);
+
+/* ---- InstanceNorm3d(affine=True, eps) statistics -> per-(n,c) scale/shift ---------------------
+ * Replaces the statistics half of nn.InstanceNorm3d (MONAI ADN "N", denoiser.py:207):
+ * scale = gamma / sqrt(var + eps), shift = beta - mean * scale, biased variance, combined from
+ * the conv kernel's slab partials in fp64. */
+int dua_instnorm_finalize(int N, int C, int rows, int c_pad, const float* partials, const float* counts,
+                          const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream);
+
+/* ---- materialise: x_i = LeakyReLU(IN(raw)) + embeddings[i], and its MaxPool3d(2) --------------
+ * Replaces the normalise/activate half of MONAI ADN for tensors with several consumers, the
+ * skip-feature add at models/basic_unet/denoiser.py:300-304, nn.MaxPool3d(2) at
+ * denoiser.py:100,106 (pretrained/basic_unet.py:99), and the skip half of torch.cat at
+ * denoiser.py:190 (out is a channel slice of the concat buffer). */
+typedef struct {
+  int dtype;
+  int N, D, H, W, C;
+  int raw_stride;               /* channel stride of raw (offset 0) */
+  int emb_stride;               /* channel stride of emb (offset 0), ignored when emb is NULL */
+  int out_stride, out_off;
+  int pool_stride;              /* channel stride of pooled (offset 0); D,H,W must be even */
+  float slope;
+} dua_materialize_desc;
+
+int dua_materialize(const dua_materialize_desc* d, const void* raw, const float* scale, const float* shift,
+                    const void* emb, void* out, void* pooled, void* stream);
+
+/* ---- layout / packing at the API boundary -------------------------------------------------- */
+/* nn.ConvTranspose3d weight fp32[Cin][Cout][2][2][2] -> [tap][cout_tile][chunk][k-group][64][16 B].
+ * Returns bytes needed when w_packed is NULL. */
+long dua_pack_deconv_weights(int dtype, int Cin, int Cout, const float* w, void* w_packed, void* stream);
+
+/* NCDHW fp32 [N][C][voxels] -> channels-last slice; channels [C, C_fill) of the slice are zeroed. */
+int dua_to_channels_last(int dtype, int N, int C, long voxels, const float* src, void* dst, int Cstride, int C_off,
+                         int C_fill, void* stream);
+int dua_from_channels_last(int dtype, int N, int C, long voxels, const void* src, int Cstride, int C_off, float* dst,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -26,7 +26,8 @@ class NativeLibraryMissing(RuntimeError):
 class Conv3Desc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("Cin", C.c_int), ("Cin_stride", C.c_int), ("Cin_off", C.c_int),
-                ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int), ("slope", C.c_float)]
+                ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int), ("slope", C.c_float),
+                ("in_add_stride", C.c_int)]
 
 
 class MaterializeDesc(C.Structure):
@@ -35,8 +36,22 @@ class MaterializeDesc(C.Structure):
                 ("pool_stride", C.c_int), ("slope", C.c_float)]
 
 
+class TailDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("voxels", C.c_long), ("K", C.c_int), ("raw_stride", C.c_int),
+                ("C", C.c_int), ("CX", C.c_int), ("mode", C.c_int), ("xin_stride", C.c_int), ("slope", C.c_float),
+                ("seed", C.c_ulonglong)]
+
+
+MODE_LOGITS, MODE_DDPM, MODE_DDIM = 0, 1, 2
+
 _P = C.c_void_p
 _SIGS = {
+    "dua_deconv_k2s2_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_q_sample": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P]),
+    "dua_sampler_step": (C.c_int, [C.c_int, C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_final_conv_sampler": (C.c_int, [C.POINTER(TailDesc)] + [_P] * 14),
+    "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dua_conv3d_k3_rows": (C.c_int, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dua_pack_conv3_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

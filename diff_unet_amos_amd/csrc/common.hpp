@@ -64,8 +64,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 struct InXform {
   const float* scale;  // [N][C] or null (input already materialised)
   const float* shift;  // [N][C]
-  const float* add;    // [N][C] or null
+  const float* add;    // [N][add_stride] or null
   float slope;
+  int add_stride;
 };
 
 template <typename T>

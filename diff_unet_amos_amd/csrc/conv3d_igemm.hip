@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
         for (int e = 0; e < EPG; ++e) {
           sc[e] = a.xf.scale[cb + e];
           sh[e] = a.xf.shift[cb + e];
-          ad[e] = a.xf.add ? a.xf.add[cb + e] : 0.f;
+          ad[e] = a.xf.add ? a.xf.add[n * a.xf.add_stride + c0 + e] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < NIT; ++j)
@@ -226,7 +226,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   constexpr int CK = KG * Elem<T>::EPG;
   Conv3Args a;
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.partials = partials; a.counts = counts;
-  a.xf = InXform{in_scale, in_shift, in_add, d->slope};
+  a.xf = InXform{in_scale, in_shift, in_add, d->slope, d->in_add_stride > 0 ? d->in_add_stride : d->Cin};
   a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
   a.Cin = d->Cin; a.Cin_stride = d->Cin_stride; a.Cin_off = d->Cin_off;
   a.Cout = d->Cout; a.Cout_stride = d->Cout_stride; a.Cout_off = d->Cout_off;

@@ -1,0 +1,264 @@
+// Gaussian-diffusion elementwise arithmetic and the fused denoiser tail.
+//
+// Reference arithmetic (guided_diffusion/gaussian_diffusion.py, GD below):
+//   q_sample        GD:187-205   x_t = sqrt(acp[t]) * x0 + sqrt(1-acp[t]) * eps
+//   p_mean_variance GD:292-313   x0^ = clamp(model_out, -1, 1); mean = c1[t]*x0^ + c2[t]*x_t
+//   p_sample        GD:430-438   x_{t-1} = mean + 1[t!=0] * exp(0.5*logvar[t]) * eps
+//   ddim_sample     GD:566-584   e = (sr[t]*x_t - x0^) / srm1[t];
+//                                x_{t-1} = x0^*sqrt(acp_prev) + sqrt(1-acp_prev-s^2)*e + 1[t!=0]*s*eps
+//   sum of x0^      models/diffusion/diffusion.py:94-98
+// The host turns the float64 schedule tables into per-sample fp32 coefficient rows exactly as
+// _extract_into_tensor does (GD:904-917, cast to fp32 after the lookup):
+//   DDPM row: {c1, c2, 1[t!=0]*exp(0.5*logvar)}        DDIM row: {sr, srm1, sqrt(acp_prev),
+//                                                       sqrt(1-acp_prev-s^2), 1[t!=0]*s}
+//
+// final_conv_sampler fuses, per voxel: InstanceNorm+LeakyReLU of the last decoder block,
+// the 1x1x1 final_conv (models/basic_unet/denoiser.py:282,311), the sampler update above, the
+// running sum of x0^, and the write of x_{t-1} into the next step's denoiser input buffer
+// (channels-last, the torch.cat([image, x]) of denoiser.py:298 in place).
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+
+namespace dua {
+
+// ---- Philox4x32-10 + Box-Muller (production-mode noise; parity tests inject eps instead) ----
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c[0]), l0 = 0xD2511F53u * c[0];
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c[2]), l1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = l1; c[2] = n2; c[3] = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+  const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;   // (0,1)
+  const float u2 = ((float)b + 0.5f) * 2.3283064365386963e-10f;
+  const float rad = sqrtf(-2.f * __logf(u1));
+  float s, c;
+  __sincosf(6.283185307179586f * u2, &s, &c);
+  z0 = rad * c; z1 = rad * s;
+}
+
+__device__ __forceinline__ float sampler_update(int mode, const float* k, float out, float xt, float eps, float& xs) {
+  xs = fminf(fmaxf(out, -1.f), 1.f);
+  if (mode == DUA_MODE_DDPM) {
+    const float mean = k[0] * xs + k[1] * xt;
+    return mean + k[2] * eps;
+  }
+  const float e = (k[0] * xt - xs) / k[1];
+  const float mean = xs * k[2] + k[3] * e;
+  return mean + k[4] * eps;
+}
+
+// ---- generic NCDHW elementwise kernels (any model callable between them) ----
+__global__ void q_sample_kernel(long per, long total, const float* __restrict__ x0, const float* __restrict__ eps,
+                                const float* __restrict__ coef, float* __restrict__ out) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / per);
+    out[i] = coef[2 * n] * x0[i] + coef[2 * n + 1] * eps[i];
+  }
+}
+
+__global__ void sampler_step_kernel(int mode, long per, long total, const float* __restrict__ model_out,
+                                    const float* __restrict__ x, const float* __restrict__ eps,
+                                    const float* __restrict__ coef, float* __restrict__ x_out,
+                                    float* __restrict__ xstart_out, float* __restrict__ xstart_sum) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / per);
+    float xs;
+    const float v = sampler_update(mode, coef + 8 * n, model_out[i], x[i], eps[i], xs);
+    x_out[i] = v;
+    if (xstart_out) xstart_out[i] = xs;
+    if (xstart_sum) xstart_sum[i] += xs;
+  }
+}
+
+// ---- fused tail: one thread = one voxel ----
+struct TailArgs {
+  const void* raw; const float* scale; const float* shift; const float* wf; const float* bf;
+  const float* coef; float* x_state; const float* noise; const int* step_word; void* xin;
+  float* xsum; float* logits; float* xstart;
+  long vox; int K, raw_stride, C, xin_stride, mode; float slope; unsigned seed_lo, seed_hi;
+};
+
+template <typename T, int CX>
+__global__ __launch_bounds__(256) void final_conv_sampler_kernel(TailArgs a) {
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [K/4][CX][4] weights, then scale[K], shift[K]
+  const int n = blockIdx.y;
+  const int K = a.K;
+  float* sc = wl + CX * K;
+  float* sh = sc + K;
+  for (int i = threadIdx.x; i < CX * K; i += 256) {
+    const int e = i & 3, c = (i >> 2) % CX, kq = i / (4 * CX);
+    wl[i] = c < a.C ? a.wf[c * K + kq * 4 + e] : 0.f;
+  }
+  for (int i = threadIdx.x; i < K; i += 256) { sc[i] = a.scale[n * K + i]; sh[i] = a.shift[n * K + i]; }
+  __syncthreads();
+  const long v = blockIdx.x * 256L + threadIdx.x;
+  if (v >= a.vox) return;
+  float acc[CX];
+#pragma unroll
+  for (int c = 0; c < CX; ++c) acc[c] = c < a.C ? a.bf[c] : 0.f;
+  const T* rp = (const T*)a.raw + ((long)n * a.vox + v) * a.raw_stride;
+  for (int kg = 0; kg < K / EPG; ++kg) {
+    const Frag f = *(const Frag*)(rp + kg * EPG);
+    float y[EPG];
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) {
+      float t = fmaf((float)f[e], sc[kg * EPG + e], sh[kg * EPG + e]);
+      t = t > 0.f ? t : t * a.slope;
+      y[e] = t;
+    }
+#pragma unroll
+    for (int q = 0; q < EPG / 4; ++q) {
+      const f32x4* wq = (const f32x4*)(wl + ((kg * EPG) / 4 + q) * CX * 4);
+#pragma unroll
+      for (int c = 0; c < CX; ++c) {
+        const f32x4 w4 = wq[c];
+        acc[c] = fmaf(y[4 * q + 0], w4[0], acc[c]);
+        acc[c] = fmaf(y[4 * q + 1], w4[1], acc[c]);
+        acc[c] = fmaf(y[4 * q + 2], w4[2], acc[c]);
+        acc[c] = fmaf(y[4 * q + 3], w4[3], acc[c]);
+      }
+    }
+  }
+  const long gv = (long)n * a.vox + v;
+  if (a.logits) {
+    for (int c = 0; c < a.C; ++c) a.logits[((long)n * a.C + c) * a.vox + v] = acc[c];
+  }
+  if (a.mode == DUA_MODE_LOGITS) return;
+
+  float eps[CX];
+  if (a.noise) {
+#pragma unroll
+    for (int c = 0; c < CX; ++c) eps[c] = c < a.C ? a.noise[((long)n * a.C + c) * a.vox + v] : 0.f;
+  } else {
+    const uint32_t step = a.step_word ? (uint32_t)a.step_word[0] : 0u;
+#pragma unroll
+    for (int q = 0; q < CX / 4; ++q) {
+      uint32_t ctr[4] = {(uint32_t)gv, (uint32_t)(gv >> 32), step, (uint32_t)q};
+      philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+      box_muller(ctr[0], ctr[1], eps[4 * q], eps[4 * q + 1]);
+      box_muller(ctr[2], ctr[3], eps[4 * q + 2], eps[4 * q + 3]);
+    }
+  }
+  float k[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = a.coef[8 * n + i];
+  float* xs_p = a.x_state + gv * CX;
+  float xn[CX], x0[CX];
+#pragma unroll
+  for (int q = 0; q < CX / 4; ++q) {
+    const f32x4 xt = *(const f32x4*)(xs_p + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xn[4 * q + e] = sampler_update(a.mode, k, acc[4 * q + e], xt[e], eps[4 * q + e], x0[4 * q + e]);
+  }
+#pragma unroll
+  for (int q = 0; q < CX / 4; ++q) {
+    f32x4 o = {xn[4 * q], xn[4 * q + 1], xn[4 * q + 2], xn[4 * q + 3]};
+    *(f32x4*)(xs_p + 4 * q) = o;
+  }
+  if (a.xsum) {
+    float* sp = a.xsum + gv * CX;
+#pragma unroll
+    for (int q = 0; q < CX / 4; ++q) {
+      f32x4 s4 = *(f32x4*)(sp + 4 * q);
+      s4[0] += x0[4 * q]; s4[1] += x0[4 * q + 1]; s4[2] += x0[4 * q + 2]; s4[3] += x0[4 * q + 3];
+      *(f32x4*)(sp + 4 * q) = s4;
+    }
+  }
+  if (a.xstart) {
+    for (int c = 0; c < a.C; ++c) a.xstart[((long)n * a.C + c) * a.vox + v] = x0[c];
+  }
+  if (a.xin) {
+    T* xp = (T*)a.xin + gv * a.xin_stride;
+#pragma unroll
+    for (int g = 0; g < CX / EPG; ++g) {
+      Frag o;
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) {
+        const int c = g * EPG + e;
+        o[e] = (T)xn[c];
+      }
+      // channels >= C of the slice hold the conditioning image / zero padding: leave them alone
+      if ((g + 1) * EPG <= a.C) *(Frag*)(xp + g * EPG) = o;
+      else
+        for (int e = 0; e < EPG; ++e)
+          if (g * EPG + e < a.C) xp[g * EPG + e] = o[e];
+    }
+  }
+}
+
+template <typename T, int CX>
+static int launch_tail(const dua_tail_desc* d, TailArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)(CX * d->K + 2 * d->K) * sizeof(float);
+  dim3 grid((unsigned)((d->voxels + 255) / 256), d->N);
+  hipLaunchKernelGGL((final_conv_sampler_kernel<T, CX>), grid, dim3(256), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int dispatch_tail(const dua_tail_desc* d, TailArgs& a, hipStream_t s) {
+  switch (d->CX) {
+    case 8: return launch_tail<T, 8>(d, a, s);
+    case 16: return launch_tail<T, 16>(d, a, s);
+    case 24: return launch_tail<T, 24>(d, a, s);
+    case 32: return launch_tail<T, 32>(d, a, s);
+  }
+  return DUA_ERR_ARG;
+}
+
+static inline unsigned nblk(long total) {
+  long b = (total + 255) / 256;
+  return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+}  // namespace dua
+
+extern "C" {
+
+int dua_q_sample(int N, long per_sample, const float* x0, const float* eps, const float* coef, float* out, void* stream) {
+  if (N <= 0 || per_sample <= 0 || !x0 || !eps || !coef || !out) return DUA_ERR_ARG;
+  const long total = N * per_sample;
+  hipLaunchKernelGGL(dua::q_sample_kernel, dim3(dua::nblk(total)), dim3(256), 0, (hipStream_t)stream, per_sample, total,
+                     x0, eps, coef, out);
+  return (int)hipGetLastError();
+}
+
+int dua_sampler_step(int mode, int N, long per_sample, const float* model_out, const float* x, const float* eps,
+                     const float* coef, float* x_out, float* xstart_out, float* xstart_sum, void* stream) {
+  if ((mode != DUA_MODE_DDPM && mode != DUA_MODE_DDIM) || N <= 0 || per_sample <= 0 || !model_out || !x || !eps ||
+      !coef || !x_out)
+    return DUA_ERR_ARG;
+  const long total = N * per_sample;
+  hipLaunchKernelGGL(dua::sampler_step_kernel, dim3(dua::nblk(total)), dim3(256), 0, (hipStream_t)stream, mode,
+                     per_sample, total, model_out, x, eps, coef, x_out, xstart_out, xstart_sum);
+  return (int)hipGetLastError();
+}
+
+int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const float* scale, const float* shift,
+                           const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
+                           const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
+                           void* stream) {
+  if (!d || !raw || !scale || !shift || !wf || !bf) return DUA_ERR_ARG;
+  if (d->K % 8 || d->raw_stride % 8 || d->K > d->raw_stride || d->C <= 0 || d->C > d->CX || d->K > 512) return DUA_ERR_ARG;
+  if (d->mode == DUA_MODE_LOGITS) { if (!logits) return DUA_ERR_ARG; }
+  else if (d->mode == DUA_MODE_DDPM || d->mode == DUA_MODE_DDIM) { if (!coef || !x_state) return DUA_ERR_ARG; }
+  else return DUA_ERR_ARG;
+  if (xin && d->xin_stride % 8) return DUA_ERR_ARG;
+  dua::TailArgs a;
+  a.raw = raw; a.scale = scale; a.shift = shift; a.wf = wf; a.bf = bf; a.coef = coef; a.x_state = x_state;
+  a.noise = noise; a.step_word = step_word; a.xin = xin; a.xsum = xstart_sum; a.logits = logits; a.xstart = xstart;
+  a.vox = d->voxels; a.K = d->K; a.raw_stride = d->raw_stride; a.C = d->C; a.xin_stride = d->xin_stride;
+  a.mode = d->mode; a.slope = d->slope;
+  a.seed_lo = (unsigned)(d->seed & 0xffffffffull); a.seed_hi = (unsigned)(d->seed >> 32);
+  if (d->dtype == DUA_F16) return dua::dispatch_tail<dua::f16>(d, a, (hipStream_t)stream);
+  if (d->dtype == DUA_F32) return dua::dispatch_tail<float>(d, a, (hipStream_t)stream);
+  return DUA_ERR_ARG;
+}
+
+}  // extern "C"

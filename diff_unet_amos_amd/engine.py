@@ -1,0 +1,343 @@
+"""Launch plan of the two Diff-UNet networks on one MI355X.
+
+Owns, per (batch, patch shape, dtype): packed weights, channels-last workspaces sized for HBM
+residency (nothing is freed between steps; a 96^3 x 16-class patch keeps ~3 GB resident), the
+timestep-embedding table, and the fixed kernel sequence of one encoder pass and one denoiser
+evaluation.  The denoiser evaluation + sampler update touches the host only to enqueue; the
+sampling loops capture it once into a HIP graph and replay it per step.
+
+Call sites in the reference that this replaces: BasicUNetEncoder.forward
+(models/basic_unet/pretrained/basic_unet.py:496-512), BasicUNetRDenoiser.forward
+(models/basic_unet/denoiser.py:284-312), and the loop bodies of
+GaussianDiffusion.p_sample_loop_progressive / ddim_sample_loop_progressive
+(guided_diffusion/gaussian_diffusion.py:487-535, 667-716).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _native as nv
+from . import ops
+
+SLOPE = 0.1          # LeakyReLU(0.1): models/diff_unet.py:34-35, pretrained/basic_unet.py:429
+EPS = 1e-5           # nn.InstanceNorm3d default
+
+
+class _Conv:
+    """One Convolution block (Conv3d + InstanceNorm affine) bound to its buffers."""
+
+
+class EmbeddingList(list):
+    """What embed_model(image) returns: indexable like the reference's list of 5 NCDHW tensors
+    (converted on first access), while the denoiser uses the channels-last device buffers."""
+
+    def __init__(self, plan, token):
+        super().__init__([None] * 5)
+        self.plan, self.token = plan, token
+
+    def __getitem__(self, i):
+        v = super().__getitem__(i)
+        if v is None:
+            p = self.plan
+            assert p.emb_token == self.token, "embeddings were overwritten by a later encoder pass"
+            v = ops.from_channels_last(p.emb[i], p.f[i])
+            super().__setitem__(i, v)
+        return v
+
+    def __iter__(self):
+        return (self[i] for i in range(5))
+
+
+class Plan:
+    """Buffers + launch sequences for one (N, D, H, W, dtype)."""
+
+    def __init__(self, net, N, D, H, W, dtype, device):
+        f = tuple(net.features)
+        assert len(f) == 6 and all(c % 8 == 0 for c in f), "feature sizes must be multiples of 8"
+        assert D % 16 == 0 and H % 16 == 0 and W % 16 == 0, \
+            "patch extents must be multiples of 16 (four 2x poolings; the reference recommends the same)"
+        assert D >= 32 and H >= 32 and W >= 32, "InstanceNorm3d needs >1 voxel at the bottom level (SURVEY F7)"
+        self.net, self.N, self.dims, self.dtype, self.dev, self.f = net, N, (D, H, W), dtype, device, f
+        self.C = net.num_classes
+        self.cx = ops.state_stride(self.C)
+        self.cin0 = -(-(self.C + 1) // 8) * 8           # [x_t (C) | image | zero pad]
+        self.up = (f[1], f[2] // 2, f[3] // 2, f[4] // 2)   # deconv output channels landing at level 0..3
+        S = [(D >> l, H >> l, W >> l) for l in range(5)]
+        self.S = S
+        z = lambda l, c, dt=dtype: torch.zeros((N, *S[l], c), dtype=dt, device=device)  # noqa: E731
+        # encoder
+        self.img_in = z(0, 8)
+        self.rawA = [z(l, f[l]) for l in range(5)]
+        self.rawB = [z(l, f[l]) for l in range(5)]
+        self.emb = [z(l, f[l]) for l in range(5)]
+        self.pool = [z(l + 1, f[l]) for l in range(4)]
+        self.emb_token = 0
+        # denoiser
+        self.xin = z(0, self.cin0)
+        self.cat = [z(l, f[l] + self.up[l]) for l in range(4)]
+        self.x4 = z(4, f[4])
+        dec_out = (f[5], f[1], f[2], f[3])
+        self.uA = [z(l, dec_out[l]) for l in range(4)]
+        self.uB = [z(l, dec_out[l]) for l in range(4)]
+        self.dec_out = dec_out
+        # statistics scratch
+        self.rows = [ops.conv3_rows(*S[l]) for l in range(5)]
+        cmax = max(-(-c // 64) * 64 for c in f)
+        self.partials = torch.zeros(N * max(r * cmax for r in self.rows) * 2 + 16, dtype=torch.float32, device=device)
+        self.counts = [torch.zeros(self.rows[l], dtype=torch.float32, device=device) for l in range(5)]
+        # sampler state
+        self.x_state = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
+        self.x_sum = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
+        self.cur_coef = torch.zeros((N, 8), dtype=torch.float32, device=device)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self.step_word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.logits = torch.zeros((N, self.C, *S[0]), dtype=torch.float32, device=device)
+        self._bind()
+        self.weights_version = None
+        self.graphs = {}
+        self.tables = {}
+
+    # ---- parameter binding -------------------------------------------------------------------
+    def _mk(self, name, block, cin_packed=None, perm=None):
+        c = _Conv()
+        c.name = name
+        c.w, c.b = block.conv.weight, block.conv.bias
+        c.gamma, c.beta = block.adn.N.weight, block.adn.N.bias
+        c.cout, c.cin = c.w.shape[0], c.w.shape[1]
+        c.cin_packed, c.perm = cin_packed, perm
+        c.scale = torch.zeros(self.N * c.cout, dtype=torch.float32, device=self.dev)
+        c.shift = torch.zeros(self.N * c.cout, dtype=torch.float32, device=self.dev)
+        c.wp = c.bp = None
+        return c
+
+    def _bind(self):
+        net = self.net
+        enc, den = net.embed_model, net.model
+        self.enc = [(self._mk("e0a", enc.conv_0.conv_0, cin_packed=8, perm=[0] + [-1] * 7), self._mk("e0b", enc.conv_0.conv_1))]
+        for i in range(4):
+            tc = enc.down[i].convs
+            self.enc.append((self._mk(f"e{i+1}a", tc.conv_0), self._mk(f"e{i+1}b", tc.conv_1)))
+        C = self.C
+        perm0 = list(range(1, C + 1)) + [0] + [-1] * (self.cin0 - C - 1)   # packed [x_t | image | pad] -> source [image | x_t]
+        self.den = [(self._mk("d0a", den.conv_0.conv_0, cin_packed=self.cin0, perm=perm0), self._mk("d0b", den.conv_0.conv_1))]
+        for i, blk in enumerate((den.down_1, den.down_2, den.down_3, den.down_4)):
+            self.den.append((self._mk(f"d{i+1}a", blk.convs.conv_0), self._mk(f"d{i+1}b", blk.convs.conv_1)))
+        ups = (den.upcat_1, den.upcat_2, den.upcat_3, den.upcat_4)          # index = level the block outputs at
+        self.dec = [(self._mk(f"u{l}a", ups[l].convs.conv_0), self._mk(f"u{l}b", ups[l].convs.conv_1)) for l in range(4)]
+        self.deconv = [ups[l].upsample.deconv for l in range(4)]
+        self.deconv_packed = [None] * 4
+        # timestep-embedding blocks in table order, with their offsets
+        blocks = [den.conv_0, den.down_1.convs, den.down_2.convs, den.down_3.convs, den.down_4.convs,
+                  den.upcat_4.convs, den.upcat_3.convs, den.upcat_2.convs, den.upcat_1.convs]
+        self.temb_blocks = blocks
+        offs, o = [], 0
+        for b in blocks:
+            offs.append(o)
+            o += b.temb_proj.weight.shape[0]
+        self.P = o
+        self.temb_off = {"d0": offs[0], "d1": offs[1], "d2": offs[2], "d3": offs[3], "d4": offs[4],
+                         "u3": offs[5], "u2": offs[6], "u1": offs[7], "u0": offs[8]}
+        self.cur_add = torch.zeros((self.N, self.P), dtype=torch.float32, device=self.dev)
+        self.temb_table = None
+
+    def _params(self):
+        return [p for p in self.net.parameters()]
+
+    def refresh_weights(self):
+        """Re-pack when any parameter changed (optimizer step, load_state_dict)."""
+        ver = tuple((p.data_ptr(), p._version) for p in self._params())
+        if ver == self.weights_version:
+            return
+        dt = self.dtype
+        with torch.no_grad():
+            for pair in self.enc + self.den + self.dec:
+                for c in pair:
+                    c.wp, c.bp = ops.pack_conv3_weights(c.w.detach().float().contiguous(), c.b.detach(), dt,
+                                                        cin_packed=c.cin_packed, perm=c.perm)
+                    c.gamma_c = c.gamma.detach().float().contiguous()
+                    c.beta_c = c.beta.detach().float().contiguous()
+            for l in range(4):
+                d = self.deconv[l]
+                self.deconv_packed[l] = ops.pack_deconv_weights(d.weight.detach().float().contiguous(), d.bias.detach(), dt)
+            den = self.net.model
+            self.wf = den.final_conv.weight.detach().float().reshape(self.C, -1).contiguous()
+            self.bf = den.final_conv.bias.detach().float().contiguous()
+            # embedding table for every original timestep (depends on weights only)
+            T = self.net.timesteps
+            half = den.temb.embedding_dim // 2
+            freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(self.dev)
+            wcat = torch.cat([b.temb_proj.weight.detach().float() for b in self.temb_blocks], 0).contiguous()
+            bcat = torch.cat([b.temb_proj.bias.detach().float() for b in self.temb_blocks], 0).contiguous()
+            d0, d1 = den.temb.dense[0], den.temb.dense[1]
+            ts = torch.arange(T, dtype=torch.int32, device=self.dev)
+            self.temb_table = ops.temb_table(ts, freqs, d0.weight.detach().float().contiguous(),
+                                             d0.bias.detach().float().contiguous(),
+                                             d1.weight.detach().float().contiguous(),
+                                             d1.bias.detach().float().contiguous(), wcat, bcat)
+        self.weights_version = ver
+        self.graphs.clear()
+
+    # ---- building blocks ------------------------------------------------------------------------
+    def _conv(self, c, x, cin, y, level, xform_from=None, add_key=None):
+        kw = {}
+        if xform_from is not None:
+            kw = dict(in_scale=xform_from.scale, in_shift=xform_from.shift)
+            if add_key is not None:
+                kw.update(in_add=self._add_view(add_key), in_add_stride=self.P)
+        rows, cpad = ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, self.partials, self.counts[level], slope=SLOPE, **kw)
+        ops.instnorm_finalize(self.N, c.cout, rows, cpad, self.partials, self.counts[level], c.gamma_c, c.beta_c,
+                              c.scale, c.shift, EPS)
+
+    def _add_view(self, key):
+        # pointer to cur_add[0, off]; rows are P apart (in_add_stride)
+        off = self.temb_off[key]
+        return self.cur_add.view(-1)[off:]
+
+    def run_encoder(self, image):
+        """BasicUNetEncoder.forward: fills self.emb[0..4] (channels-last)."""
+        self.refresh_weights()
+        N = self.N
+        assert tuple(image.shape) == (N, 1, *self.dims), f"image shape {tuple(image.shape)} != plan {(N, 1, *self.dims)}"
+        img = image.detach().float().contiguous()
+        ops.to_channels_last(img, self.img_in, 0, 8)
+        ops.to_channels_last(img, self.xin, self.C, self.cin0 - self.C)     # conditioning channel of the denoiser input
+        x, cin = self.img_in, 8
+        for l in range(5):
+            a, b = self.enc[l]
+            self._conv(a, x, cin, self.rawA[l], l)
+            self._conv(b, self.rawA[l], a.cout, self.rawB[l], l, xform_from=a)
+            ops.materialize(self.rawB[l], b.cout, b.scale, b.shift, self.emb[l], 0,
+                            pooled=self.pool[l] if l < 4 else None, slope=SLOPE)
+            if l < 4:
+                x, cin = self.pool[l], b.cout
+        self.emb_token += 1
+        return EmbeddingList(self, self.emb_token)
+
+    def stage_condition(self, image, embeddings):
+        """Make sure the denoiser's conditioning (image channel of xin, 5 embedding maps) is resident."""
+        if isinstance(embeddings, EmbeddingList) and embeddings.plan is self and embeddings.token == self.emb_token:
+            return          # run_encoder just staged both from this image
+        img = image.detach().float().contiguous()
+        assert tuple(img.shape) == (self.N, 1, *self.dims)
+        ops.to_channels_last(img, self.xin, self.C, self.cin0 - self.C)
+        self.load_embeddings(embeddings)
+
+    def load_embeddings(self, embeddings):
+        """Accept caller-supplied NCDHW embeddings (a plain list) instead of this plan's own."""
+        if isinstance(embeddings, EmbeddingList) and embeddings.plan is self and embeddings.token == self.emb_token:
+            return
+        for l in range(5):
+            e = embeddings[l]
+            assert tuple(e.shape) == (self.N, self.f[l], *self.S[l])
+            ops.to_channels_last(e.detach().float().contiguous(), self.emb[l], 0, self.f[l])
+        self.emb_token += 1
+
+    def denoiser_body(self):
+        """BasicUNetRDenoiser.forward from the staged input (self.xin) up to the raw output of the
+        last decoder block; self.cur_add must hold the embedding rows of this evaluation."""
+        f = self.f
+        x, cin = self.xin, self.cin0
+        for l in range(5):
+            a, b = self.den[l]
+            self._conv(a, x, cin, self.rawA[l], l)
+            self._conv(b, self.rawA[l], a.cout, self.rawB[l], l, xform_from=a, add_key=f"d{l}")
+            if l < 4:
+                ops.materialize(self.rawB[l], b.cout, b.scale, b.shift, self.cat[l], 0, emb=self.emb[l],
+                                pooled=self.pool[l], slope=SLOPE)
+                x, cin = self.pool[l], b.cout
+            else:
+                ops.materialize(self.rawB[4], b.cout, b.scale, b.shift, self.x4, 0, emb=self.emb[4], slope=SLOPE)
+        src, src_c, src_conv = self.x4, f[4], None
+        for l in (3, 2, 1, 0):
+            wp, bp = self.deconv_packed[l]
+            kw = dict(in_scale=src_conv.scale, in_shift=src_conv.shift) if src_conv is not None else {}
+            ops.deconv_k2s2(src, src_c, 0, wp, bp, self.up[l], self.cat[l], f[l], slope=SLOPE, **kw)
+            a, b = self.dec[l]
+            self._conv(a, self.cat[l], f[l] + self.up[l], self.uA[l], l)
+            self._conv(b, self.uA[l], a.cout, self.uB[l], l, xform_from=a, add_key=f"u{l}")
+            src, src_c, src_conv = self.uB[l], b.cout, b
+        return self.dec[0][1]
+
+    def tail(self, mode, noise=None, logits=None, xstart=None, use_sum=False, seed=0):
+        last = self.dec[0][1]
+        ops.final_conv_sampler(self.uB[0], last.cout, last.scale, last.shift, self.wf, self.bf, self.C, mode,
+                               coef=self.cur_coef, x_state=self.x_state, noise=noise, step_word=self.step_word,
+                               xin=self.xin if mode != nv.MODE_LOGITS else None,
+                               xstart_sum=self.x_sum if use_sum else None, logits=logits, xstart=xstart, slope=SLOPE,
+                               seed=seed)
+
+    # ---- public operations ------------------------------------------------------------------------
+    def denoise(self, x, t):
+        """logits = model(x, t, image, embeddings) for already-encoded image (denoiser.py:284-312)."""
+        self.refresh_weights()
+        N = self.N
+        assert tuple(x.shape) == (N, self.C, *self.dims) and t.numel() == N
+        ops.to_channels_last(x.detach().float().contiguous(), self.xin, 0, self.C)
+        rows = t.detach().to(device=self.dev, dtype=torch.int32).contiguous()
+        ops.step_begin(N, self.temb_table, self.cur_add, rows_per_sample=rows)
+        self.denoiser_body()
+        out = torch.empty((N, self.C, *self.dims), dtype=torch.float32, device=self.dev)
+        self.tail(nv.MODE_LOGITS, logits=out)
+        return out
+
+    def sample_loop(self, diffusion, kind, noise=None, step_noise=None, eta=0.0, use_graph=True, seed=0,
+                    want_final_xstart=False):
+        """T reverse steps (T = diffusion.num_timesteps) starting from ``noise`` (x_T, NCDHW) or a fresh
+        draw.  ``step_noise``: optional list of per-step NCDHW draws (parity runs); otherwise the
+        tail kernel generates eps in-kernel (Philox).  Returns dict(sample, sum_pred_xstart)."""
+        self.refresh_weights()
+        N, T = self.N, diffusion.num_timesteps
+        shape = (N, self.C, *self.dims)
+        if noise is None:
+            noise = torch.randn(*shape, device=self.dev)
+        assert tuple(noise.shape) == shape
+        x_T = noise.detach().float().contiguous()
+        ops.to_channels_last(x_T, self.x_state, 0, self.cx)
+        ops.to_channels_last(x_T, self.xin, 0, self.C)
+        self.x_sum.zero_()
+        mode = nv.MODE_DDPM if kind == "ddpm" else nv.MODE_DDIM
+        tkey = (id(diffusion), kind, float(eta))
+        if tkey not in self.tables:
+            order = list(range(T))[::-1]
+            tt = torch.tensor(order)
+            coef = diffusion.ddpm_coef(tt) if kind == "ddpm" else diffusion.ddim_coef(tt, eta)
+            tmap = diffusion.model_timesteps()
+            self.tables[tkey] = (coef.to(self.dev).contiguous(),
+                                 torch.tensor([tmap[i] for i in order], dtype=torch.int32, device=self.dev))
+        coef_table, row_of_step = self.tables[tkey]
+        self.counter.zero_()
+        if step_noise is not None:
+            assert len(step_noise) == T
+            use_graph = False
+
+        def one_step(eps):
+            ops.step_begin(N, self.temb_table, self.cur_add, row_of_step=row_of_step, counter=self.counter,
+                           coef_table=coef_table, cur_coef=self.cur_coef, step_word=self.step_word)
+            self.denoiser_body()
+            self.tail(mode, noise=eps, use_sum=True, seed=seed)
+
+        if not use_graph:
+            for k in range(T):
+                one_step(None if step_noise is None else step_noise[k].detach().float().contiguous())
+        else:
+            key = (tkey, seed)
+            g = self.graphs.get(key)
+            if g is None:
+                # warm-up outside capture (sets kernel attributes, fills caches); state is reset below
+                one_step(None)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    one_step(None)
+                self.graphs[key] = g
+                ops.to_channels_last(x_T, self.x_state, 0, self.cx)
+                ops.to_channels_last(x_T, self.xin, 0, self.C)
+                self.x_sum.zero_()
+                self.counter.zero_()
+            for _ in range(T):
+                g.replay()
+        out = {"sample": ops.from_channels_last(self.x_state, self.C),
+               "sum_pred_xstart": ops.from_channels_last(self.x_sum, self.C)}
+        return out

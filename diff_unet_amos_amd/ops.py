@@ -98,7 +98,7 @@ def conv3_rows(D, H, W):
 
 
 def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, partials, counts,
-              in_scale=None, in_shift=None, in_add=None, slope=0.1):
+              in_scale=None, in_shift=None, in_add=None, slope=0.1, in_add_stride=0):
     """Raw 3x3x3 convolution (+bias) with optional fused producer norm/activation on the input
     and InstanceNorm partial statistics on the output."""
     _cl_check(x, "x"); _cl_check(y, "y")
@@ -116,9 +116,12 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, partials, 
     assert partials.dtype == torch.float32 and partials.numel() >= N * rows * nct * 64 * 2
     assert counts.dtype == torch.float32 and counts.numel() >= rows
     if in_scale is not None:
-        for v in (in_scale, in_shift) + ((in_add,) if in_add is not None else ()):
-            assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == N * cin
-    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off, slope)
+        for v in (in_scale, in_shift):
+            assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() >= N * cin
+        if in_add is not None:
+            assert in_add.dtype == torch.float32 and in_add.numel() >= (N - 1) * (in_add_stride or cin) + cin
+    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off, slope,
+                     in_add_stride)
     del esz
     nv.check(nv.lib().dua_conv3d_k3_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), nv.ptr(in_scale),
                                         nv.ptr(in_shift), nv.ptr(in_add), nv.ptr(y), nv.ptr(partials), nv.ptr(counts),
@@ -157,3 +160,113 @@ def materialize(raw, Cc, scale, shift, out, out_off, emb=None, pooled=None, slop
     d = nv.MaterializeDesc(nv.dt_code(raw.dtype), N, D, H, W, Cc, rs, es, out.shape[-1], out_off, ps, slope)
     nv.check(nv.lib().dua_materialize(C.byref(d), nv.ptr(raw), nv.ptr(scale), nv.ptr(shift), nv.ptr(emb), nv.ptr(out),
                                       nv.ptr(pooled), nv.stream_ptr()), "dua_materialize")
+
+
+def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, in_scale=None, in_shift=None, in_add=None,
+                slope=0.1):
+    """ConvTranspose3d(k2,s2) of a channel slice of ``x`` into a channel slice of ``y`` (2x spatial)."""
+    _cl_check(x, "x"); _cl_check(y, "y")
+    N, D, H, W, cs_in = x.shape
+    assert x.dtype == y.dtype and tuple(y.shape[:4]) == (N, 2 * D, 2 * H, 2 * W)
+    assert cin % 8 == 0 and cin_off % 8 == 0 and cin_off + cin <= cs_in
+    assert cout % 8 == 0 and cout_off % 8 == 0 and cout_off + cout <= y.shape[-1]
+    ck = chunk_elems(x.dtype)
+    nch, nct = -(-cin // ck), -(-cout // 64)
+    assert w_packed.numel() == 8 * nct * nch * 4 * 64 * 16 and bias_pad.numel() == nct * 64
+    if in_scale is not None:
+        assert in_scale.numel() == N * cin and in_shift.numel() == N * cin
+    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off, slope, 0)
+    nv.check(nv.lib().dua_deconv_k2s2_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), nv.ptr(in_scale),
+                                          nv.ptr(in_shift), nv.ptr(in_add), nv.ptr(y), nv.stream_ptr()),
+             "dua_deconv_k2s2_fwd")
+
+
+def _f32c(t, name):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), f"{name}: contiguous fp32 device tensor"
+
+
+def q_sample(x0, eps, coef, out=None):
+    """coef: fp32[N,2] device."""
+    _f32c(x0, "x0"); _f32c(eps, "eps"); _f32c(coef, "coef")
+    assert eps.shape == x0.shape and coef.numel() == 2 * x0.shape[0]
+    out = torch.empty_like(x0) if out is None else out
+    _f32c(out, "out")
+    nv.check(nv.lib().dua_q_sample(x0.shape[0], x0[0].numel(), nv.ptr(x0), nv.ptr(eps), nv.ptr(coef), nv.ptr(out),
+                                   nv.stream_ptr()), "dua_q_sample")
+    return out
+
+
+def sampler_step(mode, model_out, x, eps, coef, x_out=None, xstart_out=None, xstart_sum=None):
+    for n_, t in (("model_out", model_out), ("x", x), ("eps", eps), ("coef", coef)):
+        _f32c(t, n_)
+    assert model_out.shape == x.shape == eps.shape and coef.numel() == 8 * x.shape[0]
+    x_out = torch.empty_like(x) if x_out is None else x_out
+    for t in (x_out, xstart_out, xstart_sum):
+        if t is not None:
+            _f32c(t, "out"); assert t.shape == x.shape
+    nv.check(nv.lib().dua_sampler_step(mode, x.shape[0], x[0].numel(), nv.ptr(model_out), nv.ptr(x), nv.ptr(eps),
+                                       nv.ptr(coef), nv.ptr(x_out), nv.ptr(xstart_out), nv.ptr(xstart_sum),
+                                       nv.stream_ptr()), "dua_sampler_step")
+    return x_out
+
+
+def state_stride(num_classes):
+    cx = -(-num_classes // 8) * 8
+    assert cx <= 32, "at most 32 classes"
+    return cx
+
+
+def final_conv_sampler(raw, K, scale, shift, wf, bf, num_classes, mode, coef=None, x_state=None, noise=None,
+                       step_word=None, xin=None, xstart_sum=None, logits=None, xstart=None, slope=0.1, seed=0):
+    _cl_check(raw, "raw")
+    N, D, H, W, rs = raw.shape
+    vox = D * H * W
+    cx = state_stride(num_classes)
+    assert K % 8 == 0 and K <= rs and scale.numel() >= N * K and shift.numel() >= N * K
+    _f32c(wf, "wf"); _f32c(bf, "bf")
+    assert wf.numel() == num_classes * K and bf.numel() == num_classes
+    if mode != nv.MODE_LOGITS:
+        _f32c(coef, "coef"); _f32c(x_state, "x_state")
+        assert coef.numel() >= 8 * N and x_state.numel() == N * vox * cx
+    if noise is not None:
+        _f32c(noise, "noise"); assert noise.numel() == N * num_classes * vox
+    for t in (logits, xstart):
+        if t is not None:
+            _f32c(t, "ncdhw out"); assert t.numel() == N * num_classes * vox
+    if xstart_sum is not None:
+        _f32c(xstart_sum, "xstart_sum"); assert xstart_sum.numel() == N * vox * cx
+    xs = 0
+    if xin is not None:
+        _cl_check(xin, "xin")
+        assert xin.dtype == raw.dtype and tuple(xin.shape[:4]) == (N, D, H, W) and xin.shape[-1] >= num_classes
+        xs = xin.shape[-1]
+    d = nv.TailDesc(nv.dt_code(raw.dtype), N, vox, K, rs, num_classes, cx, mode, xs, slope, seed)
+    nv.check(nv.lib().dua_final_conv_sampler(C.byref(d), nv.ptr(raw), nv.ptr(scale), nv.ptr(shift), nv.ptr(wf),
+                                             nv.ptr(bf), nv.ptr(coef), nv.ptr(x_state), nv.ptr(noise),
+                                             nv.ptr(step_word), nv.ptr(xin), nv.ptr(xstart_sum), nv.ptr(logits),
+                                             nv.ptr(xstart), nv.stream_ptr()), "dua_final_conv_sampler")
+
+
+def temb_table(timesteps, freqs, w0, b0, w1, b1, w_cat, b_cat, out=None):
+    """timesteps: int32 device [T]; returns fp32 [T, P]."""
+    assert timesteps.is_cuda and timesteps.dtype == torch.int32 and timesteps.is_contiguous()
+    for t in (freqs, w0, b0, w1, b1, w_cat, b_cat):
+        _f32c(t, "temb param")
+    half, hid, P = freqs.numel(), w1.shape[0], w_cat.shape[0]
+    assert tuple(w0.shape) == (hid, 2 * half) and tuple(w1.shape) == (hid, hid) and w_cat.shape[1] == hid
+    assert b0.numel() == hid and b1.numel() == hid and b_cat.numel() == P
+    T = timesteps.numel()
+    out = torch.empty((T, P), dtype=torch.float32, device=w0.device) if out is None else out
+    nv.check(nv.lib().dua_temb_table(T, nv.ptr(timesteps), nv.ptr(freqs), half, hid, nv.ptr(w0), nv.ptr(b0), nv.ptr(w1),
+                                     nv.ptr(b1), nv.ptr(w_cat), nv.ptr(b_cat), P, nv.ptr(out), nv.stream_ptr()),
+             "dua_temb_table")
+    return out
+
+
+def step_begin(N, table, cur_add, rows_per_sample=None, row_of_step=None, counter=None, coef_table=None,
+               cur_coef=None, step_word=None):
+    P = table.shape[1]
+    assert cur_add.numel() >= N * P
+    nv.check(nv.lib().dua_step_begin(N, P, nv.ptr(table), nv.ptr(rows_per_sample), nv.ptr(row_of_step),
+                                     nv.ptr(coef_table), nv.ptr(counter), nv.ptr(cur_add), nv.ptr(cur_coef),
+                                     nv.ptr(step_word), nv.stream_ptr()), "dua_step_begin")

@@ -34,6 +34,7 @@ typedef struct {
   int Cin, Cin_stride, Cin_off;    /* all multiples of 8 */
   int Cout, Cout_stride, Cout_off; /* all multiples of 8 */
   float slope;                     /* LeakyReLU negative slope of the fused input transform */
+  int in_add_stride;               /* per-sample stride of in_add (0 = Cin) */
 } dua_conv3_desc;
 
 /* rows of the partial-statistics matrix the call writes per batch item */
@@ -78,6 +79,70 @@ typedef struct {
 
 int dua_materialize(const dua_materialize_desc* d, const void* raw, const float* scale, const float* shift,
                     const void* emb, void* out, void* pooled, void* stream);
+
+/* ---- ConvTranspose3d(k2, s2, bias) --------------------------------------------------------
+ * Replaces MONAI UpSample(mode="deconv") = nn.ConvTranspose3d at
+ * models/basic_unet/denoiser.py:161-170, writing into the "upsampled" channel slice of the concat
+ * buffer (torch.cat at denoiser.py:190).  d->D/H/W are the INPUT extents; y has 2D x 2H x 2W. */
+int dua_deconv_k2s2_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
+                        const float* in_scale, const float* in_shift, const float* in_add, void* y, void* stream);
+
+/* ---- diffusion elementwise arithmetic (guided_diffusion/gaussian_diffusion.py) ----------------
+ * Tensors are contiguous fp32 with the batch outermost (any layout inside a sample).
+ * q_sample (:187-205): coef = fp32[N][2] = {sqrt_alphas_cumprod[t], sqrt_one_minus_alphas_cumprod[t]}. */
+int dua_q_sample(int N, long per_sample, const float* x0, const float* eps, const float* coef, float* out, void* stream);
+
+#define DUA_MODE_LOGITS 0
+#define DUA_MODE_DDPM 1   /* p_sample, :395-439   coef row {c1, c2, 1[t!=0]*exp(.5*logvar), -, -, -, -, -} */
+#define DUA_MODE_DDIM 2   /* ddim_sample, :537-586 coef row {sqrt_recip, sqrt_recipm1, sqrt(acp_prev),
+                             sqrt(1-acp_prev-sigma^2), 1[t!=0]*sigma, -, -, -} */
+/* One reverse step given the model output: x_out = update(clamp(model_out,-1,1), x, eps);
+ * xstart_out (may be NULL) = clamp(model_out); xstart_sum (may be NULL) += clamp(model_out)
+ * (models/diffusion/diffusion.py:94-98).  coef = fp32[N][8]. */
+int dua_sampler_step(int mode, int N, long per_sample, const float* model_out, const float* x, const float* eps,
+                     const float* coef, float* x_out, float* xstart_out, float* xstart_sum, void* stream);
+
+/* ---- fused denoiser tail --------------------------------------------------------------------
+ * InstanceNorm+LeakyReLU of the last decoder block -> final_conv 1x1x1
+ * (models/basic_unet/denoiser.py:282,311) -> sampler update -> running sum of x0^ -> x_{t-1} written
+ * into the next step's denoiser input slice (torch.cat([image, x]) at denoiser.py:298, in place). */
+typedef struct {
+  int dtype;
+  int N;
+  long voxels;
+  int K, raw_stride;       /* channels of the last decoder block, channel stride of raw */
+  int C, CX;               /* classes; channel stride of the fp32 sampler state (8/16/24/32) */
+  int mode;                /* DUA_MODE_* */
+  int xin_stride;          /* channel stride of xin (x_{t-1} goes to channels [0, C)) */
+  float slope;
+  unsigned long long seed; /* Philox key when noise == NULL */
+} dua_tail_desc;
+
+/* wf: fp32[C][K], bf: fp32[C].  coef: fp32[N][8] on device.  x_state: fp32[N][voxels][CX] in/out.
+ * noise: fp32 NCDHW [N][C][voxels] or NULL (in-kernel Philox4x32-10 + Box-Muller, counter =
+ * (element, *step_word)).  xin, xstart_sum ([N][voxels][CX]), logits and xstart (NCDHW fp32) may be
+ * NULL.  In DUA_MODE_LOGITS only logits is written. */
+int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const float* scale, const float* shift,
+                           const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
+                           const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
+                           void* stream);
+
+/* ---- timestep embedding ---------------------------------------------------------------------
+ * table[i][:] = concat over TwoConv blocks of temb_proj(swish(TimeStepEmbedder(timesteps[i])))
+ * (models/diffusion/utils.py:6-54; models/basic_unet/denoiser.py:51-52,65).  freqs = the
+ * exp(-ln(1e4) j/(half-1)) vector, w0 [hidden][2*half], w1 [hidden][hidden], w_cat [P][hidden]. */
+int dua_temb_table(int count, const int* timesteps, const float* freqs, int half_dim, int hidden, const float* w0,
+                   const float* b0, const float* w1, const float* b1, const float* w_cat, const float* b_cat, int P,
+                   float* table, void* stream);
+
+/* Start of one denoiser evaluation: copy the embedding row(s) and sampler coefficients of the
+ * current step into the fixed buffers the other kernels read.  Either rows_per_sample
+ * (int32[N], training / "denoise") or (row_of_step[], *counter) (sampling loops: uses step
+ * k = *counter, writes step_word[0] = k, then *counter = k + 1) selects the rows.  Replaces the
+ * per-step host work at gaussian_diffusion.py:523,703 and respace.py:123-129. */
+int dua_step_begin(int N, int P, const float* table, const int* rows_per_sample, const int* row_of_step,
+                   const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
+                   void* stream);
 
 /* ---- layout / packing at the API boundary -------------------------------------------------- */
 /* nn.ConvTranspose3d weight fp32[Cin][Cout][2][2][2] -> [tap][cout_tile][chunk][k-group][64][16 B].

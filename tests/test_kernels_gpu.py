@@ -157,3 +157,147 @@ def test_materialize(dtype, pool, with_emb):
     if pool:
         gp = ops.from_channels_last(pooled, C).cpu()
         assert torch.equal(gp, F.max_pool3d(got, 2))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(1, 64, 32, 3, 3, 3), (2, 40, 72, 2, 4, 6), (1, 16, 16, 6, 6, 6)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_deconv_k2s2(dtype, shape, fused):
+    ops = _ops()
+    N, Cin, Cout, D, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    raw = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, 2, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    scale = torch.rand(N, Cin, generator=g) + 0.5; shift = torch.randn(N, Cin, generator=g)
+    xin = raw.to(dtype).float()
+    if fused:
+        xin = F.leaky_relu(xin * scale[:, :, None, None, None] + shift[:, :, None, None, None], 0.1).to(dtype).float()
+    ref = F.conv_transpose3d(xin, w.to(dtype).float(), b, stride=2)
+    y = torch.full((N, 2 * D, 2 * H, 2 * W, Cout + 16), 9.0, dtype=dtype, device="cuda")
+    wp, bp = ops.pack_deconv_weights(w.cuda(), b.cuda(), dtype)
+    kw = dict(in_scale=scale.cuda().contiguous(), in_shift=shift.cuda().contiguous()) if fused else {}
+    ops.deconv_k2s2(_cl(raw, dtype), Cin, 0, wp, bp, Cout, y, 16, **kw)
+    got = ops.from_channels_last(y, Cout, 16).cpu()
+    assert torch.allclose(got, ref, **TOL[dtype]), float((got - ref).abs().max())
+    assert float((y[..., :16].float() - 9).abs().max()) == 0
+
+
+def test_temb_table_against_reference_golden(golden):
+    """G5 goldens come from the reference's own models/diffusion/utils.py."""
+    import math
+    ops = _ops()
+    t = torch.from_numpy(golden["G5_t"]).to(torch.int32).cuda()
+    w = {k[len("G5_w_"):]: torch.from_numpy(golden[k]).cuda() for k in golden.files if k.startswith("G5_w_")}
+    freqs = torch.exp(torch.arange(64, dtype=torch.float32) * -(math.log(10000) / 63)).cuda()
+    g = torch.Generator().manual_seed(0)
+    wc = torch.randn(40, 512, generator=g) * 0.05; bc = torch.randn(40, generator=g)
+    tab = ops.temb_table(t, freqs, w["dense.0.weight"], w["dense.0.bias"], w["dense.1.weight"], w["dense.1.bias"],
+                         wc.cuda(), bc.cuda()).cpu()
+    temb = torch.from_numpy(golden["G5_temb"])
+    ref = F.linear(temb * torch.sigmoid(temb), wc, bc)
+    assert torch.allclose(tab, ref, rtol=1e-4, atol=1e-5), float((tab - ref).abs().max())
+
+
+def test_q_sample_and_sampler_steps_against_reference_golden(golden):
+    """Elementwise sampler kernels vs goldens produced by the reference's guided_diffusion."""
+    from diff_unet_amos_amd import _native as nv
+    from diff_unet_amos_amd.gaussian_diffusion import make_spaced
+    ops = _ops()
+    d1000, d10 = make_spaced(1000, [1000]), make_spaced(1000, [10])
+    x0 = torch.from_numpy(golden["G2_x0"]).cuda(); eps = torch.from_numpy(golden["G2_eps"]).cuda()
+    for tag in "ab":
+        t = torch.from_numpy(golden[f"G2_t_{tag}"])
+        got = ops.q_sample(x0, eps, d1000.q_coef(t).cuda()).cpu().numpy()
+        assert (got == golden[f"G2_xt_{tag}"]).all()
+    x = torch.from_numpy(golden["G3_x"]).cuda(); nz = torch.from_numpy(golden["G3_noise"]).cuda()
+    for dtag, d, ts in (("s10", d10, [0, 1, 5, 9]), ("s1000", d1000, [0, 500, 999])):
+        for sname in ("half", "tanh"):
+            for ti in ts:
+                key = f"G3_{dtag}_{sname}_t{ti}"
+                mo = torch.from_numpy(golden[f"{key}_pmv_model_output"]).cuda().contiguous()
+                t = torch.tensor([ti, ti])
+                xs = torch.empty_like(x)
+                got = ops.sampler_step(nv.MODE_DDPM, mo, x, nz, d.ddpm_coef(t).cuda(), xstart_out=xs)
+                assert (got.cpu().numpy() == golden[f"{key}_psample"]).all(), key
+                assert (xs.cpu().numpy() == golden[f"{key}_pmv_pred_xstart"]).all()
+                got = ops.sampler_step(nv.MODE_DDIM, mo, x, nz, d.ddim_coef(t, 0.0).cuda())
+                assert torch.allclose(got.cpu(), torch.from_numpy(golden[f"{key}_ddim"]), rtol=1e-6, atol=1e-6), key
+                got = ops.sampler_step(nv.MODE_DDIM, mo, x, nz, d.ddim_coef(t, 0.7).cuda())
+                assert torch.allclose(got.cpu(), torch.from_numpy(golden[f"{key}_ddim_eta07"]), rtol=1e-6, atol=1e-6), key
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("C", [2, 16])
+@pytest.mark.parametrize("mode", ["logits", "ddpm", "ddim"])
+def test_final_conv_sampler(dtype, C, mode):
+    from diff_unet_amos_amd import _native as nv
+    from diff_unet_amos_amd.gaussian_diffusion import make_spaced
+    ops = _ops()
+    N, K, D, H, W = 2, 24, 4, 6, 10
+    vox = D * H * W
+    g = torch.Generator().manual_seed(C)
+    raw = torch.randn(N, K, D, H, W, generator=g)
+    scale = torch.rand(N, K, generator=g) + 0.5; shift = torch.randn(N, K, generator=g)
+    wf = torch.randn(C, K, generator=g) / K ** 0.5; bf = torch.randn(C, generator=g)
+    act = F.leaky_relu(raw.to(dtype).float() * scale[:, :, None, None, None] + shift[:, :, None, None, None], 0.1)
+    logits_ref = F.conv3d(act, wf.view(C, K, 1, 1, 1), bf)
+    cx = ops.state_stride(C)
+    d = make_spaced(1000, [10])
+    t = torch.tensor([3, 7])
+    xt = torch.randn(N, C, D, H, W, generator=g); nz = torch.randn(N, C, D, H, W, generator=g)
+    from oracle.diffusion_ref import RefDiffusion
+    rd = RefDiffusion(1000, [10])
+    fn = (lambda x, tt, **k: logits_ref)
+    args = dict(scale=scale.cuda().contiguous(), shift=shift.cuda().contiguous(), wf=wf.cuda(), bf=bf.cuda())
+    rawcl = _cl(raw, dtype)
+    logits = torch.zeros(N, C, D, H, W, device="cuda")
+    tol = dict(rtol=1e-4, atol=1e-4)
+    if mode == "logits":
+        ops.final_conv_sampler(rawcl, K, num_classes=C, mode=nv.MODE_LOGITS, logits=logits, **args)
+        assert torch.allclose(logits.cpu(), logits_ref, **tol)
+        return
+    state = torch.zeros(N, D, H, W, cx, device="cuda")
+    ops.to_channels_last(xt.cuda(), state, 0, cx)
+    xin = torch.full((N, D, H, W, cx + 8), 4.0, dtype=dtype, device="cuda")
+    xsum = torch.ones(N, D, H, W, cx, device="cuda")
+    xstart = torch.zeros(N, C, D, H, W, device="cuda")
+    if mode == "ddpm":
+        ref = rd.p_sample(fn, xt, t, nz); coef = d.ddpm_coef(t); m = nv.MODE_DDPM
+    else:
+        ref = rd.ddim_sample(fn, xt, t, nz, eta=0.3); coef = d.ddim_coef(t, 0.3); m = nv.MODE_DDIM
+    ops.final_conv_sampler(rawcl, K, num_classes=C, mode=m, coef=coef.cuda(), x_state=state, noise=nz.cuda(), xin=xin,
+                           xstart_sum=xsum, logits=logits, xstart=xstart, **args)
+    assert torch.allclose(logits.cpu(), logits_ref, **tol)
+    assert torch.allclose(ops.from_channels_last(state, C).cpu(), ref["sample"], **tol)
+    assert torch.allclose(xstart.cpu(), ref["pred_xstart"], **tol)
+    assert torch.allclose(ops.from_channels_last(xsum, C).cpu(), 1 + ref["pred_xstart"], **tol)
+    xin_tol = tol if dtype == torch.float32 else dict(rtol=2e-3, atol=2e-3)
+    assert torch.allclose(ops.from_channels_last(xin, C).cpu(), ref["sample"], **xin_tol)
+    assert float((xin[..., C:].float() - 4).abs().max()) == 0     # image / pad channels untouched
+
+
+def test_in_kernel_philox_noise_is_standard_normal():
+    from diff_unet_amos_amd import _native as nv
+    ops = _ops()
+    N, K, C, D, H, W = 1, 8, 16, 16, 32, 32
+    raw = torch.zeros(N, D, H, W, K, dtype=torch.float16, device="cuda")
+    z = torch.zeros(N * K, device="cuda")
+    state = torch.zeros(N, D, H, W, 16, device="cuda")
+    coef = torch.tensor([[0, 0, 1.0, 0, 0, 0, 0, 0]], device="cuda")     # x_new = eps
+    step = torch.tensor([5], dtype=torch.int32, device="cuda")
+    ops.final_conv_sampler(raw, K, z, z, torch.zeros(C, K, device="cuda"), torch.zeros(C, device="cuda"), C, nv.MODE_DDPM,
+                           coef=coef, x_state=state, step_word=step, seed=1234)
+    a = state.clone()
+    assert abs(float(a.mean())) < 1e-2 and abs(float(a.std()) - 1) < 1e-2
+    assert abs(float((a ** 4).mean()) - 3) < 0.1
+    flat = a.view(-1, 16)
+    assert abs(float((flat[:, 0] * flat[:, 1]).mean())) < 0.03            # Box-Muller pair uncorrelated (4 sigma at n=16384)
+    state.zero_()
+    ops.final_conv_sampler(raw, K, z, z, torch.zeros(C, K, device="cuda"), torch.zeros(C, device="cuda"), C, nv.MODE_DDPM,
+                           coef=coef, x_state=state, step_word=step, seed=1234)
+    assert torch.equal(state, a)                                          # counter-based: reproducible
+    step += 1; state.zero_()
+    ops.final_conv_sampler(raw, K, z, z, torch.zeros(C, K, device="cuda"), torch.zeros(C, device="cuda"), C, nv.MODE_DDPM,
+                           coef=coef, x_state=state, step_word=step, seed=1234)
+    assert abs(float((state * a).mean())) < 1e-2                          # fresh draw per step

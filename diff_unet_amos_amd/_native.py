@@ -26,19 +26,24 @@ class NativeLibraryMissing(RuntimeError):
 class Conv3Desc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("Cin", C.c_int), ("Cin_stride", C.c_int), ("Cin_off", C.c_int),
-                ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int), ("slope", C.c_float),
-                ("in_add_stride", C.c_int)]
+                ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int)]
+
+
+class InNorm(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("add", C.c_void_p),
+                ("add_stride", C.c_int), ("c_pad", C.c_int), ("inv_count", C.c_float), ("eps", C.c_float),
+                ("slope", C.c_float)]
 
 
 class MaterializeDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
                 ("raw_stride", C.c_int), ("emb_stride", C.c_int), ("out_stride", C.c_int), ("out_off", C.c_int),
-                ("pool_stride", C.c_int), ("slope", C.c_float)]
+                ("pool_stride", C.c_int)]
 
 
 class TailDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("voxels", C.c_long), ("K", C.c_int), ("raw_stride", C.c_int),
-                ("C", C.c_int), ("CX", C.c_int), ("mode", C.c_int), ("xin_stride", C.c_int), ("slope", C.c_float),
+                ("C", C.c_int), ("CX", C.c_int), ("mode", C.c_int), ("xin_stride", C.c_int),
                 ("seed", C.c_ulonglong)]
 
 
@@ -46,17 +51,16 @@ MODE_LOGITS, MODE_DDPM, MODE_DDIM = 0, 1, 2
 
 _P = C.c_void_p
 _SIGS = {
-    "dua_deconv_k2s2_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_deconv_k2s2_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P]),
     "dua_q_sample": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P]),
     "dua_sampler_step": (C.c_int, [C.c_int, C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "dua_final_conv_sampler": (C.c_int, [C.POINTER(TailDesc)] + [_P] * 14),
+    "dua_final_conv_sampler": (C.c_int, [C.POINTER(TailDesc), _P, C.POINTER(InNorm)] + [_P] * 11),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "dua_conv3d_k3_rows": (C.c_int, [C.POINTER(Conv3Desc)]),
-    "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P, _P]),
     "dua_pack_conv3_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
-    "dua_instnorm_finalize": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
-    "dua_materialize": (C.c_int, [C.POINTER(MaterializeDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "dua_instnorm_finalize": (C.c_int, [C.c_int, C.c_int, C.POINTER(InNorm), _P, _P, _P]),
+    "dua_materialize": (C.c_int, [C.POINTER(MaterializeDesc), _P, C.POINTER(InNorm), _P, _P, _P, _P]),
     "dua_pack_deconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_to_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dua_from_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, C.c_int, _P, _P]),

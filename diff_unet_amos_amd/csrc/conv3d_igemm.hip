@@ -6,9 +6,9 @@
 //   prologue  : InstanceNorm3d(affine) + LeakyReLU(0.1) (+ timestep-embedding bias) of the
 //               PRODUCER layer, applied while the halo tile is staged (denoiser.py:63-67);
 //               out-of-volume halo voxels stay literal zeros (padding follows the activation)
-//   epilogue  : + bias, per-(n, c) InstanceNorm partial statistics of THIS layer's output
-//               (sum and centred second moment per 64-voxel slab; combined by
-//               instnorm_finalize), coalesced 16-byte stores of the raw output.
+//   epilogue  : + bias, per-(n, c) InstanceNorm statistics of THIS layer's output (per-wave sum and
+//               centred second moment, combined per workgroup, then two fp64 atomics per channel
+//               into one of 8 replica rows), coalesced 16-byte stores of the raw output.
 //
 // GEMM view: M = output voxels, N = Cout, K = 27 taps x Cin.
 // Workgroup (256 threads = 4 waves): a 4x8x8 output tile x 64 output channels; wave w owns
@@ -31,14 +31,14 @@ constexpr int PS = HH * RS;                // 6560: halo plane stride
 constexpr int HALO_BYTES = HD * PS;        // 39360
 constexpr int BN = 64;                     // output channels per workgroup
 constexpr int WSLAB = 9 * KG * BN * 16;    // 36864: packed weights of one (chunk, kd)
-constexpr int LDS_BYTES = HALO_BYTES + WSLAB;  // 76224 -> two workgroups per CU
+constexpr int LDS_BYTES = HALO_BYTES + WSLAB;  // 76224 (+ 12 B per input channel when the prologue is fused)
 constexpr int NITEMS = HD * HH * HW * KG;  // 2400 16-byte items per halo chunk
 constexpr int NIT = (NITEMS + 255) / 256;  // 10
 }  // namespace c3
 
 struct Conv3Args {
   const void* x; const void* w; const float* bias; void* y;
-  float* partials; float* counts;
+  double* stats;
   InXform xf;
   int N, D, H, W;
   int Cin, Cin_stride, Cin_off;     // valid input channels, buffer stride, offset (elements)
@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* wlds = smem + HALO_BYTES;
+  float* xsc = (float*)(smem + LDS_BYTES);     // scale / shift / add of the fused input transform
+  float* xsh = xsc + a.nchunks * CK;
+  float* xad = xsh + a.nchunks * CK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
 
+  if (a.xf.stats != nullptr) xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);   // visible after the loop's first barrier
   const int a_base = wave * PS + (r >> 3) * RS + (r & 7) * VS + hh * 16;
   const int b_base = (hh * BN + r) * 16;
   const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 3 * WSLAB;
@@ -104,15 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
 #pragma unroll
           for (int e = 0; e < EPG; ++e) v[j][e] = (T)0.f;
       }
-      if (a.xf.scale != nullptr && cok) {
+      if (a.xf.stats != nullptr && cok) {
         float sc[EPG], sh[EPG], ad[EPG];
-        const int cb = n * a.Cin + c0;
 #pragma unroll
-        for (int e = 0; e < EPG; ++e) {
-          sc[e] = a.xf.scale[cb + e];
-          sh[e] = a.xf.shift[cb + e];
-          ad[e] = a.xf.add ? a.xf.add[n * a.xf.add_stride + c0 + e] : 0.f;
-        }
+        for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
 #pragma unroll
         for (int j = 0; j < NIT; ++j)
           if (goff[j] >= 0) v[j] = xform_frag<T>(v[j], sc, sh, ad, a.xf.slope);
@@ -194,13 +193,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
       }
     m2 += __shfl_xor(m2, 32);
     if (hh == 0) {
-      const long row = (long)tile * 4 + wave;
-      float2* p = (float2*)a.partials + ((long)n * a.ntiles * 4 + row) * a.cout_pad + ct * BN + co;
-      *p = make_float2(s, m2);
+      float* e = (float*)(smem + 4 * 64 * OS) + (wave * BN + co) * 2;   // per-wave (sum, M2) exchange
+      e[0] = s; e[1] = m2;
     }
   }
-  if (lane == 0 && ct == 0 && n == 0) a.counts[tile * 4 + wave] = cnt;
+  if (lane == 0) ((float*)(smem + 4 * 64 * OS))[4 * BN * 2 + wave] = cnt;
   __syncthreads();
+  if (wave == 0) {
+    // combine the four slabs (Chan) and publish: sum x and sum x^2 of this tile, in fp64
+    const float* e = (const float*)(smem + 4 * 64 * OS);
+    double S = 0, Q = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float k = e[4 * BN * 2 + w];
+      if (k > 0.f) {
+        const double sw = (double)e[(w * BN + lane) * 2], mw = (double)e[(w * BN + lane) * 2 + 1];
+        S += sw; Q += mw + sw * sw / (double)k;
+      }
+    }
+    if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
+  }
   if (dok) {
     constexpr int GPV = BN / EPG;            // 16-byte groups per voxel
     constexpr int VPI = 64 / GPV;            // voxels per wave-iteration
@@ -220,13 +232,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
 
 template <typename T>
 static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
-                        const float* in_scale, const float* in_shift, const float* in_add, void* y,
-                        float* partials, float* counts, hipStream_t s) {
+                        const dua_in_norm* in, void* y, double* stats, hipStream_t s) {
   using namespace c3;
   constexpr int CK = KG * Elem<T>::EPG;
   Conv3Args a;
-  a.x = x; a.w = w; a.bias = bias; a.y = y; a.partials = partials; a.counts = counts;
-  a.xf = InXform{in_scale, in_shift, in_add, d->slope, d->in_add_stride > 0 ? d->in_add_stride : d->Cin};
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
+  a.xf = make_xform(in, d->Cin);
   a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
   a.Cin = d->Cin; a.Cin_stride = d->Cin_stride; a.Cin_off = d->Cin_off;
   a.Cout = d->Cout; a.Cout_stride = d->Cout_stride; a.Cout_off = d->Cout_off;
@@ -236,14 +247,16 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   a.ntiles = td * a.tiles_h * a.tiles_w;
   const int nct = (d->Cout + BN - 1) / BN;
   a.cout_pad = nct * BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  const int lds = LDS_BYTES + (in && in->stats ? 3 * 4 * a.nchunks * CK : 0);
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 3 * 4 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_lds = LDS_BYTES + 3 * 4 * 1024;
   }
+  if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
   dim3 grid(a.ntiles, nct, d->N);
-  hipLaunchKernelGGL(conv3d_k3_kernel<T>, grid, dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(conv3d_k3_kernel<T>, grid, dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }
 
@@ -251,21 +264,16 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
 
 extern "C" {
 
-int dua_conv3d_k3_rows(const dua_conv3_desc* d) {
-  using namespace dua::c3;
-  return ((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW) * 4;
-}
-
 int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
-                      const float* in_scale, const float* in_shift, const float* in_add, void* y,
-                      float* partials, float* counts, void* stream) {
-  if (!d || !x || !w_packed || !bias_padded || !y || !partials || !counts) return DUA_ERR_ARG;
+                      const dua_in_norm* in, void* y, double* out_stats, void* stream) {
+  if (!d || !x || !w_packed || !bias_padded || !y || !out_stats) return DUA_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)
     return DUA_ERR_ARG;
+  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin)) return DUA_ERR_ARG;
   if (d->dtype == DUA_F16)
-    return dua::launch_conv3<dua::f16>(d, x, w_packed, bias_padded, in_scale, in_shift, in_add, y, partials, counts, (hipStream_t)stream);
+    return dua::launch_conv3<dua::f16>(d, x, w_packed, bias_padded, in, y, out_stats, (hipStream_t)stream);
   if (d->dtype == DUA_F32)
-    return dua::launch_conv3<float>(d, x, w_packed, bias_padded, in_scale, in_shift, in_add, y, partials, counts, (hipStream_t)stream);
+    return dua::launch_conv3<float>(d, x, w_packed, bias_padded, in, y, out_stats, (hipStream_t)stream);
   return DUA_ERR_ARG;
 }
 

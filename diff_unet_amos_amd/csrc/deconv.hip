@@ -24,7 +24,7 @@ struct DeconvArgs {
   InXform xf;
   int N, D, H, W;                  // input spatial
   int Cin, Cin_stride, Cin_off, Cout, Cout_stride, Cout_off;
-  int nchunks, nct;
+  int nchunks, nct, lds_base;
 };
 
 template <typename T>
@@ -37,6 +37,9 @@ __global__ __launch_bounds__(256) void deconv_k2s2_kernel(DeconvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* alds = smem;
   char* wlds = smem + A_BYTES;
+  float* xsc = (float*)(smem + a.lds_base);
+  float* xsh = xsc + a.nchunks * CK;
+  float* xad = xsh + a.nchunks * CK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const long vox = (long)a.D * a.H * a.W;
@@ -54,19 +57,16 @@ __global__ __launch_bounds__(256) void deconv_k2s2_kernel(DeconvArgs a) {
       for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
 
   const int kg_t = tid & 3;
+  if (a.xf.stats != nullptr) xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
   for (int ch = 0; ch < a.nchunks; ++ch) {
     __syncthreads();
     const int c0 = ch * CK + kg_t * EPG;
     const bool cok = c0 < a.Cin;
     float sc[EPG], sh[EPG], ad[EPG];
-    const bool xf = a.xf.scale != nullptr && cok;
+    const bool xf = a.xf.stats != nullptr && cok;
     if (xf) {
 #pragma unroll
-      for (int e = 0; e < EPG; ++e) {
-        sc[e] = a.xf.scale[n * a.Cin + c0 + e];
-        sh[e] = a.xf.shift[n * a.Cin + c0 + e];
-        ad[e] = a.xf.add ? a.xf.add[n * a.xf.add_stride + c0 + e] : 0.f;
-      }
+      for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -128,11 +128,11 @@ __global__ __launch_bounds__(256) void deconv_k2s2_kernel(DeconvArgs a) {
 
 template <typename T>
 static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
-                         const float* in_scale, const float* in_shift, const float* in_add, void* y, hipStream_t s) {
+                         const dua_in_norm* in, void* y, hipStream_t s) {
   constexpr int CK = dc::KG * Elem<T>::EPG;
   DeconvArgs a;
   a.x = x; a.w = w; a.bias = bias; a.y = y;
-  a.xf = InXform{in_scale, in_shift, in_add, d->slope, d->in_add_stride > 0 ? d->in_add_stride : d->Cin};
+  a.xf = make_xform(in, d->Cin);
   a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
   a.Cin = d->Cin; a.Cin_stride = d->Cin_stride; a.Cin_off = d->Cin_off;
   a.Cout = d->Cout; a.Cout_stride = d->Cout_stride; a.Cout_off = d->Cout_off;
@@ -142,25 +142,27 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   dim3 grid((unsigned)((vox + dc::TM - 1) / dc::TM), 8 * a.nct, d->N);
   constexpr int OS = dc::BN * (int)sizeof(T) + 16;
   constexpr int LDS = (dc::TM * OS > dc::A_BYTES + dc::W_BYTES) ? dc::TM * OS : dc::A_BYTES + dc::W_BYTES;
+  a.lds_base = LDS;
+  if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 3 * 4 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(deconv_k2s2_kernel<T>, grid, dim3(256), LDS, s, a);
+  hipLaunchKernelGGL(deconv_k2s2_kernel<T>, grid, dim3(256), LDS + (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0), s, a);
   return (int)hipGetLastError();
 }
 
 }  // namespace dua
 
 extern "C" int dua_deconv_k2s2_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed,
-                                   const float* bias_padded, const float* in_scale, const float* in_shift,
-                                   const float* in_add, void* y, void* stream) {
+                                   const float* bias_padded, const dua_in_norm* in, void* y, void* stream) {
   if (!d || !x || !w_packed || !bias_padded || !y) return DUA_ERR_ARG;
+  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin)) return DUA_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)
     return DUA_ERR_ARG;
-  if (d->dtype == DUA_F16) return dua::launch_deconv<dua::f16>(d, x, w_packed, bias_padded, in_scale, in_shift, in_add, y, (hipStream_t)stream);
-  if (d->dtype == DUA_F32) return dua::launch_deconv<float>(d, x, w_packed, bias_padded, in_scale, in_shift, in_add, y, (hipStream_t)stream);
+  if (d->dtype == DUA_F16) return dua::launch_deconv<dua::f16>(d, x, w_packed, bias_padded, in, y, (hipStream_t)stream);
+  if (d->dtype == DUA_F32) return dua::launch_deconv<float>(d, x, w_packed, bias_padded, in, y, (hipStream_t)stream);
   return DUA_ERR_ARG;
 }

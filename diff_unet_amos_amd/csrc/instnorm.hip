@@ -1,9 +1,9 @@
 // InstanceNorm3d(affine) statistics finalisation and the "materialise" pass.
 //
-// The convolution kernels leave, per batch item and 64-voxel slab, (sum, centred M2) of their
-// raw output.  instnorm_finalize combines the slabs in fp64 (Chan's parallel variance) into
-// the biased variance nn.InstanceNorm3d uses and emits scale = gamma*rstd, shift = beta -
-// mean*scale, which consumers apply while staging their input (common.hpp InXform).
+// The convolution kernels leave per-(n, c) fp64 sums (x, x^2) of their raw output (8 replica rows).
+// Every consumer turns them into the biased variance nn.InstanceNorm3d uses and applies scale =
+// gamma*rstd, shift = beta - mean*scale while staging its input (common.hpp InXform/xform_preamble);
+// instnorm_finalize writes the same scale/shift out for inspection.
 //
 // materialize writes an activation that has several consumers: x_i = LeakyReLU(IN(raw)) +
 // embeddings[i] (models/basic_unet/denoiser.py:300-304) into the channel slice of a concat
@@ -13,60 +13,36 @@
 
 namespace dua {
 
-// grid (ceil(C/8), N), block 256 = 32 row-lanes x 8 channels
-__global__ __launch_bounds__(256) void instnorm_finalize_kernel(int C, int rows, int c_pad, const float2* partials,
-                                                                const float* counts, const float* gamma,
-                                                                const float* beta, float eps, float* scale,
-                                                                float* shift) {
-  __shared__ double sS[32][8], sQ[32][8], sN[32][8];
-  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl, n = blockIdx.y;
-  double S = 0, Q = 0, Nn = 0;
-  if (c < C) {
-    const float2* p = partials + (long)n * rows * c_pad + c;
-    for (int rr = rl; rr < rows; rr += 32) {
-      const float k = counts[rr];
-      if (k > 0.f) {
-        const float2 v = p[(long)rr * c_pad];
-        S += (double)v.x;
-        Q += (double)v.y + (double)v.x * (double)v.x / (double)k;
-        Nn += (double)k;
-      }
-    }
-  }
-  sS[rl][cl] = S; sQ[rl][cl] = Q; sN[rl][cl] = Nn;
+__global__ void instnorm_finalize_kernel(InXform xf, int C, float* scale, float* shift) {
+  extern __shared__ float sm[];
+  const int n = blockIdx.x;
+  xform_preamble(xf, n, C, sm, sm + C, sm + 2 * C);
   __syncthreads();
-  if (rl == 0 && c < C) {
-    for (int j = 1; j < 32; ++j) { S += sS[j][cl]; Q += sQ[j][cl]; Nn += sN[j][cl]; }
-    const double mean = S / Nn;
-    double var = (Q - S * mean) / Nn;
-    if (var < 0) var = 0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma[c] * rstd;
-    scale[n * C + c] = g;
-    shift[n * C + c] = beta[c] - (float)mean * g;
-  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { scale[n * C + c] = sm[c]; shift[n * C + c] = sm[C + c]; }
 }
 
 // One thread = one 16-byte channel group of one OUTPUT voxel (pooled: of one 2x2x2 block).
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ raw, int C, int raw_stride,
-                                                          const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, float slope,
+                                                          InXform xf,
                                                           const T* __restrict__ emb, int emb_stride, T* __restrict__ out,
                                                           int out_stride, int out_off, T* __restrict__ pooled,
                                                           int pool_stride, int D, int H, int W, long total) {
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
+  extern __shared__ float sm[];
   const int gpc = C / EPG;
   const int n = blockIdx.y;
+  const float slope = xf.slope;
+  xform_preamble(xf, n, C, sm, sm + C, sm + 2 * C);
+  __syncthreads();
   const long vox_n = (long)D * H * W;
   for (long it = blockIdx.x * 256L + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
     const int cg = (int)(it % gpc);
     long v = it / gpc;
     float sc[EPG], sh[EPG];
 #pragma unroll
-    for (int e = 0; e < EPG; ++e) { sc[e] = scale[n * C + cg * EPG + e]; sh[e] = shift[n * C + cg * EPG + e]; }
+    for (int e = 0; e < EPG; ++e) { sc[e] = sm[cg * EPG + e]; sh[e] = sm[C + cg * EPG + e]; }
     if constexpr (!POOL) {
       const long gv = n * vox_n + v;
       Frag x = *(const Frag*)(raw + gv * raw_stride + cg * EPG);
@@ -116,7 +92,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
 }
 
 template <typename T>
-static int launch_materialize(const dua_materialize_desc* d, const void* raw, const float* scale, const float* shift,
+static int launch_materialize(const dua_materialize_desc* d, const void* raw, const dua_in_norm* in,
                               const void* emb, void* out, void* pooled, hipStream_t s) {
   constexpr int EPG = Elem<T>::EPG;
   const long vox = (long)d->D * d->H * d->W;
@@ -125,13 +101,15 @@ static int launch_materialize(const dua_materialize_desc* d, const void* raw, co
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   dim3 grid((unsigned)blocks, d->N);
+  const InXform xf = make_xform(in, d->C);
+  const size_t lds = 3 * sizeof(float) * d->C;
   if (pool)
-    hipLaunchKernelGGL((materialize_kernel<T, true>), grid, dim3(256), 0, s, (const T*)raw, d->C, d->raw_stride, scale,
-                       shift, d->slope, (const T*)emb, d->emb_stride, (T*)out, d->out_stride, d->out_off, (T*)pooled,
+    hipLaunchKernelGGL((materialize_kernel<T, true>), grid, dim3(256), lds, s, (const T*)raw, d->C, d->raw_stride, xf,
+                       (const T*)emb, d->emb_stride, (T*)out, d->out_stride, d->out_off, (T*)pooled,
                        d->pool_stride, d->D, d->H, d->W, total);
   else
-    hipLaunchKernelGGL((materialize_kernel<T, false>), grid, dim3(256), 0, s, (const T*)raw, d->C, d->raw_stride, scale,
-                       shift, d->slope, (const T*)emb, d->emb_stride, (T*)out, d->out_stride, d->out_off, (T*)nullptr,
+    hipLaunchKernelGGL((materialize_kernel<T, false>), grid, dim3(256), lds, s, (const T*)raw, d->C, d->raw_stride, xf,
+                       (const T*)emb, d->emb_stride, (T*)out, d->out_stride, d->out_off, (T*)nullptr,
                        0, d->D, d->H, d->W, total);
   return (int)hipGetLastError();
 }
@@ -140,23 +118,21 @@ static int launch_materialize(const dua_materialize_desc* d, const void* raw, co
 
 extern "C" {
 
-int dua_instnorm_finalize(int N, int C, int rows, int c_pad, const float* partials, const float* counts,
-                          const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream) {
-  if (N <= 0 || C <= 0 || rows <= 0 || c_pad < C || !partials || !counts || !gamma || !beta || !scale || !shift)
+int dua_instnorm_finalize(int N, int C, const dua_in_norm* in, float* scale, float* shift, void* stream) {
+  if (N <= 0 || C <= 0 || !in || !in->stats || !in->gamma || !in->beta || in->c_pad < C || !scale || !shift)
     return DUA_ERR_ARG;
-  dim3 grid((C + 7) / 8, N);
-  hipLaunchKernelGGL(dua::instnorm_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, C, rows, c_pad,
-                     (const float2*)partials, counts, gamma, beta, eps, scale, shift);
+  hipLaunchKernelGGL(dua::instnorm_finalize_kernel, dim3(N), dim3(256), 3 * sizeof(float) * C, (hipStream_t)stream,
+                     dua::make_xform(in, C), C, scale, shift);
   return (int)hipGetLastError();
 }
 
-int dua_materialize(const dua_materialize_desc* d, const void* raw, const float* scale, const float* shift,
+int dua_materialize(const dua_materialize_desc* d, const void* raw, const dua_in_norm* in,
                     const void* emb, void* out, void* pooled, void* stream) {
-  if (!d || !raw || !scale || !shift || !out) return DUA_ERR_ARG;
+  if (!d || !raw || !in || !in->stats || !in->gamma || !in->beta || in->c_pad < d->C || !out) return DUA_ERR_ARG;
   if (d->C % 8 || d->raw_stride % 8 || d->out_stride % 8 || d->out_off % 8 || (emb && d->emb_stride % 8)) return DUA_ERR_ARG;
   if (pooled && ((d->D | d->H | d->W) & 1 || d->pool_stride % 8)) return DUA_ERR_ARG;
-  if (d->dtype == DUA_F16) return dua::launch_materialize<dua::f16>(d, raw, scale, shift, emb, out, pooled, (hipStream_t)stream);
-  if (d->dtype == DUA_F32) return dua::launch_materialize<float>(d, raw, scale, shift, emb, out, pooled, (hipStream_t)stream);
+  if (d->dtype == DUA_F16) return dua::launch_materialize<dua::f16>(d, raw, in, emb, out, pooled, (hipStream_t)stream);
+  if (d->dtype == DUA_F32) return dua::launch_materialize<float>(d, raw, in, emb, out, pooled, (hipStream_t)stream);
   return DUA_ERR_ARG;
 }
 

@@ -77,10 +77,10 @@ __global__ void sampler_step_kernel(int mode, long per, long total, const float*
 
 // ---- fused tail: one thread = one voxel ----
 struct TailArgs {
-  const void* raw; const float* scale; const float* shift; const float* wf; const float* bf;
+  const void* raw; InXform xf; const float* wf; const float* bf;
   const float* coef; float* x_state; const float* noise; const int* step_word; void* xin;
   float* xsum; float* logits; float* xstart;
-  long vox; int K, raw_stride, C, xin_stride, mode; float slope; unsigned seed_lo, seed_hi;
+  long vox; int K, raw_stride, C, xin_stride, mode; unsigned seed_lo, seed_hi;
 };
 
 template <typename T, int CX>
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void final_conv_sampler_kernel(TailArgs a) {
     const int e = i & 3, c = (i >> 2) % CX, kq = i / (4 * CX);
     wl[i] = c < a.C ? a.wf[c * K + kq * 4 + e] : 0.f;
   }
-  for (int i = threadIdx.x; i < K; i += 256) { sc[i] = a.scale[n * K + i]; sh[i] = a.shift[n * K + i]; }
+  xform_preamble(a.xf, n, K, sc, sh, sh + K);
   __syncthreads();
   const long v = blockIdx.x * 256L + threadIdx.x;
   if (v >= a.vox) return;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void final_conv_sampler_kernel(TailArgs a) {
 #pragma unroll
     for (int e = 0; e < EPG; ++e) {
       float t = fmaf((float)f[e], sc[kg * EPG + e], sh[kg * EPG + e]);
-      t = t > 0.f ? t : t * a.slope;
+      t = t > 0.f ? t : t * a.xf.slope;
       y[e] = t;
     }
 #pragma unroll
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void final_conv_sampler_kernel(TailArgs a) {
 
 template <typename T, int CX>
 static int launch_tail(const dua_tail_desc* d, TailArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)(CX * d->K + 2 * d->K) * sizeof(float);
+  const size_t lds = (size_t)(CX * d->K + 3 * d->K) * sizeof(float);
   dim3 grid((unsigned)((d->voxels + 255) / 256), d->N);
   hipLaunchKernelGGL((final_conv_sampler_kernel<T, CX>), grid, dim3(256), lds, s, a);
   return (int)hipGetLastError();
@@ -240,21 +240,21 @@ int dua_sampler_step(int mode, int N, long per_sample, const float* model_out, c
   return (int)hipGetLastError();
 }
 
-int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const float* scale, const float* shift,
+int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in_norm* in,
                            const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
                            const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
                            void* stream) {
-  if (!d || !raw || !scale || !shift || !wf || !bf) return DUA_ERR_ARG;
+  if (!d || !raw || !in || !in->stats || !in->gamma || !in->beta || !wf || !bf || in->c_pad < d->K) return DUA_ERR_ARG;
   if (d->K % 8 || d->raw_stride % 8 || d->K > d->raw_stride || d->C <= 0 || d->C > d->CX || d->K > 512) return DUA_ERR_ARG;
   if (d->mode == DUA_MODE_LOGITS) { if (!logits) return DUA_ERR_ARG; }
   else if (d->mode == DUA_MODE_DDPM || d->mode == DUA_MODE_DDIM) { if (!coef || !x_state) return DUA_ERR_ARG; }
   else return DUA_ERR_ARG;
   if (xin && d->xin_stride % 8) return DUA_ERR_ARG;
   dua::TailArgs a;
-  a.raw = raw; a.scale = scale; a.shift = shift; a.wf = wf; a.bf = bf; a.coef = coef; a.x_state = x_state;
+  a.raw = raw; a.xf = dua::make_xform(in, d->K); a.wf = wf; a.bf = bf; a.coef = coef; a.x_state = x_state;
   a.noise = noise; a.step_word = step_word; a.xin = xin; a.xsum = xstart_sum; a.logits = logits; a.xstart = xstart;
   a.vox = d->voxels; a.K = d->K; a.raw_stride = d->raw_stride; a.C = d->C; a.xin_stride = d->xin_stride;
-  a.mode = d->mode; a.slope = d->slope;
+  a.mode = d->mode;
   a.seed_lo = (unsigned)(d->seed & 0xffffffffull); a.seed_hi = (unsigned)(d->seed >> 32);
   if (d->dtype == DUA_F16) return dua::dispatch_tail<dua::f16>(d, a, (hipStream_t)stream);
   if (d->dtype == DUA_F32) return dua::dispatch_tail<float>(d, a, (hipStream_t)stream);

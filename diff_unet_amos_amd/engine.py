@@ -82,11 +82,8 @@ class Plan:
         self.uA = [z(l, dec_out[l]) for l in range(4)]
         self.uB = [z(l, dec_out[l]) for l in range(4)]
         self.dec_out = dec_out
-        # statistics scratch
-        self.rows = [ops.conv3_rows(*S[l]) for l in range(5)]
-        cmax = max(-(-c // 64) * 64 for c in f)
-        self.partials = torch.zeros(N * max(r * cmax for r in self.rows) * 2 + 16, dtype=torch.float32, device=device)
-        self.counts = [torch.zeros(self.rows[l], dtype=torch.float32, device=device) for l in range(5)]
+        # InstanceNorm sums of every conv layer live in ONE fp64 arena, zeroed by a single memset per pass
+        self._stat_slices = []
         # sampler state
         self.x_state = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
         self.x_sum = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
@@ -95,6 +92,7 @@ class Plan:
         self.step_word = torch.zeros(1, dtype=torch.int32, device=device)
         self.logits = torch.zeros((N, self.C, *S[0]), dtype=torch.float32, device=device)
         self._bind()
+        self._alloc_stats()
         self.weights_version = None
         self.graphs = {}
         self.tables = {}
@@ -107,10 +105,20 @@ class Plan:
         c.gamma, c.beta = block.adn.N.weight, block.adn.N.bias
         c.cout, c.cin = c.w.shape[0], c.w.shape[1]
         c.cin_packed, c.perm = cin_packed, perm
-        c.scale = torch.zeros(self.N * c.cout, dtype=torch.float32, device=self.dev)
-        c.shift = torch.zeros(self.N * c.cout, dtype=torch.float32, device=self.dev)
         c.wp = c.bp = None
+        c.stats = c.norm = c.norm_add = None
         return c
+
+    def _alloc_stats(self):
+        convs = [c for pair in self.enc + self.den + self.dec for c in pair]
+        sizes = [self.N * ops.STAT_REPLICAS * (-(-c.cout // 64) * 64) * 2 for c in convs]
+        self.stat_arena = torch.zeros(sum(sizes), dtype=torch.float64, device=self.dev)
+        o = 0
+        for c, n in zip(convs, sizes):
+            c.stats = self.stat_arena[o:o + n].view(self.N, ops.STAT_REPLICAS, -1, 2)
+            o += n
+        n_enc = sum(sizes[:10])
+        self.enc_stats, self.den_stats = self.stat_arena[:n_enc], self.stat_arena[n_enc:]
 
     def _bind(self):
         net = self.net
@@ -158,6 +166,7 @@ class Plan:
                                                         cin_packed=c.cin_packed, perm=c.perm)
                     c.gamma_c = c.gamma.detach().float().contiguous()
                     c.beta_c = c.beta.detach().float().contiguous()
+                    c.norm = c.norm_add = None       # rebuilt lazily against the new gamma/beta
             for l in range(4):
                 d = self.deconv[l]
                 self.deconv_packed[l] = ops.pack_deconv_weights(d.weight.detach().float().contiguous(), d.bias.detach(), dt)
@@ -180,20 +189,21 @@ class Plan:
         self.graphs.clear()
 
     # ---- building blocks ------------------------------------------------------------------------
-    def _conv(self, c, x, cin, y, level, xform_from=None, add_key=None):
-        kw = {}
-        if xform_from is not None:
-            kw = dict(in_scale=xform_from.scale, in_shift=xform_from.shift)
-            if add_key is not None:
-                kw.update(in_add=self._add_view(add_key), in_add_stride=self.P)
-        rows, cpad = ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, self.partials, self.counts[level], slope=SLOPE, **kw)
-        ops.instnorm_finalize(self.N, c.cout, rows, cpad, self.partials, self.counts[level], c.gamma_c, c.beta_c,
-                              c.scale, c.shift, EPS)
+    def _norm(self, c, level, add_key=None):
+        """dua_in_norm of conv block ``c`` (the producer), optionally with a timestep-embedding bias slice."""
+        count = self.S[level][0] * self.S[level][1] * self.S[level][2]
+        if add_key is None:
+            if c.norm is None:
+                c.norm = ops.Norm(c.stats, c.gamma_c, c.beta_c, count, slope=SLOPE, eps=EPS)
+            return c.norm
+        if c.norm_add is None:
+            c.norm_add = ops.Norm(c.stats, c.gamma_c, c.beta_c, count, add=self.cur_add.view(-1)[self.temb_off[add_key]:],
+                                  add_stride=self.P, slope=SLOPE, eps=EPS)
+        return c.norm_add
 
-    def _add_view(self, key):
-        # pointer to cur_add[0, off]; rows are P apart (in_add_stride)
-        off = self.temb_off[key]
-        return self.cur_add.view(-1)[off:]
+    def _conv(self, c, x, cin, y, level, xform_from=None, add_key=None):
+        norm = None if xform_from is None else self._norm(xform_from, level, add_key)
+        ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, c.stats, norm=norm)
 
     def run_encoder(self, image):
         """BasicUNetEncoder.forward: fills self.emb[0..4] (channels-last)."""
@@ -203,13 +213,14 @@ class Plan:
         img = image.detach().float().contiguous()
         ops.to_channels_last(img, self.img_in, 0, 8)
         ops.to_channels_last(img, self.xin, self.C, self.cin0 - self.C)     # conditioning channel of the denoiser input
+        self.enc_stats.zero_()
         x, cin = self.img_in, 8
         for l in range(5):
             a, b = self.enc[l]
             self._conv(a, x, cin, self.rawA[l], l)
             self._conv(b, self.rawA[l], a.cout, self.rawB[l], l, xform_from=a)
-            ops.materialize(self.rawB[l], b.cout, b.scale, b.shift, self.emb[l], 0,
-                            pooled=self.pool[l] if l < 4 else None, slope=SLOPE)
+            ops.materialize(self.rawB[l], b.cout, self._norm(b, l), self.emb[l], 0,
+                            pooled=self.pool[l] if l < 4 else None)
             if l < 4:
                 x, cin = self.pool[l], b.cout
         self.emb_token += 1
@@ -238,22 +249,23 @@ class Plan:
         """BasicUNetRDenoiser.forward from the staged input (self.xin) up to the raw output of the
         last decoder block; self.cur_add must hold the embedding rows of this evaluation."""
         f = self.f
+        self.den_stats.zero_()
         x, cin = self.xin, self.cin0
         for l in range(5):
             a, b = self.den[l]
             self._conv(a, x, cin, self.rawA[l], l)
             self._conv(b, self.rawA[l], a.cout, self.rawB[l], l, xform_from=a, add_key=f"d{l}")
             if l < 4:
-                ops.materialize(self.rawB[l], b.cout, b.scale, b.shift, self.cat[l], 0, emb=self.emb[l],
-                                pooled=self.pool[l], slope=SLOPE)
+                ops.materialize(self.rawB[l], b.cout, self._norm(b, l), self.cat[l], 0, emb=self.emb[l],
+                                pooled=self.pool[l])
                 x, cin = self.pool[l], b.cout
             else:
-                ops.materialize(self.rawB[4], b.cout, b.scale, b.shift, self.x4, 0, emb=self.emb[4], slope=SLOPE)
+                ops.materialize(self.rawB[4], b.cout, self._norm(b, 4), self.x4, 0, emb=self.emb[4])
         src, src_c, src_conv = self.x4, f[4], None
         for l in (3, 2, 1, 0):
             wp, bp = self.deconv_packed[l]
-            kw = dict(in_scale=src_conv.scale, in_shift=src_conv.shift) if src_conv is not None else {}
-            ops.deconv_k2s2(src, src_c, 0, wp, bp, self.up[l], self.cat[l], f[l], slope=SLOPE, **kw)
+            norm = self._norm(src_conv, l + 1) if src_conv is not None else None
+            ops.deconv_k2s2(src, src_c, 0, wp, bp, self.up[l], self.cat[l], f[l], norm=norm)
             a, b = self.dec[l]
             self._conv(a, self.cat[l], f[l] + self.up[l], self.uA[l], l)
             self._conv(b, self.uA[l], a.cout, self.uB[l], l, xform_from=a, add_key=f"u{l}")
@@ -262,11 +274,10 @@ class Plan:
 
     def tail(self, mode, noise=None, logits=None, xstart=None, use_sum=False, seed=0):
         last = self.dec[0][1]
-        ops.final_conv_sampler(self.uB[0], last.cout, last.scale, last.shift, self.wf, self.bf, self.C, mode,
+        ops.final_conv_sampler(self.uB[0], last.cout, self._norm(last, 0), self.wf, self.bf, self.C, mode,
                                coef=self.cur_coef, x_state=self.x_state, noise=noise, step_word=self.step_word,
                                xin=self.xin if mode != nv.MODE_LOGITS else None,
-                               xstart_sum=self.x_sum if use_sum else None, logits=logits, xstart=xstart, slope=SLOPE,
-                               seed=seed)
+                               xstart_sum=self.x_sum if use_sum else None, logits=logits, xstart=xstart, seed=seed)
 
     # ---- public operations ------------------------------------------------------------------------
     def denoise(self, x, t):

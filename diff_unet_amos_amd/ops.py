@@ -93,14 +93,43 @@ def pack_deconv_weights(w, bias, dtype):
     return buf, b
 
 
-def conv3_rows(D, H, W):
-    return (-(-D // 4)) * (-(-H // 8)) * (-(-W // 8)) * 4
+STAT_REPLICAS = 8
 
 
-def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, partials, counts,
-              in_scale=None, in_shift=None, in_add=None, slope=0.1, in_add_stride=0):
-    """Raw 3x3x3 convolution (+bias) with optional fused producer norm/activation on the input
-    and InstanceNorm partial statistics on the output."""
+def stats_buffer(N, cout, device):
+    """Zeroed fp64 [N][8][ceil(cout/64)*64][2] accumulator a convolution adds (sum x, sum x^2) into."""
+    return torch.zeros((N, STAT_REPLICAS, -(-cout // 64) * 64, 2), dtype=torch.float64, device=device)
+
+
+class Norm:
+    """Producer-side normalisation descriptor (dua_in_norm) a consumer fuses into its input staging."""
+
+    def __init__(self, stats, gamma, beta, count, add=None, add_stride=0, slope=0.1, eps=1e-5):
+        assert stats.is_cuda and stats.dtype == torch.float64 and stats.is_contiguous() and stats.dim() == 4
+        assert stats.shape[1] == STAT_REPLICAS and stats.shape[3] == 2
+        for v in (gamma, beta):
+            assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()
+        assert gamma.numel() == beta.numel() <= stats.shape[2]
+        if add is not None:
+            assert add.is_cuda and add.dtype == torch.float32
+            assert add.numel() >= (stats.shape[0] - 1) * (add_stride or gamma.numel()) + gamma.numel()
+        self.keep = (stats, gamma, beta, add)
+        self.N, self.C = stats.shape[0], gamma.numel()
+        self.c = nv.InNorm(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), add.data_ptr() if add is not None else None,
+                           add_stride, stats.shape[2], 1.0 / count, eps, slope)
+
+    def ref(self, N, Cc):
+        assert self.N == N and self.C >= Cc, "normalisation descriptor does not match the consumer's input"
+        return C.byref(self.c)
+
+
+def _norm_ref(norm, N, Cc):
+    return None if norm is None else norm.ref(N, Cc)
+
+
+def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None):
+    """Raw 3x3x3 convolution (+bias); ``norm`` = producer descriptor of x (fused IN+LeakyReLU+add);
+    accumulates this layer's InstanceNorm sums into ``out_stats`` (must be zero on entry)."""
     _cl_check(x, "x"); _cl_check(y, "y")
     assert x.dtype == y.dtype and x.device == y.device
     N, D, H, W, cs_in = x.shape
@@ -109,43 +138,30 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, partials, 
     assert cout % 8 == 0 and cout_off % 8 == 0 and cout_off + cout <= y.shape[-1]
     ck = chunk_elems(x.dtype)
     nch, nct = -(-cin // ck), -(-cout // 64)
-    esz = x.element_size()
+    assert nch * ck <= 1024
     assert w_packed.numel() == nct * nch * 27 * 4 * 64 * 16, "packed weights do not match (Cin, Cout, dtype)"
     assert bias_pad.numel() == nct * 64 and bias_pad.dtype == torch.float32
-    rows = conv3_rows(D, H, W)
-    assert partials.dtype == torch.float32 and partials.numel() >= N * rows * nct * 64 * 2
-    assert counts.dtype == torch.float32 and counts.numel() >= rows
-    if in_scale is not None:
-        for v in (in_scale, in_shift):
-            assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() >= N * cin
-        if in_add is not None:
-            assert in_add.dtype == torch.float32 and in_add.numel() >= (N - 1) * (in_add_stride or cin) + cin
-    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off, slope,
-                     in_add_stride)
-    del esz
-    nv.check(nv.lib().dua_conv3d_k3_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), nv.ptr(in_scale),
-                                        nv.ptr(in_shift), nv.ptr(in_add), nv.ptr(y), nv.ptr(partials), nv.ptr(counts),
-                                        nv.stream_ptr()), "dua_conv3d_k3_fwd")
-    return rows, nct * 64
+    assert out_stats.dtype == torch.float64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, nct * 64, 2)
+    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
+    nv.check(nv.lib().dua_conv3d_k3_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),
+                                        nv.ptr(y), nv.ptr(out_stats), nv.stream_ptr()), "dua_conv3d_k3_fwd")
 
 
-def instnorm_finalize(N, Cc, rows, c_pad, partials, counts, gamma, beta, scale, shift, eps=1e-5):
-    for v in (gamma, beta):
-        assert v.is_cuda and v.dtype == torch.float32 and v.numel() == Cc and v.is_contiguous()
-    for v in (scale, shift):
-        assert v.is_cuda and v.dtype == torch.float32 and v.numel() >= N * Cc
-    assert partials.numel() >= N * rows * c_pad * 2 and counts.numel() >= rows
-    nv.check(nv.lib().dua_instnorm_finalize(N, Cc, rows, c_pad, nv.ptr(partials), nv.ptr(counts), nv.ptr(gamma),
-                                            nv.ptr(beta), eps, nv.ptr(scale), nv.ptr(shift), nv.stream_ptr()),
+def instnorm_finalize(norm, N, Cc):
+    """scale, shift = fp32 [N, C] exactly as consumers compute them in their preamble."""
+    dev = norm.keep[0].device
+    scale = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+    shift = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+    nv.check(nv.lib().dua_instnorm_finalize(N, Cc, norm.ref(N, Cc), nv.ptr(scale), nv.ptr(shift), nv.stream_ptr()),
              "dua_instnorm_finalize")
+    return scale, shift
 
 
-def materialize(raw, Cc, scale, shift, out, out_off, emb=None, pooled=None, slope=0.1):
+def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None):
     _cl_check(raw, "raw"); _cl_check(out, "out")
     N, D, H, W, rs = raw.shape
     assert tuple(out.shape[:4]) == (N, D, H, W) and out.dtype == raw.dtype
     assert Cc % 8 == 0 and Cc <= rs and out_off % 8 == 0 and out_off + Cc <= out.shape[-1]
-    assert scale.numel() >= N * Cc and shift.numel() >= N * Cc
     es = 0
     if emb is not None:
         _cl_check(emb, "emb")
@@ -157,13 +173,12 @@ def materialize(raw, Cc, scale, shift, out, out_off, emb=None, pooled=None, slop
         assert D % 2 == 0 and H % 2 == 0 and W % 2 == 0
         assert tuple(pooled.shape[:4]) == (N, D // 2, H // 2, W // 2) and pooled.dtype == raw.dtype and pooled.shape[-1] >= Cc
         ps = pooled.shape[-1]
-    d = nv.MaterializeDesc(nv.dt_code(raw.dtype), N, D, H, W, Cc, rs, es, out.shape[-1], out_off, ps, slope)
-    nv.check(nv.lib().dua_materialize(C.byref(d), nv.ptr(raw), nv.ptr(scale), nv.ptr(shift), nv.ptr(emb), nv.ptr(out),
+    d = nv.MaterializeDesc(nv.dt_code(raw.dtype), N, D, H, W, Cc, rs, es, out.shape[-1], out_off, ps)
+    nv.check(nv.lib().dua_materialize(C.byref(d), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(emb), nv.ptr(out),
                                       nv.ptr(pooled), nv.stream_ptr()), "dua_materialize")
 
 
-def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, in_scale=None, in_shift=None, in_add=None,
-                slope=0.1):
+def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=None):
     """ConvTranspose3d(k2,s2) of a channel slice of ``x`` into a channel slice of ``y`` (2x spatial)."""
     _cl_check(x, "x"); _cl_check(y, "y")
     N, D, H, W, cs_in = x.shape
@@ -172,13 +187,11 @@ def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, in_scale
     assert cout % 8 == 0 and cout_off % 8 == 0 and cout_off + cout <= y.shape[-1]
     ck = chunk_elems(x.dtype)
     nch, nct = -(-cin // ck), -(-cout // 64)
+    assert nch * ck <= 1024
     assert w_packed.numel() == 8 * nct * nch * 4 * 64 * 16 and bias_pad.numel() == nct * 64
-    if in_scale is not None:
-        assert in_scale.numel() == N * cin and in_shift.numel() == N * cin
-    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off, slope, 0)
-    nv.check(nv.lib().dua_deconv_k2s2_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), nv.ptr(in_scale),
-                                          nv.ptr(in_shift), nv.ptr(in_add), nv.ptr(y), nv.stream_ptr()),
-             "dua_deconv_k2s2_fwd")
+    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
+    nv.check(nv.lib().dua_deconv_k2s2_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),
+                                          nv.ptr(y), nv.stream_ptr()), "dua_deconv_k2s2_fwd")
 
 
 def _f32c(t, name):
@@ -216,13 +229,13 @@ def state_stride(num_classes):
     return cx
 
 
-def final_conv_sampler(raw, K, scale, shift, wf, bf, num_classes, mode, coef=None, x_state=None, noise=None,
-                       step_word=None, xin=None, xstart_sum=None, logits=None, xstart=None, slope=0.1, seed=0):
+def final_conv_sampler(raw, K, norm, wf, bf, num_classes, mode, coef=None, x_state=None, noise=None,
+                       step_word=None, xin=None, xstart_sum=None, logits=None, xstart=None, seed=0):
     _cl_check(raw, "raw")
     N, D, H, W, rs = raw.shape
     vox = D * H * W
     cx = state_stride(num_classes)
-    assert K % 8 == 0 and K <= rs and scale.numel() >= N * K and shift.numel() >= N * K
+    assert K % 8 == 0 and K <= rs and K <= 512
     _f32c(wf, "wf"); _f32c(bf, "bf")
     assert wf.numel() == num_classes * K and bf.numel() == num_classes
     if mode != nv.MODE_LOGITS:
@@ -240,8 +253,8 @@ def final_conv_sampler(raw, K, scale, shift, wf, bf, num_classes, mode, coef=Non
         _cl_check(xin, "xin")
         assert xin.dtype == raw.dtype and tuple(xin.shape[:4]) == (N, D, H, W) and xin.shape[-1] >= num_classes
         xs = xin.shape[-1]
-    d = nv.TailDesc(nv.dt_code(raw.dtype), N, vox, K, rs, num_classes, cx, mode, xs, slope, seed)
-    nv.check(nv.lib().dua_final_conv_sampler(C.byref(d), nv.ptr(raw), nv.ptr(scale), nv.ptr(shift), nv.ptr(wf),
+    d = nv.TailDesc(nv.dt_code(raw.dtype), N, vox, K, rs, num_classes, cx, mode, xs, seed)
+    nv.check(nv.lib().dua_final_conv_sampler(C.byref(d), nv.ptr(raw), norm.ref(N, K), nv.ptr(wf),
                                              nv.ptr(bf), nv.ptr(coef), nv.ptr(x_state), nv.ptr(noise),
                                              nv.ptr(step_word), nv.ptr(xin), nv.ptr(xstart_sum), nv.ptr(logits),
                                              nv.ptr(xstart), nv.stream_ptr()), "dua_final_conv_sampler")

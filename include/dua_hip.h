@@ -23,30 +23,40 @@ extern "C" {
 #define DUA_F16 1
 #define DUA_ERR_ARG (-22)
 
+/* ---- fused producer normalisation --------------------------------------------------------------
+ * A convolution stores its RAW output (conv + bias) and accumulates per-(n, c) sums of it into
+ * out_stats = fp64 [N][8][c_pad][2] (8 replica rows; (sum x, sum x^2); the caller zeroes it before the
+ * producing launch).  Whoever consumes the raw tensor passes this descriptor and applies
+ *   y = LeakyReLU(x * scale + shift) + add,  scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+ * (biased variance) while staging its input: InstanceNorm3d(affine) -> Dropout(0) -> LeakyReLU of MONAI's
+ * ADN (models/basic_unet/denoiser.py:206-207, models/diff_unet.py:34-35) and the temb add of
+ * TwoConv.forward (denoiser.py:65).  stats == NULL means "input is already materialised". */
+typedef struct {
+  const double* stats;       /* producer's sums, [N][8][c_pad][2] */
+  const float* gamma;        /* producer's InstanceNorm weight [C] */
+  const float* beta;         /* producer's InstanceNorm bias [C] */
+  const float* add;          /* optional fp32 [N][add_stride] bias added after the activation, or NULL */
+  int add_stride;            /* 0 = C */
+  int c_pad;                 /* channel stride of stats */
+  float inv_count;           /* 1 / (D*H*W) of the producer's output */
+  float eps;                 /* 1e-5 */
+  float slope;               /* LeakyReLU negative slope */
+} dua_in_norm;
+
 /* ---- 3x3x3 convolution --------------------------------------------------------------------
  * Replaces nn.Conv3d(k3,s1,p1,bias) built by MONAI Convolution at
- * models/basic_unet/denoiser.py:56-59 and models/basic_unet/pretrained/basic_unet.py:60-63,
- * fused with the producer's InstanceNorm3d+LeakyReLU(+temb add, denoiser.py:65) on the input
- * side and with this layer's InstanceNorm statistics on the output side. */
+ * models/basic_unet/denoiser.py:56-59 and models/basic_unet/pretrained/basic_unet.py:60-63. */
 typedef struct {
   int dtype;
   int N, D, H, W;
   int Cin, Cin_stride, Cin_off;    /* all multiples of 8 */
   int Cout, Cout_stride, Cout_off; /* all multiples of 8 */
-  float slope;                     /* LeakyReLU negative slope of the fused input transform */
-  int in_add_stride;               /* per-sample stride of in_add (0 = Cin) */
 } dua_conv3_desc;
 
-/* rows of the partial-statistics matrix the call writes per batch item */
-int dua_conv3d_k3_rows(const dua_conv3_desc* d);
-
-/* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32[ceil(Cout/64)*64].
- * in_scale/in_shift/in_add: fp32[N][Cin] or NULL (in_scale NULL = input already materialised).
- * y: raw output (conv + bias).  partials: fp32[N][rows][ceil(Cout/64)*64][2] = (sum, M2) per slab;
- * counts: fp32[rows] voxels per slab. */
+/* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32[ceil(Cout/64)*64].  in: NULL or the
+ * producer descriptor of x.  y: raw output.  out_stats: fp64 [N][8][ceil(Cout/64)*64][2], pre-zeroed. */
 int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
-                      const float* in_scale, const float* in_shift, const float* in_add, void* y,
-                      float* partials, float* counts, void* stream);
+                      const dua_in_norm* in, void* y, double* out_stats, void* stream);
 
 /* Packs nn.Conv3d weight fp32[Cout][Cin_src][3][3][3] into the kernel's slab order
  * [cout_tile][chunk][kd][kh*3+kw][k-group][64][16 B].  in_perm (device int32[Cin_packed], may be
@@ -55,12 +65,9 @@ int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_pack
 long dua_pack_conv3_weights(int dtype, int Cout, int Cin_src, int Cin_packed, const float* w, const int* in_perm,
                             void* w_packed, void* stream);
 
-/* ---- InstanceNorm3d(affine=True, eps) statistics -> per-(n,c) scale/shift ---------------------
- * Replaces the statistics half of nn.InstanceNorm3d (MONAI ADN "N", denoiser.py:207):
- * scale = gamma / sqrt(var + eps), shift = beta - mean * scale, biased variance, combined from
- * the conv kernel's slab partials in fp64. */
-int dua_instnorm_finalize(int N, int C, int rows, int c_pad, const float* partials, const float* counts,
-                          const float* gamma, const float* beta, float eps, float* scale, float* shift, void* stream);
+/* ---- InstanceNorm3d statistics -> per-(n,c) scale/shift (inspection / tests) -----------------------
+ * The same arithmetic every consumer runs in its preamble, written out: scale, shift = fp32 [N][C]. */
+int dua_instnorm_finalize(int N, int C, const dua_in_norm* in, float* scale, float* shift, void* stream);
 
 /* ---- materialise: x_i = LeakyReLU(IN(raw)) + embeddings[i], and its MaxPool3d(2) --------------
  * Replaces the normalise/activate half of MONAI ADN for tensors with several consumers, the
@@ -74,10 +81,9 @@ typedef struct {
   int emb_stride;               /* channel stride of emb (offset 0), ignored when emb is NULL */
   int out_stride, out_off;
   int pool_stride;              /* channel stride of pooled (offset 0); D,H,W must be even */
-  float slope;
 } dua_materialize_desc;
 
-int dua_materialize(const dua_materialize_desc* d, const void* raw, const float* scale, const float* shift,
+int dua_materialize(const dua_materialize_desc* d, const void* raw, const dua_in_norm* in,
                     const void* emb, void* out, void* pooled, void* stream);
 
 /* ---- ConvTranspose3d(k2, s2, bias) --------------------------------------------------------
@@ -85,7 +91,7 @@ int dua_materialize(const dua_materialize_desc* d, const void* raw, const float*
  * models/basic_unet/denoiser.py:161-170, writing into the "upsampled" channel slice of the concat
  * buffer (torch.cat at denoiser.py:190).  d->D/H/W are the INPUT extents; y has 2D x 2H x 2W. */
 int dua_deconv_k2s2_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
-                        const float* in_scale, const float* in_shift, const float* in_add, void* y, void* stream);
+                        const dua_in_norm* in, void* y, void* stream);
 
 /* ---- diffusion elementwise arithmetic (guided_diffusion/gaussian_diffusion.py) ----------------
  * Tensors are contiguous fp32 with the batch outermost (any layout inside a sample).
@@ -114,7 +120,6 @@ typedef struct {
   int C, CX;               /* classes; channel stride of the fp32 sampler state (8/16/24/32) */
   int mode;                /* DUA_MODE_* */
   int xin_stride;          /* channel stride of xin (x_{t-1} goes to channels [0, C)) */
-  float slope;
   unsigned long long seed; /* Philox key when noise == NULL */
 } dua_tail_desc;
 
@@ -122,7 +127,7 @@ typedef struct {
  * noise: fp32 NCDHW [N][C][voxels] or NULL (in-kernel Philox4x32-10 + Box-Muller, counter =
  * (element, *step_word)).  xin, xstart_sum ([N][voxels][CX]), logits and xstart (NCDHW fp32) may be
  * NULL.  In DUA_MODE_LOGITS only logits is written. */
-int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const float* scale, const float* shift,
+int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in_norm* in,
                            const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
                            const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
                            void* stream);

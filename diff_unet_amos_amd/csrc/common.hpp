@@ -74,8 +74,9 @@ struct InXform {
 };
 
 // Preamble: threads cooperatively compute scale/shift/add for channels [0, C) into LDS arrays.
-__device__ __forceinline__ void xform_preamble(const InXform& xf, int n, int C, float* sc, float* sh, float* ad) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+__device__ __forceinline__ void xform_preamble(const InXform& xf, int n, int C, float* sc, float* sh, float* ad,
+                                               int c_begin = 0) {
+  for (int c = c_begin + threadIdx.x; c < C; c += blockDim.x) {
     double S = 0, Q = 0;
 #pragma unroll
     for (int r = 0; r < STAT_REPLICAS; ++r) {

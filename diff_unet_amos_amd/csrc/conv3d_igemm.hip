@@ -36,6 +36,8 @@ constexpr int NITEMS = HD * HH * HW * KG;  // 2400 16-byte items per halo chunk
 constexpr int NIT = (NITEMS + 255) / 256;  // 10
 }  // namespace c3
 
+int g_conv_variant = 0;   // 0 = auto (v3 for >= 48^3, else v2); 1/2/3 force v1 (sync slabs), v2 (4x8x8 pipelined), v3 (8x8x8)
+
 struct Conv3Args {
   const void* x; const void* w; const float* bias; void* y;
   double* stats;
@@ -44,6 +46,8 @@ struct Conv3Args {
   int Cin, Cin_stride, Cin_off;     // valid input channels, buffer stride, offset (elements)
   int Cout, Cout_stride, Cout_off;
   int nchunks, ntiles, tiles_h, tiles_w, cout_pad;
+  int ksplit, units_per_split;      // split-K over (chunk, kd) units; partial tiles go to `part` in fp32
+  float* part;
 };
 
 template <typename T>
@@ -230,9 +234,573 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2: same tile and fragment maps, software-pipelined.  Weights arrive as 12 KB (kd,kh) slabs, loaded to
+// registers one slab ahead of the MFMAs and written into the other half of a double buffer; the next
+// chunk's halo is prefetched into registers during the last slab of the current chunk and written
+// (transformed) to LDS between two barriers.  Operand fragments of k-step t+1 are read from LDS while
+// the MFMAs of step t issue.  One barrier per slab; nothing waits on a global load that was not issued
+// a full MFMA phase earlier.
+namespace c3v2 {
+using namespace c3;
+constexpr int SLAB = 3 * KG * BN * 16;             // 12288
+constexpr int LDS_MAIN = HALO_BYTES + 2 * SLAB;    // 63936
+}  // namespace c3v2
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ABL (diagnostic builds only; outputs are wrong) bit mask: 1 = no MFMA, 2 = no fragment reads, 4 = no
+// weight staging, 8 = no halo staging, 16 = no epilogue.
+template <typename T, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
+  using namespace c3v2;
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  constexpr int CK = KG * EPG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + HALO_BYTES;
+  float* xsc = (float*)(smem + LDS_MAIN);
+  float* xsh = xsc + a.nchunks * CK;
+  float* xad = xsh + a.nchunks * CK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int tile = xcd_remap(blockIdx.x, a.ntiles);
+  const int ct = blockIdx.y, n = blockIdx.z % a.N;
+  const int tw_ = tile % a.tiles_w, th_ = (tile / a.tiles_w) % a.tiles_h, td_ = tile / (a.tiles_w * a.tiles_h);
+  const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
+  const bool fused = a.xf.stats != nullptr;
+
+  const int kg_t = tid & (KG - 1);
+  long goff[NIT]; int loff[NIT];
+  const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off;
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    int it = tid + 256 * j;
+    int hv = it >> 2;
+    int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
+    int gd = d0 + hd - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
+    bool ok = it < NITEMS && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+    goff[j] = ok ? (((long)gd * a.H + gh) * a.W + gw) * a.Cin_stride + kg_t * EPG : -1;
+    loff[j] = it < NITEMS ? hd * PS + hy * RS + hx * VS + kg_t * 16 : -1;
+  }
+  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB;
+  // Weight slabs go global -> registers (issued one slab ahead, 3 x 16 B per thread) -> LDS.  LDS-DMA
+  // (global_load_lds) would save the registers, but with one in flight hipcc (ROCm 7.2) turns every
+  // counted lgkmcnt wait of the fragment pipeline below into lgkmcnt(0).
+  // Two register sets: slab g is loaded during phase g-2 and written to LDS at the end of phase g-1, so
+  // an L2 round trip has two MFMA phases to complete.
+  f32x4 wreg[3][3];   // set = (slab index within chunk) % 3, compile-time (9 slabs per chunk keeps the cycle)
+  auto load_slab = [&](int g, int set) {       // g = global slab index (chunk * 9 + kd * 3 + kh)
+    if (ABL & 4) return;
+    const char* src = wsrc + (long)g * SLAB + tid * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wreg[set][j] = *(const f32x4*)(src + j * 4096);
+  };
+  auto store_slab = [&](int g, int set) {
+    if (ABL & 4) return;
+    char* dst = wbuf + (g & 1) * SLAB + tid * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *(f32x4*)(dst + j * 4096) = wreg[set][j];
+  };
+  Frag hv_[NIT];
+  auto load_halo = [&](int ch) {
+    if (ABL & 8) return;
+    const bool cok = ch * CK + kg_t * EPG < a.Cin;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      if (goff[j] >= 0 && cok) hv_[j] = *(const Frag*)(xin + goff[j] + ch * CK);
+      else
+#pragma unroll
+        for (int e = 0; e < EPG; ++e) hv_[j][e] = (T)0.f;
+    }
+  };
+  auto store_halo = [&](int ch) {
+    if (ABL & 8) return;
+    const int c0 = ch * CK + kg_t * EPG;
+    if (fused && c0 < a.Cin) {
+      float sc[EPG], sh[EPG], ad[EPG];
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+#pragma unroll
+      for (int j = 0; j < NIT; ++j)
+        if (goff[j] >= 0) hv_[j] = xform_frag<T>(hv_[j], sc, sh, ad, a.xf.slope);
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+      if (loff[j] >= 0) *(Frag*)(halo + loff[j]) = hv_[j];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+
+  // ---- work range: units u = chunk * 3 + kd, three (kd, kh) slabs each ----
+  const int ks_id = blockIdx.z / a.N;
+  const int u0 = ks_id * a.units_per_split;
+  const int u1 = min(a.nchunks * 3, u0 + a.units_per_split);
+  const int g0 = u0 * 3, g1 = u1 * 3;
+
+  // ---- prologue ----
+  load_slab(g0, 0);
+  load_slab(g0 + 1, 1);
+  load_halo(u0 / 3);
+  if (fused) {     // only the Cin chunks this workgroup walks (all of them unless split-K)
+    xform_preamble(a.xf, n, min(a.Cin, ((u1 + 2) / 3) * CK), xsc, xsh, xad, (u0 / 3) * CK);
+    __syncthreads();
+  }
+  store_slab(g0, 0);
+  store_halo(u0 / 3);
+  __syncthreads();
+
+  const int a_base = wave * PS + (r >> 3) * RS + (r & 7) * VS + hh * 16;
+  const int b_base = (hh * BN + r) * 16;
+  for (int u = u0; u < u1; ++u) {
+    const int kd = u % 3;
+    const bool next_chunk = kd == 2 && u + 1 < u1;     // the unit after this one starts a new Cin chunk
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int g = u * 3 + kh;
+      if (g + 2 < g1) load_slab(g + 2, (kh + 2) % 3);
+      if (kh == 0 && next_chunk) load_halo(u / 3 + 1);
+      const char* ap = halo + a_base + kd * PS + kh * RS;
+      const char* wb = wbuf + (g & 1) * SLAB + b_base;
+      // six k-steps (kw x ks); fragments of step t+1 are in flight while the MFMAs of step t issue
+      Frag fa0[2], fa1[2], fb0[2], fb1[2];
+      auto ld = [&](int t, int b) {
+        if (ABL & 2) return;
+        const int kw = t >> 1, ks = t & 1;
+        fa0[b] = *(const Frag*)(ap + kw * VS + ks * 32);
+        fb0[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16);
+        fb1[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16 + 32 * 16);
+        fa1[b] = *(const Frag*)(ap + 4 * RS + kw * VS + ks * 32);
+      };
+      ld(0, 0);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (t + 1 < 6) ld(t + 1, (t + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
+        if (ABL & 1) {
+          asm volatile("" ::"v"(fa0[t & 1]), "v"(fb0[t & 1]), "v"(fa1[t & 1]), "v"(fb1[t & 1]));
+        } else {
+          mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
+          mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
+          mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
+          mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (g + 1 < g1) store_slab(g + 1, (kh + 1) % 3);   // the other buffer: last read before the previous barrier
+      __syncthreads();   // next slab visible and everyone is done with this one
+    }
+    if (next_chunk) {
+      store_halo(u / 3 + 1);
+      __syncthreads();
+    }
+  }
+
+  if (ABL & 16) {
+    if (acc[0][0][0] == 123.f && acc[0][1][1] == 5.f && acc[1][0][2] == 7.f && acc[1][1][3] == 9.f) ((float*)a.y)[0] = 1.f;
+    return;
+  }
+  if (a.ksplit > 1) {
+    // ---- split-K: this workgroup's fp32 partial tile goes to part[ks][n][voxel][cout_pad] ----
+    constexpr int OSF = 32 * 4 + 16;
+    char* otf = smem + wave * 64 * OSF;
+    const int gdz = d0 + wave;
+    float* pout = a.part + ((long)(ks_id * a.N + n) * a.D * a.H * a.W) * a.cout_pad + ct * BN;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *(float*)(otf + (m * 32 + acc_row(i, hh)) * OSF + r * 4) = acc[m][q][i];
+      __syncthreads();
+      if (gdz < a.D) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int v = it * 8 + (lane >> 3), cg = lane & 7;
+          const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
+          if (gh < a.H && gw < a.W)
+            *(f32x4*)(pout + (((long)gdz * a.H + gh) * a.W + gw) * a.cout_pad + q * 32 + cg * 4) =
+                *(const f32x4*)(otf + v * OSF + cg * 16);
+        }
+      }
+      if (q == 0) __syncthreads();
+    }
+    return;
+  }
+  // ---- epilogue, one 32-channel half at a time (fits fp32 too) ----
+  constexpr int OS = 32 * (int)sizeof(T) + 16;
+  char* ot = smem + wave * 64 * OS;
+  float* ex = (float*)(smem + 4 * 64 * OS);          // [4 waves][64 couts][2] + [4] counts
+  const int gd = d0 + wave;
+  const bool dok = gd < a.D;
+  const float cnt = dok ? (float)(min(TH, a.H - h0) * min(TW, a.W - w0)) : 0.f;
+  T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int co = q * 32 + r;
+    const float bq = a.bias[ct * BN + co];
+    float s = 0.f;
+    float vals[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
+        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
+        T tv = (T)(acc[m][q][i] + bq);
+        float fv = ok ? (float)tv : 0.f;
+        vals[m][i] = fv;
+        s += fv;
+        *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = tv;
+      }
+    s += __shfl_xor(s, 32);
+    const float mean = cnt > 0.f ? s / cnt : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
+        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
+        const float dlt = vals[m][i] - mean;
+        m2 += ok ? dlt * dlt : 0.f;
+      }
+    m2 += __shfl_xor(m2, 32);
+    if (hh == 0) { ex[(wave * BN + co) * 2] = s; ex[(wave * BN + co) * 2 + 1] = m2; }
+    if (lane == 0) ex[4 * BN * 2 + wave] = cnt;
+    __syncthreads();
+    if (dok) {
+      constexpr int GPV = 32 / EPG;            // 16-byte groups per voxel in this half
+      constexpr int VPI = 64 / GPV;
+#pragma unroll
+      for (int it = 0; it < 64 / VPI; ++it) {
+        const int v = it * VPI + lane / GPV, cg = lane % GPV;
+        const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
+        if (gh < a.H && gw < a.W && ct * BN + q * 32 + cg * EPG < a.Cout)
+          *(Frag*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + q * 32 + cg * EPG) =
+              *(const Frag*)(ot + v * OS + cg * 16);
+      }
+    }
+    if (q == 0) __syncthreads();               // staging tile is reused by the second half
+  }
+  if (wave == 0) {
+    double S = 0, Q = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float k = ex[4 * BN * 2 + w];
+      if (k > 0.f) {
+        const double sw = (double)ex[(w * BN + lane) * 2], mw = (double)ex[(w * BN + lane) * 2 + 1];
+        S += sw; Q += mw + sw * sw / (double)k;
+      }
+    }
+    if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v3: 8x8x8 output tile (512 voxels) x 64 channels per 512-thread workgroup, one workgroup per CU.
+// Why: at 4x8x8 the kernel is bound by L2->LDS traffic, not MFMA -- every 256-voxel tile re-reads the
+// whole 64-channel weight block (2 GB per 128->64 @96^3 launch, ~20 TB/s of L2).  Doubling M halves the
+// weight traffic per FLOP and cuts halo amplification from 2.34x to 1.95x.  Eight waves (two per SIMD)
+// each own a depth slice exactly as before; weights move as 36 KB kd-slabs (9 taps), register-staged one
+// slab ahead into a double buffer; three barriers per Cin chunk.
+namespace c3v3 {
+constexpr int TD = 8, TH = 8, TW = 8, HD = 10, HH = 10, HW = 10, KG = 4, BN = 64;
+constexpr int VS = 64, RS = HW * VS + 16, PS = HH * RS;     // 64, 656, 6560
+constexpr int HALO_BYTES = HD * PS;                          // 65600
+constexpr int SLAB = 9 * KG * BN * 16;                       // 36864
+constexpr int LDS_MAIN = HALO_BYTES + 2 * SLAB;              // 139328
+constexpr int NT = 512;
+constexpr int NITEMS = HD * HH * HW * KG;                    // 4000
+constexpr int NIT = (NITEMS + NT - 1) / NT;                  // 8
+constexpr int WIT = (SLAB / 16 + NT - 1) / NT;               // 5 (last one half populated)
+}  // namespace c3v3
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv3d_k3_v3_kernel(Conv3Args a) {
+  using namespace c3v3;
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  constexpr int CK = KG * EPG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + HALO_BYTES;
+  float* xsc = (float*)(smem + LDS_MAIN);
+  float* xsh = xsc + a.nchunks * CK;
+  float* xad = xsh + a.nchunks * CK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int tile = xcd_remap(blockIdx.x, a.ntiles);
+  const int ct = blockIdx.y, n = blockIdx.z;
+  const int tw_ = tile % a.tiles_w, th_ = (tile / a.tiles_w) % a.tiles_h, td_ = tile / (a.tiles_w * a.tiles_h);
+  const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
+  const bool fused = a.xf.stats != nullptr;
+
+  const int kg_t = tid & (KG - 1);
+  int goff[NIT]; int loff[NIT];        // element offsets fit 32 bits for one batch item (checked on the host)
+  const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off;
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    int it = tid + NT * j;
+    int hv = it >> 2;
+    int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
+    int gd = d0 + hd - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
+    bool ok = it < NITEMS && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+    goff[j] = ok ? ((gd * a.H + gh) * a.W + gw) * a.Cin_stride + kg_t * EPG : -1;
+    loff[j] = it < NITEMS ? hd * PS + hy * RS + hx * VS + kg_t * 16 : -1;
+  }
+  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 3 * SLAB;
+  f32x4 wreg[WIT];
+  auto load_slab = [&](int g) {       // g = chunk * 3 + kd
+    const char* src = wsrc + (long)g * SLAB + tid * 16;
+#pragma unroll
+    for (int j = 0; j < WIT; ++j)
+      if (j < WIT - 1 || tid + NT * j < SLAB / 16) wreg[j] = *(const f32x4*)(src + j * NT * 16);
+  };
+  auto store_slab = [&](int g) {
+    char* dst = wbuf + (g & 1) * SLAB + tid * 16;
+#pragma unroll
+    for (int j = 0; j < WIT; ++j)
+      if (j < WIT - 1 || tid + NT * j < SLAB / 16) *(f32x4*)(dst + j * NT * 16) = wreg[j];
+  };
+  Frag hv_[NIT];
+  auto load_halo = [&](int ch) {
+    const bool cok = ch * CK + kg_t * EPG < a.Cin;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      if (goff[j] >= 0 && cok) hv_[j] = *(const Frag*)(xin + goff[j] + ch * CK);
+      else
+#pragma unroll
+        for (int e = 0; e < EPG; ++e) hv_[j][e] = (T)0.f;
+    }
+  };
+  auto store_halo = [&](int ch) {
+    const int c0 = ch * CK + kg_t * EPG;
+    if (fused && c0 < a.Cin) {
+      float sc[EPG], sh[EPG], ad[EPG];
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+#pragma unroll
+      for (int j = 0; j < NIT; ++j)
+        if (goff[j] >= 0) hv_[j] = xform_frag<T>(hv_[j], sc, sh, ad, a.xf.slope);
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j)
+      if (loff[j] >= 0) *(Frag*)(halo + loff[j]) = hv_[j];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+
+  load_slab(0);
+  load_halo(0);
+  if (fused) {
+    xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
+    __syncthreads();
+  }
+  store_slab(0);
+  store_halo(0);
+  __syncthreads();
+
+  const int a_base = wave * PS + (r >> 3) * RS + (r & 7) * VS + hh * 16;
+  const int b_base = (hh * BN + r) * 16;
+  const int nslabs = a.nchunks * 3;
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int g = ch * 3 + kd;
+      if (g + 1 < nslabs) load_slab(g + 1);
+      if (kd == 2 && ch + 1 < a.nchunks) load_halo(ch + 1);
+      const char* ap = halo + a_base + kd * PS;
+      const char* wb = wbuf + (g & 1) * SLAB + b_base;
+      // 18 k-steps (kh x kw x ks); fragments of step t+1 are in flight while the MFMAs of step t issue
+      Frag fa0[2], fa1[2], fb0[2], fb1[2];
+      auto ld = [&](int t, int b) {
+        const int t9 = t >> 1, ks = t & 1, kh = t9 / 3, kw = t9 % 3;
+        fa0[b] = *(const Frag*)(ap + kh * RS + kw * VS + ks * 32);
+        fb0[b] = *(const Frag*)(wb + (t9 * KG + 2 * ks) * BN * 16);
+        fb1[b] = *(const Frag*)(wb + (t9 * KG + 2 * ks) * BN * 16 + 32 * 16);
+        fa1[b] = *(const Frag*)(ap + (kh + 4) * RS + kw * VS + ks * 32);
+      };
+      ld(0, 0);
+#pragma unroll
+      for (int t = 0; t < 18; ++t) {
+        if (t + 1 < 18) ld(t + 1, (t + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
+        mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
+        mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
+        mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
+        mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (g + 1 < nslabs) store_slab(g + 1);   // the other buffer: last read before the previous barrier
+      __syncthreads();
+    }
+    if (ch + 1 < a.nchunks) {
+      store_halo(ch + 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue, one 32-channel half at a time ----
+  constexpr int OS = 32 * (int)sizeof(T) + 16;
+  char* ot = smem + wave * 64 * OS;
+  float* ex = (float*)(smem + 8 * 64 * OS);          // [8 waves][64 couts][2] + [8] counts
+  const int gd = d0 + wave;
+  const bool dok = gd < a.D;
+  const float cnt = dok ? (float)(min(TH, a.H - h0) * min(TW, a.W - w0)) : 0.f;
+  T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int co = q * 32 + r;
+    const float bq = a.bias[ct * BN + co];
+    float s = 0.f;
+    float vals[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
+        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
+        T tv = (T)(acc[m][q][i] + bq);
+        float fv = ok ? (float)tv : 0.f;
+        vals[m][i] = fv;
+        s += fv;
+        *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = tv;
+      }
+    s += __shfl_xor(s, 32);
+    const float mean = cnt > 0.f ? s / cnt : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
+        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
+        const float dlt = vals[m][i] - mean;
+        m2 += ok ? dlt * dlt : 0.f;
+      }
+    m2 += __shfl_xor(m2, 32);
+    if (hh == 0) { ex[(wave * BN + co) * 2] = s; ex[(wave * BN + co) * 2 + 1] = m2; }
+    if (lane == 0) ex[8 * BN * 2 + wave] = cnt;
+    __syncthreads();
+    if (dok) {
+      constexpr int GPV = 32 / EPG;
+      constexpr int VPI = 64 / GPV;
+#pragma unroll
+      for (int it = 0; it < 64 / VPI; ++it) {
+        const int v = it * VPI + lane / GPV, cg = lane % GPV;
+        const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
+        if (gh < a.H && gw < a.W && ct * BN + q * 32 + cg * EPG < a.Cout)
+          *(Frag*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + q * 32 + cg * EPG) =
+              *(const Frag*)(ot + v * OS + cg * 16);
+      }
+    }
+    if (q == 0) __syncthreads();
+  }
+  if (wave == 0) {
+    double S = 0, Q = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const float k = ex[8 * BN * 2 + w];
+      if (k > 0.f) {
+        const double sw = (double)ex[(w * BN + lane) * 2], mw = (double)ex[(w * BN + lane) * 2 + 1];
+        S += sw; Q += mw + sw * sw / (double)k;
+      }
+    }
+    if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
+  }
+}
+
+// ---- split-K finish: y = sum_k part[k] + bias (stored as T), and this layer's InstanceNorm sums ----
+// block = 256 threads = VL voxel lanes x G channel groups of 4; each thread walks ITER voxels.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, int N, long vox,
+                                                            int cout_pad, int Cout, const float* __restrict__ bias,
+                                                            T* __restrict__ y, int Cout_stride, int Cout_off,
+                                                            double* stats, int G, int VL, int ITER) {
+  __shared__ float red[256][8];
+  const int n = blockIdx.y;
+  const int cg = threadIdx.x % G, vl = threadIdx.x / G;
+  const int c = cg * 4;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  f32x4 b4 = *(const f32x4*)(bias + c);
+  if (vl < VL) {
+    for (int i = 0; i < ITER; ++i) {
+      const long v = ((long)blockIdx.x * ITER + i) * VL + vl;
+      if (v >= vox) break;
+      f32x4 acc = b4;
+      const float* pp = part + ((long)n * vox + v) * cout_pad + c;
+      const long kstride = (long)N * vox * cout_pad;
+      int k = 0;
+      for (; k + 4 <= ksplit; k += 4) {          // four independent loads in flight
+        const f32x4 p0 = *(const f32x4*)(pp + (k + 0) * kstride), p1 = *(const f32x4*)(pp + (k + 1) * kstride);
+        const f32x4 p2 = *(const f32x4*)(pp + (k + 2) * kstride), p3 = *(const f32x4*)(pp + (k + 3) * kstride);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (p0[e] + p1[e]) + (p2[e] + p3[e]);
+      }
+      for (; k < ksplit; ++k) {
+        const f32x4 p = *(const f32x4*)(pp + k * kstride);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += p[e];
+      }
+      T o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (T)acc[e];
+        const float f = (float)o[e];
+        s[e] += f; q[e] += f * f;
+      }
+      if (c < Cout) {
+        T* yp = y + ((long)n * vox + v) * Cout_stride + Cout_off + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yp[e] = o[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][4 + e] = q[e]; }
+  __syncthreads();
+  if (vl == 0 && c < Cout) {
+    double S[4] = {0, 0, 0, 0}, Q[4] = {0, 0, 0, 0};
+    for (int j = 0; j < VL; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { S[e] += (double)red[j * G + cg][e]; Q[e] += (double)red[j * G + cg][4 + e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < Cout) stats_add(stats, n, cout_pad, blockIdx.x & (STAT_REPLICAS - 1), c + e, S[e], Q[e]);
+  }
+}
+
+static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups) {
+  *ksplit = 1; *ups = units;
+  if (base_wgs > 64 || units <= 1) return;        // 24^3 and up: the partial-tile round trip costs more than it buys
+  int want = (320 + base_wgs - 1) / base_wgs;      // ~one workgroup per CU, each keeping >= a few units of work
+  if (want > units) want = units;
+  *ups = (units + want - 1) / want;
+  *ksplit = (units + *ups - 1) / *ups;
+}
+
 template <typename T>
 static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
-                        const dua_in_norm* in, void* y, double* stats, hipStream_t s) {
+                        const dua_in_norm* in, void* y, double* stats, float* ws, long ws_bytes, hipStream_t s) {
   using namespace c3;
   constexpr int CK = KG * Elem<T>::EPG;
   Conv3Args a;
@@ -247,16 +815,58 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   a.ntiles = td * a.tiles_h * a.tiles_w;
   const int nct = (d->Cout + BN - 1) / BN;
   a.cout_pad = nct * BN;
-  const int lds = LDS_BYTES + (in && in->stats ? 3 * 4 * a.nchunks * CK : 0);
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 3 * 4 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_lds = LDS_BYTES + 3 * 4 * 1024;
-  }
+  a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = nullptr;
   if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
-  dim3 grid(a.ntiles, nct, d->N);
-  hipLaunchKernelGGL(conv3d_k3_kernel<T>, grid, dim3(256), lds, s, a);
+  const int xf_bytes = in && in->stats ? 3 * 4 * a.nchunks * CK : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 3 * 4 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
+#ifdef DUA_ABLATE
+#define DUA_ABL_ATTR(M) hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, M>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
+    DUA_ABL_ATTR(1) DUA_ABL_ATTR(2) DUA_ABL_ATTR(4) DUA_ABL_ATTR(8) DUA_ABL_ATTR(12) DUA_ABL_ATTR(16) DUA_ABL_ATTR(19) DUA_ABL_ATTR(23) DUA_ABL_ATTR(27) DUA_ABL_ATTR(3)
+#endif
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv3d_k3_v3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v3::LDS_MAIN + 3 * 4 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  if (g_conv_variant == 3 || (g_conv_variant == 0 && d->D * d->H * d->W >= 48 * 48 * 48)) {
+    if ((long)d->D * d->H * d->W * d->Cin_stride >= (1L << 31)) return DUA_ERR_ARG;
+    const int td8 = (d->D + 7) / 8;
+    a.ntiles = td8 * a.tiles_h * a.tiles_w;
+    dim3 grid8(a.ntiles, nct, d->N);
+    hipLaunchKernelGGL(conv3d_k3_v3_kernel<T>, grid8, dim3(512), c3v3::LDS_MAIN + xf_bytes, s, a);
+    return (int)hipGetLastError();
+  }
+  const long vox = (long)d->D * d->H * d->W;
+  if (ws != nullptr && g_conv_variant == 0) {
+    int ks, ups;
+    choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups);
+    if (ks > 1 && (long)ks * d->N * vox * a.cout_pad * 4 <= ws_bytes) { a.ksplit = ks; a.units_per_split = ups; a.part = ws; }
+  }
+  dim3 grid(a.ntiles, nct, d->N * a.ksplit);
+  if (a.ksplit > 1) {
+    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
+    const int G = a.cout_pad / 4 > 256 ? 256 : a.cout_pad / 4;       // channel groups handled per block pass
+    if (a.cout_pad / 4 > 256) return DUA_ERR_ARG;
+    const int VL = 256 / G;
+    int ITER = 8;
+    while (ITER > 1 && (vox + (long)VL * ITER - 1) / ((long)VL * ITER) < 512) ITER >>= 1;
+    dim3 fgrid((unsigned)((vox + (long)VL * ITER - 1) / ((long)VL * ITER)), d->N);
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, fgrid, dim3(256), 0, s, (const float*)ws, a.ksplit, d->N, vox, a.cout_pad,
+                       d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
+    return (int)hipGetLastError();
+  }
+  if (g_conv_variant == 1)
+    hipLaunchKernelGGL(conv3d_k3_kernel<T>, grid, dim3(256), LDS_BYTES + xf_bytes, s, a);
+  else if (g_conv_variant == 2 || g_conv_variant == 0)
+    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
+#ifdef DUA_ABLATE
+#define DUA_ABL_CASE(M) else if (g_conv_variant == 100 + M) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, M>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
+  DUA_ABL_CASE(1) DUA_ABL_CASE(2) DUA_ABL_CASE(4) DUA_ABL_CASE(8) DUA_ABL_CASE(12) DUA_ABL_CASE(16) DUA_ABL_CASE(19) DUA_ABL_CASE(23) DUA_ABL_CASE(27) DUA_ABL_CASE(3)
+#endif
   return (int)hipGetLastError();
 }
 
@@ -264,16 +874,33 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
 
 extern "C" {
 
+int dua_set_option(int key, int value) {
+  if (key == 1 && ((value >= 0 && value <= 3) || (value >= 100 && value < 132))) { dua::g_conv_variant = value; return 0; }
+  return DUA_ERR_ARG;
+}
+
+long dua_conv3d_k3_workspace(const dua_conv3_desc* d) {
+  using namespace dua::c3;
+  if (!d || (d->dtype != DUA_F16 && d->dtype != DUA_F32)) return DUA_ERR_ARG;
+  const int ck = 4 * (d->dtype == DUA_F16 ? 8 : 4);
+  const int nch = (d->Cin + ck - 1) / ck, nct = (d->Cout + BN - 1) / BN;
+  const int tiles = ((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
+  int ks, ups;
+  dua::choose_split(tiles * nct * d->N, nch * 3, &ks, &ups);
+  return ks > 1 ? (long)ks * d->N * d->D * d->H * d->W * nct * BN * 4 : 0;
+}
+
 int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
-                      const dua_in_norm* in, void* y, double* out_stats, void* stream) {
+                      const dua_in_norm* in, void* y, double* out_stats, void* workspace, long workspace_bytes,
+                      void* stream) {
   if (!d || !x || !w_packed || !bias_padded || !y || !out_stats) return DUA_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)
     return DUA_ERR_ARG;
   if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin)) return DUA_ERR_ARG;
   if (d->dtype == DUA_F16)
-    return dua::launch_conv3<dua::f16>(d, x, w_packed, bias_padded, in, y, out_stats, (hipStream_t)stream);
+    return dua::launch_conv3<dua::f16>(d, x, w_packed, bias_padded, in, y, out_stats, (float*)workspace, workspace_bytes, (hipStream_t)stream);
   if (d->dtype == DUA_F32)
-    return dua::launch_conv3<float>(d, x, w_packed, bias_padded, in, y, out_stats, (hipStream_t)stream);
+    return dua::launch_conv3<float>(d, x, w_packed, bias_padded, in, y, out_stats, (float*)workspace, workspace_bytes, (hipStream_t)stream);
   return DUA_ERR_ARG;
 }
 

@@ -119,6 +119,14 @@ class Plan:
             o += n
         n_enc = sum(sizes[:10])
         self.enc_stats, self.den_stats = self.stat_arena[:n_enc], self.stat_arena[n_enc:]
+        # split-K scratch for the layers that cannot fill the chip on their own (<= 24^3)
+        need = 0
+        for pairs, levels in ((self.enc, range(5)), (self.den, range(5)), (self.dec, range(4))):
+            for l, pair in zip(levels, pairs):
+                for c in pair:
+                    cin = c.cin_packed or c.cin
+                    need = max(need, ops.conv3_workspace_bytes(self.dtype, self.N, *self.S[l], -(-cin // 8) * 8, c.cout))
+        self.splitk_ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=self.dev)
 
     def _bind(self):
         net = self.net
@@ -203,7 +211,7 @@ class Plan:
 
     def _conv(self, c, x, cin, y, level, xform_from=None, add_key=None):
         norm = None if xform_from is None else self._norm(xform_from, level, add_key)
-        ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, c.stats, norm=norm)
+        ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, c.stats, norm=norm, workspace=self.splitk_ws)
 
     def run_encoder(self, image):
         """BasicUNetEncoder.forward: fills self.emb[0..4] (channels-last)."""

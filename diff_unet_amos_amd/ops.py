@@ -127,7 +127,12 @@ def _norm_ref(norm, N, Cc):
     return None if norm is None else norm.ref(N, Cc)
 
 
-def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None):
+def conv3_workspace_bytes(dtype, N, D, H, W, cin, cout):
+    d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, cin, cin, 0, cout, cout, 0)
+    return int(nv.lib().dua_conv3d_k3_workspace(C.byref(d)))
+
+
+def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None, workspace=None):
     """Raw 3x3x3 convolution (+bias); ``norm`` = producer descriptor of x (fused IN+LeakyReLU+add);
     accumulates this layer's InstanceNorm sums into ``out_stats`` (must be zero on entry)."""
     _cl_check(x, "x"); _cl_check(y, "y")
@@ -143,8 +148,13 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
     assert bias_pad.numel() == nct * 64 and bias_pad.dtype == torch.float32
     assert out_stats.dtype == torch.float64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, nct * 64, 2)
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
+    ws_bytes = 0
+    if workspace is not None:
+        assert workspace.is_cuda and workspace.is_contiguous()
+        ws_bytes = workspace.numel() * workspace.element_size()
     nv.check(nv.lib().dua_conv3d_k3_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),
-                                        nv.ptr(y), nv.ptr(out_stats), nv.stream_ptr()), "dua_conv3d_k3_fwd")
+                                        nv.ptr(y), nv.ptr(out_stats), nv.ptr(workspace), ws_bytes, nv.stream_ptr()),
+             "dua_conv3d_k3_fwd")
 
 
 def instnorm_finalize(norm, N, Cc):

@@ -54,9 +54,17 @@ typedef struct {
 } dua_conv3_desc;
 
 /* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32[ceil(Cout/64)*64].  in: NULL or the
- * producer descriptor of x.  y: raw output.  out_stats: fp64 [N][8][ceil(Cout/64)*64][2], pre-zeroed. */
+ * producer descriptor of x.  y: raw output.  out_stats: fp64 [N][8][ceil(Cout/64)*64][2], pre-zeroed.
+ * workspace (may be NULL): scratch for split-K on layers too small to fill 256 CUs (<= 24^3): the K range
+ * (Cin chunk x kd) is divided over workgroups, fp32 partial tiles land in the workspace and a finish kernel
+ * sums them, adds the bias and takes the statistics.  dua_conv3d_k3_workspace gives the bytes that enables it. */
+long dua_conv3d_k3_workspace(const dua_conv3_desc* d);
 int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
-                      const dua_in_norm* in, void* y, double* out_stats, void* stream);
+                      const dua_in_norm* in, void* y, double* out_stats, void* workspace, long workspace_bytes,
+                      void* stream);
+
+/* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (1 synchronous slabs, 2 LDS-DMA pipelined; default 2). */
+int dua_set_option(int key, int value);
 
 /* Packs nn.Conv3d weight fp32[Cout][Cin_src][3][3][3] into the kernel's slab order
  * [cout_tile][chunk][kd][kh*3+kw][k-group][64][16 B].  in_perm (device int32[Cin_packed], may be

@@ -63,6 +63,16 @@ def _producer(raw, dtype, g, add=None):
     return ops.Norm(stats, gamma.cuda(), beta.cuda(), count, **kw), act
 
 
+@pytest.fixture
+def conv_variant(request):
+    """Force one of the conv3d_k3 kernel variants (1: sync slabs, 2: 4x8x8 pipelined, 3: 8x8x8 512-thread)."""
+    from diff_unet_amos_amd import _native as nv
+    nv.check(nv.lib().dua_set_option(1, request.param), "dua_set_option")
+    yield request.param
+    nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
+
+
+@pytest.mark.parametrize("conv_variant", [1, 2, 3], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [
     # N, Cin, Cout, D, H, W
@@ -71,8 +81,9 @@ def _producer(raw, dtype, g, add=None):
     (1, 8, 8, 4, 8, 8),
     (1, 64, 128, 12, 12, 12),
     (1, 8, 16, 2, 2, 2),         # bottom level of the 32^3 config
+    (1, 72, 64, 16, 16, 24),     # several full tiles, three Cin chunks
 ])
-def test_conv3_raw_and_stats(dtype, shape):
+def test_conv3_raw_and_stats(dtype, shape, conv_variant):
     ops = _ops()
     N, Cin, Cout, D, H, W = shape
     g = torch.Generator().manual_seed(sum(shape))
@@ -106,7 +117,41 @@ def test_conv3_raw_and_stats(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-def test_conv3_fused_input_transform_and_channel_slices(dtype):
+@pytest.mark.parametrize("shape", [(1, 128, 256, 12, 12, 12), (2, 72, 136, 6, 6, 6), (1, 136, 64, 8, 16, 16)])
+def test_conv3_split_k(dtype, shape):
+    """Layers too small to fill 256 CUs split K = (Cin chunk, kd) over workgroups; fp32 partial tiles are
+    summed by the finish kernel, which also adds the bias and takes the InstanceNorm sums."""
+    ops = _ops()
+    N, Cin, Cout, D, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    raw = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    norm, act = _producer(raw, dtype, g, add=torch.randn(N, Cin, generator=g))
+    ref = F.conv3d(act.to(dtype).float(), w.to(dtype).float(), b, padding=1)
+    nbytes = ops.conv3_workspace_bytes(dtype, N, D, H, W, Cin, Cout)
+    assert nbytes > 0, "these shapes are expected to take the split-K path"
+    ws = torch.empty(nbytes // 4, device="cuda")
+    wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), dtype)
+    y = torch.full((N, D, H, W, Cout + 8), 2.0, dtype=dtype, device="cuda")
+    stats = ops.stats_buffer(N, Cout, "cuda")
+    ops.conv3d_k3(_cl(raw, dtype), Cin, 0, wp, bp, Cout, y, 8, stats, norm=norm, workspace=ws)
+    got = ops.from_channels_last(y, Cout, 8).cpu()
+    assert torch.allclose(got, ref, **TOL[dtype]), float((got - ref).abs().max())
+    assert float((y[..., :8].float() - 2).abs().max()) == 0
+    st = stats.cpu().sum(1)[:, :Cout]
+    gd = got.double().flatten(2)
+    assert torch.allclose(st[..., 0], gd.sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(st[..., 1], (gd * gd).sum(-1), rtol=1e-5, atol=1e-3)
+    # same layer without a workspace -> fused epilogue path; results must agree
+    y2 = torch.zeros_like(y); stats2 = ops.stats_buffer(N, Cout, "cuda")
+    ops.conv3d_k3(_cl(raw, dtype), Cin, 0, wp, bp, Cout, y2, 8, stats2, norm=norm)
+    assert torch.allclose(ops.from_channels_last(y2, Cout, 8).cpu(), got, **TOL[dtype])
+
+
+@pytest.mark.parametrize("conv_variant", [1, 2, 3], indirect=True)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_conv3_fused_input_transform_and_channel_slices(dtype, conv_variant):
     """Producer IN+LeakyReLU+temb add fused into the consumer's halo staging; input read from and
     output written to channel slices of wider buffers (the concat-in-place layout)."""
     ops = _ops()

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""A/B timing of conv3d_k3 variants on the layer shapes of the 96^3 x 16-class denoiser
+(interleaved rounds in one process, HIP events on the launch stream)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diff_unet_amos_amd import ops, _native as nv
+
+SHAPES = [  # (S, Cin, Cout, fused prologue)
+    (96, 24, 64, False), (96, 64, 64, True), (96, 128, 64, False),
+    (48, 64, 64, True), (48, 128, 64, False),
+    (24, 64, 128, False), (24, 128, 128, True), (24, 256, 128, False),
+    (12, 128, 256, False), (12, 256, 256, True), (12, 512, 256, False),
+    (6, 256, 512, False), (6, 512, 512, True),
+]
+
+
+def main():
+    variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "2"])]
+    only = [int(i) for i in sys.argv[2].split(",")] if len(sys.argv) > 2 else None
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    dt = torch.float16
+    dev = "cuda"
+    print(f"{'shape':>22} " + " ".join(f"{'v%d us' % v:>9} {'TF':>7}" for v in variants))
+    for idx, (S, cin, cout, fused) in enumerate(SHAPES):
+        if only is not None and idx not in only:
+            continue
+        x = torch.randn(1, S, S, S, cin, device=dev).to(dt)
+        w = torch.randn(cout, cin, 3, 3, 3, device=dev) / (27 * cin) ** 0.5
+        wp, bp = ops.pack_conv3_weights(w, torch.zeros(cout, device=dev), dt)
+        y = torch.empty(1, S, S, S, cout, device=dev, dtype=dt)
+        stats = ops.stats_buffer(1, cout, dev)
+        nb = ops.conv3_workspace_bytes(dt, 1, S, S, S, cin, cout)
+        ws = torch.empty(max(nb, 16) // 4, device=dev)
+        norm = None
+        if fused:
+            st = ops.stats_buffer(1, cin, dev)
+            st[:, 0, :, 0] = 0.0; st[:, 0, :, 1] = float(S ** 3)
+            norm = ops.Norm(st, torch.ones(cin, device=dev), torch.zeros(cin, device=dev), S ** 3,
+                            add=torch.zeros(cin, device=dev))
+        res = {v: [] for v in variants}
+        for rd in range(rounds + 1):
+            for v in variants:
+                nv.check(nv.lib().dua_set_option(1, v), "opt")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    ops.conv3d_k3(x, cin, 0, wp, bp, cout, y, 0, stats, norm=norm, workspace=ws)
+                e1.record()
+                torch.cuda.synchronize()
+                if rd > 0:
+                    res[v].append(e0.elapsed_time(e1) / 3 * 1e3)
+        fl = 2.0 * cin * cout * 27 * S ** 3
+        out = []
+        for v in variants:
+            us = sorted(res[v])[len(res[v]) // 2]
+            out.append(f"{us:9.1f} {fl / us / 1e6:7.1f}")
+        print(f"{S:>3}^3 {cin:>4}->{cout:<4} {'fused' if fused else '     '} " + " ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,7 @@ steps on one tensor) => N independent replicas, weak scaling, no
 collective; only the timing barrier/all-reduce(MAX) touches RCCL.
 
 Extra objects in the JSON line:
-  roofline     -- for the dominant kernel (conv3d_k3_kernel, all 18 launches of a step): algorithmic
+  roofline     -- for the dominant kernel (conv3d_k3_v2_kernel, all 18 launches of a step): algorithmic
                   FLOPs per launch / average launch duration, measured with HIP events on the launch
                   stream in an instrumented eager pass of the same steps; peak = dense fp16 MFMA.
   cpu_baseline -- the CPU oracle (oracle/unet_ref.py, "port") timed on this box's host cores on a
@@ -203,7 +203,7 @@ def main():
             flops_per_launch = sum(fl) / len(fl)
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_F32_TFLOPS
-            roof = {"bound": "mfma", "kernel": "conv3d_k3_kernel", "achieved": round(achieved, 2), "peak": peak,
+            roof = {"bound": "mfma", "kernel": "conv3d_k3_v2_kernel", "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 2),

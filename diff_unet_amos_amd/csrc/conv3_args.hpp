@@ -1,0 +1,21 @@
+// Launch arguments shared by the conv3d_k3 kernel variants.
+#pragma once
+#include "common.hpp"
+
+namespace dua {
+
+struct Conv3Args {
+  const void* x; const void* w; const float* bias; void* y;
+  double* stats;
+  InXform xf;
+  int N, D, H, W;
+  int Cin, Cin_stride, Cin_off;     // valid input channels, buffer stride, offset (elements)
+  int Cout, Cout_stride, Cout_off;
+  int nchunks, ntiles, tiles_h, tiles_w, cout_pad;
+  int ksplit, units_per_split;      // split-K over (chunk, kd) units; partial tiles go to `part` in fp32
+  float* part;
+};
+
+int launch_conv3_v4(Conv3Args& a, int N, int nct, int xf_bytes, hipStream_t s);
+
+}  // namespace dua

@@ -18,6 +18,7 @@
 // stride (656 B) and the 4x8 row->voxel map make every fragment read bank-conflict free.
 #include "common.hpp"
 #include "../../include/dua_hip.h"
+#include "conv3_args.hpp"
 
 namespace dua {
 
@@ -30,209 +31,12 @@ constexpr int RS = HW * VS + 16;           // 656: halo row stride, padded (bank
 constexpr int PS = HH * RS;                // 6560: halo plane stride
 constexpr int HALO_BYTES = HD * PS;        // 39360
 constexpr int BN = 64;                     // output channels per workgroup
-constexpr int WSLAB = 9 * KG * BN * 16;    // 36864: packed weights of one (chunk, kd)
-constexpr int LDS_BYTES = HALO_BYTES + WSLAB;  // 76224 (+ 12 B per input channel when the prologue is fused)
 constexpr int NITEMS = HD * HH * HW * KG;  // 2400 16-byte items per halo chunk
 constexpr int NIT = (NITEMS + 255) / 256;  // 10
 }  // namespace c3
 
-int g_conv_variant = 0;   // 0 = auto (v3 for >= 48^3, else v2); 1/2/3 force v1 (sync slabs), v2 (4x8x8 pipelined), v3 (8x8x8)
-
-struct Conv3Args {
-  const void* x; const void* w; const float* bias; void* y;
-  double* stats;
-  InXform xf;
-  int N, D, H, W;
-  int Cin, Cin_stride, Cin_off;     // valid input channels, buffer stride, offset (elements)
-  int Cout, Cout_stride, Cout_off;
-  int nchunks, ntiles, tiles_h, tiles_w, cout_pad;
-  int ksplit, units_per_split;      // split-K over (chunk, kd) units; partial tiles go to `part` in fp32
-  float* part;
-};
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
-  using namespace c3;
-  using Frag = typename Elem<T>::Frag;
-  constexpr int EPG = Elem<T>::EPG;
-  constexpr int CK = KG * EPG;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* halo = smem;
-  char* wlds = smem + HALO_BYTES;
-  float* xsc = (float*)(smem + LDS_BYTES);     // scale / shift / add of the fused input transform
-  float* xsh = xsc + a.nchunks * CK;
-  float* xad = xsh + a.nchunks * CK;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, hh = lane >> 5;
-  const int tile = xcd_remap(blockIdx.x, a.ntiles);
-  const int ct = blockIdx.y, n = blockIdx.z;
-  const int tw_ = tile % a.tiles_w, th_ = (tile / a.tiles_w) % a.tiles_h, td_ = tile / (a.tiles_w * a.tiles_h);
-  const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
-
-  // ---- per-thread halo staging geometry (chunk invariant) ----
-  const int kg_t = tid & (KG - 1);
-  long goff[NIT]; int loff[NIT];
-  const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off;
-#pragma unroll
-  for (int j = 0; j < NIT; ++j) {
-    int it = tid + 256 * j;
-    int hv = it >> 2;
-    int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
-    int gd = d0 + hd - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
-    bool ok = it < NITEMS && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-    goff[j] = ok ? (((long)gd * a.H + gh) * a.W + gw) * a.Cin_stride + kg_t * EPG : -1;
-    loff[j] = it < NITEMS ? hd * PS + hy * RS + hx * VS + kg_t * 16 : -1;
-  }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
-
-  if (a.xf.stats != nullptr) xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);   // visible after the loop's first barrier
-  const int a_base = wave * PS + (r >> 3) * RS + (r & 7) * VS + hh * 16;
-  const int b_base = (hh * BN + r) * 16;
-  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 3 * WSLAB;
-
-  for (int ch = 0; ch < a.nchunks; ++ch) {
-    __syncthreads();  // every wave is done reading the previous chunk's halo and weights
-    // ---- stage the halo tile of this chunk: global -> registers -> (transform) -> LDS ----
-    {
-      const int c0 = ch * CK + kg_t * EPG;
-      const bool cok = c0 < a.Cin;
-      Frag v[NIT];
-#pragma unroll
-      for (int j = 0; j < NIT; ++j) {
-        if (goff[j] >= 0 && cok) v[j] = *(const Frag*)(xin + goff[j] + ch * CK);
-        else
-#pragma unroll
-          for (int e = 0; e < EPG; ++e) v[j][e] = (T)0.f;
-      }
-      if (a.xf.stats != nullptr && cok) {
-        float sc[EPG], sh[EPG], ad[EPG];
-#pragma unroll
-        for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
-#pragma unroll
-        for (int j = 0; j < NIT; ++j)
-          if (goff[j] >= 0) v[j] = xform_frag<T>(v[j], sc, sh, ad, a.xf.slope);
-      }
-#pragma unroll
-      for (int j = 0; j < NIT; ++j)
-        if (loff[j] >= 0) *(Frag*)(halo + loff[j]) = v[j];
-    }
-#pragma unroll 1
-    for (int kd = 0; kd < 3; ++kd) {
-      if (kd > 0) __syncthreads();  // previous slab fully consumed
-      {
-        const char* src = wsrc + ((long)ch * 3 + kd) * WSLAB;
-#pragma unroll
-        for (int j = 0; j < WSLAB / 16 / 256; ++j)
-          *(f32x4*)(wlds + (tid + 256 * j) * 16) = *(const f32x4*)(src + (tid + 256 * j) * 16);
-      }
-      __syncthreads();
-      const char* ap = halo + a_base + kd * PS;
-#pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9) {
-        const int kh = t9 / 3, kw = t9 % 3;
-#pragma unroll
-        for (int ks = 0; ks < KG / 2; ++ks) {
-          Frag a0 = *(const Frag*)(ap + kh * RS + kw * VS + ks * 32);
-          Frag a1 = *(const Frag*)(ap + (kh + 4) * RS + kw * VS + ks * 32);
-          Frag b0 = *(const Frag*)(wlds + b_base + (t9 * KG + 2 * ks) * BN * 16);
-          Frag b1 = *(const Frag*)(wlds + b_base + (t9 * KG + 2 * ks) * BN * 16 + 32 * 16);
-          mma32(acc[0][0], a0, b0);
-          mma32(acc[0][1], a0, b1);
-          mma32(acc[1][0], a1, b0);
-          mma32(acc[1][1], a1, b1);
-        }
-      }
-    }
-  }
-
-  // ---- epilogue: bias, InstanceNorm partials, transpose through LDS, 16-byte stores ----
-  __syncthreads();
-  constexpr int OS = BN * (int)sizeof(T) + 16;  // padded row stride of the [voxel][cout] staging tile
-  char* ot = smem + wave * 64 * OS;
-  const int gd = d0 + wave;
-  const bool dok = gd < a.D;
-  float cnt = 0.f;
-  {
-    // valid voxels of this wave's slab (same for every lane)
-    int vh = min(TH, a.H - h0), vw = min(TW, a.W - w0);
-    cnt = dok ? (float)(vh * vw) : 0.f;
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int co = q * 32 + r;
-    const float bq = a.bias[ct * BN + co];
-    float s = 0.f;
-    float vals[2][16];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
-        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
-        T tv = (T)(acc[m][q][i] + bq);
-        float fv = ok ? (float)tv : 0.f;
-        vals[m][i] = fv;
-        s += fv;
-        *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + co * (int)sizeof(T)) = tv;
-      }
-    s += __shfl_xor(s, 32);
-    const float mean = cnt > 0.f ? s / cnt : 0.f;
-    float m2 = 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
-        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
-        const float dlt = vals[m][i] - mean;
-        m2 += ok ? dlt * dlt : 0.f;
-      }
-    m2 += __shfl_xor(m2, 32);
-    if (hh == 0) {
-      float* e = (float*)(smem + 4 * 64 * OS) + (wave * BN + co) * 2;   // per-wave (sum, M2) exchange
-      e[0] = s; e[1] = m2;
-    }
-  }
-  if (lane == 0) ((float*)(smem + 4 * 64 * OS))[4 * BN * 2 + wave] = cnt;
-  __syncthreads();
-  if (wave == 0) {
-    // combine the four slabs (Chan) and publish: sum x and sum x^2 of this tile, in fp64
-    const float* e = (const float*)(smem + 4 * 64 * OS);
-    double S = 0, Q = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float k = e[4 * BN * 2 + w];
-      if (k > 0.f) {
-        const double sw = (double)e[(w * BN + lane) * 2], mw = (double)e[(w * BN + lane) * 2 + 1];
-        S += sw; Q += mw + sw * sw / (double)k;
-      }
-    }
-    if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
-  }
-  if (dok) {
-    constexpr int GPV = BN / EPG;            // 16-byte groups per voxel
-    constexpr int VPI = 64 / GPV;            // voxels per wave-iteration
-    T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
-#pragma unroll
-    for (int it = 0; it < 64 / VPI; ++it) {
-      const int v = it * VPI + lane / GPV, cg = lane % GPV;
-      const int hl = v >> 3, wl = v & 7;
-      const int gh = h0 + hl, gw = w0 + wl;
-      if (gh < a.H && gw < a.W && ct * BN + cg * EPG < a.Cout) {
-        Frag o = *(const Frag*)(ot + v * OS + cg * 16);
-        *(Frag*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + cg * EPG) = o;
-      }
-    }
-  }
-}
+// 0 = auto (v2; split-K for small layers); 2 forces v2 without split-K, 4 the wave-specialised persistent v4
+int g_conv_variant = 0;
 
 // ------------------------------------------------------------------------------------------------
 // v2: same tile and fragment maps, software-pipelined.  Weights arrive as 12 KB (kd,kh) slabs, loaded to
@@ -335,13 +139,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
       if (loff[j] >= 0) *(Frag*)(halo + loff[j]) = hv_[j];
   };
 
+  // accumulators start at the bias of the lane's output channel (split-K adds it in the finish kernel instead)
   f32x16 acc[2][2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int q = 0; q < 2; ++q) {
+    const float b0 = a.ksplit > 1 ? 0.f : a.bias[ct * BN + q * 32 + r];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[m][q][i] = b0;
+  }
 
   // ---- work range: units u = chunk * 3 + kd, three (kd, kh) slabs each ----
   const int ks_id = blockIdx.z / a.N;
@@ -439,46 +246,45 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
     return;
   }
   // ---- epilogue, one 32-channel half at a time (fits fp32 too) ----
+  // Statistics are taken from the fp32 accumulators (sum x, sum x^2 per lane over its 32 voxels, then fp64);
+  // tiles that lie fully inside the volume -- all of them at 96/48/24^3 -- skip the per-voxel masks.
   constexpr int OS = 32 * (int)sizeof(T) + 16;
   char* ot = smem + wave * 64 * OS;
-  float* ex = (float*)(smem + 4 * 64 * OS);          // [4 waves][64 couts][2] + [4] counts
+  float* ex = (float*)(smem + 4 * 64 * OS);          // [4 waves][64 couts][2]
   const int gd = d0 + wave;
   const bool dok = gd < a.D;
-  const float cnt = dok ? (float)(min(TH, a.H - h0) * min(TW, a.W - w0)) : 0.f;
+  const bool full = d0 + TD <= a.D && h0 + TH <= a.H && w0 + TW <= a.W;
   T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int co = q * 32 + r;
-    const float bq = a.bias[ct * BN + co];
-    float s = 0.f;
-    float vals[2][16];
+    float s = 0.f, ss = 0.f;
+    if (full) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
-        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
-        T tv = (T)(acc[m][q][i] + bq);
-        float fv = ok ? (float)tv : 0.f;
-        vals[m][i] = fv;
-        s += fv;
-        *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = tv;
-      }
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[m][q][i];
+          s += v;
+          ss = fmaf(v, v, ss);
+          *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = (T)v;
+        }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
+          const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
+          const float v = ok ? acc[m][q][i] : 0.f;
+          s += v;
+          ss = fmaf(v, v, ss);
+          *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = (T)v;
+        }
+    }
     s += __shfl_xor(s, 32);
-    const float mean = cnt > 0.f ? s / cnt : 0.f;
-    float m2 = 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
-        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
-        const float dlt = vals[m][i] - mean;
-        m2 += ok ? dlt * dlt : 0.f;
-      }
-    m2 += __shfl_xor(m2, 32);
-    if (hh == 0) { ex[(wave * BN + co) * 2] = s; ex[(wave * BN + co) * 2 + 1] = m2; }
-    if (lane == 0) ex[4 * BN * 2 + wave] = cnt;
+    ss += __shfl_xor(ss, 32);
+    if (hh == 0) { ex[(wave * BN + co) * 2] = s; ex[(wave * BN + co) * 2 + 1] = ss; }
     __syncthreads();
     if (dok) {
       constexpr int GPV = 32 / EPG;            // 16-byte groups per voxel in this half
@@ -487,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
       for (int it = 0; it < 64 / VPI; ++it) {
         const int v = it * VPI + lane / GPV, cg = lane % GPV;
         const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
-        if (gh < a.H && gw < a.W && ct * BN + q * 32 + cg * EPG < a.Cout)
+        if ((full || (gh < a.H && gw < a.W)) && ct * BN + q * 32 + cg * EPG < a.Cout)
           *(Frag*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + q * 32 + cg * EPG) =
               *(const Frag*)(ot + v * OS + cg * 16);
       }
@@ -497,234 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   if (wave == 0) {
     double S = 0, Q = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float k = ex[4 * BN * 2 + w];
-      if (k > 0.f) {
-        const double sw = (double)ex[(w * BN + lane) * 2], mw = (double)ex[(w * BN + lane) * 2 + 1];
-        S += sw; Q += mw + sw * sw / (double)k;
-      }
-    }
-    if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// v3: 8x8x8 output tile (512 voxels) x 64 channels per 512-thread workgroup, one workgroup per CU.
-// Why: at 4x8x8 the kernel is bound by L2->LDS traffic, not MFMA -- every 256-voxel tile re-reads the
-// whole 64-channel weight block (2 GB per 128->64 @96^3 launch, ~20 TB/s of L2).  Doubling M halves the
-// weight traffic per FLOP and cuts halo amplification from 2.34x to 1.95x.  Eight waves (two per SIMD)
-// each own a depth slice exactly as before; weights move as 36 KB kd-slabs (9 taps), register-staged one
-// slab ahead into a double buffer; three barriers per Cin chunk.
-namespace c3v3 {
-constexpr int TD = 8, TH = 8, TW = 8, HD = 10, HH = 10, HW = 10, KG = 4, BN = 64;
-constexpr int VS = 64, RS = HW * VS + 16, PS = HH * RS;     // 64, 656, 6560
-constexpr int HALO_BYTES = HD * PS;                          // 65600
-constexpr int SLAB = 9 * KG * BN * 16;                       // 36864
-constexpr int LDS_MAIN = HALO_BYTES + 2 * SLAB;              // 139328
-constexpr int NT = 512;
-constexpr int NITEMS = HD * HH * HW * KG;                    // 4000
-constexpr int NIT = (NITEMS + NT - 1) / NT;                  // 8
-constexpr int WIT = (SLAB / 16 + NT - 1) / NT;               // 5 (last one half populated)
-}  // namespace c3v3
-
-template <typename T>
-__global__ __launch_bounds__(512, 2) void conv3d_k3_v3_kernel(Conv3Args a) {
-  using namespace c3v3;
-  using Frag = typename Elem<T>::Frag;
-  constexpr int EPG = Elem<T>::EPG;
-  constexpr int CK = KG * EPG;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* halo = smem;
-  char* wbuf = smem + HALO_BYTES;
-  float* xsc = (float*)(smem + LDS_MAIN);
-  float* xsh = xsc + a.nchunks * CK;
-  float* xad = xsh + a.nchunks * CK;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, hh = lane >> 5;
-  const int tile = xcd_remap(blockIdx.x, a.ntiles);
-  const int ct = blockIdx.y, n = blockIdx.z;
-  const int tw_ = tile % a.tiles_w, th_ = (tile / a.tiles_w) % a.tiles_h, td_ = tile / (a.tiles_w * a.tiles_h);
-  const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
-  const bool fused = a.xf.stats != nullptr;
-
-  const int kg_t = tid & (KG - 1);
-  int goff[NIT]; int loff[NIT];        // element offsets fit 32 bits for one batch item (checked on the host)
-  const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off;
-#pragma unroll
-  for (int j = 0; j < NIT; ++j) {
-    int it = tid + NT * j;
-    int hv = it >> 2;
-    int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
-    int gd = d0 + hd - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
-    bool ok = it < NITEMS && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-    goff[j] = ok ? ((gd * a.H + gh) * a.W + gw) * a.Cin_stride + kg_t * EPG : -1;
-    loff[j] = it < NITEMS ? hd * PS + hy * RS + hx * VS + kg_t * 16 : -1;
-  }
-  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 3 * SLAB;
-  f32x4 wreg[WIT];
-  auto load_slab = [&](int g) {       // g = chunk * 3 + kd
-    const char* src = wsrc + (long)g * SLAB + tid * 16;
-#pragma unroll
-    for (int j = 0; j < WIT; ++j)
-      if (j < WIT - 1 || tid + NT * j < SLAB / 16) wreg[j] = *(const f32x4*)(src + j * NT * 16);
-  };
-  auto store_slab = [&](int g) {
-    char* dst = wbuf + (g & 1) * SLAB + tid * 16;
-#pragma unroll
-    for (int j = 0; j < WIT; ++j)
-      if (j < WIT - 1 || tid + NT * j < SLAB / 16) *(f32x4*)(dst + j * NT * 16) = wreg[j];
-  };
-  Frag hv_[NIT];
-  auto load_halo = [&](int ch) {
-    const bool cok = ch * CK + kg_t * EPG < a.Cin;
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      if (goff[j] >= 0 && cok) hv_[j] = *(const Frag*)(xin + goff[j] + ch * CK);
-      else
-#pragma unroll
-        for (int e = 0; e < EPG; ++e) hv_[j][e] = (T)0.f;
-    }
-  };
-  auto store_halo = [&](int ch) {
-    const int c0 = ch * CK + kg_t * EPG;
-    if (fused && c0 < a.Cin) {
-      float sc[EPG], sh[EPG], ad[EPG];
-#pragma unroll
-      for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
-#pragma unroll
-      for (int j = 0; j < NIT; ++j)
-        if (goff[j] >= 0) hv_[j] = xform_frag<T>(hv_[j], sc, sh, ad, a.xf.slope);
-    }
-#pragma unroll
-    for (int j = 0; j < NIT; ++j)
-      if (loff[j] >= 0) *(Frag*)(halo + loff[j]) = hv_[j];
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
-
-  load_slab(0);
-  load_halo(0);
-  if (fused) {
-    xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
-    __syncthreads();
-  }
-  store_slab(0);
-  store_halo(0);
-  __syncthreads();
-
-  const int a_base = wave * PS + (r >> 3) * RS + (r & 7) * VS + hh * 16;
-  const int b_base = (hh * BN + r) * 16;
-  const int nslabs = a.nchunks * 3;
-  for (int ch = 0; ch < a.nchunks; ++ch) {
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd) {
-      const int g = ch * 3 + kd;
-      if (g + 1 < nslabs) load_slab(g + 1);
-      if (kd == 2 && ch + 1 < a.nchunks) load_halo(ch + 1);
-      const char* ap = halo + a_base + kd * PS;
-      const char* wb = wbuf + (g & 1) * SLAB + b_base;
-      // 18 k-steps (kh x kw x ks); fragments of step t+1 are in flight while the MFMAs of step t issue
-      Frag fa0[2], fa1[2], fb0[2], fb1[2];
-      auto ld = [&](int t, int b) {
-        const int t9 = t >> 1, ks = t & 1, kh = t9 / 3, kw = t9 % 3;
-        fa0[b] = *(const Frag*)(ap + kh * RS + kw * VS + ks * 32);
-        fb0[b] = *(const Frag*)(wb + (t9 * KG + 2 * ks) * BN * 16);
-        fb1[b] = *(const Frag*)(wb + (t9 * KG + 2 * ks) * BN * 16 + 32 * 16);
-        fa1[b] = *(const Frag*)(ap + (kh + 4) * RS + kw * VS + ks * 32);
-      };
-      ld(0, 0);
-#pragma unroll
-      for (int t = 0; t < 18; ++t) {
-        if (t + 1 < 18) ld(t + 1, (t + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
-        mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
-        mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
-        mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
-        mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (g + 1 < nslabs) store_slab(g + 1);   // the other buffer: last read before the previous barrier
-      __syncthreads();
-    }
-    if (ch + 1 < a.nchunks) {
-      store_halo(ch + 1);
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue, one 32-channel half at a time ----
-  constexpr int OS = 32 * (int)sizeof(T) + 16;
-  char* ot = smem + wave * 64 * OS;
-  float* ex = (float*)(smem + 8 * 64 * OS);          // [8 waves][64 couts][2] + [8] counts
-  const int gd = d0 + wave;
-  const bool dok = gd < a.D;
-  const float cnt = dok ? (float)(min(TH, a.H - h0) * min(TW, a.W - w0)) : 0.f;
-  T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int co = q * 32 + r;
-    const float bq = a.bias[ct * BN + co];
-    float s = 0.f;
-    float vals[2][16];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
-        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
-        T tv = (T)(acc[m][q][i] + bq);
-        float fv = ok ? (float)tv : 0.f;
-        vals[m][i] = fv;
-        s += fv;
-        *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = tv;
-      }
-    s += __shfl_xor(s, 32);
-    const float mean = cnt > 0.f ? s / cnt : 0.f;
-    float m2 = 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
-        const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
-        const float dlt = vals[m][i] - mean;
-        m2 += ok ? dlt * dlt : 0.f;
-      }
-    m2 += __shfl_xor(m2, 32);
-    if (hh == 0) { ex[(wave * BN + co) * 2] = s; ex[(wave * BN + co) * 2 + 1] = m2; }
-    if (lane == 0) ex[8 * BN * 2 + wave] = cnt;
-    __syncthreads();
-    if (dok) {
-      constexpr int GPV = 32 / EPG;
-      constexpr int VPI = 64 / GPV;
-#pragma unroll
-      for (int it = 0; it < 64 / VPI; ++it) {
-        const int v = it * VPI + lane / GPV, cg = lane % GPV;
-        const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
-        if (gh < a.H && gw < a.W && ct * BN + q * 32 + cg * EPG < a.Cout)
-          *(Frag*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + q * 32 + cg * EPG) =
-              *(const Frag*)(ot + v * OS + cg * 16);
-      }
-    }
-    if (q == 0) __syncthreads();
-  }
-  if (wave == 0) {
-    double S = 0, Q = 0;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      const float k = ex[8 * BN * 2 + w];
-      if (k > 0.f) {
-        const double sw = (double)ex[(w * BN + lane) * 2], mw = (double)ex[(w * BN + lane) * 2 + 1];
-        S += sw; Q += mw + sw * sw / (double)k;
-      }
-    }
+    for (int w = 0; w < 4; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
     if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
   }
 }
@@ -789,6 +368,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   }
 }
 
+static inline bool ws_dummy_false() { return false; }   // v4 stays opt-in until it is validated on the GPU
+
 static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups) {
   *ksplit = 1; *ups = units;
   if (base_wgs > 64 || units <= 1) return;        // 24^3 and up: the partial-tile round trip costs more than it buys
@@ -820,25 +401,18 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   const int xf_bytes = in && in->stats ? 3 * 4 * a.nchunks * CK : 0;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 3 * 4 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
 #ifdef DUA_ABLATE
 #define DUA_ABL_ATTR(M) hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, M>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
     DUA_ABL_ATTR(1) DUA_ABL_ATTR(2) DUA_ABL_ATTR(4) DUA_ABL_ATTR(8) DUA_ABL_ATTR(12) DUA_ABL_ATTR(16) DUA_ABL_ATTR(19) DUA_ABL_ATTR(23) DUA_ABL_ATTR(27) DUA_ABL_ATTR(3)
 #endif
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv3d_k3_v3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v3::LDS_MAIN + 3 * 4 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  if (g_conv_variant == 3 || (g_conv_variant == 0 && d->D * d->H * d->W >= 48 * 48 * 48)) {
-    if ((long)d->D * d->H * d->W * d->Cin_stride >= (1L << 31)) return DUA_ERR_ARG;
-    const int td8 = (d->D + 7) / 8;
-    a.ntiles = td8 * a.tiles_h * a.tiles_w;
-    dim3 grid8(a.ntiles, nct, d->N);
-    hipLaunchKernelGGL(conv3d_k3_v3_kernel<T>, grid8, dim3(512), c3v3::LDS_MAIN + xf_bytes, s, a);
-    return (int)hipGetLastError();
+  if (sizeof(T) == 2 && d->Cin <= 128 && a.ksplit == 1 &&
+      (g_conv_variant == 4 || (g_conv_variant > 200 && g_conv_variant < 216) || (g_conv_variant == 0 && a.ntiles * nct * d->N >= 1024 && ws_dummy_false()))) {
+    a.part = ws;     // diagnostic builds write their cycle stamps here
+    return launch_conv3_v4(a, d->N, nct, xf_bytes, s);
   }
   const long vox = (long)d->D * d->H * d->W;
   if (ws != nullptr && g_conv_variant == 0) {
@@ -859,9 +433,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
     return (int)hipGetLastError();
   }
-  if (g_conv_variant == 1)
-    hipLaunchKernelGGL(conv3d_k3_kernel<T>, grid, dim3(256), LDS_BYTES + xf_bytes, s, a);
-  else if (g_conv_variant == 2 || g_conv_variant == 0)
+  if (g_conv_variant == 2 || g_conv_variant == 0 || g_conv_variant == 4)
     hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
 #ifdef DUA_ABLATE
 #define DUA_ABL_CASE(M) else if (g_conv_variant == 100 + M) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, M>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
@@ -875,7 +447,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
 extern "C" {
 
 int dua_set_option(int key, int value) {
-  if (key == 1 && ((value >= 0 && value <= 3) || (value >= 100 && value < 132))) { dua::g_conv_variant = value; return 0; }
+  if (key == 1 && (value == 0 || value == 2 || value == 4 || (value >= 100 && value < 132) || (value > 200 && value < 216))) { dua::g_conv_variant = value; return 0; }
   return DUA_ERR_ARG;
 }
 

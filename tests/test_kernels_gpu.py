@@ -65,14 +65,15 @@ def _producer(raw, dtype, g, add=None):
 
 @pytest.fixture
 def conv_variant(request):
-    """Force one of the conv3d_k3 kernel variants (1: sync slabs, 2: 4x8x8 pipelined, 3: 8x8x8 512-thread)."""
+    """Force one of the conv3d_k3 kernel variants (1: sync slabs, 2: 4x8x8 pipelined, 3: 8x8x8 512-thread,
+    4: wave-specialised persistent; fp16 and Cin <= 128 only, otherwise it falls back to 2)."""
     from diff_unet_amos_amd import _native as nv
     nv.check(nv.lib().dua_set_option(1, request.param), "dua_set_option")
     yield request.param
     nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
 
 
-@pytest.mark.parametrize("conv_variant", [1, 2, 3], indirect=True)
+@pytest.mark.parametrize("conv_variant", [2, 4], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [
     # N, Cin, Cout, D, H, W
@@ -101,19 +102,21 @@ def test_conv3_raw_and_stats(dtype, shape, conv_variant):
     got = ops.from_channels_last(y, Cout).cpu()
     assert torch.allclose(got, ref, **TOL[dtype]), float((got - ref).abs().max())
 
-    # statistics -> scale/shift, against instance_norm of the kernel's own (rounded) output
+    # statistics (taken from the fp32 accumulators) -> scale/shift, against instance_norm of the exact conv
     st = stats.cpu().sum(1)[:, :Cout]
-    gd = got.double().flatten(2)
-    assert torch.allclose(st[..., 0], gd.sum(-1), rtol=1e-6, atol=1e-4)
-    assert torch.allclose(st[..., 1], (gd * gd).sum(-1), rtol=1e-5, atol=1e-4)
+    rd = ref.double().flatten(2)
+    stol = dict(rtol=1e-5, atol=1e-3) if dtype == torch.float32 else dict(rtol=2e-3, atol=2e-2)
+    assert torch.allclose(st[..., 0], rd.sum(-1), **stol)
+    assert torch.allclose(st[..., 1], (rd * rd).sum(-1), **stol)
     gamma = torch.rand(Cout, generator=g) + 0.5
     beta = torch.randn(Cout, generator=g)
     scale, shift = ops.instnorm_finalize(ops.Norm(stats, gamma.cuda(), beta.cuda(), D * H * W), N, Cout)
-    var, mean = torch.var_mean(got.double(), dim=(2, 3, 4), unbiased=False)
+    var, mean = torch.var_mean(ref.double(), dim=(2, 3, 4), unbiased=False)
     sc_ref = gamma.double()[None] / torch.sqrt(var + 1e-5)
     sh_ref = beta.double()[None] - mean * sc_ref
-    assert torch.allclose(scale.cpu().double(), sc_ref, rtol=1e-5, atol=1e-6)
-    assert torch.allclose(shift.cpu().double(), sh_ref, rtol=1e-5, atol=1e-5)
+    ftol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=5e-3, atol=5e-3)
+    assert torch.allclose(scale.cpu().double(), sc_ref, **ftol)
+    assert torch.allclose(shift.cpu().double(), sh_ref, **ftol)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
@@ -140,7 +143,7 @@ def test_conv3_split_k(dtype, shape):
     assert torch.allclose(got, ref, **TOL[dtype]), float((got - ref).abs().max())
     assert float((y[..., :8].float() - 2).abs().max()) == 0
     st = stats.cpu().sum(1)[:, :Cout]
-    gd = got.double().flatten(2)
+    gd = got.double().flatten(2)                        # the split-K finish kernel takes its sums from the stored values
     assert torch.allclose(st[..., 0], gd.sum(-1), rtol=1e-5, atol=1e-3)
     assert torch.allclose(st[..., 1], (gd * gd).sum(-1), rtol=1e-5, atol=1e-3)
     # same layer without a workspace -> fused epilogue path; results must agree
@@ -149,7 +152,7 @@ def test_conv3_split_k(dtype, shape):
     assert torch.allclose(ops.from_channels_last(y2, Cout, 8).cpu(), got, **TOL[dtype])
 
 
-@pytest.mark.parametrize("conv_variant", [1, 2, 3], indirect=True)
+@pytest.mark.parametrize("conv_variant", [2, 4], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_conv3_fused_input_transform_and_channel_slices(dtype, conv_variant):
     """Producer IN+LeakyReLU+temb add fused into the consumer's halo staging; input read from and

@@ -203,8 +203,12 @@ def main():
             flops_per_launch = sum(fl) / len(fl)
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_F32_TFLOPS
+            traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/), fp16 path only
+            tj = os.path.join(ROOT, "profiles", "r1_conv_traffic.json")
+            if args.dtype == "f16" and os.path.exists(tj):
+                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": "conv3d_k3_v2_kernel", "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 2),
                     "conv_ms_per_step": round(avg_ms * per_step, 3),

@@ -156,6 +156,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   const int u1 = min(a.nchunks * 3, u0 + a.units_per_split);
   const int g0 = u0 * 3, g1 = u1 * 3;
 
+  unsigned long long t0s = 0, t_bar = 0, t_pro = 0, t_epi = 0;
+  if (ABL & 32) t0s = __builtin_amdgcn_s_memtime();
   // ---- prologue ----
   load_slab(g0, 0);
   load_slab(g0 + 1, 1);
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   store_slab(g0, 0);
   store_halo(u0 / 3);
   __syncthreads();
+  if (ABL & 32) t_pro = __builtin_amdgcn_s_memtime() - t0s;
 
   const int a_base = wave * PS + (r >> 3) * RS + (r & 7) * VS + hh * 16;
   const int b_base = (hh * BN + r) * 16;
@@ -205,14 +208,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      unsigned long long tb = 0;
+      if (ABL & 32) tb = __builtin_amdgcn_s_memtime();
       if (g + 1 < g1) store_slab(g + 1, (kh + 1) % 3);   // the other buffer: last read before the previous barrier
       __syncthreads();   // next slab visible and everyone is done with this one
+      if (ABL & 32) t_bar += __builtin_amdgcn_s_memtime() - tb;
     }
     if (next_chunk) {
+      unsigned long long tb = 0;
+      if (ABL & 32) tb = __builtin_amdgcn_s_memtime();
       store_halo(u / 3 + 1);
       __syncthreads();
+      if (ABL & 32) t_epi += __builtin_amdgcn_s_memtime() - tb;     // chunk-boundary halo store, reported with the epilogue
     }
   }
+  unsigned long long te = 0;
+  if (ABL & 32) te = __builtin_amdgcn_s_memtime();
 
   if (ABL & 16) {
     if (acc[0][0][0] == 123.f && acc[0][1][1] == 5.f && acc[1][0][2] == 7.f && acc[1][1][3] == 9.f) ((float*)a.y)[0] = 1.f;
@@ -305,6 +316,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
     if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
+  }
+  if ((ABL & 32) && lane == 0 && a.part != nullptr) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = (unsigned long long*)a.part + ((long)blockIdx.x * 4 + wave) * 8;
+    o[0] = now - t0s; o[1] = t_bar; o[2] = t_pro; o[3] = now - te; o[4] = t_epi; o[5] = (unsigned long long)(g1 - g0);
   }
 }
 
@@ -404,7 +420,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
 #ifdef DUA_ABLATE
 #define DUA_ABL_ATTR(M) hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, M>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
-    DUA_ABL_ATTR(1) DUA_ABL_ATTR(2) DUA_ABL_ATTR(4) DUA_ABL_ATTR(8) DUA_ABL_ATTR(12) DUA_ABL_ATTR(16) DUA_ABL_ATTR(19) DUA_ABL_ATTR(23) DUA_ABL_ATTR(27) DUA_ABL_ATTR(3)
+    DUA_ABL_ATTR(32) DUA_ABL_ATTR(1) DUA_ABL_ATTR(2) DUA_ABL_ATTR(4) DUA_ABL_ATTR(8) DUA_ABL_ATTR(12) DUA_ABL_ATTR(16) DUA_ABL_ATTR(19) DUA_ABL_ATTR(23) DUA_ABL_ATTR(27) DUA_ABL_ATTR(3)
 #endif
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -436,8 +452,8 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   if (g_conv_variant == 2 || g_conv_variant == 0 || g_conv_variant == 4)
     hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
 #ifdef DUA_ABLATE
-#define DUA_ABL_CASE(M) else if (g_conv_variant == 100 + M) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, M>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
-  DUA_ABL_CASE(1) DUA_ABL_CASE(2) DUA_ABL_CASE(4) DUA_ABL_CASE(8) DUA_ABL_CASE(12) DUA_ABL_CASE(16) DUA_ABL_CASE(19) DUA_ABL_CASE(23) DUA_ABL_CASE(27) DUA_ABL_CASE(3)
+#define DUA_ABL_CASE(M) else if (g_conv_variant == 100 + M) { a.part = ws; hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, M>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a); }
+  DUA_ABL_CASE(32) DUA_ABL_CASE(1) DUA_ABL_CASE(2) DUA_ABL_CASE(4) DUA_ABL_CASE(8) DUA_ABL_CASE(12) DUA_ABL_CASE(16) DUA_ABL_CASE(19) DUA_ABL_CASE(23) DUA_ABL_CASE(27) DUA_ABL_CASE(3)
 #endif
   return (int)hipGetLastError();
 }
@@ -447,7 +463,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
 extern "C" {
 
 int dua_set_option(int key, int value) {
-  if (key == 1 && (value == 0 || value == 2 || value == 4 || (value >= 100 && value < 132) || (value > 200 && value < 216))) { dua::g_conv_variant = value; return 0; }
+  if (key == 1 && (value == 0 || value == 2 || value == 4 || (value >= 100 && value <= 132) || (value > 200 && value < 216))) { dua::g_conv_variant = value; return 0; }
   return DUA_ERR_ARG;
 }
 

@@ -291,13 +291,13 @@ def test_q_sample_and_sampler_steps_against_reference_golden(golden):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("C", [2, 16])
+@pytest.mark.parametrize("C,K", [(2, 24), (16, 24), (16, 64), (13, 64), (9, 32)])   # K % 32 == 0 and 8 < C <= 16: MFMA tail (fp16)
 @pytest.mark.parametrize("mode", ["logits", "ddpm", "ddim"])
-def test_final_conv_sampler(dtype, C, mode):
+def test_final_conv_sampler(dtype, C, K, mode):
     from diff_unet_amos_amd import _native as nv
     from diff_unet_amos_amd.gaussian_diffusion import make_spaced
     ops = _ops()
-    N, K, D, H, W = 2, 24, 4, 6, 10
+    N, D, H, W = 2, 4, 6, 10
     vox = D * H * W
     g = torch.Generator().manual_seed(C)
     raw = torch.randn(N, K, D, H, W, generator=g)
@@ -314,7 +314,7 @@ def test_final_conv_sampler(dtype, C, mode):
     args = dict(norm=norm, wf=wf.cuda(), bf=bf.cuda())
     rawcl = _cl(raw, dtype)
     logits = torch.zeros(N, C, D, H, W, device="cuda")
-    tol = dict(rtol=1e-4, atol=1e-4)
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-3, atol=5e-3)   # fp16 head operands
     if mode == "logits":
         ops.final_conv_sampler(rawcl, K, num_classes=C, mode=nv.MODE_LOGITS, logits=logits, **args)
         assert torch.allclose(logits.cpu(), logits_ref, **tol)
@@ -339,10 +339,11 @@ def test_final_conv_sampler(dtype, C, mode):
     assert float((xin[..., C:].float() - 4).abs().max()) == 0     # image / pad channels untouched
 
 
-def test_in_kernel_philox_noise_is_standard_normal():
+@pytest.mark.parametrize("K", [8, 32])        # VALU tail / MFMA tail
+def test_in_kernel_philox_noise_is_standard_normal(K):
     from diff_unet_amos_amd import _native as nv
     ops = _ops()
-    N, K, C, D, H, W = 1, 8, 16, 16, 32, 32
+    N, C, D, H, W = 1, 16, 16, 32, 32
     raw = torch.zeros(N, D, H, W, K, dtype=torch.float16, device="cuda")
     z = ops.Norm(ops.stats_buffer(N, K, "cuda"), torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"), D * H * W)
     state = torch.zeros(N, D, H, W, 16, device="cuda")

@@ -443,7 +443,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     if (a.cout_pad / 4 > 256) return DUA_ERR_ARG;
     const int VL = 256 / G;
     int ITER = 8;
-    while (ITER > 1 && (vox + (long)VL * ITER - 1) / ((long)VL * ITER) < 512) ITER >>= 1;
+    while (ITER > 1 && (vox + (long)VL * ITER - 1) / ((long)VL * ITER) < 128) ITER >>= 1;   // >= ~128 blocks; fewer blocks = fewer fp64 atomics
     dim3 fgrid((unsigned)((vox + (long)VL * ITER - 1) / ((long)VL * ITER)), d->N);
     hipLaunchKernelGGL(splitk_finish_kernel<T>, fgrid, dim3(256), 0, s, (const float*)ws, a.ksplit, d->N, vox, a.cout_pad,
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);

@@ -58,9 +58,14 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 
 // ABL (diagnostic builds only; outputs are wrong) bit mask: 1 = no MFMA, 2 = no fragment reads, 4 = no
 // weight staging, 8 = no halo staging, 16 = no epilogue.
-template <typename T, int ABL = 0>
+// TDP = tile depth: 4 (4x8x8 voxels, wave = depth slice, two 32-row blocks per wave) or 2 (2x8x8 voxels, wave =
+// (depth slice, h half), one block per wave) -- the small tile doubles the workgroup count of the 24^3 layers.
+template <typename T, int ABL = 0, int TDP = 4>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   using namespace c3v2;
+  constexpr int TD = TDP, HD = TDP + 2, MB = TDP / 2;
+  constexpr int HALO_BYTES = HD * PS, LDS_MAIN = HALO_BYTES + 2 * SLAB;
+  constexpr int NITEMS = HD * HH * HW * KG, NIT = (NITEMS + 255) / 256;
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
   constexpr int CK = KG * EPG;
@@ -73,6 +78,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
+  const int dwave = TDP == 4 ? wave : wave >> 1;          // depth slice of this wave
+  const int hbase = TDP == 4 ? 0 : (wave & 1) * 4;        // first h row of this wave's block(s)
   const int tile = xcd_remap(blockIdx.x, a.ntiles);
   const int ct = blockIdx.y, n = blockIdx.z % a.N;
   const int tw_ = tile % a.tiles_w, th_ = (tile / a.tiles_w) % a.tiles_h, td_ = tile / (a.tiles_w * a.tiles_h);
@@ -140,12 +147,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   };
 
   // accumulators start at the bias of the lane's output channel (split-K adds it in the finish kernel instead)
-  f32x16 acc[2][2];
+  f32x16 acc[MB][2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const float b0 = a.ksplit > 1 ? 0.f : a.bias[ct * BN + q * 32 + r];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][q][i] = b0;
   }
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   __syncthreads();
   if (ABL & 32) t_pro = __builtin_amdgcn_s_memtime() - t0s;
 
-  const int a_base = wave * PS + (r >> 3) * RS + (r & 7) * VS + hh * 16;
+  const int a_base = dwave * PS + (hbase + (r >> 3)) * RS + (r & 7) * VS + hh * 16;
   const int b_base = (hh * BN + r) * 16;
   for (int u = u0; u < u1; ++u) {
     const int kd = u % 3;
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
         fa0[b] = *(const Frag*)(ap + kw * VS + ks * 32);
         fb0[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16);
         fb1[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16 + 32 * 16);
-        fa1[b] = *(const Frag*)(ap + 4 * RS + kw * VS + ks * 32);
+        if (MB == 2) fa1[b] = *(const Frag*)(ap + 4 * RS + kw * VS + ks * 32);
       };
       ld(0, 0);
 #pragma unroll
@@ -199,12 +206,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
         if (t + 1 < 6) ld(t + 1, (t + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
         if (ABL & 1) {
-          asm volatile("" ::"v"(fa0[t & 1]), "v"(fb0[t & 1]), "v"(fa1[t & 1]), "v"(fb1[t & 1]));
+          asm volatile("" ::"v"(fa0[t & 1]), "v"(fb0[t & 1]), "v"(fb1[t & 1]));
+          if (MB == 2) asm volatile("" ::"v"(fa1[t & 1]));
         } else {
           mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
           mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
-          mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
-          mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
+          if constexpr (MB == 2) {
+            mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
+            mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -226,27 +236,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   if (ABL & 32) te = __builtin_amdgcn_s_memtime();
 
   if (ABL & 16) {
-    if (acc[0][0][0] == 123.f && acc[0][1][1] == 5.f && acc[1][0][2] == 7.f && acc[1][1][3] == 9.f) ((float*)a.y)[0] = 1.f;
+    if (acc[0][0][0] == 123.f && acc[0][1][1] == 5.f) ((float*)a.y)[0] = 1.f;
     return;
   }
   if (a.ksplit > 1) {
     // ---- split-K: this workgroup's fp32 partial tile goes to part[ks][n][voxel][cout_pad] ----
     constexpr int OSF = 32 * 4 + 16;
-    char* otf = smem + wave * 64 * OSF;
-    const int gdz = d0 + wave;
+    char* otf = smem + wave * (32 * MB) * OSF;
+    const int gdz = d0 + dwave;
     float* pout = a.part + ((long)(ks_id * a.N + n) * a.D * a.H * a.W) * a.cout_pad + ct * BN;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) *(float*)(otf + (m * 32 + acc_row(i, hh)) * OSF + r * 4) = acc[m][q][i];
       __syncthreads();
       if (gdz < a.D) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < 4 * MB; ++it) {
           const int v = it * 8 + (lane >> 3), cg = lane & 7;
-          const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
+          const int gh = h0 + hbase + (v >> 3), gw = w0 + (v & 7);
           if (gh < a.H && gw < a.W)
             *(f32x4*)(pout + (((long)gdz * a.H + gh) * a.W + gw) * a.cout_pad + q * 32 + cg * 4) =
                 *(const f32x4*)(otf + v * OSF + cg * 16);
@@ -260,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   // Statistics are taken from the fp32 accumulators (sum x, sum x^2 per lane over its 32 voxels, then fp64);
   // tiles that lie fully inside the volume -- all of them at 96/48/24^3 -- skip the per-voxel masks.
   constexpr int OS = 32 * (int)sizeof(T) + 16;
-  char* ot = smem + wave * 64 * OS;
-  float* ex = (float*)(smem + 4 * 64 * OS);          // [4 waves][64 couts][2]
-  const int gd = d0 + wave;
+  char* ot = smem + wave * (32 * MB) * OS;
+  float* ex = (float*)(smem + 4 * (32 * MB) * OS);   // [4 waves][64 couts][2]
+  const int gd = d0 + dwave;
   const bool dok = gd < a.D;
   const bool full = d0 + TD <= a.D && h0 + TH <= a.H && w0 + TW <= a.W;
   T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
     float s = 0.f, ss = 0.f;
     if (full) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float v = acc[m][q][i];
@@ -282,10 +292,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
         }
     } else {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
+          const int hl = hbase + 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
           const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
           const float v = ok ? acc[m][q][i] : 0.f;
           s += v;
@@ -301,9 +311,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
       constexpr int GPV = 32 / EPG;            // 16-byte groups per voxel in this half
       constexpr int VPI = 64 / GPV;
 #pragma unroll
-      for (int it = 0; it < 64 / VPI; ++it) {
+      for (int it = 0; it < (32 * MB) / VPI; ++it) {
         const int v = it * VPI + lane / GPV, cg = lane % GPV;
-        const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
+        const int gh = h0 + hbase + (v >> 3), gw = w0 + (v & 7);
         if ((full || (gh < a.H && gw < a.W)) && ct * BN + q * 32 + cg * EPG < a.Cout)
           *(Frag*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + q * 32 + cg * EPG) =
               *(const Frag*)(ot + v * OS + cg * 16);
@@ -418,6 +428,8 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
 #ifdef DUA_ABLATE
 #define DUA_ABL_ATTR(M) hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, M>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 3 * 4 * 1024);
     DUA_ABL_ATTR(32) DUA_ABL_ATTR(1) DUA_ABL_ATTR(2) DUA_ABL_ATTR(4) DUA_ABL_ATTR(8) DUA_ABL_ATTR(12) DUA_ABL_ATTR(16) DUA_ABL_ATTR(19) DUA_ABL_ATTR(23) DUA_ABL_ATTR(27) DUA_ABL_ATTR(3)
@@ -435,6 +447,15 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     int ks, ups;
     choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups);
     if (ks > 1 && (long)ks * d->N * vox * a.cout_pad * 4 <= ws_bytes) { a.ksplit = ks; a.units_per_split = ups; a.part = ws; }
+  }
+  // 24^3-sized layers (too few 4x8x8 tiles for 256 CUs, too big for split-K to pay): 2x8x8 tiles, twice the workgroups
+  if (a.ksplit == 1 && g_conv_variant == 0 && a.ntiles * nct * d->N < 200 && a.ntiles * nct * d->N > 64) {
+    const int td2 = (d->D + 1) / 2;
+    a.ntiles = td2 * a.tiles_h * a.tiles_w;
+    dim3 grid2(a.ntiles, nct, d->N);
+    constexpr int LDS2 = 4 * c3::HH * c3::RS + 2 * c3v2::SLAB;
+    hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 0, 2>), grid2, dim3(256), LDS2 + xf_bytes, s, a);
+    return (int)hipGetLastError();
   }
   dim3 grid(a.ntiles, nct, d->N * a.ksplit);
   if (a.ksplit > 1) {

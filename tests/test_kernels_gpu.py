@@ -73,9 +73,11 @@ def conv_variant(request):
     nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
 
 
-@pytest.mark.parametrize("conv_variant", [2, 4], indirect=True)
+@pytest.mark.parametrize("conv_variant", [0, 2, 4], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [
+    (1, 64, 128, 24, 24, 24),    # auto picks 2x8x8 tiles (108 workgroups of 4x8x8 would half-fill the chip)
+    (1, 40, 72, 22, 20, 26),     # the same path with ragged edges in every axis
     # N, Cin, Cout, D, H, W
     (1, 16, 64, 8, 8, 8),
     (2, 40, 72, 6, 10, 12),      # ragged everything: partial tiles, cin/cout not multiples of the chunk/tile

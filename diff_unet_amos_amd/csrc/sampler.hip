@@ -227,35 +227,47 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
   const uint32_t step = a.step_word ? (uint32_t)a.step_word[0] : 0u;
   const f16* raw = (const f16*)a.raw + (long)n * a.vox * a.raw_stride;
   const long wbase = (blockIdx.x * 4L + wave) * 64;
+  const bool sampling = a.mode != DUA_MODE_LOGITS;
+  // Everything this wave needs from memory is requested up front (raw fragments of all four voxel blocks, the
+  // sampler state, injected noise): one memory round trip per wave instead of one per block and voxel.
+  f16x8 fr[4][KS];
+  float xt[4][4], ez[4][4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const long va = wbase + 16 * mb + c;                 // voxel whose row this lane feeds as A
+    const long vc = va < a.vox ? va : 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fr[mb][ks] = *(const f16x8*)(raw + vc * a.raw_stride + 32 * ks + 8 * kq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long v = wbase + 16 * mb + 4 * kq + j;
+      const long vj = v < a.vox ? v : 0;
+      xt[mb][j] = sampling ? a.x_state[((long)n * a.vox + vj) * 16 + c] : 0.f;
+      ez[mb][j] = (sampling && a.noise && cok) ? a.noise[((long)n * a.C + c) * a.vox + vj] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
     f32x4a acc = {bias, bias, bias, bias};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      f16x8 f;
-      if (va < a.vox) f = *(const f16x8*)(raw + va * a.raw_stride + 32 * ks + 8 * kq);
-      else
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (f16)0.f;
       f16x8 y;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float t = fmaf((float)f[e], sc[ks][e], sh[ks][e]);
+        float t = fmaf((float)fr[mb][ks][e], sc[ks][e], sh[ks][e]);
         t = t > 0.f ? t : t * a.xf.slope;
         y[e] = (f16)t;
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(y, bw[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(y, bw[ks], acc, 0, 0, 0);     // rows of voxels >= vox are never stored
     }
     // lane now holds logits of class c for voxels wbase + 16*mb + 4*kq + j
     const long v0 = wbase + 16 * mb + 4 * kq;
-    float eps[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.mode != DUA_MODE_LOGITS && !a.noise) {
+    if (sampling && !a.noise) {
       const long gid = ((long)n * a.vox + v0) * 16 + c;    // unique per (lane, block): 4 normals per call
       uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0x5eedu};
       philox4x32_10(ctr, a.seed_lo, a.seed_hi);
-      box_muller(ctr[0], ctr[1], eps[0], eps[1]);
-      box_muller(ctr[2], ctr[3], eps[2], eps[3]);
+      box_muller(ctr[0], ctr[1], ez[mb][0], ez[mb][1]);
+      box_muller(ctr[2], ctr[3], ez[mb][2], ez[mb][3]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -263,13 +275,11 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
       if (v >= a.vox || !cok) continue;
       const float lg = acc[j];
       if (a.logits) a.logits[((long)n * a.C + c) * a.vox + v] = lg;
-      if (a.mode == DUA_MODE_LOGITS) continue;
+      if (!sampling) continue;
       const long gv = (long)n * a.vox + v;
-      float e = a.noise ? a.noise[((long)n * a.C + c) * a.vox + v] : eps[j];
-      float* xs_p = a.x_state + gv * 16 + c;
       float x0;
-      const float xn = sampler_update(a.mode, k8, lg, *xs_p, e, x0);
-      *xs_p = xn;
+      const float xn = sampler_update(a.mode, k8, lg, xt[mb][j], ez[mb][j], x0);
+      a.x_state[gv * 16 + c] = xn;
       if (a.xsum) a.xsum[gv * 16 + c] += x0;
       if (a.xstart) a.xstart[((long)n * a.C + c) * a.vox + v] = x0;
       if (a.xin) ((f16*)a.xin)[gv * a.xin_stride + c] = (f16)xn;

@@ -234,6 +234,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(state, host_threads())
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()          # rank 0 also ran the instrumented roofline pass: leave together
         dist.destroy_process_group()
 
 

@@ -31,8 +31,6 @@ constexpr int RS = HW * VS + 16;           // 656: halo row stride, padded (bank
 constexpr int PS = HH * RS;                // 6560: halo plane stride
 constexpr int HALO_BYTES = HD * PS;        // 39360
 constexpr int BN = 64;                     // output channels per workgroup
-constexpr int NITEMS = HD * HH * HW * KG;  // 2400 16-byte items per halo chunk
-constexpr int NIT = (NITEMS + 255) / 256;  // 10
 }  // namespace c3
 
 // 0 = auto (v2; split-K for small layers); 2 forces v2 without split-K, 4 the wave-specialised persistent v4
@@ -168,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   // ---- prologue ----
   load_slab(g0, 0);
   load_slab(g0 + 1, 1);
+  load_slab(g0 + 2, 2);
   load_halo(u0 / 3);
   if (fused) {     // only the Cin chunks this workgroup walks (all of them unless split-K)
     xform_preamble(a.xf, n, min(a.Cin, ((u1 + 2) / 3) * CK), xsc, xsh, xad, (u0 / 3) * CK);
@@ -186,7 +185,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int g = u * 3 + kh;
-      if (g + 2 < g1) load_slab(g + 2, (kh + 2) % 3);
+      // slab g+1 (requested two phases ago) goes into the other buffer first, so that the end of the phase is
+      // nothing but the barrier; its register set is then free for slab g+3
+      if (g + 1 < g1) store_slab(g + 1, (kh + 1) % 3);
+      if (g + 3 < g1) load_slab(g + 3, kh);                       // (kh + 3) % 3 == kh
       if (kh == 0 && next_chunk) load_halo(u / 3 + 1);
       const char* ap = halo + a_base + kd * PS + kh * RS;
       const char* wb = wbuf + (g & 1) * SLAB + b_base;
@@ -220,7 +222,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
       }
       unsigned long long tb = 0;
       if (ABL & 32) tb = __builtin_amdgcn_s_memtime();
-      if (g + 1 < g1) store_slab(g + 1, (kh + 1) % 3);   // the other buffer: last read before the previous barrier
       __syncthreads();   // next slab visible and everyone is done with this one
       if (ABL & 32) t_bar += __builtin_amdgcn_s_memtime() - tb;
     }

@@ -35,6 +35,8 @@ constexpr int VS = 64, RS = HW * VS + 16, PS = HH * RS;   // 64, 656, 6560
 constexpr int HALO = HD * PS;                              // 65600
 constexpr int SLAB = 3 * KG * BN * 16;                     // 12288
 constexpr int OFF_W = 2 * HALO, OFF_X = OFF_W + 2 * SLAB;  // 131200, 155776
+constexpr int OFF_F = OFF_X + 3 * 4 * 128;                 // 157312: hand-off counters ready[2], done[2]
+constexpr int LDS_TOTAL = OFF_F + 64;
 constexpr int CK = 32;                                     // fp16 channels per chunk
 constexpr int OS = 32 * 2 + 16;                            // epilogue staging row: 32 channels fp16 + pad
 constexpr int STAGE_WAVE = 64 * OS;                        // 5120 B per consumer wave
@@ -60,8 +62,23 @@ __device__ __forceinline__ void vm_wait10(V (&r)[10]) {
                : "n"(N) : "memory");
 }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Workgroup-local hand-offs through LDS counters (no s_barrier in the steady state: a barrier drains the MFMA pipe of
+// every SIMD at once, ~430 cycles per slab here).  A wave publishes after its own LDS traffic has completed; a
+// waiter spins on one ds_read with s_sleep.  Counters only grow, so "seen >= target" can never be missed.
+__device__ __forceinline__ void lds_signal(unsigned* cnt) {
+  wait_lds();
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_wait_ge(unsigned* cnt, unsigned target) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {     // bounded: a protocol bug must not hang the GPU (results would be wrong instead)
+    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if ((int)(v - target) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
 
-template <int ABL>
+template <int ABL, int SYNC = 0>     // SYNC 0: one s_barrier per slab (default); 1: LDS counters (measured 8 % slower)
 __global__ __launch_bounds__(768, 3) void conv3d_k3_v4_kernel(Conv3Args a) {
   using namespace c4;
   using T = f16;
@@ -79,6 +96,9 @@ __global__ __launch_bounds__(768, 3) void conv3d_k3_v4_kernel(Conv3Args a) {
   const int nphase_chunks = ntl * a.nchunks;     // (tile, chunk) pairs this workgroup walks
   const int Gt = nphase_chunks * 9;              // slabs in its stream
 
+  unsigned* f_ready = (unsigned*)(smem + OFF_F);     // [2]: +1 per producer wave per slab written into that weight buffer
+  unsigned* f_done = f_ready + 2;                     // [2]: +1 per consumer wave per slab fully read from that buffer
+  if (tid < 4) f_ready[tid] = 0;
   if (fused) xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
   __syncthreads();
 
@@ -174,8 +194,8 @@ __global__ __launch_bounds__(768, 3) void conv3d_k3_v4_kernel(Conv3Args a) {
     load_pair(0, 1);
     vm_wait10<0>(hv);
     store_pair(0, 0, 1);
-    wait_lds();
-    wg_barrier();                                  // #0: slab 0 and halo 0 are in LDS
+    if (SYNC) lds_signal(&f_ready[0]);
+    else { wait_lds(); wg_barrier(); }             // #0: slab 0 and halo 0 are in LDS
     // Steady state, one phase per slab g (sl = g % 9), every phase the same straight-line code:
     //   issue the 3 loads of slab g+3; (sl 0 / 3: issue the 10 loads of halo pair 0 / 1 of the next chunk);
     //   wait for slab g+1 (issued two phases ago) and write it to the other weight buffer;
@@ -194,6 +214,8 @@ __global__ __launch_bounds__(768, 3) void conv3d_k3_v4_kernel(Conv3Args a) {
         if (sl == 0) load_pair(pcn, 0);
         if (sl == 3) load_pair(pcn, 1);
         constexpr int S1 = 0;  (void)S1;
+        // the buffer slab g+1 goes into was last read as slab g-1: all eight consumer waves must be done with it
+        if (SYNC && g >= 1) lds_wait_ge(&f_done[(g + 1) & 1], 8u * (unsigned)((g - 1) / 2 + 1));
         if (!(ABL & 2)) {
           if (sl <= 5) vm_wait3<16>(wreg[(sl + 1) % 3][0], wreg[(sl + 1) % 3][1], wreg[(sl + 1) % 3][2]);
           else         vm_wait3<6>(wreg[(sl + 1) % 3][0], wreg[(sl + 1) % 3][1], wreg[(sl + 1) % 3][2]);
@@ -203,11 +225,14 @@ __global__ __launch_bounds__(768, 3) void conv3d_k3_v4_kernel(Conv3Args a) {
           if (!(ABL & 1)) vm_wait10<6>(hv);
           store_pair(pc + 1, pcn, sl == 2 ? 0 : 1);
         }
-        wait_lds();
-        unsigned long long tb = 0;
-        if (ABL & 16) tb = __builtin_amdgcn_s_memtime();
-        wg_barrier();                              // #(g+1): slab g+1 (and by sl 5 the next halo) are in LDS
-        if (ABL & 16) p_bar += __builtin_amdgcn_s_memtime() - tb;
+        if (SYNC) lds_signal(&f_ready[(g + 1) & 1]);  // slab g+1 (and by sl 5 the next halo) are in LDS
+        else {
+          wait_lds();
+          unsigned long long tb = 0;
+          if (ABL & 16) tb = __builtin_amdgcn_s_memtime();
+          wg_barrier();
+          if (ABL & 16) p_bar += __builtin_amdgcn_s_memtime() - tb;
+        }
       }
     }
     if ((ABL & 16) && lane == 0 && a.part != nullptr) {
@@ -258,7 +283,8 @@ __global__ __launch_bounds__(768, 3) void conv3d_k3_v4_kernel(Conv3Args a) {
   double Sd[2] = {0, 0}, Qd[2] = {0, 0};           // InstanceNorm sums of channel q*32 + r, kept across tiles
   unsigned long long t_bar = 0, t_epi = 0, t_start = 0;
   if (ABL & 16) t_start = __builtin_amdgcn_s_memtime();
-  wg_barrier();                                    // #0
+  if (SYNC) lds_wait_ge(&f_ready[0], 4u);
+  else wg_barrier();                               // #0
   const char* ap = a_ptr(0, 0);
   const char* wb = b_ptr(0);
   ld(ap, wb, 0, 0);
@@ -278,8 +304,13 @@ __global__ __launch_bounds__(768, 3) void conv3d_k3_v4_kernel(Conv3Args a) {
       // slab g+1 is complete after this barrier, and they may start overwriting slab g's buffer.
       unsigned long long tb0 = 0;
       if (ABL & 16) tb0 = __builtin_amdgcn_s_memtime();
-      wait_lds();
-      wg_barrier();                                // #(g+1)
+      if (SYNC) {
+        lds_signal(&f_done[g & 1]);                                         // this wave is done with slab g
+        if (g + 1 < Gt) lds_wait_ge(&f_ready[(g + 1) & 1], 4u * (unsigned)((g + 1) / 2 + 1));   // slab g+1 is in LDS
+      } else {
+        wait_lds();
+        wg_barrier();                              // #(g+1)
+      }
       if (ABL & 16) t_bar += __builtin_amdgcn_s_memtime() - tb0;
       ap = sl < 8 ? a_ptr(pc, sl + 1) : a_ptr(pc + 1, 0);      // past the end: a harmless read of stale LDS
       wb = b_ptr(g + 1);
@@ -296,7 +327,9 @@ __global__ __launch_bounds__(768, 3) void conv3d_k3_v4_kernel(Conv3Args a) {
     const int i = pc / a.nchunks;
     int d0, h0, w0;
     tile_origin(i, d0, h0, w0);
-    char* ot = smem + (pc & 1) * HALO + wave * STAGE_WAVE;     // every halo read of this chunk happened before the last barrier
+    // the staging tile aliases this chunk's halo buffer: every consumer wave must have finished its last slab
+    if (SYNC) lds_wait_ge(&f_done[(pc * 9 + 8) & 1], 8u * (unsigned)((pc * 9 + 8) / 2 + 1));
+    char* ot = smem + (pc & 1) * HALO + wave * STAGE_WAVE;
     T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
     const int gd = d0 + wave;
     const bool dok = gd < a.D;
@@ -355,17 +388,17 @@ int launch_conv3_v4(Conv3Args& a, int N, int nct, int xf_bytes, hipStream_t s) {
     hipDeviceProp_t p;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return DUA_ERR_ARG;
     cus = p.multiProcessorCount;
-    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, OFF_X + 3 * 4 * 128);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) { cus = 0; return (int)e; }
 #ifdef DUA_ABLATE
-    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, OFF_X + 3 * 4 * 128);
-    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, OFF_X + 3 * 4 * 128);
-    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, OFF_X + 3 * 4 * 128);
-    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, OFF_X + 3 * 4 * 128);
-    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, OFF_X + 3 * 4 * 128);
-    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, OFF_X + 3 * 4 * 128);
-    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, OFF_X + 3 * 4 * 128);
-    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, OFF_X + 3 * 4 * 128);
+    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipFuncSetAttribute((const void*)conv3d_k3_v4_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
 #endif
   }
   const int td8 = (a.D + TD - 1) / TD;
@@ -375,16 +408,16 @@ int launch_conv3_v4(Conv3Args& a, int N, int nct, int xf_bytes, hipStream_t s) {
   const dim3 grid(gx, N, nct);
   switch (g_conv_variant) {
 #ifdef DUA_ABLATE
-    case 201: hipLaunchKernelGGL(conv3d_k3_v4_kernel<1>, grid, dim3(NT), OFF_X + xf_bytes, s, a); break;
-    case 202: hipLaunchKernelGGL(conv3d_k3_v4_kernel<2>, grid, dim3(NT), OFF_X + xf_bytes, s, a); break;
-    case 203: hipLaunchKernelGGL(conv3d_k3_v4_kernel<3>, grid, dim3(NT), OFF_X + xf_bytes, s, a); break;
-    case 204: hipLaunchKernelGGL(conv3d_k3_v4_kernel<4>, grid, dim3(NT), OFF_X + xf_bytes, s, a); break;
-    case 208: hipLaunchKernelGGL(conv3d_k3_v4_kernel<8>, grid, dim3(NT), OFF_X + xf_bytes, s, a); break;
-    case 207: hipLaunchKernelGGL(conv3d_k3_v4_kernel<7>, grid, dim3(NT), OFF_X + xf_bytes, s, a); break;
-    case 210: hipLaunchKernelGGL(conv3d_k3_v4_kernel<16>, grid, dim3(NT), OFF_X + xf_bytes, s, a); break;
-    case 211: hipLaunchKernelGGL(conv3d_k3_v4_kernel<19>, grid, dim3(NT), OFF_X + xf_bytes, s, a); break;
+    case 201: hipLaunchKernelGGL(conv3d_k3_v4_kernel<1>, grid, dim3(NT), LDS_TOTAL, s, a); break;
+    case 202: hipLaunchKernelGGL(conv3d_k3_v4_kernel<2>, grid, dim3(NT), LDS_TOTAL, s, a); break;
+    case 203: hipLaunchKernelGGL(conv3d_k3_v4_kernel<3>, grid, dim3(NT), LDS_TOTAL, s, a); break;
+    case 204: hipLaunchKernelGGL(conv3d_k3_v4_kernel<4>, grid, dim3(NT), LDS_TOTAL, s, a); break;
+    case 208: hipLaunchKernelGGL(conv3d_k3_v4_kernel<8>, grid, dim3(NT), LDS_TOTAL, s, a); break;
+    case 207: hipLaunchKernelGGL(conv3d_k3_v4_kernel<7>, grid, dim3(NT), LDS_TOTAL, s, a); break;
+    case 210: hipLaunchKernelGGL(conv3d_k3_v4_kernel<16>, grid, dim3(NT), LDS_TOTAL, s, a); break;
+    case 211: hipLaunchKernelGGL(conv3d_k3_v4_kernel<19>, grid, dim3(NT), LDS_TOTAL, s, a); break;
 #endif
-    default: hipLaunchKernelGGL(conv3d_k3_v4_kernel<0>, grid, dim3(NT), OFF_X + xf_bytes, s, a);
+    default: hipLaunchKernelGGL(conv3d_k3_v4_kernel<0>, grid, dim3(NT), LDS_TOTAL, s, a);
   }
   return (int)hipGetLastError();
 }

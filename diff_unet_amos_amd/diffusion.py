@@ -56,16 +56,29 @@ class Diffusion(nn.Module):
         return self.model(x=x, t=step, embeddings=embeddings, image=image)
 
     def ddim_sample(self, image: torch.Tensor) -> torch.Tensor:
-        """diffusion.py:86-102: per window, encoder once, DDIM loop, sum of the clamped x0 predictions."""
-        res = []
+        """diffusion.py:86-102: per window, encoder once, DDIM loop, sum of the clamped x0 predictions.
+
+        The reference walks the batch one sample at a time; every sample is independent (own encoder pass, own
+        x_T), so the HIP path runs the whole batch through one launch plan -- the small U-Net levels, which
+        cannot fill 256 CUs with one 96^3 patch, get B times the workgroups.  ``batched_sampling = False``
+        restores the per-sample loop."""
+        shape1 = (1, self.num_classes, *image.shape[2:])
         with torch.no_grad():
+            if getattr(self, "batched_sampling", True) and len(image) > 1:
+                embeddings = self.embed_model(image)
+                out = self.sample_diffusion.ddim_sample_loop(
+                    self.model, (len(image), *shape1[1:]), model_kwargs={"image": image, "embeddings": embeddings})
+                acc = torch.zeros((len(image), *shape1[1:]), device=image.device)
+                for s in out["all_samples"]:
+                    acc += s.to(image.device)
+                return acc
+            res = []
             for i in range(len(image)):
                 batch = image[i, ...].unsqueeze(0)
                 embeddings = self.embed_model(batch)
-                out = self.sample_diffusion.ddim_sample_loop(
-                    self.model, (1, self.num_classes, *image.shape[2:]),
-                    model_kwargs={"image": batch, "embeddings": embeddings})
-                acc = torch.zeros((1, self.num_classes, *image.shape[2:]), device=image.device)
+                out = self.sample_diffusion.ddim_sample_loop(self.model, shape1,
+                                                             model_kwargs={"image": batch, "embeddings": embeddings})
+                acc = torch.zeros(shape1, device=image.device)
                 for s in out["all_samples"]:
                     acc += s.to(image.device)
                 res.append(acc)

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--overlap", type=float, default=0.25)
     ap.add_argument("--classes", type=int, default=16)
     ap.add_argument("--gather-fp16", action="store_true")
+    ap.add_argument("--sw-batch", type=int, default=1)
     args = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     torch.cuda.set_device(local)
@@ -31,16 +32,16 @@ def main():
     vol = torch.rand(1, 1, *args.volume, generator=torch.Generator().manual_seed(1)).to(dev)
     _, _, _, _, starts = inference._plan(vol, (96, 96, 96), args.overlap)
     with torch.no_grad():
-        net(vol[:, :, :96, :96, :96].contiguous(), pred_type="ddim_sample")      # warm-up: packs weights, captures the graph
+        net(vol[:, :, :96, :96, :96].contiguous().repeat(args.sw_batch, 1, 1, 1, 1), pred_type="ddim_sample")   # warm-up: packs weights, captures the graph
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
         if world > 1:
-            out = inference.sharded_sliding_window_inference(vol, (96, 96, 96), 1, net, args.overlap, pred_type="ddim_sample",
+            out = inference.sharded_sliding_window_inference(vol, (96, 96, 96), args.sw_batch, net, args.overlap, pred_type="ddim_sample",
                                                             gather_dtype=torch.float16 if args.gather_fp16 else None)
         else:
-            out = inference.sliding_window_inference(vol, (96, 96, 96), 1, net, args.overlap, pred_type="ddim_sample")
+            out = inference.sliding_window_inference(vol, (96, 96, 96), args.sw_batch, net, args.overlap, pred_type="ddim_sample")
         seg = inference.binarise(out)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -51,7 +52,7 @@ def main():
     if rank == 0:
         nwin = len(starts)
         print(json.dumps({"workload": "sliding-window DDIM inference (BASELINE configs[2])", "volume": args.volume,
-                          "windows": nwin, "ddim_steps": args.steps, "n_gpus": world, "seconds_per_volume": dt,
+                          "windows": nwin, "ddim_steps": args.steps, "n_gpus": world, "sw_batch_size": args.sw_batch, "seconds_per_volume": dt,
                           "voxel_steps_per_s": nwin * 96 ** 3 * args.steps / dt, "windows_per_s": nwin / dt,
                           "foreground_fraction": float(seg.mean()), "finite": bool(torch.isfinite(out).all())}))
     if world > 1:

@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--batch", type=int, default=1, help="patches per GPU (BASELINE config 2 is 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -149,12 +150,13 @@ def main():
     torch.manual_seed(0)
     net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES, compute_dtype=dtype).to(dev).eval()
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    image = torch.rand(1, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
-    plan = net._rt.plan(1, (96, 96, 96), dev)
+    B = args.batch
+    image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    plan = net._rt.plan(B, (96, 96, 96), dev)
     diffusion = net.diffusion                      # 1000-step process; we time K of its steps
     with torch.no_grad():
         net.embed_model(image)                     # encoder once per patch (not in the timed region)
-        x_T = torch.randn(1, CLASSES, 96, 96, 96, device=dev)
+        x_T = torch.randn(B, CLASSES, 96, 96, 96, device=dev)
         ops.to_channels_last(x_T, plan.x_state, 0, plan.cx)
         ops.to_channels_last(x_T, plan.xin, 0, plan.C)
         plan.x_sum.zero_()
@@ -166,7 +168,7 @@ def main():
         plan.counter.zero_()
 
         def one_step():
-            ops.step_begin(1, plan.temb_table, plan.cur_add, row_of_step=row_of_step, counter=plan.counter,
+            ops.step_begin(B, plan.temb_table, plan.cur_add, row_of_step=row_of_step, counter=plan.counter,
                            coef_table=coef_table, cur_coef=plan.cur_coef, step_word=plan.step_word)
             plan.denoiser_body()
             plan.tail(nv.MODE_DDPM, noise=None, use_sum=False, seed=3)
@@ -227,14 +229,14 @@ def main():
         ms = dt / args.steps * 1e3
         line = {
             "metric": "denoised voxel-steps/sec on 96^3 16-class AMOS patches",
-            "value": world * VOX * args.steps / dt, "unit": "voxel-steps/s", "n_gpus": world, "steps": args.steps,
+            "value": world * B * VOX * args.steps / dt, "unit": "voxel-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "DiffUNet 96^3 patch, 16 classes, DDPM p_sample steps of the 1000-step process "
                                    "(BASELINE.json configs[1]); one patch per GPU, replicas only",
-                       "patch": [96, 96, 96], "classes": CLASSES, "batch_per_gpu": 1, "graph_replay": not args.no_graph,
+                       "patch": [96, 96, 96], "classes": CLASSES, "batch_per_gpu": B, "graph_replay": not args.no_graph,
                        "noise": "in-kernel Philox4x32-10", "weights": "torch.manual_seed(0) default init"},
-            "step_tflops": 1.0564e12 / (ms * 1e-3) / 1e12, "finite": finite,
+            "step_tflops": B * 1.0564e12 / (ms * 1e-3) / 1e12, "finite": finite,
         }
         if roof is not None:
             line["roofline"] = roof

@@ -126,6 +126,133 @@ __global__ __launch_bounds__(256) void deconv_k2s2_kernel(DeconvArgs a) {
   }
 }
 
+// All eight taps in one workgroup (large inputs): the 256-voxel input tile is staged once with its full channel
+// depth (the one-tap kernel above re-reads and re-normalises it for every tap), then the workgroup walks the taps:
+// weights of tap t+1 are prefetched while tap t multiplies, every tap ends with its own pixel-shuffle store.
+template <typename T>
+__global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) {
+  using namespace dc;
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  constexpr int CK = KG * EPG;
+  constexpr int OSQ = 32 * (int)sizeof(T) + 16;             // staging row: one 32-channel half
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int VSA = a.nchunks * 64 + 16;                      // bytes per staged voxel (odd multiple of 16: conflict-free)
+  char* alds = smem;
+  char* wlds = alds + TM * VSA;                             // 2 x nchunks x 4 KB
+  char* stg = wlds + 2 * a.nchunks * W_BYTES;               // 256 x OSQ
+  float* xsc = (float*)(stg + TM * OSQ);
+  float* xsh = xsc + a.nchunks * CK;
+  float* xad = xsh + a.nchunks * CK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const long vox = (long)a.D * a.H * a.W;
+  const long v0 = (long)blockIdx.x * TM;
+  const int ct = blockIdx.y, n = blockIdx.z;
+  const T* xin = (const T*)a.x + (long)n * vox * a.Cin_stride + a.Cin_off;
+  const int wtap = a.nchunks * W_BYTES;                     // bytes of one tap's weights for this cout tile
+  const char* wsrc = (const char*)a.w + (long)ct * wtap;    // tap t: + t * nct * wtap
+  const int kg_t = tid & 3;
+
+  if (a.xf.stats != nullptr) {
+    xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
+    __syncthreads();
+  }
+  // ---- stage the input tile, every chunk ----
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+    const int c0 = ch * CK + kg_t * EPG;
+    const bool cok = c0 < a.Cin;
+    const bool xf = a.xf.stats != nullptr && cok;
+    float sc[EPG], sh[EPG], ad[EPG];
+    if (xf) {
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+    }
+    Frag f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long v = v0 + (tid >> 2) + 64 * j;
+      f[j] = *(const Frag*)(xin + (v < vox && cok ? v * a.Cin_stride + c0 : 0));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int vl = (tid >> 2) + 64 * j;
+      const bool ok = v0 + vl < vox && cok;
+      Frag g = f[j];
+      if (xf) g = xform_frag<T>(g, sc, sh, ad, a.xf.slope);
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) g[e] = ok ? g[e] : (T)0.f;
+      *(Frag*)(alds + vl * VSA + ch * 64 + kg_t * 16) = g;
+    }
+  }
+  // weights of tap 0
+  for (int i = tid; i < wtap / 16; i += 256) *(f32x4*)(wlds + i * 16) = *(const f32x4*)(wsrc + i * 16);
+  __syncthreads();
+
+  const int H2 = 2 * a.H, W2 = 2 * a.W;
+  T* yout = (T*)a.y + (long)n * vox * 8 * a.Cout_stride + a.Cout_off + ct * BN;
+  const float bq0 = a.bias[ct * BN + r], bq1 = a.bias[ct * BN + 32 + r];
+  char* ot = stg + wave * 64 * OSQ;
+  for (int tap = 0; tap < 8; ++tap) {
+    // prefetch the next tap's weights into registers (at most nchunks <= 8 pieces per thread)
+    f32x4 wn[8];
+    const char* wnext = wsrc + (long)(tap + 1) * a.nct * wtap;
+    if (tap < 7) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < a.nchunks) wn[j] = *(const f32x4*)(wnext + (tid + 256 * j) * 16);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc[m][0][i] = bq0; acc[m][1][i] = bq1; }
+    const char* wb = wlds + (tap & 1) * wtap;
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+#pragma unroll
+      for (int ks = 0; ks < KG / 2; ++ks) {
+        const Frag a0 = *(const Frag*)(alds + (wave * 64 + r) * VSA + ch * 64 + (2 * ks + hh) * 16);
+        const Frag a1 = *(const Frag*)(alds + (wave * 64 + 32 + r) * VSA + ch * 64 + (2 * ks + hh) * 16);
+        const Frag b0 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + r) * 16);
+        const Frag b1 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + 32 + r) * 16);
+        mma32(acc[0][0], a0, b0);
+        mma32(acc[0][1], a0, b1);
+        mma32(acc[1][0], a1, b0);
+        mma32(acc[1][1], a1, b1);
+      }
+    }
+    if (tap < 7) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < a.nchunks) *(f32x4*)(wlds + ((tap + 1) & 1) * wtap + (tid + 256 * j) * 16) = wn[j];
+    }
+    // pixel-shuffle store of this tap, one 32-channel half at a time through the wave's own staging rows
+    const int ti = tap >> 2, tj = (tap >> 1) & 1, tk = tap & 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *(T*)(ot + (m * 32 + acc_row(i, hh)) * OSQ + r * (int)sizeof(T)) = (T)acc[m][q][i];
+      __builtin_amdgcn_wave_barrier();
+      constexpr int GPV = 32 / EPG, VPI = 64 / GPV;
+#pragma unroll
+      for (int it = 0; it < 64 / VPI; ++it) {
+        const int vl = it * VPI + lane / GPV, cg = lane % GPV;
+        const long v = v0 + wave * 64 + vl;
+        if (v < vox && ct * BN + q * 32 + cg * EPG < a.Cout) {
+          const int w = (int)(v % a.W); const long t = v / a.W;
+          const int h = (int)(t % a.H), d = (int)(t / a.H);
+          const long ov = ((long)(2 * d + ti) * H2 + (2 * h + tj)) * W2 + (2 * w + tk);
+          *(Frag*)(yout + ov * a.Cout_stride + q * 32 + cg * EPG) = *(const Frag*)(ot + vl * OSQ + cg * 16);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();      // next tap's weights are in place, this tap's buffer is free
+  }
+}
+
 template <typename T>
 static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
                          const dua_in_norm* in, void* y, hipStream_t s) {
@@ -139,6 +266,19 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   a.nchunks = (d->Cin + CK - 1) / CK;
   a.nct = (d->Cout + dc::BN - 1) / dc::BN;
   const long vox = (long)d->D * d->H * d->W;
+  if (vox >= 256L * 128 && a.nchunks <= 4) {          // enough tiles to fill the chip with one workgroup per 8 taps
+    const int lds = dc::TM * (a.nchunks * 64 + 16) + 2 * a.nchunks * dc::W_BYTES + dc::TM * (32 * (int)sizeof(T) + 16) +
+                    (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0);
+    static bool attr2 = false;
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_alltaps_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr2 = true;
+    }
+    dim3 grid2((unsigned)((vox + dc::TM - 1) / dc::TM), a.nct, d->N);
+    hipLaunchKernelGGL(deconv_k2s2_alltaps_kernel<T>, grid2, dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+  }
   dim3 grid((unsigned)((vox + dc::TM - 1) / dc::TM), 8 * a.nct, d->N);
   constexpr int OS = dc::BN * (int)sizeof(T) + 16;
   constexpr int LDS = (dc::TM * OS > dc::A_BYTES + dc::W_BYTES) ? dc::TM * OS : dc::A_BYTES + dc::W_BYTES;

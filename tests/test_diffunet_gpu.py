@@ -223,3 +223,21 @@ def test_batched_ddim_loop_matches_per_sample_oracle():
     got = sum(s for s in out["all_samples"]).cpu()
     d = (got - want).abs()
     assert d.max() < 2e-2 and d.mean() < 1e-3, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.float16, 0.15)])
+def test_odd_class_count_non_cubic_patch_batch3(dtype, tol):
+    """13 classes (BTCV), a 32x48x64 patch (different tile counts per axis, partial tiles at the lower levels),
+    batch of 3 with three different timesteps."""
+    kw = dict(in_channels=1, out_channels=13, features=(8, 16, 16, 32, 64, 8))
+    net, ref = _pair(kw, dtype)
+    g = torch.Generator().manual_seed(21)
+    image = torch.rand(3, 1, 32, 48, 64, generator=g)
+    x = torch.randn(3, 13, 32, 48, 64, generator=g)
+    t = torch.tensor([0, 421, 999])
+    with torch.no_grad():
+        want = ref(image=image, x=x, step=t, pred_type="denoise")
+        got = net(image=image.cuda(), x=x.cuda(), step=t.cuda(), pred_type="denoise").cpu()
+    d = (got - want).abs()
+    print(f"\n[{dtype}] 13 classes, 32x48x64, N=3: |dlogit| max {d.max():.3e} mean {d.mean():.3e}")
+    assert d.max() < tol

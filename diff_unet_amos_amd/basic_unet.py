@@ -74,7 +74,8 @@ def _refuse_autograd(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise NotImplementedError(
             "the MI355X hot path is forward-only in this build (backward kernels are the next scope row); "
-            "call under torch.no_grad()")
+            "call under torch.no_grad(), or opt in to the torch-autograd training fallback with "
+            "DiffUNet.enable_autograd_fallback()")
 
 
 class BasicUNetEncoder(nn.Module):

@@ -51,6 +51,9 @@ class Diffusion(nn.Module):
     def denoise(self, image: torch.Tensor, x: torch.Tensor, step: torch.Tensor) -> torch.Tensor:
         """diffusion.py:71-84."""
         assert image.size(0) == x.size(0) == step.size(0)
+        if torch.is_grad_enabled() and getattr(self, "autograd_fallback", False):
+            from .training import autograd_denoise        # explicit, opt-in, torch kernels (training.py)
+            return autograd_denoise(self, image, x, step)
         _refuse_autograd(x, image, *self.parameters())
         embeddings = self.embed_model(image)
         return self.model(x=x, t=step, embeddings=embeddings, image=image)

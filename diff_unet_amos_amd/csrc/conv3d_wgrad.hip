@@ -1,0 +1,254 @@
+// Weight gradient of the 3x3x3 (pad 1, stride 1) convolution on the gfx950 matrix cores.
+//
+//   dW[co][ci][kd][kh][kw] += sum_{n,d,h,w} dy[n,d,h,w,co] * x[n,d+kd-1,h+kh-1,w+kw-1,ci]
+//
+// Backward-by-weights of every Conv3d the training step reaches (train.py:258-268 -> loss.backward() through
+// models/basic_unet/denoiser.py:56-59 and pretrained/basic_unet.py:60-63).
+//
+// GEMM view: M = Cout, N = 27 taps x Cin, K = voxels -- the contraction runs over the axis that is SLOW in the
+// channels-last activations, so both MFMA operands are k-strided in memory.  f16: the tiles are staged in LDS
+// exactly as they lie in HBM ([voxel][32 channels], 64-byte rows) and read with ds_read_b64_tr_b16, gfx950's
+// transposing LDS read (a 4-voxel x 16-channel block per 16 lanes, delivered channel-per-lane); a tap shift is an
+// address offset on the x image.  f32 (parity mode): MFMA 32x32x2 takes one k per lane, plain ds_read_b32.
+//
+// Workgroup (384 threads = 6 waves) = one kd plane of taps x 64 co x 64 ci, persistent over a strided list of
+// 2x8x8-voxel tiles: wave (kh, ci half) keeps 3 (kw) x 2 (co half) 32x32 fp32 accumulators in registers for its
+// whole tile list and adds them to dW (reference layout, fp32 atomics) once at the end.  The next tile's x and
+// dy are prefetched into registers while the current one is multiplied.
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+
+namespace dua {
+namespace wg {
+constexpr int TD = 2, TH = 8, TW = 8, TV = TD * TH * TW;      // 128 output voxels per tile
+constexpr int XH = TH + 2, XW = TW + 2, XV = TD * XH * XW;    // 200 input voxels per tile and kd
+constexpr int NT = 384;
+typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+struct Args {
+  const void* x; const void* dy; float* dw; const int* perm;
+  int N, D, H, W;
+  int Cin, Cin_stride, Cin_off, Cin_src;
+  int Cout, Cout_stride, Cout_off;
+  int ncc, tiles_d, tiles_h, tiles_w, total_tiles, P;
+};
+}  // namespace wg
+
+template <typename T>
+__global__ __launch_bounds__(wg::NT) void conv3d_k3_wgrad_kernel(wg::Args a) {
+  using namespace wg;
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  constexpr int G = 64 / EPG;                      // 16-byte groups per voxel per 64-channel chunk
+  constexpr int RSB = 32 * (int)sizeof(T);         // LDS row: 32 channels of one voxel
+  constexpr int XIMG = XV * RSB, YIMG = TV * RSB;  // one 32-channel half image
+  constexpr int NX = (XV * G + NT - 1) / NT, NY = (TV * G + NT - 1) / NT;
+  constexpr int KV = sizeof(T) == 2 ? 16 : 8;      // voxels per mma32 call
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem;                 // [2][XV][32]
+  char* Ys = smem + 2 * XIMG;      // [2][TV][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kh = wave % 3, cih = wave / 3;
+  const int kd = blockIdx.z;
+  const int ct = blockIdx.y / a.ncc, cc = blockIdx.y % a.ncc;
+  const int hl = lane >> 5;
+
+  // per-thread staging items: x item -> (pd, hy, hx, g), dy item -> (voxel, g)
+  int xl[NX], xc[NX], yl[NY], yc[NY];      // LDS byte offset (-1: no item) / packed source coordinates (-1: zero fill)
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const int it = tid + NT * j, v = it / G, g = it % G;
+    const int pd = v / (XH * XW), rem = v % (XH * XW), hy = rem / XW, hx = rem % XW;
+    const bool inl = it < XV * G;
+    xc[j] = inl && cc * 64 + g * EPG < a.Cin ? (pd << 16) | (hy << 8) | hx : -1;
+    xl[j] = inl ? ((g * EPG) >> 5) * XIMG + v * RSB + ((g * EPG) & 31) * (int)sizeof(T) : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < NY; ++j) {
+    const int it = tid + NT * j, v = it / G, g = it % G;
+    const bool inl = it < TV * G;
+    yc[j] = inl && ct * 64 + g * EPG < a.Cout ? v : -1;
+    yl[j] = inl ? ((g * EPG) >> 5) * YIMG + v * RSB + ((g * EPG) & 31) * (int)sizeof(T) : -1;
+  }
+  const int xg_off = cc * 64, yg_off = ct * 64;
+
+  Frag xr[NX], yr[NY];
+  auto zero = [](Frag& f) {
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) f[e] = (T)0.f;
+  };
+  auto load_tile = [&](int tile) {
+    int t = tile;
+    const int tw_ = t % a.tiles_w; t /= a.tiles_w;
+    const int th_ = t % a.tiles_h; t /= a.tiles_h;
+    const int td_ = t % a.tiles_d; const int n = t / a.tiles_d;
+    const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
+    const T* xb = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off + xg_off;
+    const T* yb = (const T*)a.dy + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + yg_off;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      zero(xr[j]);
+      if (xc[j] >= 0) {
+        const int gd = d0 + kd - 1 + (xc[j] >> 16), gh = h0 - 1 + ((xc[j] >> 8) & 255), gw = w0 - 1 + (xc[j] & 255);
+        const int g = (tid + NT * j) % G;
+        if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
+          xr[j] = *(const Frag*)(xb + (((long)gd * a.H + gh) * a.W + gw) * a.Cin_stride + g * EPG);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      zero(yr[j]);
+      if (yc[j] >= 0) {
+        const int v = yc[j], gd = d0 + (v >> 6), gh = h0 + ((v >> 3) & 7), gw = w0 + (v & 7);
+        const int g = (tid + NT * j) % G;
+        if (gd < a.D && gh < a.H && gw < a.W)
+          yr[j] = *(const Frag*)(yb + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + g * EPG);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      if (xl[j] >= 0) *(Frag*)(Xs + xl[j]) = xr[j];
+#pragma unroll
+    for (int j = 0; j < NY; ++j)
+      if (yl[j] >= 0) *(Frag*)(Ys + yl[j]) = yr[j];
+  };
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // lane constants of the operand fetch
+  int a_off[2], b_row[2], b_col;       // f16: two transposed reads (r = 0, 1); f32: unused slots
+  if constexpr (sizeof(T) == 2) {
+    const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g1 = (lane >> 4) & 1;
+    b_col = (16 * g1 + 4 * p) * 2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      a_off[r] = (8 * hl + 4 * r + q) * RSB + b_col;     // + step * 16 * RSB + coh * YIMG
+      b_row[r] = hl * XW + 4 * r + q;                     // x row (within plane) = (hrow + kh) * XW + w + kw
+    }
+  } else {
+    b_col = (lane & 31) * 4;
+    a_off[0] = a_off[1] = 0; b_row[0] = b_row[1] = 0;
+  }
+
+  int tile = blockIdx.x;
+  if (tile < a.total_tiles) load_tile(tile);
+  for (; tile < a.total_tiles; tile += a.P) {
+    __syncthreads();                       // previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    if (tile + a.P < a.total_tiles) load_tile(tile + a.P);
+#pragma unroll 2
+    for (int s = 0; s < TV / KV; ++s) {
+      Frag fa[2], fb[3];
+      if constexpr (sizeof(T) == 2) {
+        // voxels 16 s + 8 hl + 4 r + q: d = s >> 2, hrow = 2 (s & 3) + hl, w = 4 r + q
+        const int d = s >> 2, hr0 = 2 * (s & 3);
+#pragma unroll
+        for (int coh = 0; coh < 2; ++coh) {
+          h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) h4*)(Ys + coh * YIMG + s * 16 * RSB + a_off[0]));
+          h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) h4*)(Ys + coh * YIMG + s * 16 * RSB + a_off[1]));
+          f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4v = __builtin_bit_cast(f16x4, hi);
+          fa[coh] = __builtin_shufflevector(l4, h4v, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        const int rowbase = (d * XH + hr0 + kh) * XW;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) h4*)(Xs + cih * XIMG + (rowbase + b_row[0] + kw) * RSB + b_col));
+          h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) h4*)(Xs + cih * XIMG + (rowbase + b_row[1] + kw) * RSB + b_col));
+          f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4v = __builtin_bit_cast(f16x4, hi);
+          fb[kw] = __builtin_shufflevector(l4, h4v, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      } else {
+        // voxels 8 s + 2 e + hl (e = 0..3): one w row; d = s >> 3, hrow = s & 7, w = 2 e + hl
+        const int d = s >> 3, hrow = s & 7;
+#pragma unroll
+        for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            fa[coh][e] = *(const float*)(Ys + coh * YIMG + (s * 8 + 2 * e + hl) * RSB + b_col);
+        const int rowbase = (d * XH + hrow + kh) * XW;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            fb[kw][e] = *(const float*)(Xs + cih * XIMG + (rowbase + 2 * e + hl + kw) * RSB + b_col);
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int coh = 0; coh < 2; ++coh) mma32(acc[kw][coh], fa[coh], fb[kw]);
+    }
+  }
+
+  // acc[kw][coh]: lane column = ci (lane & 31), register i -> co row acc_row(i, hl)
+  const int cip = cc * 64 + cih * 32 + (lane & 31);
+  int ci = -1;
+  if (cip < a.Cin) ci = a.perm ? a.perm[cip] : cip;
+  if (ci >= 0 && ci < a.Cin_src) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = ct * 64 + coh * 32 + acc_row(i, hl);
+          if (co < a.Cout)
+            unsafeAtomicAdd(a.dw + ((long)co * a.Cin_src + ci) * 27 + kd * 9 + kh * 3 + kw, acc[kw][coh][i]);
+        }
+  }
+}
+
+template <typename T>
+static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
+                        const int* perm, hipStream_t s) {
+  using namespace wg;
+  Args a;
+  a.x = x; a.dy = dy; a.dw = dw; a.perm = perm;
+  a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
+  a.Cin = d->Cin; a.Cin_stride = d->Cin_stride; a.Cin_off = d->Cin_off; a.Cin_src = Cin_src;
+  a.Cout = d->Cout; a.Cout_stride = d->Cout_stride; a.Cout_off = d->Cout_off;
+  a.ncc = (d->Cin + 63) / 64;
+  const int nct = (d->Cout + 63) / 64;
+  a.tiles_d = (d->D + TD - 1) / TD; a.tiles_h = (d->H + TH - 1) / TH; a.tiles_w = (d->W + TW - 1) / TW;
+  a.total_tiles = d->N * a.tiles_d * a.tiles_h * a.tiles_w;
+  const int combos = nct * a.ncc * 3;
+  int P = (2 * 256 + combos - 1) / combos;          // ~2 workgroups per CU in flight
+  if (P > a.total_tiles) P = a.total_tiles;
+  if (P < 1) P = 1;
+  a.P = P;
+  const int lds = 2 * (XV + TV) * 32 * (int)sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<T>, dim3(P, nct * a.ncc, 3), dim3(NT), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace dua
+
+extern "C" int dua_conv3d_k3_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
+                                   const int* in_perm, void* stream) {
+  if (!d || !x || !dy || !dw || Cin_src <= 0) return DUA_ERR_ARG;
+  if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)
+    return DUA_ERR_ARG;
+  if (!in_perm && Cin_src > d->Cin) return DUA_ERR_ARG;
+  if (d->dtype == DUA_F16) return dua::launch_wgrad<dua::f16>(d, x, dy, dw, Cin_src, in_perm, (hipStream_t)stream);
+  if (d->dtype == DUA_F32) return dua::launch_wgrad<float>(d, x, dy, dw, Cin_src, in_perm, (hipStream_t)stream);
+  return DUA_ERR_ARG;
+}

@@ -157,6 +157,27 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
              "dua_conv3d_k3_fwd")
 
 
+def conv3d_k3_wgrad(x, cin, cin_off, dy, cout, cout_off, dw, perm=None):
+    """dw[Cout, Cin_src, 3,3,3] (fp32, reference layout) += weight gradient of the 3x3x3 convolution that mapped
+    channels [cin_off, cin_off+cin) of ``x`` to channels [cout_off, cout_off+cout) of ``dy``'s buffer."""
+    _cl_check(x, "x"); _cl_check(dy, "dy")
+    assert x.dtype == dy.dtype and x.device == dy.device
+    N, D, H, W, cs_in = x.shape
+    assert tuple(dy.shape[:4]) == (N, D, H, W)
+    assert cin % 8 == 0 and cin_off % 8 == 0 and cin_off + cin <= cs_in
+    assert cout % 8 == 0 and cout_off % 8 == 0 and cout_off + cout <= dy.shape[-1]
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.dim() == 5 and tuple(dw.shape[2:]) == (3, 3, 3)
+    assert dw.shape[0] == cout
+    cin_src = dw.shape[1]
+    if perm is None:
+        assert cin_src <= cin
+    else:
+        assert perm.dtype == torch.int32 and perm.numel() >= -(-cin // 64) * 64
+    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, dy.shape[-1], cout_off)
+    nv.check(nv.lib().dua_conv3d_k3_wgrad(C.byref(d), nv.ptr(x), nv.ptr(dy), nv.ptr(dw), cin_src, nv.ptr(perm), nv.stream_ptr()),
+             "dua_conv3d_k3_wgrad")
+
+
 def instnorm_finalize(norm, N, Cc):
     """scale, shift = fp32 [N, C] exactly as consumers compute them in their preamble."""
     dev = norm.keep[0].device

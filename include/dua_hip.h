@@ -63,6 +63,15 @@ int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_pack
                       const dua_in_norm* in, void* y, double* out_stats, void* workspace, long workspace_bytes,
                       void* stream);
 
+/* Weight gradient of the same convolution (backward of train.py:258-268 through denoiser.py:56-59):
+ *   dw[co][ci][kd][kh][kw] += sum over (n, voxel) of dy[n, v, co] * x[n, v + tap - 1, ci]
+ * d describes the FORWARD convolution (x: Cin channels at Cin_off of a Cin_stride buffer; dy: Cout channels at
+ * Cout_off of a Cout_stride buffer, same N/D/H/W).  dw: fp32 [Cout][Cin_src][27] in the reference's layout,
+ * ACCUMULATED into with fp32 atomics (zero it first).  in_perm (device int[ceil(Cin/64)*64]) or NULL maps a packed
+ * input channel of x to its source channel in dw (negative = padding), as in dua_pack_conv3_weights. */
+int dua_conv3d_k3_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
+                        const int* in_perm, void* stream);
+
 /* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (1 synchronous slabs, 2 LDS-DMA pipelined; default 2). */
 int dua_set_option(int key, int value);
 

@@ -367,3 +367,52 @@ def test_in_kernel_philox_noise_is_standard_normal(K):
     ops.final_conv_sampler(raw, K, z, torch.zeros(C, K, device="cuda"), torch.zeros(C, device="cuda"), C, nv.MODE_DDPM,
                            coef=coef, x_state=state, step_word=step, seed=1234)
     assert abs(float((state * a).mean())) < 1e-2                          # fresh draw per step
+
+
+# ------------------------------------------------------------------------------------------------
+# backward kernels (training row): weight gradient of the 3x3x3 convolution, data gradient through the
+# forward kernel with flipped/transposed weights
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [
+    # N, D, H, W, Cin, Cout
+    (1, 8, 8, 8, 64, 64),
+    (2, 6, 10, 12, 16, 8),        # ragged tiles, channel counts below one chunk
+    (1, 16, 16, 16, 128, 64),     # two ci chunks (concat input)
+    (2, 4, 4, 4, 72, 136),        # ragged chunk and tile in the channel axes
+    (1, 3, 5, 7, 8, 8),
+])
+def test_conv3_wgrad_matches_torch(dtype, shape):
+    N, D, H, W, Cin, Cout = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    cs_in, cs_out = Cin + 8, Cout + 16                 # strided buffers with an offset
+    x = torch.randn(N, D, H, W, cs_in, generator=g, device=dev).to(dtype)
+    dy = torch.randn(N, D, H, W, cs_out, generator=g, device=dev).to(dtype)
+    dw = torch.zeros(Cout, Cin, 3, 3, 3, device=dev)
+    _ops().conv3d_k3_wgrad(x, Cin, 8, dy, Cout, 16, dw)
+    xr = x[..., 8:8 + Cin].permute(0, 4, 1, 2, 3).double()
+    dyr = dy[..., 16:16 + Cout].permute(0, 4, 1, 2, 3).double()
+    want = torch.nn.grad.conv3d_weight(xr, (Cout, Cin, 3, 3, 3), dyr, padding=1)
+    scale = want.abs().max().item()
+    tol = 2e-5 if dtype == torch.float32 else 2e-3    # fp16 operands are exact products; fp32 accumulation order differs
+    assert (dw.double() - want).abs().max().item() <= tol * scale
+
+
+@pytest.mark.gpu
+def test_conv3_wgrad_permuted_input_channels():
+    """First denoiser conv: packed input = [x_t(C) | image | pad]; dw comes back in the reference's channel order."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    N, D, H, W, Cin_src, Cout = 1, 8, 8, 8, 5, 16
+    Cp = 8
+    perm = torch.full((64,), -1, dtype=torch.int32, device=dev)
+    perm[:4] = torch.arange(1, 5, dtype=torch.int32)      # packed 0..3 = source 1..4 (x_t), packed 4 = source 0 (image)
+    perm[4] = 0
+    x = torch.randn(N, D, H, W, Cp, generator=g, device=dev)
+    dy = torch.randn(N, D, H, W, Cout, generator=g, device=dev)
+    dw = torch.zeros(Cout, Cin_src, 3, 3, 3, device=dev)
+    _ops().conv3d_k3_wgrad(x, Cp, 0, dy, Cout, 0, dw, perm=perm)
+    src = torch.stack([x[..., 4], x[..., 0], x[..., 1], x[..., 2], x[..., 3]], dim=1).double()
+    want = torch.nn.grad.conv3d_weight(src, (Cout, Cin_src, 3, 3, 3), dy.permute(0, 4, 1, 2, 3).double(), padding=1)
+    assert (dw.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()

@@ -60,7 +60,8 @@ _SIGS = {
     "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dua_conv3d_k3_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P, _P, C.c_long, _P]),
-    "dua_conv3d_k3_wgrad": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.c_int, _P, _P]),
+    "dua_conv3d_k3_wgrad_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
+    "dua_conv3d_k3_wgrad": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.c_int, _P, _P, C.c_long, _P]),
     "dua_pack_conv3_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "dua_instnorm_finalize": (C.c_int, [C.c_int, C.c_int, C.POINTER(InNorm), _P, _P, _P]),
     "dua_materialize": (C.c_int, [C.POINTER(MaterializeDesc), _P, C.POINTER(InNorm), _P, _P, _P, _P]),

@@ -26,7 +26,7 @@ constexpr int NT = 384;
 typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 struct Args {
-  const void* x; const void* dy; float* dw; const int* perm;
+  const void* x; const void* dy; float* dw; const int* perm; float* part;
   int N, D, H, W;
   int Cin, Cin_stride, Cin_off, Cin_src;
   int Cout, Cout_stride, Cout_off;
@@ -35,7 +35,7 @@ struct Args {
 }  // namespace wg
 
 template <typename T>
-__global__ __launch_bounds__(wg::NT) void conv3d_k3_wgrad_kernel(wg::Args a) {
+__device__ __forceinline__ void wgrad_body(const wg::Args& a) {
   using namespace wg;
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
@@ -194,6 +194,18 @@ __global__ __launch_bounds__(wg::NT) void conv3d_k3_wgrad_kernel(wg::Args a) {
   }
 
   // acc[kw][coh]: lane column = ci (lane & 31), register i -> co row acc_row(i, hl)
+  if (a.part) {
+    // partial sums [P][combo][kd][kh][kw][co 64][ci 64], summed by wgrad_reduce_kernel (no atomics: every workgroup
+    // would otherwise hit the same Cout*Cin*27 addresses)
+    float* pp = a.part + ((((long)blockIdx.x * gridDim.y + blockIdx.y) * 3 + kd) * 9 + kh * 3) * 4096 + cih * 32 + (lane & 31);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pp[kw * 4096 + (coh * 32 + acc_row(i, hl)) * 64] = acc[kw][coh][i];
+    return;
+  }
   const int cip = cc * 64 + cih * 32 + (lane & 31);
   int ci = -1;
   if (cip < a.Cin) ci = a.perm ? a.perm[cip] : cip;
@@ -211,9 +223,49 @@ __global__ __launch_bounds__(wg::NT) void conv3d_k3_wgrad_kernel(wg::Args a) {
   }
 }
 
+// ~200 VGPRs: one workgroup (6 waves) per CU.  Forcing 168 VGPRs for two per CU measured 45 % SLOWER (spills in
+// the k loop), so the occupancy is left to the register allocator.
+template <typename T>
+__global__ __launch_bounds__(wg::NT) void conv3d_k3_wgrad_kernel(wg::Args a) {
+  wgrad_body<T>(a);
+}
+
+// dw[co][ci_src][tap] += sum_p part[p][combo][tap][co][ci]; one thread per (combo, tap, co, ci)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int P, int ncc, int ncombo,
+                                                           int Cin, int Cin_src, int Cout, const int* __restrict__ perm,
+                                                           float* __restrict__ dw) {
+  const long per_p = (long)ncombo * 27 * 4096;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < per_p; i += (long)gridDim.x * 256) {
+    const int cil = (int)(i & 63), col = (int)((i >> 6) & 63);
+    const int tap = (int)((i >> 12) % 27), combo = (int)((i >> 12) / 27);
+    const int co = (combo / ncc) * 64 + col, cip = (combo % ncc) * 64 + cil;
+    if (co >= Cout || cip >= Cin) continue;
+    const int ci = perm ? perm[cip] : cip;
+    if (ci < 0 || ci >= Cin_src) continue;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 3 < P; p += 4) {
+      s0 += part[(long)p * per_p + i]; s1 += part[(long)(p + 1) * per_p + i];
+      s2 += part[(long)(p + 2) * per_p + i]; s3 += part[(long)(p + 3) * per_p + i];
+    }
+    for (; p < P; ++p) s0 += part[(long)p * per_p + i];
+    dw[((long)co * Cin_src + ci) * 27 + tap] += (s0 + s1) + (s2 + s3);
+  }
+}
+
+static inline int wgrad_partitions(const dua_conv3_desc* d, int* combos_out) {
+  using namespace wg;
+  const int combos = ((d->Cout + 63) / 64) * ((d->Cin + 63) / 64) * 3;
+  const int total = d->N * ((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
+  int P = (2 * 256 + combos - 1) / combos;          // ~2 workgroups per CU in flight
+  if (P > total) P = total;
+  if (combos_out) *combos_out = combos;
+  return P < 1 ? 1 : P;
+}
+
 template <typename T>
 static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
-                        const int* perm, hipStream_t s) {
+                        const int* perm, float* ws, long ws_bytes, hipStream_t s) {
   using namespace wg;
   Args a;
   a.x = x; a.dy = dy; a.dw = dw; a.perm = perm;
@@ -224,11 +276,10 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
   const int nct = (d->Cout + 63) / 64;
   a.tiles_d = (d->D + TD - 1) / TD; a.tiles_h = (d->H + TH - 1) / TH; a.tiles_w = (d->W + TW - 1) / TW;
   a.total_tiles = d->N * a.tiles_d * a.tiles_h * a.tiles_w;
-  const int combos = nct * a.ncc * 3;
-  int P = (2 * 256 + combos - 1) / combos;          // ~2 workgroups per CU in flight
-  if (P > a.total_tiles) P = a.total_tiles;
-  if (P < 1) P = 1;
+  int combos;
+  const int P = wgrad_partitions(d, &combos);
   a.P = P;
+  a.part = (ws && (long)P * combos * 9 * 4096 * 4 <= ws_bytes && P > 1) ? ws : nullptr;
   const int lds = 2 * (XV + TV) * 32 * (int)sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
@@ -237,18 +288,31 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
     attr_set = true;
   }
   hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<T>, dim3(P, nct * a.ncc, 3), dim3(NT), lds, s, a);
+  if (a.part) {
+    const long per_p = (long)nct * a.ncc * 27 * 4096;
+    long nb = (per_p + 255) / 256;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, s, a.part, P, a.ncc,
+                       nct * a.ncc, d->Cin, Cin_src, d->Cout, perm, dw);
+  }
   return (int)hipGetLastError();
 }
 
 }  // namespace dua
 
+extern "C" long dua_conv3d_k3_wgrad_workspace(const dua_conv3_desc* d) {
+  if (!d) return DUA_ERR_ARG;
+  int combos;
+  const int P = dua::wgrad_partitions(d, &combos);
+  return P > 1 ? (long)P * combos * 9 * 4096 * 4 : 0;
+}
+
 extern "C" int dua_conv3d_k3_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
-                                   const int* in_perm, void* stream) {
+                                   const int* in_perm, void* workspace, long workspace_bytes, void* stream) {
   if (!d || !x || !dy || !dw || Cin_src <= 0) return DUA_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)
     return DUA_ERR_ARG;
   if (!in_perm && Cin_src > d->Cin) return DUA_ERR_ARG;
-  if (d->dtype == DUA_F16) return dua::launch_wgrad<dua::f16>(d, x, dy, dw, Cin_src, in_perm, (hipStream_t)stream);
-  if (d->dtype == DUA_F32) return dua::launch_wgrad<float>(d, x, dy, dw, Cin_src, in_perm, (hipStream_t)stream);
+  if (d->dtype == DUA_F16) return dua::launch_wgrad<dua::f16>(d, x, dy, dw, Cin_src, in_perm, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+  if (d->dtype == DUA_F32) return dua::launch_wgrad<float>(d, x, dy, dw, Cin_src, in_perm, (float*)workspace, workspace_bytes, (hipStream_t)stream);
   return DUA_ERR_ARG;
 }

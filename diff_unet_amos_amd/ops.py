@@ -157,7 +157,7 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
              "dua_conv3d_k3_fwd")
 
 
-def conv3d_k3_wgrad(x, cin, cin_off, dy, cout, cout_off, dw, perm=None):
+def conv3d_k3_wgrad(x, cin, cin_off, dy, cout, cout_off, dw, perm=None, workspace=None):
     """dw[Cout, Cin_src, 3,3,3] (fp32, reference layout) += weight gradient of the 3x3x3 convolution that mapped
     channels [cin_off, cin_off+cin) of ``x`` to channels [cout_off, cout_off+cout) of ``dy``'s buffer."""
     _cl_check(x, "x"); _cl_check(dy, "dy")
@@ -174,8 +174,24 @@ def conv3d_k3_wgrad(x, cin, cin_off, dy, cout, cout_off, dw, perm=None):
     else:
         assert perm.dtype == torch.int32 and perm.numel() >= -(-cin // 64) * 64
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, dy.shape[-1], cout_off)
-    nv.check(nv.lib().dua_conv3d_k3_wgrad(C.byref(d), nv.ptr(x), nv.ptr(dy), nv.ptr(dw), cin_src, nv.ptr(perm), nv.stream_ptr()),
-             "dua_conv3d_k3_wgrad")
+    if workspace is None:
+        need = nv.lib().dua_conv3d_k3_wgrad_workspace(C.byref(d))
+        workspace = _wgrad_ws(need, x.device) if need > 0 else None
+    ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    nv.check(nv.lib().dua_conv3d_k3_wgrad(C.byref(d), nv.ptr(x), nv.ptr(dy), nv.ptr(dw), cin_src, nv.ptr(perm),
+                                          nv.ptr(workspace), ws_bytes, nv.stream_ptr()), "dua_conv3d_k3_wgrad")
+
+
+_WGRAD_WS = {}
+
+
+def _wgrad_ws(nbytes, device):
+    """One grow-only scratch buffer per device for the weight-gradient partial sums (stream-ordered reuse)."""
+    buf = _WGRAD_WS.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WGRAD_WS[device] = buf
+    return buf
 
 
 def instnorm_finalize(norm, N, Cc):

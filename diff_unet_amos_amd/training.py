@@ -164,3 +164,166 @@ class DDPTrainer:
         loss.backward()
         self.optimizer.step()
         return loss.detach()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Native-convolution training path: every 3x3x3 convolution (forward, data gradient, weight gradient -- >95 % of
+# the step's FLOPs) runs on the HIP kernels of this package inside a torch.autograd.Function; activations are
+# channels-last [N, D, H, W, C] in the compute dtype (fp16 with fp32 master weights and a GradScaler, or fp32).
+# What is still torch: InstanceNorm/LeakyReLU/temb add (elementwise + reductions), MaxPool, the k2s2 transposed
+# convolution and the 1x1 head as plain library GEMMs, the loss, AdamW.  They are the next kernels to write.
+class _Conv3dK3(torch.autograd.Function):
+    """y = conv3d(x, w, b), 3x3x3 / pad 1, channels-last.  forward: dua_conv3d_k3_fwd; backward: the same kernel on
+    dy with the weights flipped and transposed (data gradient) + dua_conv3d_k3_wgrad (weight gradient)."""
+
+    @staticmethod
+    def _run(x, w, bias, cout):
+        from . import ops
+        N, D, H, W, cs = x.shape
+        wp, bp = ops.pack_conv3_weights(w, bias, x.dtype, cin_packed=cs)
+        y = torch.empty((N, D, H, W, cout), dtype=x.dtype, device=x.device)
+        stats = ops.stats_buffer(N, cout, x.device)
+        ops.conv3d_k3(x, cs, 0, wp, bp, cout, y, 0, stats)
+        return y
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        assert x.is_contiguous() and x.shape[-1] % 8 == 0 and weight.shape[0] % 8 == 0 and weight.shape[1] <= x.shape[-1]
+        ctx.save_for_backward(x, weight)
+        return _Conv3dK3._run(x, weight.detach().float().contiguous(), bias.detach().float(), weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        cout, cin = weight.shape[:2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().float().flip(2, 3, 4).transpose(0, 1).contiguous()       # [Cin, Cout, 3,3,3]
+            dx = _Conv3dK3._run(dy, wt, None, x.shape[-1])
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+            ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dy, cout, 0, dw)
+            dw = dw.to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            db = torch.sum(dy, dim=(0, 1, 2, 3), dtype=torch.float32)
+        return dx, dw, db
+
+
+def _cl_pad(x_ncdhw, dtype):
+    """NCDHW -> channels-last with the channel count padded to a multiple of 8 (zeros)."""
+    N, C = x_ncdhw.shape[:2]
+    cp = -(-C // 8) * 8
+    out = x_ncdhw.new_zeros((N, *x_ncdhw.shape[2:], cp), dtype=dtype)
+    out[..., :C] = x_ncdhw.permute(0, 2, 3, 4, 1)
+    return out
+
+
+def _two_conv_cl(block, x, temb):
+    for i, cb in enumerate((block.conv_0, block.conv_1)):
+        y = _Conv3dK3.apply(x, cb.conv.weight, cb.conv.bias)
+        yf = y.float()
+        var, mean = torch.var_mean(yf, dim=(1, 2, 3), unbiased=False, keepdim=True)
+        z = (yf - mean) * torch.rsqrt(var + 1e-5) * cb.adn.N.weight + cb.adn.N.bias
+        z = F.leaky_relu(z, 0.1)
+        if i == 0 and temb is not None:
+            s = temb * torch.sigmoid(temb)
+            z = z + F.linear(s, block.temb_proj.weight, block.temb_proj.bias)[:, None, None, None, :]
+        x = z.to(y.dtype)
+    return x
+
+
+def _pool_cl(x):
+    return F.max_pool3d(x.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _deconv_cl(up, x):
+    """ConvTranspose3d k2 s2 as one GEMM: [voxels, Cin] @ [Cin, Cout*8], then a pixel shuffle."""
+    N, D, H, W, Cin = x.shape
+    w = up.deconv.weight                                     # [Cin, Cout, 2,2,2]
+    Cout = w.shape[1]
+    y = x.reshape(-1, Cin) @ w.reshape(Cin, Cout * 8).to(x.dtype)
+    y = y.view(N, D, H, W, Cout, 2, 2, 2).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(N, 2 * D, 2 * H, 2 * W, Cout)
+    return y + up.deconv.bias.to(x.dtype)
+
+
+def native_conv_denoise(net, image, x, step, dtype=torch.float16):
+    """Diffusion.denoise (diffusion.py:71-84) for training: HIP convolutions under torch autograd.  Returns fp32
+    logits [N, C, D, H, W]."""
+    enc, den = net.embed_model, net.model
+    img = _cl_pad(image, dtype)
+    emb = [_two_conv_cl(enc.conv_0, img, None)]
+    for d in enc.down:
+        emb.append(_two_conv_cl(d.convs, _pool_cl(emb[-1]), None))
+    temb = _time_embedding(den.temb, step)
+    h = _cl_pad(torch.cat([image, x], dim=1), dtype)
+    x0 = _two_conv_cl(den.conv_0, h, temb) + emb[0]
+    x1 = _two_conv_cl(den.down_1.convs, _pool_cl(x0), temb) + emb[1]
+    x2 = _two_conv_cl(den.down_2.convs, _pool_cl(x1), temb) + emb[2]
+    x3 = _two_conv_cl(den.down_3.convs, _pool_cl(x2), temb) + emb[3]
+    x4 = _two_conv_cl(den.down_4.convs, _pool_cl(x3), temb) + emb[4]
+
+    def up(block, lo, skip):
+        return _two_conv_cl(block.convs, torch.cat([skip, _deconv_cl(block.upsample, lo)], dim=-1), temb)
+
+    u4 = up(den.upcat_4, x4, x3)
+    u3 = up(den.upcat_3, u4, x2)
+    u2 = up(den.upcat_2, u3, x1)
+    u1 = up(den.upcat_1, u2, x0)
+    wf = den.final_conv.weight
+    logits = u1 @ wf.reshape(wf.shape[0], -1).t().to(u1.dtype) + den.final_conv.bias.to(u1.dtype)
+    return logits.permute(0, 4, 1, 2, 3).float()
+
+
+class NativeConvTrainer:
+    """Single-GPU-per-process trainer on the native-convolution path: fp32 master weights, fp16 activations and
+    gradients with dynamic loss scaling (or plain fp32), AdamW as train.py:121-126.  Under torch.distributed the
+    gradients are averaged with one flat all-reduce per step (RCCL on a GPU node)."""
+
+    def __init__(self, net, lr=2e-4, weight_decay=1e-4, losses="mse,bce,dice", loss_combine="sum",
+                 dtype=torch.float16, init_scale=2.0 ** 12):
+        self.net, self.dtype = net, dtype
+        self.criterion = Loss(losses, loss_combine)
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay)
+        self.scale, self.good_steps = (init_scale if dtype == torch.float16 else 1.0), 0
+
+    def _allreduce(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in self.params])
+        dist.all_reduce(flat)
+        flat /= dist.get_world_size()
+        off = 0
+        for p in self.params:
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def step(self, images, labels, noise=None, t=None):
+        x_start = labels * 2 - 1
+        if t is None:
+            t, _ = self.net.sampler.sample(x_start.shape[0], x_start.device)
+        noise = torch.randn_like(x_start) if noise is None else noise
+        x_t = self.net.diffusion.q_sample(x_start, t, noise)                     # HIP kernel
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            loss = self.criterion(native_conv_denoise(self.net, images, x_t, t, self.dtype), labels)
+            (loss * self.scale).backward()
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        self._allreduce()
+        if self.scale != 1.0:
+            finite = torch.stack([torch.isfinite(p.grad).all() for p in self.params]).all()
+            if not bool(finite):                                                 # overflow: skip, halve the scale
+                self.scale, self.good_steps = self.scale / 2, 0
+                return loss.detach()
+            for p in self.params:
+                p.grad.mul_(1.0 / self.scale)
+            self.good_steps += 1
+            if self.good_steps >= 200:
+                self.scale, self.good_steps = self.scale * 2, 0
+        self.optimizer.step()
+        return loss.detach()

@@ -68,9 +68,12 @@ int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_pack
  * d describes the FORWARD convolution (x: Cin channels at Cin_off of a Cin_stride buffer; dy: Cout channels at
  * Cout_off of a Cout_stride buffer, same N/D/H/W).  dw: fp32 [Cout][Cin_src][27] in the reference's layout,
  * ACCUMULATED into with fp32 atomics (zero it first).  in_perm (device int[ceil(Cin/64)*64]) or NULL maps a packed
- * input channel of x to its source channel in dw (negative = padding), as in dua_pack_conv3_weights. */
+ * input channel of x to its source channel in dw (negative = padding), as in dua_pack_conv3_weights.
+ * workspace (dua_conv3d_k3_wgrad_workspace bytes; may be NULL): per-workgroup partial sums, reduced by a second
+ * kernel -- without it every workgroup adds into dw with fp32 atomics (correct, much slower). */
+long dua_conv3d_k3_wgrad_workspace(const dua_conv3_desc* d);
 int dua_conv3d_k3_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
-                        const int* in_perm, void* stream);
+                        const int* in_perm, void* workspace, long workspace_bytes, void* stream);
 
 /* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (1 synchronous slabs, 2 LDS-DMA pipelined; default 2). */
 int dua_set_option(int key, int value);

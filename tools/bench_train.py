@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diff_unet_amos_amd.diff_unet import DiffUNet          # noqa: E402
-from diff_unet_amos_amd.training import DDPTrainer         # noqa: E402
+from diff_unet_amos_amd.training import DDPTrainer, NativeConvTrainer         # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=5)
@@ -18,11 +18,13 @@ ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--classes", type=int, default=16)
 ap.add_argument("--size", type=int, default=96)
+ap.add_argument("--path", default="native-conv", choices=["native-conv", "autograd"])
+ap.add_argument("--dtype", default="float16")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = DiffUNet(in_channels=1, out_channels=a.classes).to(dev)
-tr = DDPTrainer(net)
+tr = NativeConvTrainer(net, dtype=getattr(torch, a.dtype)) if a.path == "native-conv" else DDPTrainer(net)
 image = torch.rand(a.batch, 1, a.size, a.size, a.size, device=dev)
 labels = (torch.rand(a.batch, a.classes, a.size, a.size, a.size, device=dev) > 0.8).float()
 for _ in range(a.warmup):
@@ -33,7 +35,8 @@ for _ in range(a.steps):
     loss = tr.step(image, labels)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "native": False,
-                  "path": "torch autograd fallback (MIOpen/rocBLAS), q_sample = HIP", "batch": a.batch,
+print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "native": a.path == "native-conv",
+                  "path": ("HIP conv fwd/dgrad/wgrad under autograd; norm/pool/deconv/head/loss/AdamW = torch; " + a.dtype)
+                  if a.path == "native-conv" else "torch autograd fallback (MIOpen/rocBLAS) fp32, q_sample = HIP", "batch": a.batch,
                   "size": a.size, "classes": a.classes, "loss": float(loss),
                   "max_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}))

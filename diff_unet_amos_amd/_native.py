@@ -41,6 +41,12 @@ class MaterializeDesc(C.Structure):
                 ("pool_stride", C.c_int)]
 
 
+class NormBwdDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("voxels", C.c_long), ("C", C.c_int), ("da_stride", C.c_int),
+                ("da_off", C.c_int), ("raw_stride", C.c_int), ("raw_off", C.c_int), ("out_stride", C.c_int),
+                ("out_off", C.c_int)]
+
+
 class TailDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("voxels", C.c_long), ("K", C.c_int), ("raw_stride", C.c_int),
                 ("C", C.c_int), ("CX", C.c_int), ("mode", C.c_int), ("xin_stride", C.c_int),
@@ -64,6 +70,8 @@ _SIGS = {
     "dua_conv3d_k3_wgrad": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.c_int, _P, _P, C.c_long, _P]),
     "dua_pack_conv3_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "dua_instnorm_finalize": (C.c_int, [C.c_int, C.c_int, C.POINTER(InNorm), _P, _P, _P]),
+    "dua_instnorm_bwd_reduce": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P]),
+    "dua_instnorm_bwd_apply": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P, _P]),
     "dua_materialize": (C.c_int, [C.POINTER(MaterializeDesc), _P, C.POINTER(InNorm), _P, _P, _P, _P]),
     "dua_pack_deconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_to_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, _P, C.c_int, C.c_int, C.c_int, _P]),

@@ -5,7 +5,7 @@
 // gamma*rstd, shift = beta - mean*scale while staging its input (common.hpp InXform/xform_preamble);
 // instnorm_finalize writes the same scale/shift out for inspection.
 //
-// materialize writes an activation that has several consumers: x_i = LeakyReLU(IN(raw)) +
+// materialize writes an activation that has several consumers: x_i = LeakyReLU(IN(raw)) [+ add[n, c]] +
 // embeddings[i] (models/basic_unet/denoiser.py:300-304) into the channel slice of a concat
 // buffer, and optionally its MaxPool3d(2) (denoiser.py:100,106) for the next level.
 #include "common.hpp"
@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
   for (long it = blockIdx.x * 256L + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
     const int cg = (int)(it % gpc);
     long v = it / gpc;
-    float sc[EPG], sh[EPG];
+    float sc[EPG], sh[EPG], ad[EPG];
 #pragma unroll
-    for (int e = 0; e < EPG; ++e) { sc[e] = sm[cg * EPG + e]; sh[e] = sm[C + cg * EPG + e]; }
+    for (int e = 0; e < EPG; ++e) { sc[e] = sm[cg * EPG + e]; sh[e] = sm[C + cg * EPG + e]; ad[e] = sm[2 * C + cg * EPG + e]; }
     if constexpr (!POOL) {
       const long gv = n * vox_n + v;
       Frag x = *(const Frag*)(raw + gv * raw_stride + cg * EPG);
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
 #pragma unroll
       for (int e = 0; e < EPG; ++e) {
         float y = fmaf((float)x[e], sc[e], sh[e]);
-        y = y > 0.f ? y : y * slope;
+        y = (y > 0.f ? y : y * slope) + ad[e];
         if (emb) y += (float)ev[e];
         o[e] = (T)y;
       }
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
 #pragma unroll
         for (int e = 0; e < EPG; ++e) {
           float y = fmaf((float)x[e], sc[e], sh[e]);
-          y = y > 0.f ? y : y * slope;
+          y = (y > 0.f ? y : y * slope) + ad[e];
           if (emb) y += (float)ev[e];
           o[e] = (T)y;
           mx[e] = fmaxf(mx[e], (float)o[e]);

@@ -1,0 +1,179 @@
+// Backward of  a = LeakyReLU(InstanceNorm3d_affine(y)) [+ add[n, c]] [+ emb]  (MONAI ADN "NDA" + the timestep-embedding
+// bias of TwoConv.forward, models/basic_unet/denoiser.py:63-67,206-207) for the training step (train.py:258-268).
+//
+// Forward kept the raw convolution output y and its per-(n, c) sums, never the normalised tensor, so both passes
+// recompute z = (y - mean) * rstd * gamma + beta from them:
+//   reduce : S0 = sum dA,  S1 = sum dZ,  S2 = sum dZ * zhat      with dZ = dA * (z > 0 ? 1 : slope), zhat = (y - mean) * rstd
+//            -> d add[n, c] = S0,  d beta[c] = sum_n S1,  d gamma[c] = sum_n S2
+//   apply  : dY = gamma * rstd * (dZ - S1 / V - zhat * S2 / V)
+// Both are one streaming pass over dA and y (HBM bound): thread = one 16-byte channel group, fixed per thread, walking
+// voxels; per-block LDS reduction, then fp64 atomics into one of 8 replica rows (as the forward statistics).
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+
+namespace dua {
+
+// mean / rstd / gamma / beta of channels [0, C) into LDS
+__device__ __forceinline__ void norm_preamble(const InXform& xf, int n, int C, float* mu, float* rs, float* ga, float* be) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double S = 0, Q = 0;
+#pragma unroll
+    for (int r = 0; r < STAT_REPLICAS; ++r) {
+      const double* p = xf.stats + (((long)n * STAT_REPLICAS + r) * xf.c_pad + c) * 2;
+      S += p[0]; Q += p[1];
+    }
+    const double mean = S * (double)xf.inv_count;
+    double var = Q * (double)xf.inv_count - mean * mean;
+    var = var > 0 ? var : 0;
+    mu[c] = (float)mean;
+    rs[c] = (float)(1.0 / sqrt(var + (double)xf.eps));
+    ga[c] = xf.gamma[c];
+    be[c] = xf.beta[c];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict__ dA, int da_stride, int da_off,
+                                                            const T* __restrict__ raw, int raw_stride, int raw_off,
+                                                            InXform xf, int C, long vox, double* __restrict__ sums) {
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  extern __shared__ float sm[];
+  float* mu = sm; float* rs = sm + C; float* ga = sm + 2 * C; float* be = sm + 3 * C;
+  float* red = sm + 4 * C;                    // [256][3 * EPG]
+  const int gpc = C / EPG, n = blockIdx.y;
+  norm_preamble(xf, n, C, mu, rs, ga, be);
+  __syncthreads();
+  const int tpg = 256 / gpc;                  // threads sharing one channel group; threads beyond tpg * gpc idle
+  const int cg = threadIdx.x % gpc, vl = threadIdx.x / gpc;
+  float m[EPG], r[EPG], g[EPG], b[EPG], s0[EPG], s1[EPG], s2[EPG];
+#pragma unroll
+  for (int e = 0; e < EPG; ++e) {
+    m[e] = mu[cg * EPG + e]; r[e] = rs[cg * EPG + e]; g[e] = ga[cg * EPG + e]; b[e] = be[cg * EPG + e];
+    s0[e] = s1[e] = s2[e] = 0.f;
+  }
+  const float slope = xf.slope;
+  for (long v = (long)blockIdx.x * tpg + vl; v < vox && vl < tpg; v += (long)gridDim.x * tpg) {
+    const long gv = n * vox + v;
+    const Frag da = *(const Frag*)(dA + gv * da_stride + da_off + cg * EPG);
+    const Frag y = *(const Frag*)(raw + gv * raw_stride + raw_off + cg * EPG);
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) {
+      const float zh = ((float)y[e] - m[e]) * r[e];
+      const float z = fmaf(zh, g[e], b[e]);
+      const float d = (float)da[e];
+      const float dz = z > 0.f ? d : d * slope;
+      s0[e] += d; s1[e] += dz; s2[e] = fmaf(dz, zh, s2[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPG; ++e) {
+    red[threadIdx.x * 3 * EPG + e] = s0[e];
+    red[threadIdx.x * 3 * EPG + EPG + e] = s1[e];
+    red[threadIdx.x * 3 * EPG + 2 * EPG + e] = s2[e];
+  }
+  __syncthreads();
+  // thread t < 3 * C: (which, channel) -> sum over the tpg threads of that channel group
+  for (int t = threadIdx.x; t < 3 * C; t += 256) {
+    const int which = t / C, c = t % C, cgc = c / EPG, e = c % EPG;
+    double acc = 0;
+    for (int j = 0; j < tpg; ++j) acc += (double)red[(j * gpc + cgc) * 3 * EPG + which * EPG + e];
+    unsafeAtomicAdd(sums + (((long)n * STAT_REPLICAS + (blockIdx.x & (STAT_REPLICAS - 1))) * xf.c_pad + c) * 4 + which, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ dA, int da_stride, int da_off,
+                                                           const T* __restrict__ raw, int raw_stride, int raw_off,
+                                                           InXform xf, const double* __restrict__ sums, int C, long vox,
+                                                           T* __restrict__ out, int out_stride, int out_off) {
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  extern __shared__ float sm[];
+  float* mu = sm; float* rs = sm + C; float* ga = sm + 2 * C; float* be = sm + 3 * C;
+  float* k1 = sm + 4 * C; float* k2 = sm + 5 * C;       // S1 / V, S2 / V
+  const int gpc = C / EPG, n = blockIdx.y;
+  norm_preamble(xf, n, C, mu, rs, ga, be);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a1 = 0, a2 = 0;
+#pragma unroll
+    for (int r = 0; r < STAT_REPLICAS; ++r) {
+      const double* p = sums + (((long)n * STAT_REPLICAS + r) * xf.c_pad + c) * 4;
+      a1 += p[1]; a2 += p[2];
+    }
+    k1[c] = (float)(a1 * (double)xf.inv_count);
+    k2[c] = (float)(a2 * (double)xf.inv_count);
+  }
+  __syncthreads();
+  const float slope = xf.slope;
+  const long total = vox * gpc;
+  for (long it = blockIdx.x * 256L + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+    const int cg = (int)(it % gpc);
+    const long gv = n * vox + it / gpc;
+    const Frag da = *(const Frag*)(dA + gv * da_stride + da_off + cg * EPG);
+    const Frag y = *(const Frag*)(raw + gv * raw_stride + raw_off + cg * EPG);
+    Frag o;
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) {
+      const int c = cg * EPG + e;
+      const float zh = ((float)y[e] - mu[c]) * rs[c];
+      const float z = fmaf(zh, ga[c], be[c]);
+      const float d = (float)da[e];
+      const float dz = z > 0.f ? d : d * slope;
+      o[e] = (T)(ga[c] * rs[c] * (dz - k1[c] - zh * k2[c]));
+    }
+    *(Frag*)(out + gv * out_stride + out_off + cg * EPG) = o;
+  }
+}
+
+template <typename T>
+static int launch_bwd(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in, double* sums,
+                      void* out, hipStream_t s) {
+  constexpr int EPG = Elem<T>::EPG;
+  const InXform xf = make_xform(in, d->C);
+  const int gpc = d->C / EPG;
+  if (gpc > 256) return DUA_ERR_ARG;
+  if (!out) {
+    const int tpg = 256 / gpc;
+    long blocks = (d->voxels + (long)tpg * 8 - 1) / ((long)tpg * 8);      // >= 8 voxels per thread
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const size_t lds = sizeof(float) * (4 * d->C + 256 * 3 * EPG);
+    hipLaunchKernelGGL(in_bwd_reduce_kernel<T>, dim3((unsigned)blocks, d->N), dim3(256), lds, s, (const T*)dA, d->da_stride,
+                       d->da_off, (const T*)raw, d->raw_stride, d->raw_off, xf, d->C, d->voxels, sums);
+  } else {
+    long blocks = (d->voxels * gpc + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3((unsigned)blocks, d->N), dim3(256), sizeof(float) * 6 * d->C, s,
+                       (const T*)dA, d->da_stride, d->da_off, (const T*)raw, d->raw_stride, d->raw_off, xf,
+                       (const double*)sums, d->C, d->voxels, (T*)out, d->out_stride, d->out_off);
+  }
+  return (int)hipGetLastError();
+}
+
+static bool bwd_args_ok(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in, const void* sums) {
+  if (!d || !dA || !raw || !in || !in->stats || !in->gamma || !in->beta || !sums) return false;
+  if (d->N <= 0 || d->voxels <= 0 || d->C <= 0 || d->C % 8 || d->C > 1024 || in->c_pad < d->C) return false;
+  if (d->da_stride % 8 || d->da_off % 8 || d->raw_stride % 8 || d->raw_off % 8) return false;
+  return d->dtype == DUA_F16 || d->dtype == DUA_F32;
+}
+
+}  // namespace dua
+
+extern "C" {
+
+int dua_instnorm_bwd_reduce(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
+                            double* sums, void* stream) {
+  if (!dua::bwd_args_ok(d, dA, raw, in, sums)) return DUA_ERR_ARG;
+  return d->dtype == DUA_F16 ? dua::launch_bwd<dua::f16>(d, dA, raw, in, sums, nullptr, (hipStream_t)stream)
+                             : dua::launch_bwd<float>(d, dA, raw, in, sums, nullptr, (hipStream_t)stream);
+}
+
+int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
+                           const double* sums, void* dY, void* stream) {
+  if (!dua::bwd_args_ok(d, dA, raw, in, sums) || !dY || d->out_stride % 8 || d->out_off % 8) return DUA_ERR_ARG;
+  return d->dtype == DUA_F16 ? dua::launch_bwd<dua::f16>(d, dA, raw, in, (double*)sums, dY, (hipStream_t)stream)
+                             : dua::launch_bwd<float>(d, dA, raw, in, (double*)sums, dY, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -204,6 +204,26 @@ def instnorm_finalize(norm, N, Cc):
     return scale, shift
 
 
+def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0):
+    """Backward of LeakyReLU(IN(raw)) [+ add] for channels [0, Cc) of ``raw``: writes d raw into ``dY`` and returns the
+    fp64 sums [N, Cc, 3] = (sum dA, sum dZ, sum dZ * zhat) -> d add, d beta (sum over n), d gamma (sum over n)."""
+    _cl_check(dA, "dA"); _cl_check(raw, "raw"); _cl_check(dY, "dY")
+    N = raw.shape[0]
+    vox = raw.shape[1] * raw.shape[2] * raw.shape[3]
+    assert dA.dtype == raw.dtype == dY.dtype and tuple(dA.shape[:4]) == tuple(raw.shape[:4]) == tuple(dY.shape[:4])
+    assert Cc % 8 == 0 and Cc <= raw.shape[-1] and da_off % 8 == 0 and da_off + Cc <= dA.shape[-1]
+    assert dy_off % 8 == 0 and dy_off + Cc <= dY.shape[-1]
+    cpad = norm.keep[0].shape[2]
+    sums = torch.zeros((N, STAT_REPLICAS, cpad, 4), dtype=torch.float64, device=raw.device)
+    d = nv.NormBwdDesc(nv.dt_code(raw.dtype), N, vox, Cc, dA.shape[-1], da_off, raw.shape[-1], 0, dY.shape[-1], dy_off)
+    L = nv.lib()
+    nv.check(L.dua_instnorm_bwd_reduce(C.byref(d), nv.ptr(dA), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(sums), nv.stream_ptr()),
+             "dua_instnorm_bwd_reduce")
+    nv.check(L.dua_instnorm_bwd_apply(C.byref(d), nv.ptr(dA), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(sums), nv.ptr(dY),
+                                      nv.stream_ptr()), "dua_instnorm_bwd_apply")
+    return sums.sum(1)[:, :Cc, :3]
+
+
 def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None):
     _cl_check(raw, "raw"); _cl_check(out, "out")
     N, D, H, W, rs = raw.shape

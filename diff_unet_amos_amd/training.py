@@ -170,8 +170,9 @@ class DDPTrainer:
 # Native-convolution training path: every 3x3x3 convolution (forward, data gradient, weight gradient -- >95 % of
 # the step's FLOPs) runs on the HIP kernels of this package inside a torch.autograd.Function; activations are
 # channels-last [N, D, H, W, C] in the compute dtype (fp16 with fp32 master weights and a GradScaler, or fp32).
-# What is still torch: InstanceNorm/LeakyReLU/temb add (elementwise + reductions), MaxPool, the k2s2 transposed
-# convolution and the 1x1 head as plain library GEMMs, the loss, AdamW.  They are the next kernels to write.
+# InstanceNorm + LeakyReLU + temb/embedding adds are fused around them (materialize forward, reduce/apply backward).
+# What is still torch: MaxPool, concat, the k2s2 transposed convolution and the 1x1 head as plain library GEMMs, the
+# timestep MLP, the loss, AdamW.  They are the next kernels to write.
 class _Conv3dK3(torch.autograd.Function):
     """y = conv3d(x, w, b), 3x3x3 / pad 1, channels-last.  forward: dua_conv3d_k3_fwd; backward: the same kernel on
     dy with the weights flipped and transposed (data gradient) + dua_conv3d_k3_wgrad (weight gradient)."""
@@ -220,18 +221,60 @@ def _cl_pad(x_ncdhw, dtype):
     return out
 
 
-def _two_conv_cl(block, x, temb):
-    for i, cb in enumerate((block.conv_0, block.conv_1)):
-        y = _Conv3dK3.apply(x, cb.conv.weight, cb.conv.bias)
-        yf = y.float()
-        var, mean = torch.var_mean(yf, dim=(1, 2, 3), unbiased=False, keepdim=True)
-        z = (yf - mean) * torch.rsqrt(var + 1e-5) * cb.adn.N.weight + cb.adn.N.bias
-        z = F.leaky_relu(z, 0.1)
-        if i == 0 and temb is not None:
-            s = temb * torch.sigmoid(temb)
-            z = z + F.linear(s, block.temb_proj.weight, block.temb_proj.bias)[:, None, None, None, :]
-        x = z.to(y.dtype)
-    return x
+class _ConvNormAct(torch.autograd.Function):
+    """a = LeakyReLU(InstanceNorm(conv3d(x, w, b))) [+ add[n, c]] [+ emb] -- one MONAI Convolution block (+ the temb bias /
+    the encoder embedding that follow it in TwoConv.forward / BasicUNetRDenoiser.forward), all on the HIP kernels:
+    forward  = conv (raw output + statistics in its epilogue) -> materialize;
+    backward = norm/activation backward (reduce + apply) -> data gradient (conv kernel) + weight gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, add, emb):
+        from . import ops
+        N, D, H, W, cs = x.shape
+        cout = weight.shape[0]
+        assert x.is_contiguous() and cs % 8 == 0 and cout % 8 == 0 and weight.shape[1] <= cs
+        wp, bp = ops.pack_conv3_weights(weight.detach().float().contiguous(), bias.detach().float(), x.dtype, cin_packed=cs)
+        raw = torch.empty((N, D, H, W, cout), dtype=x.dtype, device=x.device)
+        stats = ops.stats_buffer(N, cout, x.device)
+        ops.conv3d_k3(x, cs, 0, wp, bp, cout, raw, 0, stats)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        a32 = add.detach().float().contiguous() if add is not None else None
+        norm = ops.Norm(stats, g32, b32, D * H * W, add=a32, add_stride=cout)
+        act = torch.empty_like(raw)
+        ops.materialize(raw, cout, norm, act, 0, emb=emb.detach() if emb is not None else None)
+        ctx.save_for_backward(x, weight, raw, stats, g32, b32)
+        ctx.has_add, ctx.has_emb = add is not None, emb is not None
+        return act
+
+    @staticmethod
+    def backward(ctx, dA):
+        from . import ops
+        x, weight, raw, stats, g32, b32 = ctx.saved_tensors
+        dA = dA.contiguous()
+        N, D, H, W, cout = raw.shape
+        norm = ops.Norm(stats, g32, b32, D * H * W)
+        dY = torch.empty_like(raw)
+        sums = ops.instnorm_bwd(dA, 0, raw, cout, norm, dY)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().float().flip(2, 3, 4).transpose(0, 1).contiguous()
+            dx = _Conv3dK3._run(dY, wt, None, x.shape[-1])
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dY, cout, 0, dw)
+        db = torch.zeros(cout, dtype=torch.float32, device=x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
+        dgamma, dbeta = sums[:, :, 2].sum(0).float(), sums[:, :, 1].sum(0).float()
+        dadd = sums[:, :, 0].float() if ctx.has_add else None
+        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None)
+
+
+def _two_conv_cl(block, x, temb, emb=None):
+    add = None
+    if temb is not None:
+        add = F.linear(temb * torch.sigmoid(temb), block.temb_proj.weight, block.temb_proj.bias)
+    c0, c1 = block.conv_0, block.conv_1
+    h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None)
+    return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb)
 
 
 def _pool_cl(x):
@@ -258,11 +301,11 @@ def native_conv_denoise(net, image, x, step, dtype=torch.float16):
         emb.append(_two_conv_cl(d.convs, _pool_cl(emb[-1]), None))
     temb = _time_embedding(den.temb, step)
     h = _cl_pad(torch.cat([image, x], dim=1), dtype)
-    x0 = _two_conv_cl(den.conv_0, h, temb) + emb[0]
-    x1 = _two_conv_cl(den.down_1.convs, _pool_cl(x0), temb) + emb[1]
-    x2 = _two_conv_cl(den.down_2.convs, _pool_cl(x1), temb) + emb[2]
-    x3 = _two_conv_cl(den.down_3.convs, _pool_cl(x2), temb) + emb[3]
-    x4 = _two_conv_cl(den.down_4.convs, _pool_cl(x3), temb) + emb[4]
+    x0 = _two_conv_cl(den.conv_0, h, temb, emb[0])
+    x1 = _two_conv_cl(den.down_1.convs, _pool_cl(x0), temb, emb[1])
+    x2 = _two_conv_cl(den.down_2.convs, _pool_cl(x1), temb, emb[2])
+    x3 = _two_conv_cl(den.down_3.convs, _pool_cl(x2), temb, emb[3])
+    x4 = _two_conv_cl(den.down_4.convs, _pool_cl(x3), temb, emb[4])
 
     def up(block, lo, skip):
         return _two_conv_cl(block.convs, torch.cat([skip, _deconv_cl(block.upsample, lo)], dim=-1), temb)

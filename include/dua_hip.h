@@ -75,6 +75,25 @@ long dua_conv3d_k3_wgrad_workspace(const dua_conv3_desc* d);
 int dua_conv3d_k3_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
                         const int* in_perm, void* workspace, long workspace_bytes, void* stream);
 
+/* Backward of a = LeakyReLU(InstanceNorm3d_affine(y)) [+ add] [+ emb] (denoiser.py:63-67,206-207 under
+ * train.py:258-268).  y (raw) and its forward statistics (in->stats) are what the forward kept.
+ *   reduce: sums[N][8][in->c_pad][4] (fp64, pre-zeroed) += (sum dA, sum dZ, sum dZ*zhat, unused) per replica row;
+ *           d add[n,c] = sum over replicas of [0]; d beta[c] = sum_n [1]; d gamma[c] = sum_n [2]
+ *   apply : dY = gamma*rstd*(dZ - S1/V - zhat*S2/V), written to channels [out_off, out_off+C) of dY's buffer. */
+typedef struct {
+  int dtype;
+  int N;
+  long voxels;                 /* D*H*W */
+  int C;                       /* multiple of 8, <= 1024 */
+  int da_stride, da_off;
+  int raw_stride, raw_off;
+  int out_stride, out_off;     /* apply only */
+} dua_norm_bwd_desc;
+int dua_instnorm_bwd_reduce(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
+                            double* sums, void* stream);
+int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
+                           const double* sums, void* dY, void* stream);
+
 /* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (1 synchronous slabs, 2 LDS-DMA pipelined; default 2). */
 int dua_set_option(int key, int value);
 

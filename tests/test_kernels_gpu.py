@@ -416,3 +416,43 @@ def test_conv3_wgrad_permuted_input_channels():
     src = torch.stack([x[..., 4], x[..., 0], x[..., 1], x[..., 2], x[..., 3]], dim=1).double()
     want = torch.nn.grad.conv3d_weight(src, (Cout, Cin_src, 3, 3, 3), dy.permute(0, 4, 1, 2, 3).double(), padding=1)
     assert (dw.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 64), (1, 6, 10, 4, 24), (2, 4, 4, 4, 136), (1, 2, 2, 2, 512)])
+def test_instnorm_lrelu_backward_matches_autograd(dtype, shape):
+    """conv stats -> materialize (+ per-(n,c) add) forward, then the reduce/apply backward pair against torch autograd
+    of instance_norm -> leaky_relu -> + add on the same raw tensor."""
+    ops = _ops()
+    N, D, H, W, Cc = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    raw = (torch.randn(N, D, H, W, Cc, generator=g, device=dev) * 1.5 + 0.3).to(dtype)
+    gamma = torch.rand(Cc, generator=g, device=dev) + 0.5
+    beta = torch.randn(Cc, generator=g, device=dev) * 0.2
+    add = torch.randn(N, Cc, generator=g, device=dev)
+    dA = torch.randn(N, D, H, W, Cc, generator=g, device=dev).to(dtype)
+    V = D * H * W
+    cpad = -(-Cc // 64) * 64
+    stats = torch.zeros(N, 8, cpad, 2, dtype=torch.float64, device=dev)
+    rd = raw.double()
+    stats[:, 0, :Cc, 0] = rd.sum((1, 2, 3))
+    stats[:, 0, :Cc, 1] = (rd * rd).sum((1, 2, 3))
+    norm = ops.Norm(stats, gamma, beta, V, add=add, add_stride=Cc)
+    act = torch.empty_like(raw)
+    ops.materialize(raw, Cc, norm, act, 0)
+    dY = torch.empty_like(raw)
+    sums = ops.instnorm_bwd(dA, 0, raw, Cc, norm, dY)
+    # reference: autograd in fp64 on NCDHW
+    r = rd.permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    gm, bt, ad = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), add.double().requires_grad_(True)
+    a = F.leaky_relu(F.instance_norm(r, weight=gm, bias=bt, eps=1e-5), 0.1) + ad[:, :, None, None, None]
+    a.backward(dA.double().permute(0, 4, 1, 2, 3))
+    tol = 1e-4 if dtype == torch.float32 else 4e-3
+    assert (act.double().permute(0, 4, 1, 2, 3) - a.detach()).abs().max().item() < (1e-5 if dtype == torch.float32 else 2e-2)
+    want = r.grad.permute(0, 2, 3, 4, 1)
+    assert (dY.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    assert torch.allclose(sums[:, :, 0], ad.grad, rtol=1e-4, atol=1e-4 * V ** 0.5)
+    assert torch.allclose(sums[:, :, 1].sum(0), bt.grad, rtol=1e-4, atol=1e-4 * V ** 0.5)
+    assert torch.allclose(sums[:, :, 2].sum(0), gm.grad, rtol=1e-4, atol=1e-4 * V ** 0.5)

@@ -36,7 +36,7 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "native": a.path == "native-conv",
-                  "path": ("HIP conv fwd/dgrad/wgrad under autograd; norm/pool/deconv/head/loss/AdamW = torch; " + a.dtype)
+                  "path": ("HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; pool/deconv/head/loss/AdamW = torch; " + a.dtype)
                   if a.path == "native-conv" else "torch autograd fallback (MIOpen/rocBLAS) fp32, q_sample = HIP", "batch": a.batch,
                   "size": a.size, "classes": a.classes, "loss": float(loss),
                   "max_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}))

@@ -359,12 +359,13 @@ class NativeConvTrainer:
                 p.grad = torch.zeros_like(p)
         self._allreduce()
         if self.scale != 1.0:
-            finite = torch.stack([torch.isfinite(p.grad).all() for p in self.params]).all()
-            if not bool(finite):                                                 # overflow: skip, halve the scale
+            # one multi-tensor kernel: grads *= 1/scale, found_inf = any non-finite
+            found_inf = torch.zeros(1, dtype=torch.float32, device=self.params[0].device)
+            inv = torch.full((1,), 1.0 / self.scale, dtype=torch.float32, device=self.params[0].device)
+            torch._amp_foreach_non_finite_check_and_unscale_([p.grad for p in self.params], found_inf, inv)
+            if bool(found_inf.item()):                                           # overflow: skip, halve the scale
                 self.scale, self.good_steps = self.scale / 2, 0
                 return loss.detach()
-            for p in self.params:
-                p.grad.mul_(1.0 / self.scale)
             self.good_steps += 1
             if self.good_steps >= 200:
                 self.scale, self.good_steps = self.scale * 2, 0

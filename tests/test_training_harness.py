@@ -196,3 +196,56 @@ def test_native_conv_trainer_learns():
     image, labels, noise, t = image.to(dev), labels.to(dev), noise.to(dev), t.to(dev)
     losses = [float(tr.step(image, labels, noise=noise, t=t)) for _ in range(10)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def _native_ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share cuda:0; gloo moves CUDA tensors via the host
+    try:
+        from diff_unet_amos_amd.training import NativeConvTrainer
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        net = DiffUNet(**KW).to(dev)
+        tr = NativeConvTrainer(net, lr=1e-3, dtype=torch.float32)
+        image, labels, noise, t = _data(2, 7)
+        sl = slice(rank, rank + 1)
+        loss = tr.step(image[sl].to(dev), labels[sl].to(dev), noise=noise[sl].to(dev), t=t[sl].to(dev))
+        q.put((rank, float(loss), {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_native_trainer_two_ranks_equal_union_batch():
+    """Two processes (one GPU, gloo) each train on their own sample; the flat gradient all-reduce must leave both with
+    the parameters single-process training on the two-sample batch produces (oracle autograd, CPU)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 177) % 2000
+    procs = [ctx.Process(target=_native_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = {r: (l, sd) for r, l, sd in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+    torch.manual_seed(0)
+    net = DiffUNet(**KW)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4)
+    crit = Loss()
+    image, labels, noise, t = _data(2, 7)
+    opt.zero_grad()
+    total = 0
+    for i in range(2):
+        total = total + training_step(net, image[i:i + 1], labels[i:i + 1], crit, noise=noise[i:i + 1], t=t[i:i + 1]) / 2
+    total.backward()
+    opt.step()
+    worst = 0.0
+    for k, v in net.state_dict().items():
+        if k.endswith("conv.bias"):       # zero true gradient: Adam turns rounding noise into +-lr steps on both sides
+            continue
+        worst = max(worst, float(np.abs(outs[0][1][k] - v.detach().numpy()).max()))
+    assert worst < 2e-4, worst

@@ -30,12 +30,14 @@ labels = (torch.rand(a.batch, a.classes, a.size, a.size, a.size, device=dev) > 0
 for _ in range(a.warmup):
     tr.step(image, labels)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
+per = []
 for _ in range(a.steps):
+    t0 = time.perf_counter()
     loss = tr.step(image, labels)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "native": a.path == "native-conv",
+    torch.cuda.synchronize()
+    per.append(time.perf_counter() - t0)
+dt = sum(per) / len(per)
+print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "median_ms": sorted(per)[len(per) // 2] * 1e3, "per_step_ms": [round(x * 1e3, 2) for x in per], "native": a.path == "native-conv",
                   "path": ("HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; pool/deconv/head/loss/AdamW = torch; " + a.dtype)
                   if a.path == "native-conv" else "torch autograd fallback (MIOpen/rocBLAS) fp32, q_sample = HIP", "batch": a.batch,
                   "size": a.size, "classes": a.classes, "loss": float(loss),

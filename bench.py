@@ -15,7 +15,8 @@ collective; only the timing barrier/all-reduce(MAX) touches RCCL.
 Extra objects in the JSON line:
   roofline     -- for the dominant kernel (conv3d_k3_v2_kernel, all 18 launches of a step): algorithmic
                   FLOPs per launch / average launch duration, measured with HIP events on the launch
-                  stream in an instrumented eager pass of the same steps; peak = dense fp16 MFMA.
+                  stream: each of the step's 18 launches replayed back to back between one event pair
+                  (split-K layers without their finish kernel); peak = dense fp16 MFMA.
   cpu_baseline -- the CPU oracle (oracle/unet_ref.py, "port") timed on this box's host cores on a
                   bounded sample (1 warm-up + 2 denoiser evaluations at the same 96^3 x 16 shape).
 """
@@ -52,40 +53,43 @@ def conv3_flops(plan):
     return out
 
 
-def time_conv_launches(plan, steps):
-    """Instrumented eager pass: HIP events (torch.cuda.Event on the launch stream) around every
-    conv3d_k3 launch of `steps` denoiser evaluations.  Returns (avg ms per launch, launches/step)."""
+def time_conv_launches(plan, reps):
+    """HIP events (torch.cuda.Event on the launch stream) around the conv3d_k3 kernel: one eager denoiser evaluation
+    records the arguments of its 18 launches; each launch is then replayed `reps` times back to back between ONE event
+    pair (an event pair around a single ~30 us launch reads the command-processor gaps as kernel time).  Split-K layers
+    are replayed without their finish kernel (dua_set_option(2, 1)), so the figure is conv3d_k3_v2_kernel alone, as the
+    rocprofv3 summary lists it.  Returns (avg ms per launch, launches/step, ms by launch)."""
+    from diff_unet_amos_amd import _native as nv
     from diff_unet_amos_amd import ops
     real = ops.conv3d_k3
-    pairs = []
+    calls = []
 
     def wrapped(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = real(*a, **k)
-        e1.record()
-        pairs.append((e0, e1))
-        return r
+        calls.append((a, k))
+        return real(*a, **k)
 
     ops.conv3d_k3 = wrapped
     try:
-        for _ in range(steps):
-            plan.denoiser_body()
+        plan.denoiser_body()
         torch.cuda.synchronize()
     finally:
         ops.conv3d_k3 = real
-    # an event pair around nothing still reads a few microseconds: calibrate and take it off every launch
-    empty = []
-    for _ in range(200):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); e1.record()
-        empty.append((e0, e1))
-    torch.cuda.synchronize()
-    base = sorted(a.elapsed_time(b) for a, b in empty)[100]
-    ms = [max(a.elapsed_time(b) - base, 1e-4) for a, b in pairs]
-    per_step = len(pairs) // steps
-    by_launch = [sum(ms[i::per_step]) / steps for i in range(per_step)]
-    return sum(ms) / len(ms), per_step, by_launch
+    by_launch = []
+    nv.check(nv.lib().dua_set_option(2, 1), "dua_set_option")
+    try:
+        for a, k in calls:
+            for _ in range(3):
+                real(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                real(*a, **k)
+            e1.record()
+            torch.cuda.synchronize()
+            by_launch.append(e0.elapsed_time(e1) / reps)
+    finally:
+        nv.check(nv.lib().dua_set_option(2, 0), "dua_set_option")
+    return sum(by_launch) / len(by_launch), len(calls), by_launch
 
 
 def host_threads():
@@ -208,7 +212,7 @@ def main():
         roof = None
         if rank == 0 and not args.no_roofline:
             fl = conv3_flops(plan)
-            avg_ms, per_step, by_launch = time_conv_launches(plan, 5)
+            avg_ms, per_step, by_launch = time_conv_launches(plan, 20)
             assert per_step == len(fl)
             flops_per_launch = sum(fl) / len(fl)
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
@@ -222,6 +226,8 @@ def main():
                     "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 2),
                     "conv_ms_per_step": round(avg_ms * per_step, 3),
+                    "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
+                    "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
                     "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3",
                                        "tflops": round(max(fl) / (by_launch[fl.index(max(fl))] * 1e-3) / 1e12, 2)}}
 

@@ -35,6 +35,7 @@ constexpr int BN = 64;                     // output channels per workgroup
 
 // 0 = auto (v2; split-K for small layers); 2 forces v2 without split-K, 4 the wave-specialised persistent v4
 int g_conv_variant = 0;
+int g_skip_splitk_finish = 0;   // diagnostics (dua_set_option(2, 1)): time the split-K main kernel alone; outputs are not finished
 
 // ------------------------------------------------------------------------------------------------
 // v2: same tile and fragment maps, software-pipelined.  Weights arrive as 12 KB (kd,kh) slabs, loaded to
@@ -461,6 +462,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   dim3 grid(a.ntiles, nct, d->N * a.ksplit);
   if (a.ksplit > 1) {
     hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
+    if (g_skip_splitk_finish) return (int)hipGetLastError();
     const int G = a.cout_pad / 4 > 256 ? 256 : a.cout_pad / 4;       // channel groups handled per block pass
     if (a.cout_pad / 4 > 256) return DUA_ERR_ARG;
     const int VL = 256 / G;
@@ -486,6 +488,7 @@ extern "C" {
 
 int dua_set_option(int key, int value) {
   if (key == 1 && (value == 0 || value == 2 || value == 4 || (value >= 100 && value <= 132) || (value > 200 && value < 216))) { dua::g_conv_variant = value; return 0; }
+  if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
   return DUA_ERR_ARG;
 }
 

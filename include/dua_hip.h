@@ -94,7 +94,8 @@ int dua_instnorm_bwd_reduce(const dua_norm_bwd_desc* d, const void* dA, const vo
 int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
                            const double* sums, void* dY, void* stream);
 
-/* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (1 synchronous slabs, 2 LDS-DMA pipelined; default 2). */
+/* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (0 auto, 2 = v2 without split-K, 4 = wave-specialised v4);
+ * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid). */
 int dua_set_option(int key, int value);
 
 /* Packs nn.Conv3d weight fp32[Cout][Cin_src][3][3][3] into the kernel's slab order

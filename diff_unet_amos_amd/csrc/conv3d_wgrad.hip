@@ -19,6 +19,8 @@
 #include "../../include/dua_hip.h"
 
 namespace dua {
+int g_wgrad_abl = 0;
+int g_wgrad_variant = 0;   // dua_set_option(4, v): bit 0 = plain (partition-major) block order, bit 1 = two workgroups' worth of partitions per CU
 namespace wg {
 constexpr int TD = 2, TH = 8, TW = 8, TV = TD * TH * TW;      // 128 output voxels per tile
 constexpr int XH = TH + 2, XW = TW + 2, XV = TD * XH * XW;    // 200 input voxels per tile and kd
@@ -30,8 +32,11 @@ struct Args {
   int N, D, H, W;
   int Cin, Cin_stride, Cin_off, Cin_src;
   int Cout, Cout_stride, Cout_off;
-  int ncc, tiles_d, tiles_h, tiles_w, total_tiles, P;
+  int ncc, ncombo, tiles_d, tiles_h, tiles_w, total_tiles, P;
+  int plain_order;
+  int abl;     // diagnostic builds (-DDUA_ABLATE): 1 = no MFMA, 2 = no fragment reads, 4 = no global loads, 8 = no LDS stores
 };
+
 }  // namespace wg
 
 template <typename T>
@@ -50,8 +55,14 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kh = wave % 3, cih = wave / 3;
-  const int kd = blockIdx.z;
-  const int ct = blockIdx.y / a.ncc, cc = blockIdx.y % a.ncc;
+  // 1-D grid, XCD-aware: block b runs on XCD b % 8; the three kd workgroups of one (partition, co tile, ci chunk) get
+  // ids 24 j + 8 kd + x, i.e. the same XCD, dispatched together -- they read the same x / dy tiles through one L2.
+  const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+  int kd = rr % 3, pc = (rr / 3) * 8 + xcd;
+  if (a.plain_order) { pc = blockIdx.x % (a.P * a.ncombo); kd = blockIdx.x / (a.P * a.ncombo); if (kd > 2) return; }
+  if (pc >= a.P * a.ncombo) return;
+  const int part_id = pc % a.P, combo = pc / a.P;
+  const int ct = combo / a.ncc, cc = combo % a.ncc;
   const int hl = lane >> 5;
 
   // per-thread staging items: x item -> (pd, hy, hx, g), dy item -> (voxel, g)
@@ -79,6 +90,9 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
     for (int e = 0; e < EPG; ++e) f[e] = (T)0.f;
   };
   auto load_tile = [&](int tile) {
+#ifdef DUA_ABLATE
+    if (a.abl & 4) return;
+#endif
     int t = tile;
     const int tw_ = t % a.tiles_w; t /= a.tiles_w;
     const int th_ = t % a.tiles_h; t /= a.tiles_h;
@@ -108,6 +122,9 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
     }
   };
   auto store_tile = [&]() {
+#ifdef DUA_ABLATE
+    if (a.abl & 8) return;
+#endif
 #pragma unroll
     for (int j = 0; j < NX; ++j)
       if (xl[j] >= 0) *(Frag*)(Xs + xl[j]) = xr[j];
@@ -139,7 +156,7 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
     a_off[0] = a_off[1] = 0; b_row[0] = b_row[1] = 0;
   }
 
-  int tile = blockIdx.x;
+  int tile = part_id;
   if (tile < a.total_tiles) load_tile(tile);
   for (; tile < a.total_tiles; tile += a.P) {
     __syncthreads();                       // previous tile's fragment reads are done
@@ -149,6 +166,11 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
 #pragma unroll 2
     for (int s = 0; s < TV / KV; ++s) {
       Frag fa[2], fb[3];
+#ifdef DUA_ABLATE
+      if (a.abl & 2) {
+        for (int e = 0; e < EPG; ++e) { fa[0][e] = fa[1][e] = (T)(float)s; fb[0][e] = fb[1][e] = fb[2][e] = (T)(float)lane; }
+      } else
+#endif
       if constexpr (sizeof(T) == 2) {
         // voxels 16 s + 8 hl + 4 r + q: d = s >> 2, hrow = 2 (s & 3) + hl, w = 4 r + q
         const int d = s >> 2, hr0 = 2 * (s & 3);
@@ -189,7 +211,12 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-        for (int coh = 0; coh < 2; ++coh) mma32(acc[kw][coh], fa[coh], fb[kw]);
+        for (int coh = 0; coh < 2; ++coh) {
+#ifdef DUA_ABLATE
+          if (a.abl & 1) { acc[kw][coh][0] += (float)fa[coh][0] * (float)fb[kw][0]; continue; }
+#endif
+          mma32(acc[kw][coh], fa[coh], fb[kw]);
+        }
     }
   }
 
@@ -197,7 +224,7 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
   if (a.part) {
     // partial sums [P][combo][kd][kh][kw][co 64][ci 64], summed by wgrad_reduce_kernel (no atomics: every workgroup
     // would otherwise hit the same Cout*Cin*27 addresses)
-    float* pp = a.part + ((((long)blockIdx.x * gridDim.y + blockIdx.y) * 3 + kd) * 9 + kh * 3) * 4096 + cih * 32 + (lane & 31);
+    float* pp = a.part + ((((long)part_id * a.ncombo + combo) * 3 + kd) * 9 + kh * 3) * 4096 + cih * 32 + (lane & 31);
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
@@ -257,8 +284,12 @@ static inline int wgrad_partitions(const dua_conv3_desc* d, int* combos_out) {
   using namespace wg;
   const int combos = ((d->Cout + 63) / 64) * ((d->Cin + 63) / 64) * 3;
   const int total = d->N * ((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
-  int P = (2 * 256 + combos - 1) / combos;          // ~2 workgroups per CU in flight
+  // ~3 workgroups per CU over the launch (one resident at a time): measured 1.8x faster than exactly one persistent
+  // workgroup per CU on the 96^3 layers (580 vs 1035 us), 2 and 4+ per CU in between
+  const int mult = g_wgrad_variant >> 1 ? g_wgrad_variant >> 1 : (total < 32 ? 1 : 3);   // tiny levels: fewer partial sums
+  int P = (256 * mult + combos - 1) / combos;
   if (P > total) P = total;
+  if (P >= 8) P = (P + 7) & ~7;                      // whole groups of 8 (one partition per XCD); fewer: plain order
   if (combos_out) *combos_out = combos;
   return P < 1 ? 1 : P;
 }
@@ -279,6 +310,9 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
   int combos;
   const int P = wgrad_partitions(d, &combos);
   a.P = P;
+  a.ncombo = nct * a.ncc;
+  a.abl = g_wgrad_abl;
+  a.plain_order = (g_wgrad_variant & 1) || P < 8;
   a.part = (ws && (long)P * combos * 9 * 4096 * 4 <= ws_bytes && P > 1) ? ws : nullptr;
   const int lds = 2 * (XV + TV) * 32 * (int)sizeof(T);
   static bool attr_set = false;
@@ -287,7 +321,8 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<T>, dim3(P, nct * a.ncc, 3), dim3(NT), lds, s, a);
+  const int groups = (P * a.ncombo + 7) / 8;        // groups of 8 (partition, combo) pairs, one per XCD
+  hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<T>, dim3(a.plain_order ? P * a.ncombo * 3 : groups * 24), dim3(NT), lds, s, a);
   if (a.part) {
     const long per_p = (long)nct * a.ncc * 27 * 4096;
     long nb = (per_p + 255) / 256;

@@ -95,7 +95,9 @@ int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const voi
                            const double* sums, void* dY, void* stream);
 
 /* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (0 auto, 2 = v2 without split-K, 4 = wave-specialised v4);
- * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid). */
+ * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid);
+ * key 3: ablation mask of the weight-gradient kernel (diagnostic builds, -DDUA_ABLATE); key 4: weight-gradient launch
+ * shape (bit 0 = plain block order, bits 1.. = workgroups per CU over the launch, 0 = default policy). */
 int dua_set_option(int key, int value);
 
 /* Packs nn.Conv3d weight fp32[Cout][Cin_src][3][3][3] into the kernel's slab order

@@ -14,7 +14,7 @@ from diff_unet_amos_amd.training import DDPTrainer, NativeConvTrainer         # 
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=5)
-ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--classes", type=int, default=16)
 ap.add_argument("--size", type=int, default=96)

@@ -35,6 +35,7 @@ constexpr int BN = 64;                     // output channels per workgroup
 
 // 0 = auto (v2; split-K for small layers); 2 forces v2 without split-K, 4 the wave-specialised persistent v4
 int g_conv_variant = 0;
+int g_v4_grid_quarters = 4;
 int g_skip_splitk_finish = 0;
 extern int g_wgrad_abl;
 extern int g_wgrad_variant;   // diagnostics (dua_set_option(2, 1)): time the split-K main kernel alone; outputs are not finished
@@ -492,6 +493,7 @@ int dua_set_option(int key, int value) {
   if (key == 1 && (value == 0 || value == 2 || value == 4 || (value >= 100 && value <= 132) || (value > 200 && value < 216))) { dua::g_conv_variant = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only
+  if (key == 5 && value >= 1 && value <= 32) { dua::g_v4_grid_quarters = value; return 0; }
   if (key == 4 && value >= 0 && value < 64) { dua::g_wgrad_variant = value; return 0; }
   return DUA_ERR_ARG;
 }

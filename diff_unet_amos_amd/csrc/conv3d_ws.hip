@@ -403,8 +403,10 @@ int launch_conv3_v4(Conv3Args& a, int N, int nct, int xf_bytes, hipStream_t s) {
   }
   const int td8 = (a.D + TD - 1) / TD;
   a.ntiles = td8 * a.tiles_h * a.tiles_w;
-  const int gx = a.ntiles < cus ? a.ntiles : cus;
   extern int g_conv_variant;
+  extern int g_v4_grid_quarters;                    // dua_set_option(5, q): workgroups = q/4 per CU (default 4 = one per CU)
+  const int want = cus * g_v4_grid_quarters / 4;
+  const int gx = a.ntiles < want ? a.ntiles : want;
   const dim3 grid(gx, N, nct);
   switch (g_conv_variant) {
 #ifdef DUA_ABLATE

@@ -1,0 +1,123 @@
+// Segmentation loss of the training step and its gradient, fused:  losses/loss.py:25-86 with losses = "mse,bce,dice",
+// loss_combine = "sum" (the diffusion configs), i.e.
+//   L = mean((sigmoid(p) - y)^2) + mean(BCEWithLogits(p, y)) + mean_{n,c}(1 - (2 I + e) / (S + Y + e)),
+//   I = sum_v s*y, S = sum_v s, Y = sum_v y, e = 1e-5   (MONAI DiceLoss(sigmoid=True) defaults)
+// p: logits channels-last [N][V][C] (compute dtype), y: labels NCDHW fp32 [N][C][V] as the reference's loader hands them.
+//   reduce: sums[N*C*4 + 2] (fp64, pre-zeroed) += (I, S, Y, -) per (n, c), then (sum of squared errors, sum of BCE terms)
+//   grad  : dp = g * [ (2 (s - y) s (1 - s) + (s - y)) / M  +  dice'_{n,c} * s (1 - s) ],  M = N*C*V,
+//           dice'_{n,c} = -(2 y (D + e) - (2 I + e)) / (D + e)^2 / (N C),  D = S + Y;  g = *gscale (device scalar)
+// Both are one streaming pass (HBM bound): a thread owns one voxel and walks the C channels; labels are read coalesced
+// per channel, logits as one contiguous run per voxel.
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+
+namespace dua {
+
+constexpr int LOSS_MAXC = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_loss_reduce_kernel(const T* __restrict__ p, int p_stride,
+                                                              const float* __restrict__ y, int C, long V,
+                                                              double* __restrict__ sums, int N) {
+  __shared__ float red[4][3 * LOSS_MAXC + 2];
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mse = 0.f, bce = 0.f;
+  // per-channel partials live in LDS (C can be 16..64; registers indexed dynamically would spill)
+  for (int i = threadIdx.x; i < 4 * (3 * LOSS_MAXC + 2); i += 256) (&red[0][0])[i] = 0.f;
+  __syncthreads();
+  for (int c = 0; c < C; ++c) {
+    float I = 0.f, S = 0.f, Y = 0.f;
+    for (long v = blockIdx.x * 256L + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+      const float pv = (float)p[((long)n * V + v) * p_stride + c];
+      const float yv = y[((long)n * C + c) * V + v];
+      const float s = 1.f / (1.f + __expf(-pv));
+      I += s * yv; S += s; Y += yv;
+      const float d = s - yv;
+      mse = fmaf(d, d, mse);
+      bce += fmaxf(pv, 0.f) - pv * yv + log1pf(__expf(-fabsf(pv)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { I += __shfl_xor(I, o); S += __shfl_xor(S, o); Y += __shfl_xor(Y, o); }
+    if (lane == 0) { red[wave][3 * c] = I; red[wave][3 * c + 1] = S; red[wave][3 * c + 2] = Y; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mse += __shfl_xor(mse, o); bce += __shfl_xor(bce, o); }
+  if (lane == 0) { red[wave][3 * LOSS_MAXC] = mse; red[wave][3 * LOSS_MAXC + 1] = bce; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    const double t = (double)red[0][i] + (double)red[1][i] + (double)red[2][i] + (double)red[3][i];
+    unsafeAtomicAdd(sums + ((long)n * C + i / 3) * 4 + i % 3, t);
+  }
+  if (threadIdx.x < 2) {
+    const int i = 3 * LOSS_MAXC + threadIdx.x;
+    unsafeAtomicAdd(sums + (long)N * C * 4 + threadIdx.x,
+                    (double)red[0][i] + (double)red[1][i] + (double)red[2][i] + (double)red[3][i]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_loss_grad_kernel(const T* __restrict__ p, int p_stride,
+                                                            const float* __restrict__ y, int C, long V,
+                                                            const double* __restrict__ sums, int N,
+                                                            const float* __restrict__ gscale, T* __restrict__ dp,
+                                                            int dp_stride) {
+  __shared__ float k0[LOSS_MAXC], k1[LOSS_MAXC];     // dice' = k0 * y + k1
+  const int n = blockIdx.y;
+  const float g = gscale ? *gscale : 1.f;
+  const float invM = 1.f / ((float)N * (float)C * (float)V), invNC = 1.f / ((float)N * (float)C);
+  if (threadIdx.x < C) {
+    const double* q = sums + ((long)n * C + threadIdx.x) * 4;
+    const double De = q[1] + q[2] + 1e-5, Ie = 2.0 * q[0] + 1e-5;
+    k0[threadIdx.x] = (float)(-2.0 / De) * invNC;
+    k1[threadIdx.x] = (float)(Ie / (De * De)) * invNC;
+  }
+  __syncthreads();
+  for (long v = blockIdx.x * 256L + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+    const T* pr = p + ((long)n * V + v) * p_stride;
+    T* dr = dp + ((long)n * V + v) * dp_stride;
+    for (int c = 0; c < C; ++c) {
+      const float pv = (float)pr[c];
+      const float yv = y[((long)n * C + c) * V + v];
+      const float s = 1.f / (1.f + __expf(-pv));
+      const float ds = s * (1.f - s), d = s - yv;
+      dr[c] = (T)(g * ((2.f * d * ds + d) * invM + (k0[c] * yv + k1[c]) * ds));
+    }
+  }
+}
+
+}  // namespace dua
+
+extern "C" {
+
+int dua_seg_loss_reduce(int dtype, int N, int C, long voxels, const void* logits, int logits_stride, const float* labels,
+                        double* sums, void* stream) {
+  if (!logits || !labels || !sums || N <= 0 || C <= 0 || C > dua::LOSS_MAXC || voxels <= 0 || logits_stride < C) return DUA_ERR_ARG;
+  long b = (voxels + 255) / 256;
+  dim3 grid((unsigned)(b > 512 ? 512 : b), N);
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::seg_loss_reduce_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)logits,
+                       logits_stride, labels, C, voxels, sums, N);
+  else if (dtype == DUA_F32)
+    hipLaunchKernelGGL(dua::seg_loss_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)logits,
+                       logits_stride, labels, C, voxels, sums, N);
+  else return DUA_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, int logits_stride, const float* labels,
+                      const double* sums, const float* gscale, void* dlogits, int dlogits_stride, void* stream) {
+  if (!logits || !labels || !sums || !dlogits || N <= 0 || C <= 0 || C > dua::LOSS_MAXC || voxels <= 0 ||
+      logits_stride < C || dlogits_stride < C) return DUA_ERR_ARG;
+  long b = (voxels + 255) / 256;
+  dim3 grid((unsigned)(b > 4096 ? 4096 : b), N);
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::seg_loss_grad_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)logits,
+                       logits_stride, labels, C, voxels, sums, N, gscale, (dua::f16*)dlogits, dlogits_stride);
+  else if (dtype == DUA_F32)
+    hipLaunchKernelGGL(dua::seg_loss_grad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)logits,
+                       logits_stride, labels, C, voxels, sums, N, gscale, (float*)dlogits, dlogits_stride);
+  else return DUA_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -224,6 +224,34 @@ def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0):
     return sums.sum(1)[:, :Cc, :3]
 
 
+def seg_loss_reduce(logits, labels):
+    """logits: channels-last [N, D, H, W, Cs] (first C = labels.shape[1] channels); labels fp32 [N, C, D, H, W].
+    Returns (L as a 0-dim fp32 tensor, the fp64 sums the gradient kernel needs)."""
+    assert logits.is_cuda and logits.is_contiguous() and logits.dim() == 5
+    N, Cc = labels.shape[:2]
+    V = labels.shape[2] * labels.shape[3] * labels.shape[4]
+    assert labels.is_cuda and labels.dtype == torch.float32 and labels.is_contiguous()
+    assert tuple(logits.shape[:4]) == (N, *labels.shape[2:]) and logits.shape[-1] >= Cc
+    sums = torch.zeros(N * Cc * 4 + 2, dtype=torch.float64, device=logits.device)
+    nv.check(nv.lib().dua_seg_loss_reduce(nv.dt_code(logits.dtype), N, Cc, V, nv.ptr(logits), logits.shape[-1], nv.ptr(labels),
+                                          nv.ptr(sums), nv.stream_ptr()), "dua_seg_loss_reduce")
+    q = sums[:N * Cc * 4].view(N, Cc, 4)
+    M = float(N * Cc * V)
+    dice = (1.0 - (2.0 * q[..., 0] + 1e-5) / (q[..., 1] + q[..., 2] + 1e-5)).mean()
+    return (sums[-2] / M + sums[-1] / M + dice).float(), sums
+
+
+def seg_loss_grad(logits, labels, sums, gscale):
+    N, Cc = labels.shape[:2]
+    V = labels.shape[2] * labels.shape[3] * labels.shape[4]
+    out = torch.zeros_like(logits) if logits.shape[-1] > Cc else torch.empty_like(logits)
+    g = gscale.detach().float().reshape(1).contiguous() if gscale is not None else None
+    nv.check(nv.lib().dua_seg_loss_grad(nv.dt_code(logits.dtype), N, Cc, V, nv.ptr(logits), logits.shape[-1], nv.ptr(labels),
+                                        nv.ptr(sums), nv.ptr(g), nv.ptr(out), out.shape[-1], nv.stream_ptr()),
+             "dua_seg_loss_grad")
+    return out
+
+
 def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None):
     _cl_check(raw, "raw"); _cl_check(out, "out")
     N, D, H, W, rs = raw.shape

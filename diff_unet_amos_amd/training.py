@@ -171,8 +171,8 @@ class DDPTrainer:
 # the step's FLOPs) runs on the HIP kernels of this package inside a torch.autograd.Function; activations are
 # channels-last [N, D, H, W, C] in the compute dtype (fp16 with fp32 master weights and a GradScaler, or fp32).
 # InstanceNorm + LeakyReLU + temb/embedding adds are fused around them (materialize forward, reduce/apply backward).
-# What is still torch: MaxPool, concat, the k2s2 transposed convolution and the 1x1 head as plain library GEMMs, the
-# timestep MLP, the loss, AdamW.  They are the next kernels to write.
+# The mse+bce+dice loss is one reduce + one gradient kernel.  What is still torch: MaxPool, concat, the k2s2 transposed
+# convolution and the 1x1 head as plain library GEMMs, the timestep MLP, AdamW.  They are the next kernels to write.
 class _Conv3dK3(torch.autograd.Function):
     """y = conv3d(x, w, b), 3x3x3 / pad 1, channels-last.  forward: dua_conv3d_k3_fwd; backward: the same kernel on
     dy with the weights flipped and transposed (data gradient) + dua_conv3d_k3_wgrad (weight gradient)."""
@@ -291,9 +291,31 @@ def _deconv_cl(up, x):
     return y + up.deconv.bias.to(x.dtype)
 
 
+class _SegLoss(torch.autograd.Function):
+    """mse + bce + dice ("sum") on channels-last logits: one reduce pass forward, one gradient pass backward."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        from . import ops
+        L, sums = ops.seg_loss_reduce(logits, labels)
+        ctx.save_for_backward(logits, labels, sums)
+        return L
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        logits, labels, sums = ctx.saved_tensors
+        return ops.seg_loss_grad(logits, labels, sums, g), None
+
+
 def native_conv_denoise(net, image, x, step, dtype=torch.float16):
     """Diffusion.denoise (diffusion.py:71-84) for training: HIP convolutions under torch autograd.  Returns fp32
     logits [N, C, D, H, W]."""
+    return native_logits_cl(net, image, x, step, dtype).permute(0, 4, 1, 2, 3).float()
+
+
+def native_logits_cl(net, image, x, step, dtype=torch.float16):
+    """Same network, logits left channels-last [N, D, H, W, C] in the compute dtype (what the fused loss consumes)."""
     enc, den = net.embed_model, net.model
     img = _cl_pad(image, dtype)
     emb = [_two_conv_cl(enc.conv_0, img, None)]
@@ -315,8 +337,7 @@ def native_conv_denoise(net, image, x, step, dtype=torch.float16):
     u2 = up(den.upcat_2, u3, x1)
     u1 = up(den.upcat_1, u2, x0)
     wf = den.final_conv.weight
-    logits = u1 @ wf.reshape(wf.shape[0], -1).t().to(u1.dtype) + den.final_conv.bias.to(u1.dtype)
-    return logits.permute(0, 4, 1, 2, 3).float()
+    return u1 @ wf.reshape(wf.shape[0], -1).t().to(u1.dtype) + den.final_conv.bias.to(u1.dtype)
 
 
 class NativeConvTrainer:
@@ -328,6 +349,7 @@ class NativeConvTrainer:
                  dtype=torch.float16, init_scale=2.0 ** 12):
         self.net, self.dtype = net, dtype
         self.criterion = Loss(losses, loss_combine)
+        self.fused_loss = sorted(losses.split(",")) == ["bce", "dice", "mse"] and loss_combine == "sum"
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay)
         self.scale, self.good_steps = (init_scale if dtype == torch.float16 else 1.0), 0
@@ -352,7 +374,10 @@ class NativeConvTrainer:
         x_t = self.net.diffusion.q_sample(x_start, t, noise)                     # HIP kernel
         self.optimizer.zero_grad(set_to_none=True)
         with torch.enable_grad():
-            loss = self.criterion(native_conv_denoise(self.net, images, x_t, t, self.dtype), labels)
+            if self.fused_loss and labels.dtype == torch.float32:
+                loss = _SegLoss.apply(native_logits_cl(self.net, images, x_t, t, self.dtype), labels.contiguous())
+            else:
+                loss = self.criterion(native_conv_denoise(self.net, images, x_t, t, self.dtype), labels)
             (loss * self.scale).backward()
         for p in self.params:
             if p.grad is None:

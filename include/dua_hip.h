@@ -94,6 +94,17 @@ int dua_instnorm_bwd_reduce(const dua_norm_bwd_desc* d, const void* dA, const vo
 int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
                            const double* sums, void* dY, void* stream);
 
+/* Loss of the training step and its gradient (losses/loss.py:25-86, losses "mse,bce,dice" combined by "sum"; MONAI
+ * DiceLoss(sigmoid=True) defaults):  L = mean((sigmoid(p)-y)^2) + mean(BCEWithLogits(p,y)) + mean_{n,c}(1 - (2I+e)/(S+Y+e)).
+ * logits: channels-last [N][voxels][logits_stride] (first C used); labels: fp32 NCDHW [N][C][voxels].
+ * reduce: sums (fp64 [N*C*4 + 2], pre-zeroed) += per (n,c) (I = sum s*y, S = sum s, Y = sum y, -), then
+ *         (sum (s-y)^2, sum of BCE terms); the caller forms L from them.
+ * grad  : dlogits = *gscale * dL/dp (gscale: device fp32 scalar or NULL = 1), same layout as logits. */
+int dua_seg_loss_reduce(int dtype, int N, int C, long voxels, const void* logits, int logits_stride, const float* labels,
+                        double* sums, void* stream);
+int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, int logits_stride, const float* labels,
+                      const double* sums, const float* gscale, void* dlogits, int dlogits_stride, void* stream);
+
 /* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (0 auto, 2 = v2 without split-K, 4 = wave-specialised v4);
  * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid);
  * key 3: ablation mask of the weight-gradient kernel (diagnostic builds, -DDUA_ABLATE); key 4: weight-gradient launch

@@ -456,3 +456,27 @@ def test_instnorm_lrelu_backward_matches_autograd(dtype, shape):
     assert torch.allclose(sums[:, :, 0], ad.grad, rtol=1e-4, atol=1e-4 * V ** 0.5)
     assert torch.allclose(sums[:, :, 1].sum(0), bt.grad, rtol=1e-4, atol=1e-4 * V ** 0.5)
     assert torch.allclose(sums[:, :, 2].sum(0), gm.grad, rtol=1e-4, atol=1e-4 * V ** 0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 8, 8), (1, 3, 5, 6, 7), (2, 13, 16, 8, 4)])
+def test_seg_loss_and_gradient_match_torch(dtype, shape):
+    """Fused mse+bce+dice loss and its gradient against the torch formulas of training.Loss (fp64)."""
+    from diff_unet_amos_amd.training import Loss
+    ops = _ops()
+    N, Cc, D, H, W = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    logits = (torch.randn(N, D, H, W, Cc, generator=g, device=dev) * 3).to(dtype)
+    labels = (torch.rand(N, Cc, D, H, W, generator=g, device=dev) > 0.7).float()
+    L, sums = ops.seg_loss_reduce(logits, labels)
+    gs = torch.tensor(3.0, device=dev)
+    dl = ops.seg_loss_grad(logits, labels, sums, gs)
+    p = logits.double().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    want = Loss("mse,bce,dice", "sum")(p, labels.double())
+    (want * 3.0).backward()
+    assert abs(float(L) - float(want)) < 1e-5 * max(1.0, abs(float(want)))
+    wg = p.grad.permute(0, 2, 3, 4, 1)
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert (dl.double() - wg).abs().max().item() <= tol * wg.abs().max().item()

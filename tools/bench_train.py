@@ -38,7 +38,7 @@ for _ in range(a.steps):
     per.append(time.perf_counter() - t0)
 dt = sum(per) / len(per)
 print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "median_ms": sorted(per)[len(per) // 2] * 1e3, "per_step_ms": [round(x * 1e3, 2) for x in per], "native": a.path == "native-conv",
-                  "path": ("HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; pool/deconv/head/loss/AdamW = torch; " + a.dtype)
+                  "path": ("HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; fused mse+bce+dice loss kernels; pool/deconv/head/AdamW = torch; " + a.dtype)
                   if a.path == "native-conv" else "torch autograd fallback (MIOpen/rocBLAS) fp32, q_sample = HIP", "batch": a.batch,
                   "size": a.size, "classes": a.classes, "loss": float(loss),
                   "max_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}))

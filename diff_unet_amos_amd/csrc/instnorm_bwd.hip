@@ -177,3 +177,81 @@ int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const voi
 }
 
 }  // extern "C"
+
+// ---- MaxPool3d(2) backward, fused with the sum of the two gradient paths of x_l -----------------------------------
+// x_l feeds the skip half of the decoder's concat AND the pooling of the next level (denoiser.py:100,106,190):
+//   out[v] = dA[v] + (v is the arg-max of its 2x2x2 window ? dP[window] : 0)
+// The arg-max is recomputed from the stored activation, first maximum in (d, h, w) scan order as torch's max_pool3d.
+namespace dua {
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_add_kernel(const T* __restrict__ act, int act_stride, int act_off,
+                                                               const T* __restrict__ dA, int da_stride, int da_off,
+                                                               const T* __restrict__ dP, int dp_stride,
+                                                               T* __restrict__ out, int out_stride, int C, int D, int H,
+                                                               int W, long total) {
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  const int gpc = C / EPG, n = blockIdx.y;
+  const int W2 = W >> 1, H2 = H >> 1;
+  const long vox_n = (long)D * H * W;
+  for (long it = blockIdx.x * 256L + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+    const int cg = (int)(it % gpc);
+    long v = it / gpc;
+    const int pw = (int)(v % W2); v /= W2;
+    const int ph = (int)(v % H2); const int pd = (int)(v / H2);
+    const long pv = n * (vox_n >> 3) + ((long)pd * H2 + ph) * W2 + pw;
+    const Frag g = *(const Frag*)(dP + pv * dp_stride + cg * EPG);
+    Frag a[8];
+    long gv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int d = 2 * pd + (k >> 2), h = 2 * ph + ((k >> 1) & 1), w = 2 * pw + (k & 1);
+      gv[k] = n * vox_n + ((long)d * H + h) * W + w;
+      a[k] = *(const Frag*)(act + gv[k] * act_stride + act_off + cg * EPG);
+    }
+    int arg[EPG];
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) {
+      float mx = (float)a[0][e];
+      arg[e] = 0;
+#pragma unroll
+      for (int k = 1; k < 8; ++k)
+        if ((float)a[k][e] > mx) { mx = (float)a[k][e]; arg[e] = k; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      Frag o;
+      if (dA) o = *(const Frag*)(dA + gv[k] * da_stride + da_off + cg * EPG);
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) {
+        const float base = dA ? (float)o[e] : 0.f;
+        o[e] = (T)(base + (arg[e] == k ? (float)g[e] : 0.f));
+      }
+      *(Frag*)(out + gv[k] * out_stride + cg * EPG) = o;
+    }
+  }
+}
+
+}  // namespace dua
+
+extern "C" int dua_maxpool2_bwd_add(int dtype, int N, int D, int H, int W, int C, const void* act, int act_stride,
+                                    int act_off, const void* dA, int da_stride, int da_off, const void* dP, int dp_stride,
+                                    void* out, int out_stride, void* stream) {
+  if (!act || !dP || !out || N <= 0 || C <= 0 || C % 8 || (D | H | W) & 1 || D <= 0 || H <= 0 || W <= 0) return DUA_ERR_ARG;
+  if (act_stride % 8 || act_off % 8 || dp_stride % 8 || out_stride % 8 || (dA && (da_stride % 8 || da_off % 8))) return DUA_ERR_ARG;
+  const int epg = dtype == DUA_F16 ? 8 : 4;
+  const long total = (long)(D / 2) * (H / 2) * (W / 2) * (C / epg);
+  long b = (total + 255) / 256;
+  dim3 grid((unsigned)(b > 8192 ? 8192 : b), N);
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::maxpool2_bwd_add_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)act,
+                       act_stride, act_off, (const dua::f16*)dA, da_stride, da_off, (const dua::f16*)dP, dp_stride,
+                       (dua::f16*)out, out_stride, C, D, H, W, total);
+  else if (dtype == DUA_F32)
+    hipLaunchKernelGGL(dua::maxpool2_bwd_add_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)act,
+                       act_stride, act_off, (const float*)dA, da_stride, da_off, (const float*)dP, dp_stride, (float*)out,
+                       out_stride, C, D, H, W, total);
+  else return DUA_ERR_ARG;
+  return (int)hipGetLastError();
+}

@@ -224,6 +224,21 @@ def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0):
     return sums.sum(1)[:, :Cc, :3]
 
 
+def maxpool2_bwd_add(act, act_off, Cc, dA, da_off, dP):
+    """dA[..., da_off:da_off+Cc] (or zeros when dA is None) + MaxPool3d(2) backward of dP routed through ``act``."""
+    _cl_check(act, "act"); _cl_check(dP, "dP")
+    N, D, H, W, _ = act.shape
+    assert tuple(dP.shape[:4]) == (N, D // 2, H // 2, W // 2) and dP.shape[-1] >= Cc and dP.dtype == act.dtype
+    if dA is not None:
+        _cl_check(dA, "dA")
+        assert tuple(dA.shape[:4]) == (N, D, H, W) and dA.dtype == act.dtype
+    out = torch.empty((N, D, H, W, Cc), dtype=act.dtype, device=act.device)
+    nv.check(nv.lib().dua_maxpool2_bwd_add(nv.dt_code(act.dtype), N, D, H, W, Cc, nv.ptr(act), act.shape[-1], act_off,
+                                           nv.ptr(dA), dA.shape[-1] if dA is not None else 0, da_off, nv.ptr(dP),
+                                           dP.shape[-1], nv.ptr(out), Cc, nv.stream_ptr()), "dua_maxpool2_bwd_add")
+    return out
+
+
 def seg_loss_reduce(logits, labels):
     """logits: channels-last [N, D, H, W, Cs] (first C = labels.shape[1] channels); labels fp32 [N, C, D, H, W].
     Returns (L as a 0-dim fp32 tensor, the fp64 sums the gradient kernel needs)."""

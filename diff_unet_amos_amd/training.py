@@ -171,7 +171,8 @@ class DDPTrainer:
 # the step's FLOPs) runs on the HIP kernels of this package inside a torch.autograd.Function; activations are
 # channels-last [N, D, H, W, C] in the compute dtype (fp16 with fp32 master weights and a GradScaler, or fp32).
 # InstanceNorm + LeakyReLU + temb/embedding adds are fused around them (materialize forward, reduce/apply backward).
-# The mse+bce+dice loss is one reduce + one gradient kernel.  What is still torch: MaxPool, concat, the k2s2 transposed
+# MaxPool comes out of the materialize pass (forward) and a routed-add kernel (backward).  The mse+bce+dice loss is one
+# reduce + one gradient kernel.  What is still torch: concat, the k2s2 transposed
 # convolution and the 1x1 head as plain library GEMMs, the timestep MLP, AdamW.  They are the next kernels to write.
 class _Conv3dK3(torch.autograd.Function):
     """y = conv3d(x, w, b), 3x3x3 / pad 1, channels-last.  forward: dua_conv3d_k3_fwd; backward: the same kernel on
@@ -228,7 +229,7 @@ class _ConvNormAct(torch.autograd.Function):
     backward = norm/activation backward (reduce + apply) -> data gradient (conv kernel) + weight gradient kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, add, emb):
+    def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False):
         from . import ops
         N, D, H, W, cs = x.shape
         cout = weight.shape[0]
@@ -241,17 +242,20 @@ class _ConvNormAct(torch.autograd.Function):
         a32 = add.detach().float().contiguous() if add is not None else None
         norm = ops.Norm(stats, g32, b32, D * H * W, add=a32, add_stride=cout)
         act = torch.empty_like(raw)
-        ops.materialize(raw, cout, norm, act, 0, emb=emb.detach() if emb is not None else None)
-        ctx.save_for_backward(x, weight, raw, stats, g32, b32)
-        ctx.has_add, ctx.has_emb = add is not None, emb is not None
-        return act
+        pooled = torch.empty((N, D // 2, H // 2, W // 2, cout), dtype=x.dtype, device=x.device) if pool else None
+        ops.materialize(raw, cout, norm, act, 0, emb=emb.detach() if emb is not None else None, pooled=pooled)
+        ctx.save_for_backward(x, weight, raw, stats, g32, b32, act if pool else None)
+        ctx.has_add, ctx.has_emb, ctx.pool = add is not None, emb is not None, pool
+        return (act, pooled) if pool else act
 
     @staticmethod
-    def backward(ctx, dA):
+    def backward(ctx, dA, dP=None):
         from . import ops
-        x, weight, raw, stats, g32, b32 = ctx.saved_tensors
-        dA = dA.contiguous()
+        x, weight, raw, stats, g32, b32, act = ctx.saved_tensors
         N, D, H, W, cout = raw.shape
+        if ctx.pool and dP is not None:       # MaxPool3d(2) backward + the skip-path gradient in one pass
+            dA = ops.maxpool2_bwd_add(act, 0, cout, dA.contiguous() if dA is not None else None, 0, dP.contiguous())
+        dA = dA.contiguous()
         norm = ops.Norm(stats, g32, b32, D * H * W)
         dY = torch.empty_like(raw)
         sums = ops.instnorm_bwd(dA, 0, raw, cout, norm, dY)
@@ -265,16 +269,16 @@ class _ConvNormAct(torch.autograd.Function):
         db = torch.zeros(cout, dtype=torch.float32, device=x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
         dgamma, dbeta = sums[:, :, 2].sum(0).float(), sums[:, :, 1].sum(0).float()
         dadd = sums[:, :, 0].float() if ctx.has_add else None
-        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None)
+        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None
 
 
-def _two_conv_cl(block, x, temb, emb=None):
+def _two_conv_cl(block, x, temb, emb=None, pool=False):
     add = None
     if temb is not None:
         add = F.linear(temb * torch.sigmoid(temb), block.temb_proj.weight, block.temb_proj.bias)
     c0, c1 = block.conv_0, block.conv_1
     h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None)
-    return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb)
+    return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb, pool)
 
 
 def _pool_cl(x):
@@ -318,16 +322,20 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
     """Same network, logits left channels-last [N, D, H, W, C] in the compute dtype (what the fused loss consumes)."""
     enc, den = net.embed_model, net.model
     img = _cl_pad(image, dtype)
-    emb = [_two_conv_cl(enc.conv_0, img, None)]
-    for d in enc.down:
-        emb.append(_two_conv_cl(d.convs, _pool_cl(emb[-1]), None))
+    e, pe = _two_conv_cl(enc.conv_0, img, None, None, True)
+    emb = [e]
+    for i, d in enumerate(enc.down):                 # the pooled copy of each level comes out of its materialize pass
+        last = i == len(enc.down) - 1
+        r = _two_conv_cl(d.convs, pe, None, None, not last)
+        e, pe = (r, None) if last else r
+        emb.append(e)
     temb = _time_embedding(den.temb, step)
     h = _cl_pad(torch.cat([image, x], dim=1), dtype)
-    x0 = _two_conv_cl(den.conv_0, h, temb, emb[0])
-    x1 = _two_conv_cl(den.down_1.convs, _pool_cl(x0), temb, emb[1])
-    x2 = _two_conv_cl(den.down_2.convs, _pool_cl(x1), temb, emb[2])
-    x3 = _two_conv_cl(den.down_3.convs, _pool_cl(x2), temb, emb[3])
-    x4 = _two_conv_cl(den.down_4.convs, _pool_cl(x3), temb, emb[4])
+    x0, p0 = _two_conv_cl(den.conv_0, h, temb, emb[0], True)
+    x1, p1 = _two_conv_cl(den.down_1.convs, p0, temb, emb[1], True)
+    x2, p2 = _two_conv_cl(den.down_2.convs, p1, temb, emb[2], True)
+    x3, p3 = _two_conv_cl(den.down_3.convs, p2, temb, emb[3], True)
+    x4 = _two_conv_cl(den.down_4.convs, p3, temb, emb[4])
 
     def up(block, lo, skip):
         return _two_conv_cl(block.convs, torch.cat([skip, _deconv_cl(block.upsample, lo)], dim=-1), temb)

@@ -94,6 +94,14 @@ int dua_instnorm_bwd_reduce(const dua_norm_bwd_desc* d, const void* dA, const vo
 int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
                            const double* sums, void* dY, void* stream);
 
+/* Backward of nn.MaxPool3d(2) (denoiser.py:100,106) fused with the sum of x_l's two gradient paths:
+ *   out[v] = dA[v] (or 0 when dA is NULL) + (v is the arg-max of its 2x2x2 window ? dP[window] : 0),
+ * arg-max recomputed from the stored activation (first maximum in d,h,w scan order, as torch).  D, H, W = the
+ * un-pooled extent (even); act/dA are channel slices [off, off+C) of strided buffers, dP/out start at channel 0. */
+int dua_maxpool2_bwd_add(int dtype, int N, int D, int H, int W, int C, const void* act, int act_stride, int act_off,
+                         const void* dA, int da_stride, int da_off, const void* dP, int dp_stride, void* out,
+                         int out_stride, void* stream);
+
 /* Loss of the training step and its gradient (losses/loss.py:25-86, losses "mse,bce,dice" combined by "sum"; MONAI
  * DiceLoss(sigmoid=True) defaults):  L = mean((sigmoid(p)-y)^2) + mean(BCEWithLogits(p,y)) + mean_{n,c}(1 - (2I+e)/(S+Y+e)).
  * logits: channels-last [N][voxels][logits_stride] (first C used); labels: fp32 NCDHW [N][C][voxels].

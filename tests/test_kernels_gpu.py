@@ -480,3 +480,24 @@ def test_seg_loss_and_gradient_match_torch(dtype, shape):
     wg = p.grad.permute(0, 2, 3, 4, 1)
     tol = 1e-5 if dtype == torch.float32 else 2e-3
     assert (dl.double() - wg).abs().max().item() <= tol * wg.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_maxpool_backward_add_matches_torch(dtype):
+    """Ties included (fp16 values on a coarse grid): the routed gradient must follow torch's first-maximum rule."""
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    N, D, H, W, Cc = 2, 4, 6, 8, 24
+    act = (torch.randint(-3, 4, (N, D, H, W, Cc + 8), generator=g, device=dev).float() * 0.5).to(dtype)   # many ties
+    dA = torch.randn(N, D, H, W, Cc + 16, generator=g, device=dev).to(dtype)
+    dP = torch.randn(N, D // 2, H // 2, W // 2, Cc, generator=g, device=dev).to(dtype)
+    out = ops.maxpool2_bwd_add(act, 8, Cc, dA, 16, dP)
+    a = act[..., 8:8 + Cc].permute(0, 4, 1, 2, 3).double().contiguous().requires_grad_(True)
+    F.max_pool3d(a, 2).backward(dP.permute(0, 4, 1, 2, 3).double())
+    want = a.grad.permute(0, 2, 3, 4, 1) + dA[..., 16:16 + Cc].double()
+    tol = 1e-6 if dtype == torch.float32 else 4e-3
+    assert (out.double() - want).abs().max().item() <= tol
+    out0 = ops.maxpool2_bwd_add(act, 8, Cc, None, 0, dP)
+    assert (out0.double() - a.grad.permute(0, 2, 3, 4, 1)).abs().max().item() <= tol

@@ -58,12 +58,29 @@ __global__ __launch_bounds__(256) void deconv_k2s2_kernel(DeconvArgs a) {
 
   const int kg_t = tid & 3;
   if (a.xf.stats != nullptr) xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
+  // chunk ch+1 is loaded into registers while chunk ch multiplies (deep layers walk 8-16 chunks per workgroup and
+  // were pure load latency without it)
+  Frag pa[4];
+  f32x4 pw;
+  auto load_chunk = [&](int ch) {
+    const int c0 = ch * CK + kg_t * EPG;
+    const bool cok = c0 < a.Cin;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long v = v0 + (tid >> 2) + 64 * j;
+      if (v < vox && cok) pa[j] = *(const Frag*)(xin + v * a.Cin_stride + c0);
+      else
+#pragma unroll
+        for (int e = 0; e < EPG; ++e) pa[j][e] = (T)0.f;
+    }
+    pw = *(const f32x4*)(wsrc + (long)ch * W_BYTES + tid * 16);
+  };
+  load_chunk(0);
   for (int ch = 0; ch < a.nchunks; ++ch) {
     __syncthreads();
     const int c0 = ch * CK + kg_t * EPG;
-    const bool cok = c0 < a.Cin;
+    const bool xf = a.xf.stats != nullptr && c0 < a.Cin;
     float sc[EPG], sh[EPG], ad[EPG];
-    const bool xf = a.xf.stats != nullptr && cok;
     if (xf) {
 #pragma unroll
       for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
@@ -71,19 +88,13 @@ __global__ __launch_bounds__(256) void deconv_k2s2_kernel(DeconvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int vl = (tid >> 2) + 64 * j;
-      const long v = v0 + vl;
-      Frag f;
-      if (v < vox && cok) {
-        f = *(const Frag*)(xin + v * a.Cin_stride + c0);
-        if (xf) f = xform_frag<T>(f, sc, sh, ad, a.xf.slope);
-      } else {
-#pragma unroll
-        for (int e = 0; e < EPG; ++e) f[e] = (T)0.f;
-      }
+      Frag f = pa[j];
+      if (xf && v0 + vl < vox) f = xform_frag<T>(f, sc, sh, ad, a.xf.slope);
       *(Frag*)(alds + vl * VS + kg_t * 16) = f;
     }
-    *(f32x4*)(wlds + tid * 16) = *(const f32x4*)(wsrc + (long)ch * W_BYTES + tid * 16);
+    *(f32x4*)(wlds + tid * 16) = pw;
     __syncthreads();
+    if (ch + 1 < a.nchunks) load_chunk(ch + 1);
 #pragma unroll
     for (int ks = 0; ks < KG / 2; ++ks) {
       Frag a0 = *(const Frag*)(alds + (wave * 64 + r) * VS + (2 * ks + hh) * 16);

@@ -241,3 +241,68 @@ def test_odd_class_count_non_cubic_patch_batch3(dtype, tol):
     d = (got - want).abs()
     print(f"\n[{dtype}] 13 classes, 32x48x64, N=3: |dlogit| max {d.max():.3e} mean {d.mean():.3e}")
     assert d.max() < tol
+
+
+# ---- sliding-window inference with the real sampler, sharded over two processes (row 8(e)/(f-1)) -----------------
+def _sw_predictor(net):
+    def predictor(x, **kw):
+        # x_T comes from the device generator: seed it from the window so a window's result does not depend on which
+        # rank (or in which order) it is sampled
+        torch.manual_seed(int(x.double().abs().sum().item() * 1e3) % (2 ** 31))
+        return net(image=x, **kw)
+    return predictor
+
+
+def _sw_setup():
+    from diff_unet_amos_amd.diff_unet import DiffUNet
+    torch.manual_seed(3)
+    net = DiffUNet(sample_steps=4, compute_dtype=torch.float32, **TINY).cuda().eval()
+    g = torch.Generator().manual_seed(9)
+    image = torch.rand(1, 1, 40, 48, 32, generator=g).cuda()
+    return net, image
+
+
+def _sw_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from diff_unet_amos_amd import inference
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # one GPU on the test box: gloo carries the CUDA tensors
+    try:
+        net, image = _sw_setup()
+        with torch.no_grad():
+            out = inference.sharded_sliding_window_inference(image, (32, 32, 32), 1, _sw_predictor(net), 0.25,
+                                                             pred_type="ddim_sample")
+        q.put((rank, out.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sliding_window_with_the_hip_sampler_two_ranks():
+    """Engine.infer's sliding-window DDIM sampling (engine.py:167-182) through the HIP path: two processes deal the
+    windows between them and all-gather; every rank must hold the blend single-process inference produces."""
+    import os
+    import torch.multiprocessing as mp
+    from diff_unet_amos_amd import inference
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 311) % 2000
+    procs = [ctx.Process(target=_sw_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    net, image = _sw_setup()
+    with torch.no_grad():
+        want = inference.sliding_window_inference(image, (32, 32, 32), 1, _sw_predictor(net), 0.25,
+                                                  pred_type="ddim_sample").cpu().numpy()
+    assert want.shape == (1, 2, 40, 48, 32) and np.isfinite(want).all()
+    assert np.array_equal(outs[0], outs[1])
+    # same windows, same seeds; the only freedom is the order of the fp64 statistics atomics
+    assert np.abs(outs[0] - want).max() < 1e-3, np.abs(outs[0] - want).max()
+    seg_a = inference.binarise(torch.from_numpy(outs[0]))
+    seg_b = inference.binarise(torch.from_numpy(want))
+    assert (seg_a != seg_b).float().mean().item() < 1e-4

@@ -20,7 +20,7 @@
 
 namespace dua {
 int g_wgrad_abl = 0;
-int g_wgrad_variant = 0;   // dua_set_option(4, v): bit 0 = plain (partition-major) block order, bit 1 = two workgroups' worth of partitions per CU
+int g_wgrad_variant = 0;   // dua_set_option(4, v): bit 0 = plain (partition-major) block order, bits 1-4 = workgroups per CU over the launch (0 = policy), bit 5 = plain k loop
 namespace wg {
 constexpr int TD = 2, TH = 8, TW = 8, TV = TD * TH * TW;      // 128 output voxels per tile
 constexpr int XH = TH + 2, XW = TW + 2, XV = TD * XH * XW;    // 200 input voxels per tile and kd
@@ -39,7 +39,7 @@ struct Args {
 
 }  // namespace wg
 
-template <typename T>
+template <typename T, bool PIPE>
 __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
   using namespace wg;
   using Frag = typename Elem<T>::Frag;
@@ -163,6 +163,47 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
     store_tile();
     __syncthreads();
     if (tile + a.P < a.total_tiles) load_tile(tile + a.P);
+    if constexpr (PIPE && sizeof(T) == 2) {
+      // explicit two-stage pipeline: the 10 transposed reads of k-step s+1 are issued before the 6 MFMAs of step s
+      const char* ya = Ys + a_off[0];
+      const char* yb = Ys + a_off[1];
+      const char* xa = Xs + cih * XIMG + (kh * XW + b_row[0]) * RSB + b_col;
+      const char* xb = Xs + cih * XIMG + (kh * XW + b_row[1]) * RSB + b_col;
+      auto rd = [&](int s, Frag* pa, Frag* pb) {
+        const int yo = s * 16 * RSB, xo = ((s >> 2) * XH + 2 * (s & 3)) * XW * RSB;
+#pragma unroll
+        for (int coh = 0; coh < 2; ++coh) {
+          h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(ya + coh * YIMG + yo));
+          h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(yb + coh * YIMG + yo));
+          pa[coh] = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(xa + xo + kw * RSB));
+          h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(xb + xo + kw * RSB));
+          pb[kw] = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      };
+      auto mm = [&](const Frag* pa, const Frag* pb) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int coh = 0; coh < 2; ++coh) mma32(acc[kw][coh], pa[coh], pb[kw]);
+      };
+      Frag A0[2], B0[3], A1[2], B1[3];
+      rd(0, A0, B0);
+#pragma unroll
+      for (int s = 0; s < TV / KV; s += 2) {
+        rd(s + 1, A1, B1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(A0, B0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < TV / KV) rd(s + 2, A0, B0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(A1, B1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
 #pragma unroll 2
     for (int s = 0; s < TV / KV; ++s) {
       Frag fa[2], fb[3];
@@ -252,9 +293,9 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
 
 // ~200 VGPRs: one workgroup (6 waves) per CU.  Forcing 168 VGPRs for two per CU measured 45 % SLOWER (spills in
 // the k loop), so the occupancy is left to the register allocator.
-template <typename T>
+template <typename T, bool PIPE>
 __global__ __launch_bounds__(wg::NT) void conv3d_k3_wgrad_kernel(wg::Args a) {
-  wgrad_body<T>(a);
+  wgrad_body<T, PIPE>(a);
 }
 
 // dw[co][ci_src][tap] += sum_p part[p][combo][tap][co][ci]; one thread per (combo, tap, co, ci)
@@ -286,7 +327,8 @@ static inline int wgrad_partitions(const dua_conv3_desc* d, int* combos_out) {
   const int total = d->N * ((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
   // ~3 workgroups per CU over the launch (one resident at a time): measured 1.8x faster than exactly one persistent
   // workgroup per CU on the 96^3 layers (580 vs 1035 us), 2 and 4+ per CU in between
-  const int mult = g_wgrad_variant >> 1 ? g_wgrad_variant >> 1 : (total < 32 ? 1 : 3);   // tiny levels: fewer partial sums
+  const int mv = (g_wgrad_variant & 31) >> 1;        // bit 5 selects the pipelined k loop, not a launch shape
+  const int mult = mv ? mv : (total < 32 ? 1 : 3);   // tiny levels: fewer partial sums
   int P = (256 * mult + combos - 1) / combos;
   if (P > total) P = total;
   if (P >= 8) P = (P + 7) & ~7;                      // whole groups of 8 (one partition per XCD); fewer: plain order
@@ -317,12 +359,18 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
   const int lds = 2 * (XV + TV) * 32 * (int)sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int groups = (P * a.ncombo + 7) / 8;        // groups of 8 (partition, combo) pairs, one per XCD
-  hipLaunchKernelGGL(conv3d_k3_wgrad_kernel<T>, dim3(a.plain_order ? P * a.ncombo * 3 : groups * 24), dim3(NT), lds, s, a);
+  const dim3 grid(a.plain_order ? P * a.ncombo * 3 : groups * 24);
+  // f16 default: explicit two-stage k loop (reads of step s+1 before the MFMAs of step s): 3-7 % over hipcc's own
+  // schedule on every layer shape in a same-process A/B; dua_set_option(4, 32) selects the plain loop.  f32: plain.
+  if (sizeof(T) == 2 && !(g_wgrad_variant & 32)) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<T, true>), grid, dim3(NT), lds, s, a);
+  else hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<T, false>), grid, dim3(NT), lds, s, a);
   if (a.part) {
     const long per_p = (long)nct * a.ncc * 27 * 4096;
     long nb = (per_p + 255) / 256;

@@ -400,6 +400,25 @@ def test_conv3_wgrad_matches_torch(dtype, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", [32, 1, 2])      # plain k loop; plain block order; one workgroup per CU
+def test_conv3_wgrad_launch_variants_agree(variant):
+    from diff_unet_amos_amd import _native as nv
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(variant)
+    x = torch.randn(2, 12, 16, 16, 64, generator=g, device=dev).half()
+    dy = torch.randn(2, 12, 16, 16, 64, generator=g, device=dev).half()
+    base = torch.zeros(64, 64, 3, 3, 3, device=dev)
+    _ops().conv3d_k3_wgrad(x, 64, 0, dy, 64, 0, base)
+    nv.check(nv.lib().dua_set_option(4, variant), "opt")
+    try:
+        other = torch.zeros(64, 64, 3, 3, 3, device=dev)
+        _ops().conv3d_k3_wgrad(x, 64, 0, dy, 64, 0, other)
+    finally:
+        nv.check(nv.lib().dua_set_option(4, 0), "opt")
+    assert (base - other).abs().max().item() <= 2e-4 * base.abs().max().item()     # fp32 summation order only
+
+
+@pytest.mark.gpu
 def test_conv3_wgrad_permuted_input_channels():
     """First denoiser conv: packed input = [x_t(C) | image | pad]; dw comes back in the reference's channel order."""
     dev = torch.device("cuda:0")

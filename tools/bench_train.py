@@ -20,6 +20,7 @@ ap.add_argument("--classes", type=int, default=16)
 ap.add_argument("--size", type=int, default=96)
 ap.add_argument("--path", default="native-conv", choices=["native-conv", "autograd"])
 ap.add_argument("--dtype", default="float16")
+ap.add_argument("--ab-wgrad", default="", help="comma list of dua_set_option(4, v) values: time the loop once per value, same process")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -37,7 +38,22 @@ for _ in range(a.steps):
     torch.cuda.synchronize()
     per.append(time.perf_counter() - t0)
 dt = sum(per) / len(per)
-print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "median_ms": sorted(per)[len(per) // 2] * 1e3, "per_step_ms": [round(x * 1e3, 2) for x in per], "native": a.path == "native-conv",
+ab = {}
+if a.ab_wgrad:
+    from diff_unet_amos_amd import _native as nv
+    for v in [int(x) for x in a.ab_wgrad.split(",")]:
+        nv.check(nv.lib().dua_set_option(4, v), "opt")
+        tr.step(image, labels)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(a.steps):
+            t0 = time.perf_counter()
+            tr.step(image, labels)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ab.setdefault(str(v), []).append(round(sorted(ts)[len(ts) // 2] * 1e3, 2))
+    nv.check(nv.lib().dua_set_option(4, 0), "opt")
+print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "median_ms": sorted(per)[len(per) // 2] * 1e3, "per_step_ms": [round(x * 1e3, 2) for x in per], "ab_wgrad_median_ms": ab, "native": a.path == "native-conv",
                   "path": ("HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; fused mse+bce+dice loss kernels; pool/deconv/head/AdamW = torch; " + a.dtype)
                   if a.path == "native-conv" else "torch autograd fallback (MIOpen/rocBLAS) fp32, q_sample = HIP", "batch": a.batch,
                   "size": a.size, "classes": a.classes, "loss": float(loss),

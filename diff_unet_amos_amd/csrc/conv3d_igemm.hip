@@ -454,7 +454,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     if (ks > 1 && (long)ks * d->N * vox * a.cout_pad * 4 <= ws_bytes) { a.ksplit = ks; a.units_per_split = ups; a.part = ws; }
   }
   // 24^3-sized layers (too few 4x8x8 tiles for 256 CUs, too big for split-K to pay): 2x8x8 tiles, twice the workgroups
-  if (a.ksplit == 1 && g_conv_variant == 0 && a.ntiles * nct * d->N < 200 && a.ntiles * nct * d->N > 64) {
+  if (a.ksplit == 1 && ((g_conv_variant == 0 && a.ntiles * nct * d->N < 200 && a.ntiles * nct * d->N > 64) || g_conv_variant == 3)) {
     const int td2 = (d->D + 1) / 2;
     a.ntiles = td2 * a.tiles_h * a.tiles_w;
     dim3 grid2(a.ntiles, nct, d->N);
@@ -490,7 +490,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
 extern "C" {
 
 int dua_set_option(int key, int value) {
-  if (key == 1 && (value == 0 || value == 2 || value == 4 || (value >= 100 && value <= 132) || (value > 200 && value < 216))) { dua::g_conv_variant = value; return 0; }
+  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 4 || (value >= 100 && value <= 132) || (value > 200 && value < 216))) { dua::g_conv_variant = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only
   if (key == 5 && value >= 1 && value <= 32) { dua::g_v4_grid_quarters = value; return 0; }

@@ -113,7 +113,8 @@ int dua_seg_loss_reduce(int dtype, int N, int C, long voxels, const void* logits
 int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, int logits_stride, const float* labels,
                       const double* sums, const float* gscale, void* dlogits, int dlogits_stride, void* stream);
 
-/* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (0 auto, 2 = v2 without split-K, 4 = wave-specialised v4);
+/* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (0 auto, 2 = v2 without split-K, 3 = v2 with 2x8x8 tiles,
+ * 4 = wave-specialised v4);
  * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid);
  * key 3: ablation mask of the weight-gradient kernel (diagnostic builds, -DDUA_ABLATE); key 4: weight-gradient launch
  * shape (bit 0 = plain block order, bits 1-4 = workgroups per CU over the launch, 0 = default policy; bit 5 = the

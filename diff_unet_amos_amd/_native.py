@@ -73,6 +73,9 @@ _SIGS = {
     "dua_instnorm_bwd_reduce": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P]),
     "dua_instnorm_bwd_apply": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P, _P]),
     "dua_maxpool2_bwd_add": (C.c_int, [C.c_int] * 6 + [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P]),
+    "dua_head_fwd": (C.c_int, [C.c_int, C.c_long, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "dua_head_bwd_workspace": (C.c_long, [C.c_long]),
+    "dua_head_bwd": (C.c_int, [C.c_int, C.c_long, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_long, _P]),
     "dua_seg_loss_reduce": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, _P, _P, _P]),
     "dua_seg_loss_grad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "dua_materialize": (C.c_int, [C.POINTER(MaterializeDesc), _P, C.POINTER(InNorm), _P, _P, _P, _P]),

@@ -1,0 +1,196 @@
+// The 1x1x1 output convolution of the denoiser (final_conv, models/basic_unet/denoiser.py:282,311) for the TRAINING
+// step -- forward on a materialised activation and the whole backward in one pass:
+//   forward : logits[v][k] = b[k] + sum_c u[v][c] * W[k][c]
+//   backward: du[v][c] = sum_k dlog[v][k] * W[k][c];  dW[k][c] += sum_v dlog[v][k] * u[v][c];  db[k] += sum_v dlog[v][k]
+// (the sampling path has its own fused tail, sampler.hip).  K = classes <= 16, C <= 64: 2*K*C FLOP per voxel against
+// (C + K) elements of traffic -- HBM bound, so plain VALU FMAs with the weights in registers; torch runs these as
+// tall-skinny library GEMMs (K = 1.8 M voxels deep for dW) that took 1.6 + 0.2 ms of a 25 ms step.
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+
+namespace dua {
+
+constexpr int HEAD_K = 16, HEAD_C = 64, HEAD_TV = 64;     // class / channel capacity, voxels per tile
+
+// thread = (k = tid & 15, vq = tid >> 4): 16 voxels per sub-pass, W[k][:] in registers
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ u, int u_stride, int C,
+                                                       const float* __restrict__ W, const float* __restrict__ b, int K,
+                                                       T* __restrict__ out, int out_stride, long total) {
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  constexpr int RS = HEAD_C * (int)sizeof(T) + 16;          // padded tile row: the 4 voxels of a wave hit different banks
+  __shared__ __attribute__((aligned(16))) char tile[HEAD_TV * RS];
+  const int k = threadIdx.x & 15, vq = threadIdx.x >> 4;
+  float w[HEAD_C];
+#pragma unroll
+  for (int c = 0; c < HEAD_C; ++c) w[c] = (k < K && c < C) ? W[k * C + c] : 0.f;
+  const float bk = k < K ? b[k] : 0.f;
+  const int gpc = C / EPG;
+  for (long t0 = (long)blockIdx.x * HEAD_TV; t0 < total; t0 += (long)gridDim.x * HEAD_TV) {
+    __syncthreads();
+    for (int it = threadIdx.x; it < HEAD_TV * gpc; it += 256) {
+      const int vl = it / gpc, g = it % gpc;
+      Frag f;
+      if (t0 + vl < total) f = *(const Frag*)(u + (t0 + vl) * u_stride + g * EPG);
+      else
+#pragma unroll
+        for (int e = 0; e < EPG; ++e) f[e] = (T)0.f;
+      *(Frag*)(tile + vl * RS + g * 16) = f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < HEAD_TV / 16; ++sub) {
+      const int vl = sub * 16 + vq;
+      float acc = bk;
+#pragma unroll
+      for (int g = 0; g < HEAD_C / EPG; ++g) {
+        if (g < gpc) {
+          const Frag f = *(const Frag*)(tile + vl * RS + g * 16);
+#pragma unroll
+          for (int e = 0; e < EPG; ++e) acc = fmaf((float)f[e], w[g * EPG + e], acc);
+        }
+      }
+      if (k < K && t0 + vl < total) out[(t0 + vl) * out_stride + k] = (T)acc;
+    }
+  }
+}
+
+// thread = (c = tid & 63, vq = tid >> 6): 4 voxels per sub-pass; W[:][c] and the dW[:][c] partials in registers
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlog, int dl_stride, int K,
+                                                       const T* __restrict__ u, int u_stride, int C,
+                                                       const float* __restrict__ W, T* __restrict__ du, int du_stride,
+                                                       float* __restrict__ dW, float* __restrict__ db,
+                                                       float* __restrict__ part, long total) {
+  __shared__ float dl[HEAD_TV][HEAD_K];
+  __shared__ float red[4][HEAD_K + 1][HEAD_C];
+  const int c = threadIdx.x & 63, vq = threadIdx.x >> 6;
+  float w[HEAD_K], dwp[HEAD_K], dbp = 0.f;
+#pragma unroll
+  for (int k = 0; k < HEAD_K; ++k) { w[k] = (k < K && c < C) ? W[k * C + c] : 0.f; dwp[k] = 0.f; }
+  for (long t0 = (long)blockIdx.x * HEAD_TV; t0 < total; t0 += (long)gridDim.x * HEAD_TV) {
+    // all 16 activations this thread needs from the tile are requested up front: one HBM latency per tile, not per voxel
+    // branch-free (clamped addresses, select afterwards): a load under a lane-dependent branch sits in its own basic
+    // block and hipcc waits for it there -- 16 serialised HBM round trips per tile
+    T ur[HEAD_TV / 4];
+    const int cl = c < C ? c : C - 1;
+#pragma unroll
+    for (int sub = 0; sub < HEAD_TV / 4; ++sub) {
+      long v = t0 + sub * 4 + vq;
+      v = v < total ? v : total - 1;
+      ur[sub] = u[v * u_stride + cl];
+    }
+    float uv[HEAD_TV / 4];
+#pragma unroll
+    for (int sub = 0; sub < HEAD_TV / 4; ++sub) uv[sub] = (c < C && t0 + sub * 4 + vq < total) ? (float)ur[sub] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < HEAD_TV * HEAD_K / 256; ++j) {
+      const int it = threadIdx.x + 256 * j, vl = it / HEAD_K, k = it % HEAD_K;
+      long v = t0 + vl;
+      const bool ok = k < K && v < total;
+      v = v < total ? v : total - 1;
+      const T d = dlog[v * dl_stride + (k < K ? k : K - 1)];
+      dl[vl][k] = ok ? (float)d : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < HEAD_TV / 4; ++sub) {
+      const int vl = sub * 4 + vq;
+      const long v = t0 + vl;
+      float g = 0.f;
+#pragma unroll
+      for (int k = 0; k < HEAD_K; ++k) {
+        const float d = dl[vl][k];
+        g = fmaf(d, w[k], g);
+        dwp[k] = fmaf(d, uv[sub], dwp[k]);
+      }
+      if (c < HEAD_K) dbp += dl[vl][c];
+      if (c < C && v < total) du[v * du_stride + c] = (T)g;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < HEAD_K; ++k) red[vq][k][c] = dwp[k];
+  red[vq][HEAD_K][c] = dbp;
+  __syncthreads();
+  for (int i = threadIdx.x; i < (HEAD_K + 1) * HEAD_C; i += 256) {
+    const int k = i / HEAD_C, cc = i % HEAD_C;
+    const float s = (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
+    if (part) part[(long)blockIdx.x * (HEAD_K + 1) * HEAD_C + i] = s;       // summed by head_reduce_kernel
+    else if (k < K && cc < C) unsafeAtomicAdd(dW + k * C + cc, s);          // ~1000 blocks on ~1000 addresses: slow
+    else if (k == HEAD_K && cc < K) unsafeAtomicAdd(db + cc, s);
+  }
+}
+
+// dW[k][c] += sum over blocks of part[block][k][c]; db[k] += sum of part[block][HEAD_K][k]
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ part, int nblocks, int K, int C,
+                                                          float* __restrict__ dW, float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (HEAD_K + 1) * HEAD_C) return;
+  const int k = i / HEAD_C, cc = i % HEAD_C;
+  const bool is_w = k < K && cc < C, is_b = k == HEAD_K && cc < K;
+  if (!is_w && !is_b) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    s0 += part[(long)b * (HEAD_K + 1) * HEAD_C + i]; s1 += part[(long)(b + 1) * (HEAD_K + 1) * HEAD_C + i];
+    s2 += part[(long)(b + 2) * (HEAD_K + 1) * HEAD_C + i]; s3 += part[(long)(b + 3) * (HEAD_K + 1) * HEAD_C + i];
+  }
+  for (; b < nblocks; ++b) s0 += part[(long)b * (HEAD_K + 1) * HEAD_C + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (is_w) dW[k * C + cc] += s; else db[cc] += s;
+}
+
+static inline unsigned head_blocks(long total) {
+  long b = (total + HEAD_TV - 1) / HEAD_TV;
+  return (unsigned)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+}  // namespace dua
+
+extern "C" {
+
+int dua_head_fwd(int dtype, long voxels, int C, int K, const void* u, int u_stride, const float* W, const float* b,
+                 void* logits, int logits_stride, void* stream) {
+  if (!u || !W || !b || !logits || voxels <= 0 || C <= 0 || C > dua::HEAD_C || C % 8 || K <= 0 || K > dua::HEAD_K ||
+      u_stride % 8 || u_stride < C || logits_stride < K) return DUA_ERR_ARG;
+  dim3 grid(dua::head_blocks(voxels));
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::head_fwd_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)u, u_stride,
+                       C, W, b, K, (dua::f16*)logits, logits_stride, voxels);
+  else if (dtype == DUA_F32)
+    hipLaunchKernelGGL(dua::head_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)u, u_stride, C, W,
+                       b, K, (float*)logits, logits_stride, voxels);
+  else return DUA_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+long dua_head_bwd_workspace(long voxels) {
+  if (voxels <= 0) return DUA_ERR_ARG;
+  const long tiles = (voxels + dua::HEAD_TV - 1) / dua::HEAD_TV;
+  return (tiles > 1024 ? 1024 : tiles) * (dua::HEAD_K + 1) * dua::HEAD_C * 4;
+}
+
+int dua_head_bwd(int dtype, long voxels, int C, int K, const void* dlogits, int dlogits_stride, const void* u,
+                 int u_stride, const float* W, void* du, int du_stride, float* dW, float* db, void* workspace,
+                 long workspace_bytes, void* stream) {
+  if (!dlogits || !u || !W || !du || !dW || !db || voxels <= 0 || C <= 0 || C > dua::HEAD_C || K <= 0 ||
+      K > dua::HEAD_K || dlogits_stride < K || u_stride < C || du_stride < C) return DUA_ERR_ARG;
+  const long tiles = (voxels + dua::HEAD_TV - 1) / dua::HEAD_TV;
+  dim3 grid((unsigned)(tiles > 1024 ? 1024 : tiles));
+  float* part = (workspace && workspace_bytes >= dua_head_bwd_workspace(voxels)) ? (float*)workspace : nullptr;
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::head_bwd_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)dlogits,
+                       dlogits_stride, K, (const dua::f16*)u, u_stride, C, W, (dua::f16*)du, du_stride, dW, db, part, voxels);
+  else if (dtype == DUA_F32)
+    hipLaunchKernelGGL(dua::head_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dlogits,
+                       dlogits_stride, K, (const float*)u, u_stride, C, W, (float*)du, du_stride, dW, db, part, voxels);
+  else return DUA_ERR_ARG;
+  if (part)
+    hipLaunchKernelGGL(dua::head_reduce_kernel, dim3(((dua::HEAD_K + 1) * dua::HEAD_C + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, part, (int)grid.x, K, C, dW, db);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -239,6 +239,39 @@ def maxpool2_bwd_add(act, act_off, Cc, dA, da_off, dP):
     return out
 
 
+HEAD_MAX_K, HEAD_MAX_C = 16, 64
+
+
+def head_fwd(u, weight, bias):
+    """logits [N, D, H, W, K] = 1x1x1 convolution of the channels-last activation ``u`` (weight fp32 [K, C], bias fp32 [K])."""
+    _cl_check(u, "u")
+    K, Cc = weight.shape
+    assert K <= HEAD_MAX_K and Cc <= HEAD_MAX_C and Cc % 8 == 0 and Cc <= u.shape[-1]
+    assert weight.dtype == torch.float32 and weight.is_contiguous() and bias.dtype == torch.float32 and bias.numel() == K
+    out = torch.empty((*u.shape[:4], K), dtype=u.dtype, device=u.device)
+    vox = u.numel() // u.shape[-1]
+    nv.check(nv.lib().dua_head_fwd(nv.dt_code(u.dtype), vox, Cc, K, nv.ptr(u), u.shape[-1], nv.ptr(weight), nv.ptr(bias),
+                                   nv.ptr(out), K, nv.stream_ptr()), "dua_head_fwd")
+    return out
+
+
+def head_bwd(dlogits, u, weight):
+    """(du, dW [K, C], db [K]) of head_fwd."""
+    _cl_check(u, "u")
+    K, Cc = weight.shape
+    assert dlogits.is_cuda and dlogits.is_contiguous() and dlogits.dtype == u.dtype and dlogits.shape[-1] == K
+    assert tuple(dlogits.shape[:4]) == tuple(u.shape[:4]) and u.shape[-1] == Cc
+    du = torch.empty_like(u)
+    dW = torch.zeros((K, Cc), dtype=torch.float32, device=u.device)
+    db = torch.zeros(K, dtype=torch.float32, device=u.device)
+    vox = u.numel() // Cc
+    ws = _wgrad_ws(int(nv.lib().dua_head_bwd_workspace(vox)), u.device)         # shared grow-only scratch (stream-ordered)
+    nv.check(nv.lib().dua_head_bwd(nv.dt_code(u.dtype), vox, Cc, K, nv.ptr(dlogits), K, nv.ptr(u), Cc, nv.ptr(weight),
+                                   nv.ptr(du), Cc, nv.ptr(dW), nv.ptr(db), nv.ptr(ws), ws.numel(), nv.stream_ptr()),
+             "dua_head_bwd")
+    return du, dW, db
+
+
 def seg_loss_reduce(logits, labels):
     """logits: channels-last [N, D, H, W, Cs] (first C = labels.shape[1] channels); labels fp32 [N, C, D, H, W].
     Returns (L as a 0-dim fp32 tensor, the fp64 sums the gradient kernel needs)."""

@@ -172,8 +172,8 @@ class DDPTrainer:
 # channels-last [N, D, H, W, C] in the compute dtype (fp16 with fp32 master weights and a GradScaler, or fp32).
 # InstanceNorm + LeakyReLU + temb/embedding adds are fused around them (materialize forward, reduce/apply backward).
 # MaxPool comes out of the materialize pass (forward) and a routed-add kernel (backward).  The mse+bce+dice loss is one
-# reduce + one gradient kernel.  What is still torch: concat, the k2s2 transposed
-# convolution and the 1x1 head as plain library GEMMs, the timestep MLP, AdamW.  They are the next kernels to write.
+# reduce + one gradient kernel; the 1x1 head is a forward and a one-pass backward kernel.  What is still torch:
+# concat, the k2s2 transposed convolution as a plain library GEMM, the timestep MLP, AdamW.  They are the next kernels to write.
 class _Conv3dK3(torch.autograd.Function):
     """y = conv3d(x, w, b), 3x3x3 / pad 1, channels-last.  forward: dua_conv3d_k3_fwd; backward: the same kernel on
     dy with the weights flipped and transposed (data gradient) + dua_conv3d_k3_wgrad (weight gradient)."""
@@ -295,6 +295,25 @@ def _deconv_cl(up, x):
     return y + up.deconv.bias.to(x.dtype)
 
 
+class _Head(torch.autograd.Function):
+    """final_conv (1x1x1): dua_head_fwd / dua_head_bwd (du, dW, db in one pass over the activation)."""
+
+    @staticmethod
+    def forward(ctx, u, weight, bias):
+        from . import ops
+        w2 = weight.detach().float().reshape(weight.shape[0], -1).contiguous()
+        ctx.save_for_backward(u, w2)
+        ctx.wshape = weight.shape
+        return ops.head_fwd(u, w2, bias.detach().float().contiguous())
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        from . import ops
+        u, w2 = ctx.saved_tensors
+        du, dW, db = ops.head_bwd(dlogits.contiguous(), u, w2)
+        return du, dW.view(ctx.wshape), db
+
+
 class _SegLoss(torch.autograd.Function):
     """mse + bce + dice ("sum") on channels-last logits: one reduce pass forward, one gradient pass backward."""
 
@@ -344,7 +363,11 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
     u3 = up(den.upcat_3, u4, x2)
     u2 = up(den.upcat_2, u3, x1)
     u1 = up(den.upcat_1, u2, x0)
+    from . import ops
     wf = den.final_conv.weight
+    if wf.shape[0] <= ops.HEAD_MAX_K and u1.shape[-1] <= ops.HEAD_MAX_C:
+        return _Head.apply(u1, wf, den.final_conv.bias)
+    # more classes / channels than the head kernel holds in registers: plain library GEMM
     return u1 @ wf.reshape(wf.shape[0], -1).t().to(u1.dtype) + den.final_conv.bias.to(u1.dtype)
 
 

@@ -102,6 +102,20 @@ int dua_maxpool2_bwd_add(int dtype, int N, int D, int H, int W, int C, const voi
                          const void* dA, int da_stride, int da_off, const void* dP, int dp_stride, void* out,
                          int out_stride, void* stream);
 
+/* final_conv (1x1x1, denoiser.py:282,311) for the training step, on a materialised activation u (channels-last
+ * [voxels][u_stride], first C channels; C <= 64, multiple of 8) with W fp32 [K][C], b fp32 [K], K <= 16 classes:
+ *   fwd: logits[v][k] = b[k] + sum_c u[v][c] W[k][c]
+ *   bwd: du[v][c] = sum_k dlogits[v][k] W[k][c];  dW[k][c] += sum_v dlogits[v][k] u[v][c];  db[k] += sum_v dlogits[v][k]
+ * dW, db are ACCUMULATED into (zero them first).  workspace (dua_head_bwd_workspace bytes; may be NULL): per-block
+ * partial sums reduced by a second kernel; without it ~1000 blocks add into ~1000 addresses with fp32 atomics
+ * (correct, ~10x slower).  voxels counts all samples of the batch. */
+int dua_head_fwd(int dtype, long voxels, int C, int K, const void* u, int u_stride, const float* W, const float* b,
+                 void* logits, int logits_stride, void* stream);
+long dua_head_bwd_workspace(long voxels);
+int dua_head_bwd(int dtype, long voxels, int C, int K, const void* dlogits, int dlogits_stride, const void* u,
+                 int u_stride, const float* W, void* du, int du_stride, float* dW, float* db, void* workspace,
+                 long workspace_bytes, void* stream);
+
 /* Loss of the training step and its gradient (losses/loss.py:25-86, losses "mse,bce,dice" combined by "sum"; MONAI
  * DiceLoss(sigmoid=True) defaults):  L = mean((sigmoid(p)-y)^2) + mean(BCEWithLogits(p,y)) + mean_{n,c}(1 - (2I+e)/(S+Y+e)).
  * logits: channels-last [N][voxels][logits_stride] (first C used); labels: fp32 NCDHW [N][C][voxels].

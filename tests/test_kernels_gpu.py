@@ -520,3 +520,27 @@ def test_maxpool_backward_add_matches_torch(dtype):
     assert (out.double() - want).abs().max().item() <= tol
     out0 = ops.maxpool2_bwd_add(act, 8, Cc, None, 0, dP)
     assert (out0.double() - a.grad.permute(0, 2, 3, 4, 1)).abs().max().item() <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 64, 16), (1, 3, 5, 7, 8, 2), (2, 6, 4, 10, 32, 13)])
+def test_head_forward_backward_match_torch(dtype, shape):
+    ops = _ops()
+    N, D, H, W, Cc, K = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    u = torch.randn(N, D, H, W, Cc, generator=g, device=dev).to(dtype)
+    w = torch.randn(K, Cc, generator=g, device=dev) * 0.2
+    b = torch.randn(K, generator=g, device=dev)
+    dl = torch.randn(N, D, H, W, K, generator=g, device=dev).to(dtype)
+    out = ops.head_fwd(u, w, b)
+    du, dW, db = ops.head_bwd(dl, u, w)
+    ud, wd, bd = u.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    want = ud @ wd.t() + bd
+    want.backward(dl.double())
+    ftol = 1e-5 if dtype == torch.float32 else 4e-3
+    assert (out.double() - want.detach()).abs().max().item() <= ftol * max(1.0, want.abs().max().item())
+    assert (du.double() - ud.grad).abs().max().item() <= ftol * max(1.0, ud.grad.abs().max().item())
+    assert torch.allclose(dW.double(), wd.grad, rtol=1e-4, atol=1e-4 * wd.grad.abs().max().item())
+    assert torch.allclose(db.double(), bd.grad, rtol=1e-4, atol=1e-4 * bd.grad.abs().max().item())

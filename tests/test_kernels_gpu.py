@@ -544,3 +544,50 @@ def test_head_forward_backward_match_torch(dtype, shape):
     assert (du.double() - ud.grad).abs().max().item() <= ftol * max(1.0, ud.grad.abs().max().item())
     assert torch.allclose(dW.double(), wd.grad, rtol=1e-4, atol=1e-4 * wd.grad.abs().max().item())
     assert torch.allclose(db.double(), bd.grad, rtol=1e-4, atol=1e-4 * bd.grad.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_conv3_random_shapes_forward_dgrad_wgrad(seed):
+    """Seeded random geometry (ragged tiles in every axis, channel counts that are not multiples of a chunk or a 64-wide
+    tile, batch 1-3, both dtypes, with and without a split-K workspace): forward, the data gradient through the forward
+    kernel with flipped/transposed weights, and the weight gradient, each against torch in fp64 on the same operands."""
+    import random
+    ops = _ops()
+    rnd = random.Random(1000 + seed)
+    dtype = torch.float16 if seed % 2 else torch.float32
+    N = rnd.choice([1, 1, 2, 3])
+    D, H, W = (rnd.choice([1, 2, 3, 5, 6, 8, 9, 12, 17]) for _ in range(3))
+    Cin, Cout = rnd.choice([8, 16, 24, 40, 64, 72, 136]), rnd.choice([8, 16, 24, 64, 72, 136])
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn(N, D, H, W, Cin, generator=g, device=dev).to(dtype)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g, device=dev) / (27 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g, device=dev)
+    dy = torch.randn(N, D, H, W, Cout, generator=g, device=dev).to(dtype)
+
+    def conv(inp, weight, bias, cout):
+        wp, bp = ops.pack_conv3_weights(weight.contiguous(), bias, dtype, cin_packed=inp.shape[-1])
+        out = torch.empty((*inp.shape[:4], cout), dtype=dtype, device=dev)
+        nb = ops.conv3_workspace_bytes(dtype, N, D, H, W, inp.shape[-1], cout)
+        ws = torch.empty(max(nb, 16) // 4, device=dev) if (nb > 0 and seed % 3) else None
+        ops.conv3d_k3(inp, inp.shape[-1], 0, wp, bp, cout, out, 0, ops.stats_buffer(N, cout, dev), workspace=ws)
+        return out
+
+    wq = w.to(dtype).double()
+    xd = x.double().permute(0, 4, 1, 2, 3)
+    dyd = dy.double().permute(0, 4, 1, 2, 3)
+    tol = 2e-5 if dtype == torch.float32 else 3e-3
+
+    y = conv(x, w, b, Cout)
+    want = F.conv3d(xd, wq, b.double(), padding=1).permute(0, 2, 3, 4, 1)
+    assert (y.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), ("fwd", N, D, H, W, Cin, Cout)
+
+    dx = conv(dy, w.flip(2, 3, 4).transpose(0, 1), None, Cin)
+    want = torch.nn.grad.conv3d_input(xd.shape, wq, dyd, padding=1).permute(0, 2, 3, 4, 1)
+    assert (dx.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), ("dgrad", N, D, H, W, Cin, Cout)
+
+    dw = torch.zeros(Cout, Cin, 3, 3, 3, device=dev)
+    ops.conv3d_k3_wgrad(x, Cin, 0, dy, Cout, 0, dw)
+    want = torch.nn.grad.conv3d_weight(xd, (Cout, Cin, 3, 3, 3), dyd, padding=1)
+    assert (dw.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), ("wgrad", N, D, H, W, Cin, Cout)

@@ -69,6 +69,7 @@ _SIGS = {
     "dua_conv3d_k3_wgrad_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_wgrad": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.c_int, _P, _P, C.c_long, _P]),
     "dua_pack_conv3_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "dua_pack_conv3_weights_dgrad": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_instnorm_finalize": (C.c_int, [C.c_int, C.c_int, C.POINTER(InNorm), _P, _P, _P]),
     "dua_instnorm_bwd_reduce": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P]),
     "dua_instnorm_bwd_apply": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P, _P]),

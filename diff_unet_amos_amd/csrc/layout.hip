@@ -32,6 +32,29 @@ __global__ void pack_conv3_kernel(int Cout, int Cin_src, int nchunks, const floa
   }
 }
 
+// ---- the same layout for the DATA-GRADIENT convolution: dx = conv3(dy, W') with W'[ci][co][tap] = W[co][ci][26 - tap]
+// (spatially flipped, in/out channels swapped), read straight from the forward weights [Cout][Cin][27] ----
+template <typename T>
+__global__ void pack_conv3_dgrad_kernel(int Cout, int Cin, int nchunks, const float* __restrict__ w,
+                                        T* __restrict__ out, long total) {
+  constexpr int EPG = Elem<T>::EPG;
+  constexpr int CK = 4 * EPG;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long t = i;
+    const int e = (int)(t % EPG); t /= EPG;
+    const int o_l = (int)(t % 64); t /= 64;
+    const int kg = (int)(t % 4); t /= 4;
+    const int t9 = (int)(t % 9); t /= 9;
+    const int kd = (int)(t % 3); t /= 3;
+    const int ch = (int)(t % nchunks); const int ot = (int)(t / nchunks);
+    const int ci = ot * 64 + o_l;                     // output channel of the gradient conv = forward input channel
+    const int co = ch * CK + kg * EPG + e;            // its input channel = forward output channel
+    float v = 0.f;
+    if (ci < Cin && co < Cout) v = w[((long)co * Cin + ci) * 27 + 26 - (kd * 9 + t9)];
+    out[i] = (T)v;
+  }
+}
+
 // ---- deconv k2 s2 weights: [Cin][Cout][8] fp32 -> [tap][ct][chunk][kg][64][EPG] ----
 template <typename T>
 __global__ void pack_deconv_kernel(int Cin, int Cout, int nchunks, int nct, const float* __restrict__ w,
@@ -101,6 +124,25 @@ long dua_pack_conv3_weights(int dtype, int Cout, int Cin_src, int Cin_packed, co
   else
     hipLaunchKernelGGL(dua::pack_conv3_kernel<float>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
                        Cout, Cin_src, nchunks, w, in_perm, (float*)w_packed, total);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? bytes : -(long)e;
+}
+
+long dua_pack_conv3_weights_dgrad(int dtype, int Cout, int Cin, int Cout_packed, const float* w, void* w_packed,
+                                  void* stream) {
+  const int epg = dtype == DUA_F16 ? 8 : 4, ck = 4 * epg;
+  if ((dtype != DUA_F16 && dtype != DUA_F32) || Cout <= 0 || Cin <= 0 || Cout_packed < Cout) return DUA_ERR_ARG;
+  const int nchunks = (Cout_packed + ck - 1) / ck, not_ = (Cin + 63) / 64;
+  const long total = (long)not_ * nchunks * 27 * 4 * 64 * epg;
+  const long bytes = total * (dtype == DUA_F16 ? 2 : 4);
+  if (!w_packed) return bytes;
+  if (!w) return DUA_ERR_ARG;
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::pack_conv3_dgrad_kernel<dua::f16>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
+                       Cout, Cin, nchunks, w, (dua::f16*)w_packed, total);
+  else
+    hipLaunchKernelGGL(dua::pack_conv3_dgrad_kernel<float>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
+                       Cout, Cin, nchunks, w, (float*)w_packed, total);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? bytes : -(long)e;
 }

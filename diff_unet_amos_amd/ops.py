@@ -76,6 +76,21 @@ def pack_conv3_weights(w, bias, dtype, cin_packed=None, perm=None):
     return buf, b
 
 
+def pack_conv3_weights_dgrad(w, dtype, cout_packed=None):
+    """Forward weights [Cout, Cin, 3,3,3] -> (packed weights of the data-gradient convolution dy -> dx, zero bias)."""
+    assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.is_contiguous()
+    cout, cin = w.shape[:2]
+    cout_packed = cout if cout_packed is None else cout_packed
+    L, code = nv.lib(), nv.dt_code(dtype)
+    nbytes = L.dua_pack_conv3_weights_dgrad(code, cout, cin, cout_packed, None, None, None)
+    assert nbytes > 0
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    rc = L.dua_pack_conv3_weights_dgrad(code, cout, cin, cout_packed, nv.ptr(w), nv.ptr(buf), nv.stream_ptr())
+    if rc != nbytes:
+        raise RuntimeError(f"dua_pack_conv3_weights_dgrad failed ({rc})")
+    return buf, torch.zeros(-(-cin // 64) * 64, dtype=torch.float32, device=w.device)
+
+
 def pack_deconv_weights(w, bias, dtype):
     assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 5 and tuple(w.shape[2:]) == (2, 2, 2)
     w = w.contiguous()

@@ -189,6 +189,16 @@ class _Conv3dK3(torch.autograd.Function):
         return y
 
     @staticmethod
+    def _dgrad(dy, w, cin_padded):
+        """dx [.., cin_padded] = data gradient: the forward kernel on dy with W' packed straight from w."""
+        from . import ops
+        N, D, H, W, cs = dy.shape
+        wp, bp = ops.pack_conv3_weights_dgrad(w, dy.dtype, cout_packed=cs)
+        dx = torch.empty((N, D, H, W, cin_padded), dtype=dy.dtype, device=dy.device)
+        ops.conv3d_k3(dy, cs, 0, wp, bp, cin_padded, dx, 0, ops.stats_buffer(N, cin_padded, dy.device))
+        return dx
+
+    @staticmethod
     def forward(ctx, x, weight, bias):
         assert x.is_contiguous() and x.shape[-1] % 8 == 0 and weight.shape[0] % 8 == 0 and weight.shape[1] <= x.shape[-1]
         ctx.save_for_backward(x, weight)
@@ -202,8 +212,7 @@ class _Conv3dK3(torch.autograd.Function):
         cout, cin = weight.shape[:2]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().float().flip(2, 3, 4).transpose(0, 1).contiguous()       # [Cin, Cout, 3,3,3]
-            dx = _Conv3dK3._run(dy, wt, None, x.shape[-1])
+            dx = _Conv3dK3._dgrad(dy, weight.detach().float().contiguous(), x.shape[-1])
         if ctx.needs_input_grad[1]:
             dw = torch.zeros((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
             ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dy, cout, 0, dw)
@@ -261,8 +270,7 @@ class _ConvNormAct(torch.autograd.Function):
         sums = ops.instnorm_bwd(dA, 0, raw, cout, norm, dY)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().float().flip(2, 3, 4).transpose(0, 1).contiguous()
-            dx = _Conv3dK3._run(dY, wt, None, x.shape[-1])
+            dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1])
         if ctx.needs_input_grad[1]:
             dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
             ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dY, cout, 0, dw)

@@ -72,6 +72,11 @@ int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_pack
  * workspace (dua_conv3d_k3_wgrad_workspace bytes; may be NULL): per-workgroup partial sums, reduced by a second
  * kernel -- without it every workgroup adds into dw with fp32 atomics (correct, much slower). */
 long dua_conv3d_k3_wgrad_workspace(const dua_conv3_desc* d);
+/* Data gradient of the same convolution: dx = dua_conv3d_k3_fwd(dy, W') with W'[ci][co][tap] = W[co][ci][26-tap].
+ * This packs W' straight from the forward weights w (fp32 [Cout][Cin][27]) for a dy buffer of Cout_packed (>= Cout)
+ * channels; same return convention as dua_pack_conv3_weights (bytes; query with w_packed == NULL). */
+long dua_pack_conv3_weights_dgrad(int dtype, int Cout, int Cin, int Cout_packed, const float* w, void* w_packed,
+                                  void* stream);
 int dua_conv3d_k3_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
                         const int* in_perm, void* workspace, long workspace_bytes, void* stream);
 

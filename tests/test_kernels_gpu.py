@@ -583,7 +583,12 @@ def test_conv3_random_shapes_forward_dgrad_wgrad(seed):
     want = F.conv3d(xd, wq, b.double(), padding=1).permute(0, 2, 3, 4, 1)
     assert (y.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), ("fwd", N, D, H, W, Cin, Cout)
 
-    dx = conv(dy, w.flip(2, 3, 4).transpose(0, 1), None, Cin)
+    if seed % 4 < 2:        # weights flipped/transposed by torch, packed as a forward convolution
+        dx = conv(dy, w.flip(2, 3, 4).transpose(0, 1), None, Cin)
+    else:                   # packed straight from the forward weights (dua_pack_conv3_weights_dgrad)
+        wp, bp = ops.pack_conv3_weights_dgrad(w.contiguous(), dtype, cout_packed=Cout)
+        dx = torch.empty((N, D, H, W, Cin), dtype=dtype, device=dev)
+        ops.conv3d_k3(dy, Cout, 0, wp, bp, Cin, dx, 0, ops.stats_buffer(N, Cin, dev))
     want = torch.nn.grad.conv3d_input(xd.shape, wq, dyd, padding=1).permute(0, 2, 3, 4, 1)
     assert (dx.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), ("dgrad", N, D, H, W, Cin, Cout)
 

@@ -379,14 +379,34 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
     return u1 @ wf.reshape(wf.shape[0], -1).t().to(u1.dtype) + den.final_conv.bias.to(u1.dtype)
 
 
+class _NativeModule(torch.nn.Module):
+    """nn.Module face of native_logits_cl, so torch's DistributedDataParallel reducer can hook the parameters."""
+
+    def __init__(self, net, dtype):
+        super().__init__()
+        self.net, self.dtype = net, dtype
+
+    def forward(self, images, x_t, t):
+        return native_logits_cl(self.net, images, x_t, t, self.dtype)
+
+
 class NativeConvTrainer:
-    """Single-GPU-per-process trainer on the native-convolution path: fp32 master weights, fp16 activations and
-    gradients with dynamic loss scaling (or plain fp32), AdamW as train.py:121-126.  Under torch.distributed the
-    gradients are averaged with one flat all-reduce per step (RCCL on a GPU node)."""
+    """One-process-per-GPU trainer on the native-convolution path: fp32 master weights, fp16 activations and gradients
+    with dynamic loss scaling (or plain fp32), AdamW as train.py:121-126.  Under torch.distributed the gradients are
+    averaged by torch's DDP reducer (``overlap=True``: 32 MB buckets all-reduced while the rest of backward still
+    runs; RCCL on a GPU node) or by one flat all-reduce after backward (``overlap=False``)."""
 
     def __init__(self, net, lr=2e-4, weight_decay=1e-4, losses="mse,bce,dice", loss_combine="sum",
-                 dtype=torch.float16, init_scale=2.0 ** 12):
+                 dtype=torch.float16, init_scale=2.0 ** 12, overlap=True):
+        import torch.distributed as dist
         self.net, self.dtype = net, dtype
+        self.module = _NativeModule(net, dtype)
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.overlap = overlap and self.distributed
+        if self.overlap:
+            from torch.nn.parallel import DistributedDataParallel
+            dev = next(net.parameters()).device
+            self.module = DistributedDataParallel(self.module, device_ids=[dev.index], bucket_cap_mb=32)
         self.criterion = Loss(losses, loss_combine)
         self.fused_loss = sorted(losses.split(",")) == ["bce", "dice", "mse"] and loss_combine == "sum"
         self.params = [p for p in net.parameters() if p.requires_grad]
@@ -395,7 +415,7 @@ class NativeConvTrainer:
 
     def _allreduce(self):
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self.distributed or self.overlap:          # the DDP reducer already averaged them during backward
             return
         flat = torch.cat([p.grad.reshape(-1) for p in self.params])
         dist.all_reduce(flat)
@@ -414,9 +434,9 @@ class NativeConvTrainer:
         self.optimizer.zero_grad(set_to_none=True)
         with torch.enable_grad():
             if self.fused_loss and labels.dtype == torch.float32:
-                loss = _SegLoss.apply(native_logits_cl(self.net, images, x_t, t, self.dtype), labels.contiguous())
+                loss = _SegLoss.apply(self.module(images, x_t, t), labels.contiguous())
             else:
-                loss = self.criterion(native_conv_denoise(self.net, images, x_t, t, self.dtype), labels)
+                loss = self.criterion(self.module(images, x_t, t).permute(0, 4, 1, 2, 3).float(), labels)
             (loss * self.scale).backward()
         for p in self.params:
             if p.grad is None:

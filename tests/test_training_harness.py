@@ -198,7 +198,7 @@ def test_native_conv_trainer_learns():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
-def _native_ddp_worker(rank, world, port, q):
+def _native_ddp_worker(rank, world, port, q, overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share cuda:0; gloo moves CUDA tensors via the host
     try:
@@ -206,7 +206,7 @@ def _native_ddp_worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         torch.manual_seed(0)
         net = DiffUNet(**KW).to(dev)
-        tr = NativeConvTrainer(net, lr=1e-3, dtype=torch.float32)
+        tr = NativeConvTrainer(net, lr=1e-3, dtype=torch.float32, overlap=overlap)
         image, labels, noise, t = _data(2, 7)
         sl = slice(rank, rank + 1)
         loss = tr.step(image[sl].to(dev), labels[sl].to(dev), noise=noise[sl].to(dev), t=t[sl].to(dev))
@@ -217,13 +217,15 @@ def _native_ddp_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_native_trainer_two_ranks_equal_union_batch():
-    """Two processes (one GPU, gloo) each train on their own sample; the flat gradient all-reduce must leave both with
-    the parameters single-process training on the two-sample batch produces (oracle autograd, CPU)."""
+@pytest.mark.parametrize("overlap", [True, False])
+def test_native_trainer_two_ranks_equal_union_batch(overlap):
+    """Two processes (one GPU, gloo) each train on their own sample; the gradient averaging (DDP reducer buckets
+    overlapped with backward, or one flat all-reduce after it) must leave both with the parameters single-process
+    training on the two-sample batch produces (oracle autograd, CPU)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() + 177) % 2000
-    procs = [ctx.Process(target=_native_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_native_ddp_worker, args=(r, 2, port + int(overlap), q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     outs = {r: (l, sd) for r, l, sd in (q.get(timeout=300) for _ in range(2))}

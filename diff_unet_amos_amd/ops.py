@@ -254,6 +254,38 @@ def maxpool2_bwd_add(act, act_off, Cc, dA, da_off, dP):
     return out
 
 
+def deconv_k2s2_bwd(x, cin, cin_off, dy, cout, cout_off, w, need_dx=True, need_dw=True):
+    """Backward of deconv_k2s2: x [N,D,H,W,*] (slice cin@cin_off), dy [N,2D,2H,2W,*] (slice cout@cout_off, read in place),
+    w fp32 [Cin, Cout, 2,2,2].  Returns (dx [N,D,H,W,cin] or None, dw fp32 like w or None)."""
+    _cl_check(x, "x"); _cl_check(dy, "dy")
+    N, D, H, W, cs_in = x.shape
+    assert x.dtype == dy.dtype and tuple(dy.shape[:4]) == (N, 2 * D, 2 * H, 2 * W)
+    assert cin % 8 == 0 and cin_off % 8 == 0 and cin_off + cin <= cs_in
+    assert cout % 8 == 0 and cout_off % 8 == 0 and cout_off + cout <= dy.shape[-1]
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (cin, cout, 2, 2, 2)
+    L, code = nv.lib(), nv.dt_code(x.dtype)
+    dx = dw = wp = ws = None
+    ws_bytes = 0
+    d_out = nv.Conv3Desc(code, N, D, H, W, cin, cin, 0, cout, dy.shape[-1], cout_off)      # dx is its own dense buffer
+    if need_dx:
+        nbytes = L.dua_pack_deconv_weights_dgrad(code, cin, cout, None, None, None)
+        wp = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        rc = L.dua_pack_deconv_weights_dgrad(code, cin, cout, nv.ptr(w), nv.ptr(wp), nv.stream_ptr())
+        if rc != nbytes:
+            raise RuntimeError(f"dua_pack_deconv_weights_dgrad failed ({rc})")
+        dx = torch.empty((N, D, H, W, cin), dtype=x.dtype, device=x.device)
+        nv.check(L.dua_deconv_k2s2_bwd(C.byref(d_out), None, nv.ptr(dy), nv.ptr(wp), nv.ptr(dx), None, None, 0,
+                                       nv.stream_ptr()), "dua_deconv_k2s2_bwd(dx)")
+    if need_dw:
+        d_in = nv.Conv3Desc(code, N, D, H, W, cin, cs_in, cin_off, cout, dy.shape[-1], cout_off)
+        ws_bytes = int(L.dua_deconv_k2s2_bwd_workspace(C.byref(d_in)))
+        ws = _wgrad_ws(ws_bytes, x.device)
+        dw = torch.zeros_like(w)
+        nv.check(L.dua_deconv_k2s2_bwd(C.byref(d_in), nv.ptr(x), nv.ptr(dy), None, None, nv.ptr(dw), nv.ptr(ws), ws.numel(),
+                                       nv.stream_ptr()), "dua_deconv_k2s2_bwd(dw)")
+    return dx, dw
+
+
 HEAD_MAX_K, HEAD_MAX_C = 16, 64
 
 

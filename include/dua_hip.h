@@ -107,6 +107,18 @@ int dua_maxpool2_bwd_add(int dtype, int N, int D, int H, int W, int C, const voi
                          const void* dA, int da_stride, int da_off, const void* dP, int dp_stride, void* out,
                          int out_stride, void* stream);
 
+/* Backward of ConvTranspose3d(k2, s2) (denoiser.py:161-170) for the training step.  d describes the FORWARD op (as
+ * dua_deconv_k2s2_fwd): x = Cin channels at Cin_off of a Cin_stride buffer, N/D/H/W its extent; dy = Cout channels at
+ * Cout_off of a Cout_stride buffer with extent 2D x 2H x 2W (e.g. the gradient of the concat buffer, read in place).
+ *   dx (or NULL): data gradient, written to the same slice geometry as x; needs w_packed_dgrad from
+ *                 dua_pack_deconv_weights_dgrad (w = fp32 [Cin][Cout][8], the reference's layout)
+ *   dw (or NULL): fp32 [Cin][Cout][8], ACCUMULATED into; needs x and a workspace of dua_deconv_k2s2_bwd_workspace bytes
+ * (the bias gradient is a plain column sum of dy and is left to the caller). */
+long dua_pack_deconv_weights_dgrad(int dtype, int Cin, int Cout, const float* w, void* w_packed, void* stream);
+long dua_deconv_k2s2_bwd_workspace(const dua_conv3_desc* d);
+int dua_deconv_k2s2_bwd(const dua_conv3_desc* d, const void* x, const void* dy, const void* w_packed_dgrad, void* dx,
+                        float* dw, void* workspace, long workspace_bytes, void* stream);
+
 /* final_conv (1x1x1, denoiser.py:282,311) for the training step, on a materialised activation u (channels-last
  * [voxels][u_stride], first C channels; C <= 64, multiple of 8) with W fp32 [K][C], b fp32 [K], K <= 16 classes:
  *   fwd: logits[v][k] = b[k] + sum_c u[v][c] W[k][c]

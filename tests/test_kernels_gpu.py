@@ -596,3 +596,32 @@ def test_conv3_random_shapes_forward_dgrad_wgrad(seed):
     ops.conv3d_k3_wgrad(x, Cin, 0, dy, Cout, 0, dw)
     want = torch.nn.grad.conv3d_weight(xd, (Cout, Cin, 3, 3, 3), dyd, padding=1)
     assert (dw.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), ("wgrad", N, D, H, W, Cin, Cout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [
+    # N, D, H, W (input), Cin, Cout
+    (1, 4, 4, 4, 64, 64),
+    (2, 3, 5, 6, 16, 8),          # ragged tile, channels below one chunk / tile
+    (1, 6, 6, 6, 136, 72),        # several chunks and tiles in both channel axes
+    (2, 8, 8, 8, 64, 32),         # more than one 128-voxel tile per sample
+])
+def test_deconv_backward_matches_torch(dtype, shape):
+    """Data and weight gradient of ConvTranspose3d(k2, s2), dy read in place from a channel slice of a wider buffer."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    x = torch.randn(N, D, H, W, Cin + 8, generator=g, device=dev).to(dtype)
+    dcat = torch.randn(N, 2 * D, 2 * H, 2 * W, Cout + 24, generator=g, device=dev).to(dtype)
+    w = torch.randn(Cin, Cout, 2, 2, 2, generator=g, device=dev) / (Cin ** 0.5)
+    dx, dw = ops.deconv_k2s2_bwd(x, Cin, 8, dcat, Cout, 24, w)
+    xr = x[..., 8:].permute(0, 4, 1, 2, 3).double().contiguous().requires_grad_(True)
+    wr = w.to(dtype).double().requires_grad_(True)
+    y = F.conv_transpose3d(xr, wr, stride=2)
+    y.backward(dcat[..., 24:].permute(0, 4, 1, 2, 3).double())
+    tol = 2e-5 if dtype == torch.float32 else 3e-3
+    want_dx = xr.grad.permute(0, 2, 3, 4, 1)
+    assert (dx.double() - want_dx).abs().max().item() <= tol * max(1.0, want_dx.abs().max().item())
+    assert (dw.double() - wr.grad).abs().max().item() <= tol * max(1.0, wr.grad.abs().max().item())

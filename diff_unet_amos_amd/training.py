@@ -172,8 +172,9 @@ class DDPTrainer:
 # channels-last [N, D, H, W, C] in the compute dtype (fp16 with fp32 master weights and a GradScaler, or fp32).
 # InstanceNorm + LeakyReLU + temb/embedding adds are fused around them (materialize forward, reduce/apply backward).
 # MaxPool comes out of the materialize pass (forward) and a routed-add kernel (backward).  The mse+bce+dice loss is one
-# reduce + one gradient kernel; the 1x1 head is a forward and a one-pass backward kernel.  What is still torch:
-# concat, the k2s2 transposed convolution as a plain library GEMM, the timestep MLP, AdamW.  They are the next kernels to write.
+# reduce + one gradient kernel; the 1x1 head is a forward and a one-pass backward kernel; the k2s2 transposed convolution writes/reads its half of the concat buffer in place (forward
+# kernel of the sampler, data- and weight-gradient kernels).  What is still torch: the copy of the skip half into the concat
+# buffer, the timestep MLP, AdamW.
 class _Conv3dK3(torch.autograd.Function):
     """y = conv3d(x, w, b), 3x3x3 / pad 1, channels-last.  forward: dua_conv3d_k3_fwd; backward: the same kernel on
     dy with the weights flipped and transposed (data gradient) + dua_conv3d_k3_wgrad (weight gradient)."""
@@ -231,6 +232,53 @@ def _cl_pad(x_ncdhw, dtype):
     return out
 
 
+def _slice_of(t):
+    """(buffer, channel offset) with t == buffer[..., off:off+C], without a copy when t is a channel slice of a contiguous
+    channels-last buffer (the gradient of a concat half): the backward kernels take (stride, offset) operands."""
+    if t.is_contiguous():
+        return t, 0
+    N, D, H, W, Cc = t.shape
+    st = t.stride()
+    ct = st[3]
+    if st == (D * H * W * ct, H * W * ct, W * ct, ct, 1) and ct % 8 == 0:
+        off = t.storage_offset() % ct
+        if off % 8 == 0 and off + Cc <= ct:
+            return t.as_strided((N, D, H, W, ct), st, t.storage_offset() - off), off
+    return t.contiguous(), 0
+
+
+class _UpCat(torch.autograd.Function):
+    """cat([skip, ConvTranspose3d_k2s2(lo)], channel axis) (UpCat.forward, denoiser.py:184-191): the transposed convolution
+    writes its half of the concat buffer in place; backward reads its half of the buffer's gradient in place (data gradient
+    + weight gradient kernels) and hands the skip half on as a view."""
+
+    @staticmethod
+    def forward(ctx, lo, skip, weight, bias):
+        from . import ops
+        N, D, H, W, cs = skip.shape
+        cin, cout = weight.shape[:2]
+        assert lo.is_contiguous() and lo.shape[-1] == cin and cin % 8 == 0 and cout % 8 == 0 and cs % 8 == 0
+        cat = torch.empty((N, D, H, W, cs + cout), dtype=skip.dtype, device=skip.device)
+        cat[..., :cs].copy_(skip)
+        w32 = weight.detach().float().contiguous()
+        wp, bp = ops.pack_deconv_weights(w32, bias.detach().float(), skip.dtype)
+        ops.deconv_k2s2(lo, cin, 0, wp, bp, cout, cat, cs)
+        ctx.save_for_backward(lo, w32)
+        ctx.cs = cs
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        from . import ops
+        lo, w32 = ctx.saved_tensors
+        dcat = dcat.contiguous()
+        cs, (cin, cout) = ctx.cs, w32.shape[:2]
+        dx, dw = ops.deconv_k2s2_bwd(lo, cin, 0, dcat, cout, cs, w32, need_dx=ctx.needs_input_grad[0],
+                                     need_dw=ctx.needs_input_grad[2])
+        db = torch.sum(dcat[..., cs:], dim=(0, 1, 2, 3), dtype=torch.float32) if ctx.needs_input_grad[3] else None
+        return dx, (dcat[..., :cs] if ctx.needs_input_grad[1] else None), dw, db
+
+
 class _ConvNormAct(torch.autograd.Function):
     """a = LeakyReLU(InstanceNorm(conv3d(x, w, b))) [+ add[n, c]] [+ emb] -- one MONAI Convolution block (+ the temb bias /
     the encoder embedding that follow it in TwoConv.forward / BasicUNetRDenoiser.forward), all on the HIP kernels:
@@ -262,12 +310,13 @@ class _ConvNormAct(torch.autograd.Function):
         from . import ops
         x, weight, raw, stats, g32, b32, act = ctx.saved_tensors
         N, D, H, W, cout = raw.shape
+        buf, off = _slice_of(dA) if dA is not None else (None, 0)       # a concat half's gradient is read in place
         if ctx.pool and dP is not None:       # MaxPool3d(2) backward + the skip-path gradient in one pass
-            dA = ops.maxpool2_bwd_add(act, 0, cout, dA.contiguous() if dA is not None else None, 0, dP.contiguous())
-        dA = dA.contiguous()
+            dA = buf = ops.maxpool2_bwd_add(act, 0, cout, buf, off, dP.contiguous())
+            off = 0
         norm = ops.Norm(stats, g32, b32, D * H * W)
         dY = torch.empty_like(raw)
-        sums = ops.instnorm_bwd(dA, 0, raw, cout, norm, dY)
+        sums = ops.instnorm_bwd(buf, off, raw, cout, norm, dY)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1])
@@ -287,20 +336,6 @@ def _two_conv_cl(block, x, temb, emb=None, pool=False):
     c0, c1 = block.conv_0, block.conv_1
     h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None)
     return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb, pool)
-
-
-def _pool_cl(x):
-    return F.max_pool3d(x.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1).contiguous()
-
-
-def _deconv_cl(up, x):
-    """ConvTranspose3d k2 s2 as one GEMM: [voxels, Cin] @ [Cin, Cout*8], then a pixel shuffle."""
-    N, D, H, W, Cin = x.shape
-    w = up.deconv.weight                                     # [Cin, Cout, 2,2,2]
-    Cout = w.shape[1]
-    y = x.reshape(-1, Cin) @ w.reshape(Cin, Cout * 8).to(x.dtype)
-    y = y.view(N, D, H, W, Cout, 2, 2, 2).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(N, 2 * D, 2 * H, 2 * W, Cout)
-    return y + up.deconv.bias.to(x.dtype)
 
 
 class _Head(torch.autograd.Function):
@@ -365,7 +400,8 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
     x4 = _two_conv_cl(den.down_4.convs, p3, temb, emb[4])
 
     def up(block, lo, skip):
-        return _two_conv_cl(block.convs, torch.cat([skip, _deconv_cl(block.upsample, lo)], dim=-1), temb)
+        dc = block.upsample.deconv
+        return _two_conv_cl(block.convs, _UpCat.apply(lo, skip, dc.weight, dc.bias), temb)
 
     u4 = up(den.upcat_4, x4, x3)
     u3 = up(den.upcat_3, u4, x2)
@@ -397,9 +433,11 @@ class NativeConvTrainer:
     runs; RCCL on a GPU node) or by one flat all-reduce after backward (``overlap=False``)."""
 
     def __init__(self, net, lr=2e-4, weight_decay=1e-4, losses="mse,bce,dice", loss_combine="sum",
-                 dtype=torch.float16, init_scale=2.0 ** 12, overlap=True):
+                 dtype=torch.float16, init_scale=2.0 ** 12, overlap=True, graph=False, fused_optimizer=False):
         import torch.distributed as dist
         self.net, self.dtype = net, dtype
+        self.lr, self.weight_decay, self.init_scale = lr, weight_decay, init_scale
+        self.use_graph, self._graph = graph, None
         self.module = _NativeModule(net, dtype)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.overlap = overlap and self.distributed
@@ -410,7 +448,9 @@ class NativeConvTrainer:
         self.criterion = Loss(losses, loss_combine)
         self.fused_loss = sorted(losses.split(",")) == ["bce", "dice", "mse"] and loss_combine == "sum"
         self.params = [p for p in net.parameters() if p.requires_grad]
-        self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay)
+        # graph mode always uses the fused capturable AdamW; ``fused_optimizer`` selects the same kernel for eager steps
+        self.optimizer = (torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=True, capturable=True)
+                          if fused_optimizer else torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay))
         self.scale, self.good_steps = (init_scale if dtype == torch.float16 else 1.0), 0
 
     def _allreduce(self):
@@ -425,7 +465,80 @@ class NativeConvTrainer:
             p.grad.copy_(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
+    # ---- whole-step HIP graph (single process): the eager step issues ~3,000 launches and is host-bound once the kernels
+    # take < 22 ms; one replay per step removes the host from the loop.  Everything a step decides stays on the device:
+    # the timestep -> (sqrt(a_bar), sqrt(1 - a_bar)) gather, the fp16 overflow check (found_inf feeds the fused AdamW,
+    # which skips the update itself) and the loss-scale update (torch._amp_update_scale_).
+    def _graph_body(self):
+        from . import ops
+        g = self._g
+        x_start = g["labels"] * 2 - 1
+        x_t = ops.q_sample(x_start.contiguous(), g["noise"], g["qtab"][g["t"]].contiguous())
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            loss = _SegLoss.apply(self.module(g["images"], x_t, g["t"]), g["labels"])
+            (loss * g["scale"]).backward()
+        grads = [p.grad for p in self.params]
+        g["found_inf"].zero_()
+        torch._amp_foreach_non_finite_check_and_unscale_(grads, g["found_inf"], g["scale"].reciprocal())
+        self.optimizer.grad_scale, self.optimizer.found_inf = None, g["found_inf"]
+        self.optimizer.step()
+        torch._amp_update_scale_(g["scale"], g["growth"], g["found_inf"], 2.0, 0.5, 200)
+        return loss.detach()
+
+    def _build_graph(self, images, labels):
+        assert not self.distributed, "graph mode is single-process; use overlap=True under torch.distributed"
+        assert self.fused_loss and labels.dtype == torch.float32
+        dev = images.device
+        d = self.net.diffusion
+        self.optimizer = torch.optim.AdamW(self.params, lr=self.lr, weight_decay=self.weight_decay, fused=True, capturable=True)
+        self._g = dict(images=images.clone(), labels=labels.contiguous().clone(), noise=torch.zeros_like(labels),
+                       t=torch.zeros(labels.shape[0], dtype=torch.long, device=dev),
+                       qtab=torch.stack([torch.as_tensor(d.sqrt_alphas_cumprod), torch.as_tensor(d.sqrt_one_minus_alphas_cumprod)],
+                                        dim=1).float().to(dev).contiguous(),
+                       scale=torch.full((), self.init_scale if self.dtype == torch.float16 else 1.0, device=dev),
+                       growth=torch.zeros((), dtype=torch.int32, device=dev), found_inf=torch.zeros((), device=dev))
+        saved = [p.detach().clone() for p in self.params]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                       # warm-up: lazy kernel attributes, workspaces, optimizer state tensors
+                self._g["noise"].normal_()
+                self._graph_body()
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self._graph):
+            self._g["loss"] = self._graph_body()
+        # the warm-up steps were real updates: put weights, Adam moments/step counter and the loss scale back
+        with torch.no_grad():
+            for p, q in zip(self.params, saved):
+                p.copy_(q)
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            self._g["scale"].fill_(self.init_scale if self.dtype == torch.float16 else 1.0)
+            self._g["growth"].zero_()
+
+    def _graph_step(self, images, labels, noise, t):
+        if self._graph is None:
+            self._build_graph(images, labels)
+        g = self._g
+        g["images"].copy_(images); g["labels"].copy_(labels)
+        if t is None:
+            t, _ = self.net.sampler.sample(labels.shape[0], labels.device)
+        g["t"].copy_(t)
+        if noise is None:
+            g["noise"].normal_()
+        else:
+            g["noise"].copy_(noise)
+        self._graph.replay()
+        return g["loss"]
+
     def step(self, images, labels, noise=None, t=None):
+        if self.use_graph:
+            return self._graph_step(images, labels, noise, t)
         x_start = labels * 2 - 1
         if t is None:
             t, _ = self.net.sampler.sample(x_start.shape[0], x_start.device)

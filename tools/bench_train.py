@@ -20,13 +20,14 @@ ap.add_argument("--classes", type=int, default=16)
 ap.add_argument("--size", type=int, default=96)
 ap.add_argument("--path", default="native-conv", choices=["native-conv", "autograd"])
 ap.add_argument("--dtype", default="float16")
+ap.add_argument("--graph", action="store_true", help="replay the whole training step as one HIP graph")
 ap.add_argument("--no-gc", action="store_true", help="disable the Python cyclic GC during the timed loop (diagnosis)")
 ap.add_argument("--ab-wgrad", default="", help="comma list of dua_set_option(4, v) values: time the loop once per value, same process")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = DiffUNet(in_channels=1, out_channels=a.classes).to(dev)
-tr = NativeConvTrainer(net, dtype=getattr(torch, a.dtype)) if a.path == "native-conv" else DDPTrainer(net)
+tr = NativeConvTrainer(net, dtype=getattr(torch, a.dtype), graph=a.graph) if a.path == "native-conv" else DDPTrainer(net)
 image = torch.rand(a.batch, 1, a.size, a.size, a.size, device=dev)
 labels = (torch.rand(a.batch, a.classes, a.size, a.size, a.size, device=dev) > 0.8).float()
 for _ in range(a.warmup):
@@ -59,7 +60,7 @@ if a.ab_wgrad:
         ab.setdefault(str(v), []).append(round(sorted(ts)[len(ts) // 2] * 1e3, 2))
     nv.check(nv.lib().dua_set_option(4, 0), "opt")
 print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "median_ms": sorted(per)[len(per) // 2] * 1e3, "per_step_ms": [round(x * 1e3, 2) for x in per], "ab_wgrad_median_ms": ab, "native": a.path == "native-conv",
-                  "path": ("HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; fused mse+bce+dice loss, pooling and 1x1-head kernels; concat/deconv GEMM/AdamW = torch; " + a.dtype)
-                  if a.path == "native-conv" else "torch autograd fallback (MIOpen/rocBLAS) fp32, q_sample = HIP", "batch": a.batch,
+                  "path": ("HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; fused loss, pooling, 1x1-head and transposed-conv (in-place concat) kernels; AdamW = torch; " + a.dtype)
+                  if a.path == "native-conv" else "torch autograd fallback (MIOpen/rocBLAS) fp32, q_sample = HIP", "graph": a.graph, "batch": a.batch,
                   "size": a.size, "classes": a.classes, "loss": float(loss),
                   "max_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}))

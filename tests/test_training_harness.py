@@ -287,3 +287,48 @@ def test_graph_replayed_training_step_equals_eager():
     # same kernels, same order, same optimizer: the replayed step must reproduce the eager one (this also proves the
     # graph's warm-up iterations left weights, Adam state and the loss scale untouched)
     assert graph_gap < 1e-6, graph_gap
+
+
+@pytest.mark.gpu
+def test_full_size_gradients_fp16_path_vs_oracle():
+    """Config-4 geometry (96^3 patch, 16 classes, full feature widths; batch 1 to bound the CPU oracle's time): parameter
+    gradients of the fp16 HIP training path against the oracle network under torch autograd in fp32 on the host."""
+    from diff_unet_amos_amd.training import native_logits_cl, _SegLoss
+    kw = dict(in_channels=1, out_channels=16)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ref = RefDiffUNet(**kw)
+    net = DiffUNet(**kw)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(dev)
+    g = torch.Generator().manual_seed(41)
+    image = torch.rand(1, 1, 96, 96, 96, generator=g)
+    labels = (torch.rand(1, 16, 96, 96, 96, generator=g) > 0.8).float()
+    noise = torch.randn(1, 16, 96, 96, 96, generator=g)
+    t = torch.tensor([417])
+    x_t = ref.diffusion.q_sample(labels * 2 - 1, t, noise)
+    crit = Loss()
+    want = ref(image=image, x=x_t, step=t, pred_type="denoise")
+    lw = crit(want, labels)
+    lw.backward()
+    scale = 4096.0
+    logits = native_logits_cl(net, image.to(dev), x_t.to(dev), t.to(dev), torch.float16)
+    lg = _SegLoss.apply(logits, labels.to(dev))
+    (lg * scale).backward()
+    assert abs(float(lg) - float(lw)) < 2e-3 * float(lw)
+    gp = dict(net.named_parameters())
+    num = den = 0.0
+    coss = []
+    for k, p in ref.named_parameters():
+        if k.endswith("conv.bias"):
+            continue
+        a = gp[k].grad.detach().cpu().double() / scale
+        b = p.grad.double()
+        num += float(((a - b) ** 2).sum()); den += float((b ** 2).sum())
+        if b.numel() >= 64:
+            coss.append((float((a * b).sum() / (a.norm() * b.norm() + 1e-30)), k))
+    coss.sort()
+    rel = (num / den) ** 0.5
+    print(f"[96^3 x 16, fp16 path] loss {float(lg):.6f} vs {float(lw):.6f}; whole-gradient relative L2 error {rel:.2e}; "
+          f"lowest cosine: " + ", ".join(f"{k} {c:.4f}" for c, k in coss[:3]))
+    assert rel < 3e-2 and coss[0][0] > 0.98, (rel, coss[0])

@@ -69,9 +69,24 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
   float w[HEAD_K], dwp[HEAD_K], dbp = 0.f;
 #pragma unroll
   for (int k = 0; k < HEAD_K; ++k) { w[k] = (k < K && c < C) ? W[k * C + c] : 0.f; dwp[k] = 0.f; }
-  for (long t0 = (long)blockIdx.x * HEAD_TV; t0 < total; t0 += (long)gridDim.x * HEAD_TV) {
-    // all 16 activations this thread needs from the tile are requested up front: one HBM latency per tile, not per voxel
-    // branch-free (clamped addresses, select afterwards): a load under a lane-dependent branch sits in its own basic
+  // this thread's share of a tile's dlogits (4 of the 64 x 16 values), loaded one tile ahead of its use
+  constexpr int NDL = HEAD_TV * HEAD_K / 256;
+  T pdl[NDL];
+  auto load_dl = [&](long t0) {
+#pragma unroll
+    for (int j = 0; j < NDL; ++j) {
+      const int it = threadIdx.x + 256 * j, vl = it / HEAD_K, k = it % HEAD_K;
+      long v = t0 + vl;
+      v = v < total ? v : total - 1;
+      pdl[j] = dlog[v * dl_stride + (k < K ? k : K - 1)];
+    }
+  };
+  const long tstep = (long)gridDim.x * HEAD_TV;
+  long t0 = (long)blockIdx.x * HEAD_TV;
+  if (t0 < total) load_dl(t0);
+  for (; t0 < total; t0 += tstep) {
+    // all 16 activations this thread needs from the tile are requested up front: one HBM latency per tile, not per voxel.
+    // Branch-free (clamped addresses, select afterwards): a load under a lane-dependent branch sits in its own basic
     // block and hipcc waits for it there -- 16 serialised HBM round trips per tile
     T ur[HEAD_TV / 4];
     const int cl = c < C ? c : C - 1;
@@ -81,20 +96,17 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
       v = v < total ? v : total - 1;
       ur[sub] = u[v * u_stride + cl];
     }
+    __syncthreads();                      // the previous tile's dl reads are done
+#pragma unroll
+    for (int j = 0; j < NDL; ++j) {
+      const int it = threadIdx.x + 256 * j, vl = it / HEAD_K, k = it % HEAD_K;
+      dl[vl][k] = (k < K && t0 + vl < total) ? (float)pdl[j] : 0.f;
+    }
+    __syncthreads();
+    if (t0 + tstep < total) load_dl(t0 + tstep);
     float uv[HEAD_TV / 4];
 #pragma unroll
     for (int sub = 0; sub < HEAD_TV / 4; ++sub) uv[sub] = (c < C && t0 + sub * 4 + vq < total) ? (float)ur[sub] : 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < HEAD_TV * HEAD_K / 256; ++j) {
-      const int it = threadIdx.x + 256 * j, vl = it / HEAD_K, k = it % HEAD_K;
-      long v = t0 + vl;
-      const bool ok = k < K && v < total;
-      v = v < total ? v : total - 1;
-      const T d = dlog[v * dl_stride + (k < K ? k : K - 1)];
-      dl[vl][k] = ok ? (float)d : 0.f;
-    }
-    __syncthreads();
 #pragma unroll
     for (int sub = 0; sub < HEAD_TV / 4; ++sub) {
       const int vl = sub * 4 + vq;
@@ -132,14 +144,16 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
   const bool is_w = k < K && cc < C, is_b = k == HEAD_K && cc < K;
   if (!is_w && !is_b) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;      // blockIdx.y takes one slice of the partials
+  int b = blockIdx.y * per;
+  nblocks = min(nblocks, b + per);
   for (; b + 3 < nblocks; b += 4) {
     s0 += part[(long)b * (HEAD_K + 1) * HEAD_C + i]; s1 += part[(long)(b + 1) * (HEAD_K + 1) * HEAD_C + i];
     s2 += part[(long)(b + 2) * (HEAD_K + 1) * HEAD_C + i]; s3 += part[(long)(b + 3) * (HEAD_K + 1) * HEAD_C + i];
   }
   for (; b < nblocks; ++b) s0 += part[(long)b * (HEAD_K + 1) * HEAD_C + i];
   const float s = (s0 + s1) + (s2 + s3);
-  if (is_w) dW[k * C + cc] += s; else db[cc] += s;
+  if (is_w) unsafeAtomicAdd(dW + k * C + cc, s); else unsafeAtomicAdd(db + cc, s);     // gridDim.y adds per address
 }
 
 static inline unsigned head_blocks(long total) {
@@ -188,7 +202,7 @@ int dua_head_bwd(int dtype, long voxels, int C, int K, const void* dlogits, int 
                        dlogits_stride, K, (const float*)u, u_stride, C, W, (float*)du, du_stride, dW, db, part, voxels);
   else return DUA_ERR_ARG;
   if (part)
-    hipLaunchKernelGGL(dua::head_reduce_kernel, dim3(((dua::HEAD_K + 1) * dua::HEAD_C + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(dua::head_reduce_kernel, dim3(((dua::HEAD_K + 1) * dua::HEAD_C + 255) / 256, 16), dim3(256), 0,
                        (hipStream_t)stream, part, (int)grid.x, K, C, dW, db);
   return (int)hipGetLastError();
 }

@@ -494,7 +494,7 @@ int dua_set_option(int key, int value) {
   if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only
   if (key == 5 && value >= 1 && value <= 32) { dua::g_v4_grid_quarters = value; return 0; }
-  if (key == 4 && value >= 0 && value < 64) { dua::g_wgrad_variant = value; return 0; }
+  if (key == 4 && value >= 0 && value < 128) { dua::g_wgrad_variant = value; return 0; }
   return DUA_ERR_ARG;
 }
 

@@ -11,8 +11,9 @@
 // transposing LDS read (a 4-voxel x 16-channel block per 16 lanes, delivered channel-per-lane); a tap shift is an
 // address offset on the x image.  f32 (parity mode): MFMA 32x32x2 takes one k per lane, plain ds_read_b32.
 //
-// Workgroup (384 threads = 6 waves) = one kd plane of taps x 64 co x 64 ci, persistent over a strided list of
-// 2x8x8-voxel tiles: wave (kh, ci half) keeps 3 (kw) x 2 (co half) 32x32 fp32 accumulators in registers for its
+// Workgroup = one kd plane of taps x 64 co x 64 ci, persistent over a strided list of 2x8x8-voxel tiles.  f16: 768
+// threads = 12 waves, wave (kh, ci half, co half) keeps 3 (kw) 32x32 fp32 accumulators (three waves per SIMD, every
+// SIMD the same MFMA load); f32 / the 6-wave form: wave (kh, ci half) keeps 3 (kw) x 2 (co half) accumulators for its
 // whole tile list and adds them to dW (reference layout, fp32 atomics) once at the end.  The next tile's x and
 // dy are prefetched into registers while the current one is multiplied.
 #include "common.hpp"
@@ -20,7 +21,7 @@
 
 namespace dua {
 int g_wgrad_abl = 0;
-int g_wgrad_variant = 0;   // dua_set_option(4, v): bit 0 = plain (partition-major) block order, bits 1-4 = workgroups per CU over the launch (0 = policy), bit 5 = plain k loop
+int g_wgrad_variant = 0;   // dua_set_option(4, v): bit 0 = plain (partition-major) block order, bits 1-4 = workgroups per CU over the launch (0 = policy), bit 5 = 6 waves + plain k loop, bit 6 = 6 waves + pipelined k loop (default: 12 waves)
 namespace wg {
 constexpr int TD = 2, TH = 8, TW = 8, TV = TD * TH * TW;      // 128 output voxels per tile
 constexpr int XH = TH + 2, XW = TW + 2, XV = TD * XH * XW;    // 200 input voxels per tile and kd
@@ -39,8 +40,9 @@ struct Args {
 
 }  // namespace wg
 
-template <typename T, bool PIPE>
+template <typename T, bool PIPE, int NCOH>
 __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
+  constexpr int NT = NCOH == 2 ? 384 : 768;          // 6 waves (two co halves each) or 12 waves (one co half each)
   using namespace wg;
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
@@ -54,7 +56,7 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
   char* Ys = smem + 2 * XIMG;      // [2][TV][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kh = wave % 3, cih = wave / 3;
+  const int kh = wave % 3, cih = (wave / 3) & 1, coh0 = NCOH == 2 ? 0 : wave / 6;
   // 1-D grid, XCD-aware: block b runs on XCD b % 8; the three kd workgroups of one (partition, co tile, ci chunk) get
   // ids 24 j + 8 kd + x, i.e. the same XCD, dispatched together -- they read the same x / dy tiles through one L2.
   const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
@@ -133,11 +135,11 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
       if (yl[j] >= 0) *(Frag*)(Ys + yl[j]) = yr[j];
   };
 
-  f32x16 acc[3][2];
+  f32x16 acc[3][NCOH];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NCOH; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -172,9 +174,9 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
       auto rd = [&](int s, Frag* pa, Frag* pb) {
         const int yo = s * 16 * RSB, xo = ((s >> 2) * XH + 2 * (s & 3)) * XW * RSB;
 #pragma unroll
-        for (int coh = 0; coh < 2; ++coh) {
-          h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(ya + coh * YIMG + yo));
-          h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(yb + coh * YIMG + yo));
+        for (int coh = 0; coh < NCOH; ++coh) {
+          h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(ya + (coh0 + coh) * YIMG + yo));
+          h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(yb + (coh0 + coh) * YIMG + yo));
           pa[coh] = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
@@ -188,9 +190,9 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-          for (int coh = 0; coh < 2; ++coh) mma32(acc[kw][coh], pa[coh], pb[kw]);
+          for (int coh = 0; coh < NCOH; ++coh) mma32(acc[kw][coh], pa[coh], pb[kw]);
       };
-      Frag A0[2], B0[3], A1[2], B1[3];
+      Frag A0[NCOH], B0[3], A1[NCOH], B1[3];
       rd(0, A0, B0);
 #pragma unroll
       for (int s = 0; s < TV / KV; s += 2) {
@@ -206,21 +208,21 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
     } else
 #pragma unroll 2
     for (int s = 0; s < TV / KV; ++s) {
-      Frag fa[2], fb[3];
+      Frag fa[NCOH], fb[3];
 #ifdef DUA_ABLATE
       if (a.abl & 2) {
-        for (int e = 0; e < EPG; ++e) { fa[0][e] = fa[1][e] = (T)(float)s; fb[0][e] = fb[1][e] = fb[2][e] = (T)(float)lane; }
+        for (int e = 0; e < EPG; ++e) { fa[0][e] = fa[NCOH - 1][e] = (T)(float)s; fb[0][e] = fb[1][e] = fb[2][e] = (T)(float)lane; }
       } else
 #endif
       if constexpr (sizeof(T) == 2) {
         // voxels 16 s + 8 hl + 4 r + q: d = s >> 2, hrow = 2 (s & 3) + hl, w = 4 r + q
         const int d = s >> 2, hr0 = 2 * (s & 3);
 #pragma unroll
-        for (int coh = 0; coh < 2; ++coh) {
+        for (int coh = 0; coh < NCOH; ++coh) {
           h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-              (__attribute__((address_space(3))) h4*)(Ys + coh * YIMG + s * 16 * RSB + a_off[0]));
+              (__attribute__((address_space(3))) h4*)(Ys + (coh0 + coh) * YIMG + s * 16 * RSB + a_off[0]));
           h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-              (__attribute__((address_space(3))) h4*)(Ys + coh * YIMG + s * 16 * RSB + a_off[1]));
+              (__attribute__((address_space(3))) h4*)(Ys + (coh0 + coh) * YIMG + s * 16 * RSB + a_off[1]));
           f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4v = __builtin_bit_cast(f16x4, hi);
           fa[coh] = __builtin_shufflevector(l4, h4v, 0, 1, 2, 3, 4, 5, 6, 7);
         }
@@ -238,10 +240,10 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
         // voxels 8 s + 2 e + hl (e = 0..3): one w row; d = s >> 3, hrow = s & 7, w = 2 e + hl
         const int d = s >> 3, hrow = s & 7;
 #pragma unroll
-        for (int coh = 0; coh < 2; ++coh)
+        for (int coh = 0; coh < NCOH; ++coh)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            fa[coh][e] = *(const float*)(Ys + coh * YIMG + (s * 8 + 2 * e + hl) * RSB + b_col);
+            fa[coh][e] = *(const float*)(Ys + (coh0 + coh) * YIMG + (s * 8 + 2 * e + hl) * RSB + b_col);
         const int rowbase = (d * XH + hrow + kh) * XW;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
@@ -252,7 +254,7 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-        for (int coh = 0; coh < 2; ++coh) {
+        for (int coh = 0; coh < NCOH; ++coh) {
 #ifdef DUA_ABLATE
           if (a.abl & 1) { acc[kw][coh][0] += (float)fa[coh][0] * (float)fb[kw][0]; continue; }
 #endif
@@ -269,9 +271,9 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-      for (int coh = 0; coh < 2; ++coh)
+      for (int coh = 0; coh < NCOH; ++coh)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pp[kw * 4096 + (coh * 32 + acc_row(i, hl)) * 64] = acc[kw][coh][i];
+        for (int i = 0; i < 16; ++i) pp[kw * 4096 + ((coh0 + coh) * 32 + acc_row(i, hl)) * 64] = acc[kw][coh][i];
     return;
   }
   const int cip = cc * 64 + cih * 32 + (lane & 31);
@@ -281,10 +283,10 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-      for (int coh = 0; coh < 2; ++coh)
+      for (int coh = 0; coh < NCOH; ++coh)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int co = ct * 64 + coh * 32 + acc_row(i, hl);
+          const int co = ct * 64 + (coh0 + coh) * 32 + acc_row(i, hl);
           if (co < a.Cout)
             unsafeAtomicAdd(a.dw + ((long)co * a.Cin_src + ci) * 27 + kd * 9 + kh * 3 + kw, acc[kw][coh][i]);
         }
@@ -295,7 +297,13 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
 // the k loop), so the occupancy is left to the register allocator.
 template <typename T, bool PIPE>
 __global__ __launch_bounds__(wg::NT) void conv3d_k3_wgrad_kernel(wg::Args a) {
-  wgrad_body<T, PIPE>(a);
+  wgrad_body<T, PIPE, 2>(a);
+}
+// 12 waves, three per SIMD (<= 168 VGPRs): wave = (kh, ci half, co half) with 3 accumulators -- every SIMD carries the
+// same MFMA load; the 6-wave form leaves two SIMDs with one wave
+template <typename T>
+__global__ __launch_bounds__(768) void conv3d_k3_wgrad12_kernel(wg::Args a) {
+  wgrad_body<T, true, 1>(a);
 }
 
 // dw[co][ci_src][tap] += sum_p part[p][combo][tap][co][ci]; one thread per (combo, tap, co, ci)
@@ -327,7 +335,7 @@ static inline int wgrad_partitions(const dua_conv3_desc* d, int* combos_out) {
   const int total = d->N * ((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
   // ~3 workgroups per CU over the launch (one resident at a time): measured 1.8x faster than exactly one persistent
   // workgroup per CU on the 96^3 layers (580 vs 1035 us), 2 and 4+ per CU in between
-  const int mv = (g_wgrad_variant & 31) >> 1;        // bit 5 selects the pipelined k loop, not a launch shape
+  const int mv = (g_wgrad_variant & 31) >> 1;        // bits 5, 6 select kernel forms, not a launch shape
   const int mult = mv ? mv : (total < 32 ? 1 : 3);   // tiny levels: fewer partial sums
   int P = (256 * mult + combos - 1) / combos;
   if (P > total) P = total;
@@ -367,6 +375,17 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
   }
   const int groups = (P * a.ncombo + 7) / 8;        // groups of 8 (partition, combo) pairs, one per XCD
   const dim3 grid(a.plain_order ? P * a.ncombo * 3 : groups * 24);
+  // f16 default: the 12-wave form (-5...-14 % against the 6-wave one on every layer shape, same-process A/B);
+  // dua_set_option(4, 64) selects the 6-wave pipelined form, (4, 32) its compiler-scheduled k loop.  f32: 6 waves.
+  if (sizeof(T) == 2 && !(g_wgrad_variant & (64 | 32))) {
+    static bool attr12 = false;
+    if (!attr12) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad12_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      attr12 = true;
+    }
+    hipLaunchKernelGGL(conv3d_k3_wgrad12_kernel<T>, grid, dim3(768), lds, s, a);
+  } else
   // f16 default: explicit two-stage k loop (reads of step s+1 before the MFMAs of step s): 3-7 % over hipcc's own
   // schedule on every layer shape in a same-process A/B; dua_set_option(4, 32) selects the plain loop.  f32: plain.
   if (sizeof(T) == 2 && !(g_wgrad_variant & 32)) hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<T, true>), grid, dim3(NT), lds, s, a);

@@ -400,7 +400,7 @@ def test_conv3_wgrad_matches_torch(dtype, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [32, 1, 2])      # plain k loop; plain block order; one workgroup per CU
+@pytest.mark.parametrize("variant", [32, 1, 2, 64])  # plain k loop; plain block order; one workgroup per CU; 12 waves
 def test_conv3_wgrad_launch_variants_agree(variant):
     from diff_unet_amos_amd import _native as nv
     dev = torch.device("cuda:0")

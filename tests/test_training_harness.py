@@ -332,3 +332,24 @@ def test_full_size_gradients_fp16_path_vs_oracle():
     print(f"[96^3 x 16, fp16 path] loss {float(lg):.6f} vs {float(lw):.6f}; whole-gradient relative L2 error {rel:.2e}; "
           f"lowest cosine: " + ", ".join(f"{k} {c:.4f}" for c, k in coss[:3]))
     assert rel < 3e-2 and coss[0][0] > 0.98, (rel, coss[0])
+
+
+@pytest.mark.gpu
+def test_graph_trainer_fp16_dynamic_loss_scale():
+    """fp16 graph mode: an absurd initial loss scale must overflow, be halved on the device step by step (the fused
+    AdamW skipping those updates), and training must then proceed -- without any host decision inside the replay."""
+    from diff_unet_amos_amd.training import NativeConvTrainer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = DiffUNet(**KW).to(dev)
+    w0 = net.model.conv_0.conv_0.conv.weight.detach().clone()
+    tr = NativeConvTrainer(net, lr=2e-3, dtype=torch.float16, graph=True, init_scale=2.0 ** 40)
+    image, labels, noise, t = _data(2, 11)
+    image, labels, noise, t = image.to(dev), labels.to(dev), noise.to(dev), t.to(dev)
+    first = float(tr.step(image, labels, noise=noise, t=t))
+    assert float(tr._g["found_inf"]) == 1.0 and float(tr._g["scale"]) == 2.0 ** 39       # overflow seen, scale halved
+    assert torch.equal(net.model.conv_0.conv_0.conv.weight.detach(), w0)                   # and the update was skipped
+    losses = [first] + [float(tr.step(image, labels, noise=noise, t=t)) for _ in range(40)]
+    assert float(tr._g["scale"]) < 2.0 ** 30 and all(np.isfinite(losses))
+    assert not torch.equal(net.model.conv_0.conv_0.conv.weight.detach(), w0)
+    assert losses[-1] < losses[0], (losses[0], losses[-1])

@@ -48,7 +48,10 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
   constexpr int EPG = Elem<T>::EPG;
   constexpr int G = 64 / EPG;                      // 16-byte groups per voxel per 64-channel chunk
   constexpr int RSB = 32 * (int)sizeof(T);         // LDS row: 32 channels of one voxel
-  constexpr int XIMG = XV * RSB, YIMG = TV * RSB;  // one 32-channel half image
+  // one 32-channel half image; +64 B so that the two halves of a voxel, written by the 8 lanes of one ds_write_b128
+  // group, fall into different halves of the 32 write banks (stores bank on (a/4) mod 32, not mod 64: a first +128 B
+  // pad changed nothing) -- unpadded, SQ_LDS_BANK_CONFLICT was 14 % of the LDS cycles, all on the staging writes
+  constexpr int XIMG = XV * RSB + 64, YIMG = TV * RSB + 64;
   constexpr int NX = (XV * G + NT - 1) / NT, NY = (TV * G + NT - 1) / NT;
   constexpr int KV = sizeof(T) == 2 ? 16 : 8;      // voxels per mma32 call
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -364,7 +367,7 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
   a.abl = g_wgrad_abl;
   a.plain_order = (g_wgrad_variant & 1) || P < 8;
   a.part = (ws && (long)P * combos * 9 * 4096 * 4 <= ws_bytes && P > 1) ? ws : nullptr;
-  const int lds = 2 * (XV + TV) * 32 * (int)sizeof(T);
+  const int lds = 2 * (XV + TV) * 32 * (int)sizeof(T) + 4 * 64;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

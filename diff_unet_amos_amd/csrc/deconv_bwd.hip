@@ -143,7 +143,8 @@ __global__ __launch_bounds__(dwg::NT) void deconv_k2s2_wgrad_kernel(DeconvBwdArg
   constexpr int TV = tile_voxels<T>();
   constexpr int G = 64 / EPG;
   constexpr int RSB = 32 * (int)sizeof(T);
-  constexpr int IMG = TV * RSB;                    // one 32-channel half image of one tile
+  constexpr int IMG = TV * RSB + 64;               // one 32-channel half image of one tile; +64 B: the two halves of a voxel
+                                                   // land in different halves of the 32 store banks (as conv3d_wgrad.hip)
   constexpr int KV = sizeof(T) == 2 ? 16 : 8;      // voxels per mma32 call
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xs = smem;                                 // [2][TV][32]
@@ -311,7 +312,7 @@ static int launch_deconv_bwd(const dua_conv3_desc* d, const void* x, const void*
     a.P = P; a.ncc = (d->Cout + 63) / 64;
     constexpr int TV = dwg::tile_voxels<T>();
     a.total_tiles = (int)(d->N * ((vox + TV - 1) / TV));
-    const int lds = 18 * TV * 32 * (int)sizeof(T);
+    const int lds = 18 * (TV * 32 * (int)sizeof(T) + 64);
     static bool attr2 = false;
     if (!attr2) {
       hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

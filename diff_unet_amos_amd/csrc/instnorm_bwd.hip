@@ -107,6 +107,34 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
   __syncthreads();
   const float slope = xf.slope;
   const long total = vox * gpc;
+  if (256 % gpc == 0) {
+    // the grid stride is a multiple of gpc, so a thread keeps ONE channel group: its six per-channel constants live in
+    // registers (read from LDS inside the loop they made this HBM-bound pass LDS-bound: 48 ds_reads per 16-byte group,
+    // SQ_LDS_IDX_ACTIVE ~ 70 % of the kernel's cycles, half of them bank conflicts)
+    const int cg = threadIdx.x % gpc;
+    float m[EPG], r[EPG], g[EPG], b[EPG], q1[EPG], q2[EPG];
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) {
+      const int c = cg * EPG + e;
+      m[e] = mu[c]; r[e] = rs[c]; g[e] = ga[c]; b[e] = be[c]; q1[e] = k1[c]; q2[e] = k2[c];
+    }
+    for (long it = blockIdx.x * 256L + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+      const long gv = n * vox + it / gpc;
+      const Frag da = *(const Frag*)(dA + gv * da_stride + da_off + cg * EPG);
+      const Frag y = *(const Frag*)(raw + gv * raw_stride + raw_off + cg * EPG);
+      Frag o;
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) {
+        const float zh = ((float)y[e] - m[e]) * r[e];
+        const float z = fmaf(zh, g[e], b[e]);
+        const float d = (float)da[e];
+        const float dz = z > 0.f ? d : d * slope;
+        o[e] = (T)(g[e] * r[e] * (dz - q1[e] - zh * q2[e]));
+      }
+      *(Frag*)(out + gv * out_stride + out_off + cg * EPG) = o;
+    }
+    return;
+  }
   for (long it = blockIdx.x * 256L + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
     const int cg = (int)(it % gpc);
     const long gv = n * vox + it / gpc;

@@ -353,3 +353,30 @@ def test_graph_trainer_fp16_dynamic_loss_scale():
     assert float(tr._g["scale"]) < 2.0 ** 30 and all(np.isfinite(losses))
     assert not torch.equal(net.model.conv_0.conv_0.conv.weight.detach(), w0)
     assert losses[-1] < losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.gpu
+def test_native_trainer_unfused_loss_configuration():
+    """A loss configuration outside the fused kernel ("mse,dice" combined by "mean") takes the torch Loss on the HIP
+    network's logits; one step must match the oracle's gradient direction and learn."""
+    from diff_unet_amos_amd.training import NativeConvTrainer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = DiffUNet(**KW).to(dev)
+    tr = NativeConvTrainer(net, lr=2e-3, dtype=torch.float32, losses="mse,dice", loss_combine="mean")
+    assert not tr.fused_loss
+    image, labels, noise, t = _data(2, 13)
+    image, labels, noise, t = image.to(dev), labels.to(dev), noise.to(dev), t.to(dev)
+    losses = [float(tr.step(image, labels, noise=noise, t=t)) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    ref = RefDiffUNet(**KW)
+    torch.manual_seed(0)
+    net2 = DiffUNet(**KW)
+    ref.load_state_dict(net2.state_dict())
+    x_t = ref.diffusion.q_sample(labels.cpu() * 2 - 1, t.cpu(), noise.cpu())
+    want = Loss("mse,dice", "mean")(ref(image=image.cpu(), x=x_t, step=t.cpu(), pred_type="denoise"), labels.cpu())
+    torch.manual_seed(0)
+    net3 = DiffUNet(**KW).to(dev)
+    tr3 = NativeConvTrainer(net3, lr=0.0, dtype=torch.float32, losses="mse,dice", loss_combine="mean")
+    got = float(tr3.step(image, labels, noise=noise, t=t))
+    assert abs(got - float(want)) < 1e-5 * max(1.0, abs(float(want))), (got, float(want))

@@ -399,7 +399,6 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   }
 }
 
-static inline bool ws_dummy_false() { return false; }   // v4 stays opt-in until it is validated on the GPU
 
 static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups) {
   *ksplit = 1; *ups = units;
@@ -443,7 +442,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     attr_set = true;
   }
   if (sizeof(T) == 2 && d->Cin <= 128 && a.ksplit == 1 &&
-      (g_conv_variant == 4 || (g_conv_variant > 200 && g_conv_variant < 216) || (g_conv_variant == 0 && a.ntiles * nct * d->N >= 1024 && ws_dummy_false()))) {
+      (g_conv_variant == 4 || (g_conv_variant > 200 && g_conv_variant < 216))) {   // v4 is opt-in: validated, not faster
     a.part = ws;     // diagnostic builds write their cycle stamps here
     return launch_conv3_v4(a, d->N, nct, xf_bytes, s);
   }

@@ -149,7 +149,8 @@ int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, 
  * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid);
  * key 3: ablation mask of the weight-gradient kernel (diagnostic builds, -DDUA_ABLATE); key 4: weight-gradient launch
  * shape (bit 0 = plain block order, bits 1-4 = workgroups per CU over the launch, 0 = default policy; bit 6 = the
- * 6-wave form instead of the 12-wave one, bit 5 = 6 waves with the compiler-scheduled k loop). */
+ * 6-wave form instead of the 12-wave one, bit 5 = 6 waves with the compiler-scheduled k loop); key 5: workgroups per CU of
+ * the v4 convolution in quarters (default 4). */
 int dua_set_option(int key, int value);
 
 /* Packs nn.Conv3d weight fp32[Cout][Cin_src][3][3][3] into the kernel's slab order

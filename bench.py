@@ -140,11 +140,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # one rank per GPU on a real node.  Rehearsal on a one-GPU box only: DUA_BENCH_BACKEND=gloo lets several ranks
+    # share device 0 (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
+    backend = os.environ.get("DUA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from diff_unet_amos_amd import _native as nv
     from diff_unet_amos_amd import ops

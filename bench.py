@@ -178,12 +178,13 @@ def main():
         coef_table = diffusion.ddpm_coef(torch.tensor(order)).to(dev).contiguous()
         row_of_step = torch.tensor(order, dtype=torch.int32, device=dev)
         plan.counter.zero_()
+        plan.new_seed(3 + rank)
 
         def one_step():
             ops.step_begin(B, plan.temb_table, plan.cur_add, row_of_step=row_of_step, counter=plan.counter,
                            coef_table=coef_table, cur_coef=plan.cur_coef, step_word=plan.step_word)
             plan.denoiser_body()
-            plan.tail(nv.MODE_DDPM, noise=None, use_sum=False, seed=3)
+            plan.tail(nv.MODE_DDPM, noise=None, use_sum=False)
 
         assert args.warmup + args.steps + 2 <= T, "the 1000-step process bounds warmup+steps"
         one_step()

@@ -50,7 +50,7 @@ class NormBwdDesc(C.Structure):
 class TailDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("voxels", C.c_long), ("K", C.c_int), ("raw_stride", C.c_int),
                 ("C", C.c_int), ("CX", C.c_int), ("mode", C.c_int), ("xin_stride", C.c_int),
-                ("seed", C.c_ulonglong)]
+                ("seed", C.c_ulonglong), ("seed_dev", C.c_void_p)]
 
 
 MODE_LOGITS, MODE_DDPM, MODE_DDIM = 0, 1, 2
@@ -63,7 +63,7 @@ _SIGS = {
     "dua_sampler_step": (C.c_int, [C.c_int, C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dua_final_conv_sampler": (C.c_int, [C.POINTER(TailDesc), _P, C.POINTER(InNorm)] + [_P] * 11),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
-    "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dua_conv3d_k3_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P, _P, C.c_long, _P]),
     "dua_conv3d_k3_wgrad_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
@@ -81,7 +81,8 @@ _SIGS = {
     "dua_head_bwd_workspace": (C.c_long, [C.c_long]),
     "dua_head_bwd": (C.c_int, [C.c_int, C.c_long, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_long, _P]),
     "dua_seg_loss_reduce": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, _P, _P, _P]),
-    "dua_seg_loss_grad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
+    "dua_seg_loss_grad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, _P, _P, _P, C.c_float, C.c_float,
+                                    C.c_float, _P, C.c_int, _P]),
     "dua_materialize": (C.c_int, [C.POINTER(MaterializeDesc), _P, C.POINTER(InNorm), _P, _P, _P, _P]),
     "dua_pack_deconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_to_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, _P, C.c_int, C.c_int, C.c_int, _P]),

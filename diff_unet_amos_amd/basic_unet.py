@@ -8,7 +8,9 @@ state-dict keys are identical:
 The reference builds these blocks through MONAI factories (Convolution -> conv/adn.N/adn.D/adn.A,
 UpSample(mode="deconv") -> deconv); here torch.nn layers are used only to own and initialise the
 parameters under those names.  ``forward`` never runs them: it dispatches to the HIP launch plan
-(engine.py).  Calling with autograd enabled is refused -- backward kernels are not built yet.
+(engine.py).  The launch plan is the inference path; training goes through ``Diffusion.forward(pred_type="denoise")``,
+which runs the forward AND backward HIP kernels under autograd (training.py).  Calling one of the two sub-networks
+on its own with gradients requested is refused with a pointer to that entry.
 """
 from __future__ import annotations
 
@@ -70,12 +72,16 @@ class TimeStepEmbedder(nn.Module):
         self.dense = nn.ModuleList([nn.Linear(embedding_dim, out_features), nn.Linear(out_features, out_features)])
 
 
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def _refuse_autograd(*tensors):
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+    if _wants_grad(*tensors):
         raise NotImplementedError(
-            "the MI355X hot path is forward-only in this build (backward kernels are the next scope row); "
-            "call under torch.no_grad(), or opt in to the torch-autograd training fallback with "
-            "DiffUNet.enable_autograd_fallback()")
+            "embed_model / model called on their own run the inference launch plan, which keeps no autograd tape; "
+            "for gradients call DiffUNet.forward(image=..., x=..., step=..., pred_type=\"denoise\") (HIP forward and "
+            "backward kernels, training.native_conv_denoise) or wrap the call in torch.no_grad()")
 
 
 class BasicUNetEncoder(nn.Module):

@@ -16,6 +16,4 @@ struct Conv3Args {
   float* part;
 };
 
-int launch_conv3_v4(Conv3Args& a, int N, int nct, int xf_bytes, hipStream_t s);
-
 }  // namespace dua

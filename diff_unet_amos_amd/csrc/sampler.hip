@@ -81,7 +81,13 @@ struct TailArgs {
   const float* coef; float* x_state; const float* noise; const int* step_word; void* xin;
   float* xsum; float* logits; float* xstart;
   long vox; int K, raw_stride, C, xin_stride, mode; unsigned seed_lo, seed_hi;
+  const unsigned long long* seed_dev;
 };
+
+__device__ __forceinline__ void philox_key(const TailArgs& a, uint32_t& k0, uint32_t& k1) {
+  k0 = a.seed_lo; k1 = a.seed_hi;
+  if (a.seed_dev) { const unsigned long long s = *a.seed_dev; k0 = (uint32_t)s; k1 = (uint32_t)(s >> 32); }
+}
 
 template <typename T, int CX>
 __global__ __launch_bounds__(256) void final_conv_sampler_kernel(TailArgs a) {
@@ -138,10 +144,12 @@ __global__ __launch_bounds__(256) void final_conv_sampler_kernel(TailArgs a) {
     for (int c = 0; c < CX; ++c) eps[c] = c < a.C ? a.noise[((long)n * a.C + c) * a.vox + v] : 0.f;
   } else {
     const uint32_t step = a.step_word ? (uint32_t)a.step_word[0] : 0u;
+    uint32_t key0, key1;
+    philox_key(a, key0, key1);
 #pragma unroll
     for (int q = 0; q < CX / 4; ++q) {
       uint32_t ctr[4] = {(uint32_t)gv, (uint32_t)(gv >> 32), step, (uint32_t)q};
-      philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+      philox4x32_10(ctr, key0, key1);
       box_muller(ctr[0], ctr[1], eps[4 * q], eps[4 * q + 1]);
       box_muller(ctr[2], ctr[3], eps[4 * q + 2], eps[4 * q + 3]);
     }
@@ -225,6 +233,8 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
 #pragma unroll
   for (int i = 0; i < 8; ++i) k8[i] = a.coef ? a.coef[8 * n + i] : 0.f;
   const uint32_t step = a.step_word ? (uint32_t)a.step_word[0] : 0u;
+  uint32_t key0, key1;
+  philox_key(a, key0, key1);
   const f16* raw = (const f16*)a.raw + (long)n * a.vox * a.raw_stride;
   const long wbase = (blockIdx.x * 4L + wave) * 64;
   const bool sampling = a.mode != DUA_MODE_LOGITS;
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
     if (sampling && !a.noise) {
       const long gid = ((long)n * a.vox + v0) * 16 + c;    // unique per (lane, block): 4 normals per call
       uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0x5eedu};
-      philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+      philox4x32_10(ctr, key0, key1);
       box_muller(ctr[0], ctr[1], ez[mb][0], ez[mb][1]);
       box_muller(ctr[2], ctr[3], ez[mb][2], ez[mb][3]);
     }
@@ -350,6 +360,7 @@ int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in
   a.vox = d->voxels; a.K = d->K; a.raw_stride = d->raw_stride; a.C = d->C; a.xin_stride = d->xin_stride;
   a.mode = d->mode;
   a.seed_lo = (unsigned)(d->seed & 0xffffffffull); a.seed_hi = (unsigned)(d->seed >> 32);
+  a.seed_dev = d->seed_dev;
   if (d->dtype == DUA_F16 && d->CX == 16 && d->K % 32 == 0 && (d->K == 32 || d->K == 64 || d->K == 128)) {
     dim3 grid((unsigned)((d->voxels + 255) / 256), d->N);
     const size_t lds = (size_t)3 * d->K * sizeof(float);

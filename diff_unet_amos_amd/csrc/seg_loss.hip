@@ -1,10 +1,11 @@
-// Segmentation loss of the training step and its gradient, fused:  losses/loss.py:25-86 with losses = "mse,bce,dice",
-// loss_combine = "sum" (the diffusion configs), i.e.
+// Segmentation loss of the training step and its gradient, fused:  losses/loss.py:25-86 for any subset of the names
+// "mse", "bce", "dice" (weights w_* = 0 or 1) under loss_combine "sum" / "mean" / "log" (the combine's derivative
+// reaches the kernel through *gscale); the diffusion configs use all three with "sum", i.e.
 //   L = mean((sigmoid(p) - y)^2) + mean(BCEWithLogits(p, y)) + mean_{n,c}(1 - (2 I + e) / (S + Y + e)),
 //   I = sum_v s*y, S = sum_v s, Y = sum_v y, e = 1e-5   (MONAI DiceLoss(sigmoid=True) defaults)
 // p: logits channels-last [N][V][C] (compute dtype), y: labels NCDHW fp32 [N][C][V] as the reference's loader hands them.
 //   reduce: sums[N*C*4 + 2] (fp64, pre-zeroed) += (I, S, Y, -) per (n, c), then (sum of squared errors, sum of BCE terms)
-//   grad  : dp = g * [ (2 (s - y) s (1 - s) + (s - y)) / M  +  dice'_{n,c} * s (1 - s) ],  M = N*C*V,
+//   grad  : dp = g * [ (w_mse 2 (s - y) s (1 - s) + w_bce (s - y)) / M  +  w_dice dice'_{n,c} * s (1 - s) ],  M = N*C*V,
 //           dice'_{n,c} = -(2 y (D + e) - (2 I + e)) / (D + e)^2 / (N C),  D = S + Y;  g = *gscale (device scalar)
 // Both are one streaming pass (HBM bound): a thread owns one voxel and walks the C channels; labels are read coalesced
 // per channel, logits as one contiguous run per voxel.
@@ -59,12 +60,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void seg_loss_grad_kernel(const T* __restrict__ p, int p_stride,
                                                             const float* __restrict__ y, int C, long V,
                                                             const double* __restrict__ sums, int N,
-                                                            const float* __restrict__ gscale, T* __restrict__ dp,
-                                                            int dp_stride) {
+                                                            const float* __restrict__ gscale, float w_mse, float w_bce,
+                                                            float w_dice, T* __restrict__ dp, int dp_stride) {
   __shared__ float k0[LOSS_MAXC], k1[LOSS_MAXC];     // dice' = k0 * y + k1
   const int n = blockIdx.y;
   const float g = gscale ? *gscale : 1.f;
-  const float invM = 1.f / ((float)N * (float)C * (float)V), invNC = 1.f / ((float)N * (float)C);
+  const float invM = 1.f / ((float)N * (float)C * (float)V), invNC = w_dice / ((float)N * (float)C);
+  const float a_mse = 2.f * w_mse * invM, a_bce = w_bce * invM;
   if (threadIdx.x < C) {
     const double* q = sums + ((long)n * C + threadIdx.x) * 4;
     const double De = q[1] + q[2] + 1e-5, Ie = 2.0 * q[0] + 1e-5;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void seg_loss_grad_kernel(const T* __restrict_
       const float yv = y[((long)n * C + c) * V + v];
       const float s = 1.f / (1.f + __expf(-pv));
       const float ds = s * (1.f - s), d = s - yv;
-      dr[c] = (T)(g * ((2.f * d * ds + d) * invM + (k0[c] * yv + k1[c]) * ds));
+      dr[c] = (T)(g * (a_mse * d * ds + a_bce * d + (k0[c] * yv + k1[c]) * ds));
     }
   }
 }
@@ -105,17 +107,18 @@ int dua_seg_loss_reduce(int dtype, int N, int C, long voxels, const void* logits
 }
 
 int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, int logits_stride, const float* labels,
-                      const double* sums, const float* gscale, void* dlogits, int dlogits_stride, void* stream) {
+                      const double* sums, const float* gscale, float w_mse, float w_bce, float w_dice, void* dlogits,
+                      int dlogits_stride, void* stream) {
   if (!logits || !labels || !sums || !dlogits || N <= 0 || C <= 0 || C > dua::LOSS_MAXC || voxels <= 0 ||
       logits_stride < C || dlogits_stride < C) return DUA_ERR_ARG;
   long b = (voxels + 255) / 256;
   dim3 grid((unsigned)(b > 4096 ? 4096 : b), N);
   if (dtype == DUA_F16)
     hipLaunchKernelGGL(dua::seg_loss_grad_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)logits,
-                       logits_stride, labels, C, voxels, sums, N, gscale, (dua::f16*)dlogits, dlogits_stride);
+                       logits_stride, labels, C, voxels, sums, N, gscale, w_mse, w_bce, w_dice, (dua::f16*)dlogits, dlogits_stride);
   else if (dtype == DUA_F32)
     hipLaunchKernelGGL(dua::seg_loss_grad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)logits,
-                       logits_stride, labels, C, voxels, sums, N, gscale, (float*)dlogits, dlogits_stride);
+                       logits_stride, labels, C, voxels, sums, N, gscale, w_mse, w_bce, w_dice, (float*)dlogits, dlogits_stride);
   else return DUA_ERR_ARG;
   return (int)hipGetLastError();
 }

@@ -61,23 +61,33 @@ __global__ __launch_bounds__(256) void temb_table_kernel(const int* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void step_begin_kernel(int N, int P, const float* __restrict__ table,
+__global__ __launch_bounds__(256) void step_begin_kernel(int N, int P, const float* __restrict__ table, int table_rows,
                                                          const int* __restrict__ rows_per_sample,
-                                                         const int* __restrict__ row_of_step,
+                                                         const int* __restrict__ row_of_step, int nsteps,
                                                          const float* __restrict__ coef_table, int* counter,
                                                          float* __restrict__ cur_add, float* __restrict__ cur_coef,
-                                                         int* step_word) {
+                                                         int* step_word, int* err_word) {
+  // Every index that comes from device memory is range-checked here: an out-of-range timestep or step counter must
+  // not turn into a wild read (a GPU memory fault can reset the node).  Offenders are clamped and reported.
   int k = 0;
-  if (!rows_per_sample) k = *counter;
+  bool bad = false;
+  if (!rows_per_sample) {
+    k = *counter;
+    if (k < 0 || k >= nsteps) { bad = true; k = k < 0 ? 0 : nsteps - 1; }
+  }
   for (int n = 0; n < N; ++n) {
-    const int row = rows_per_sample ? rows_per_sample[n] : row_of_step[k];
+    int row = rows_per_sample ? rows_per_sample[n] : row_of_step[k];
+    if (row < 0 || row >= table_rows) { bad = true; row = row < 0 ? 0 : table_rows - 1; }
     for (int i = threadIdx.x; i < P; i += 256) cur_add[(long)n * P + i] = table[(long)row * P + i];
     if (coef_table && threadIdx.x < 8) cur_coef[8 * n + threadIdx.x] = coef_table[8 * k + threadIdx.x];
   }
   __syncthreads();
-  if (threadIdx.x == 0 && !rows_per_sample) {
-    if (step_word) step_word[0] = k;
-    *counter = k + 1;
+  if (threadIdx.x == 0) {
+    if (bad && err_word) *err_word = 1;
+    if (!rows_per_sample) {
+      if (step_word) step_word[0] = k;
+      *counter = k + 1;
+    }
   }
 }
 
@@ -97,14 +107,14 @@ int dua_temb_table(int count, const int* timesteps, const float* freqs, int half
   return (int)hipGetLastError();
 }
 
-int dua_step_begin(int N, int P, const float* table, const int* rows_per_sample, const int* row_of_step,
-                   const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
-                   void* stream) {
-  if (N <= 0 || P <= 0 || !table || !cur_add) return DUA_ERR_ARG;
-  if (!rows_per_sample && (!row_of_step || !counter)) return DUA_ERR_ARG;
+int dua_step_begin(int N, int P, const float* table, int table_rows, const int* rows_per_sample, const int* row_of_step,
+                   int nsteps, const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
+                   int* err_word, void* stream) {
+  if (N <= 0 || P <= 0 || !table || table_rows <= 0 || !cur_add) return DUA_ERR_ARG;
+  if (!rows_per_sample && (!row_of_step || !counter || nsteps <= 0)) return DUA_ERR_ARG;
   if (coef_table && !cur_coef) return DUA_ERR_ARG;
-  hipLaunchKernelGGL(dua::step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, N, P, table, rows_per_sample,
-                     row_of_step, coef_table, counter, cur_add, cur_coef, step_word);
+  hipLaunchKernelGGL(dua::step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, N, P, table, table_rows,
+                     rows_per_sample, row_of_step, nsteps, coef_table, counter, cur_add, cur_coef, step_word, err_word);
   return (int)hipGetLastError();
 }
 

@@ -68,13 +68,6 @@ class DiffUNet(Diffusion):
         object.__setattr__(self.embed_model, "_rt", rt)
         object.__setattr__(self.model, "_rt", rt)
 
-    def enable_autograd_fallback(self, on: bool = True):
-        """Opt in to running ``pred_type="denoise"`` through torch autograd (torch's own kernels) whenever grad mode is
-        on -- what a training loop needs until the native backward kernels exist (training.py).  Sampling and
-        no-grad evaluation keep using the HIP path."""
-        self.autograd_fallback = bool(on)
-        return self
-
     def set_compute_dtype(self, dtype: torch.dtype):
         """torch.float16: fp16 operands / fp32 accumulate (production, the reference's AMP envelope);
         torch.float32: exact-fp32 MFMA (parity mode)."""

@@ -1,7 +1,9 @@
 """``Diffusion``: the drop-in boundary of the hot path.
 
 Same constructor, attributes and ``forward(image, x, step, pred_type)`` dispatch as the reference's
-models/diffusion/diffusion.py:11-102; the three branches run on HIP kernels.
+models/diffusion/diffusion.py:11-102; the three branches run on HIP kernels.  ``pred_type="denoise"`` under autograd
+(what Trainer.training_step calls, train.py:258-268) runs the same kernels forward and their backward kernels through
+``training.native_conv_denoise``; without grad it runs the inference launch plan (engine.py).
 """
 from __future__ import annotations
 
@@ -10,7 +12,7 @@ from typing import Sequence
 import torch
 import torch.nn as nn
 
-from .basic_unet import _refuse_autograd
+from .basic_unet import _wants_grad
 from .gaussian_diffusion import UniformSampler, make_spaced
 
 
@@ -51,10 +53,9 @@ class Diffusion(nn.Module):
     def denoise(self, image: torch.Tensor, x: torch.Tensor, step: torch.Tensor) -> torch.Tensor:
         """diffusion.py:71-84."""
         assert image.size(0) == x.size(0) == step.size(0)
-        if torch.is_grad_enabled() and getattr(self, "autograd_fallback", False):
-            from .training import autograd_denoise        # explicit, opt-in, torch kernels (training.py)
-            return autograd_denoise(self, image, x, step)
-        _refuse_autograd(x, image, *self.parameters())
+        if _wants_grad(x, image, *self.parameters()):
+            from .training import native_conv_denoise     # HIP forward + backward kernels under autograd
+            return native_conv_denoise(self, image, x, step, self.compute_dtype)
         embeddings = self.embed_model(image)
         return self.model(x=x, t=step, embeddings=embeddings, image=image)
 

@@ -90,6 +90,9 @@ class Plan:
         self.cur_coef = torch.zeros((N, 8), dtype=torch.float32, device=device)
         self.counter = torch.zeros(1, dtype=torch.int32, device=device)
         self.step_word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.err_word = torch.zeros(1, dtype=torch.int32, device=device)     # set by step_begin on an out-of-range index
+        self.seed_word = torch.zeros(1, dtype=torch.int64, device=device)    # Philox key of the current sampling call
+        self.calls = 0
         self.logits = torch.zeros((N, self.C, *S[0]), dtype=torch.float32, device=device)
         self._bind()
         self._alloc_stats()
@@ -280,12 +283,31 @@ class Plan:
             src, src_c, src_conv = self.uB[l], b.cout, b
         return self.dec[0][1]
 
-    def tail(self, mode, noise=None, logits=None, xstart=None, use_sum=False, seed=0):
+    def tail(self, mode, noise=None, logits=None, xstart=None, use_sum=False):
+        """The Philox key of in-kernel noise is read from self.seed_word at run time (see new_seed)."""
         last = self.dec[0][1]
         ops.final_conv_sampler(self.uB[0], last.cout, self._norm(last, 0), self.wf, self.bf, self.C, mode,
                                coef=self.cur_coef, x_state=self.x_state, noise=noise, step_word=self.step_word,
                                xin=self.xin if mode != nv.MODE_LOGITS else None,
-                               xstart_sum=self.x_sum if use_sum else None, logits=logits, xstart=xstart, seed=seed)
+                               xstart_sum=self.x_sum if use_sum else None, logits=logits, xstart=xstart,
+                               seed_dev=self.seed_word)
+
+    def new_seed(self, seed=None):
+        """Key of this call's in-kernel noise.  The reference draws a fresh th.randn_like every step of every call
+        (gaussian_diffusion.py:430,576); the counter-based generator needs a fresh KEY per call for the same effect:
+        one draw from torch's CPU generator (so torch.manual_seed governs it), mixed with the rank so that replicas
+        do not share a noise field.  The key lives in a device word, not in the captured graph."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    seed ^= (dist.get_rank() + 1) * 0x9E3779B97F4A7C15 & (2 ** 62 - 1)
+            except Exception:       # pragma: no cover - torch.distributed not built
+                pass
+        self.calls += 1
+        self.seed_word.fill_(int(seed) & (2 ** 63 - 1))
+        return seed
 
     # ---- public operations ------------------------------------------------------------------------
     def denoise(self, x, t):
@@ -294,18 +316,28 @@ class Plan:
         N = self.N
         assert tuple(x.shape) == (N, self.C, *self.dims) and t.numel() == N
         ops.to_channels_last(x.detach().float().contiguous(), self.xin, 0, self.C)
+        T = self.temb_table.shape[0]
+        on_host = not t.is_cuda
+        if on_host and not bool(((t >= 0) & (t < T)).all()):
+            raise ValueError(f"timestep out of range: the model was built for 0 <= t < {T}, got {t.tolist()}")
         rows = t.detach().to(device=self.dev, dtype=torch.int32).contiguous()
-        ops.step_begin(N, self.temb_table, self.cur_add, rows_per_sample=rows)
+        if not on_host:
+            self.err_word.zero_()
+        ops.step_begin(N, self.temb_table, self.cur_add, rows_per_sample=rows, err_word=self.err_word)
         self.denoiser_body()
         out = torch.empty((N, self.C, *self.dims), dtype=torch.float32, device=self.dev)
         self.tail(nv.MODE_LOGITS, logits=out)
+        if not on_host and int(self.err_word.item()):     # device-resident t: the kernel clamped it, say so
+            raise ValueError(f"timestep out of range: the model was built for 0 <= t < {T}")
         return out
 
-    def sample_loop(self, diffusion, kind, noise=None, step_noise=None, eta=0.0, use_graph=True, seed=0,
-                    want_final_xstart=False):
+    def sample_loop(self, diffusion, kind, noise=None, step_noise=None, eta=0.0, use_graph=True, seed=None,
+                    want_final_xstart=False, snapshots=None):
         """T reverse steps (T = diffusion.num_timesteps) starting from ``noise`` (x_T, NCDHW) or a fresh
         draw.  ``step_noise``: optional list of per-step NCDHW draws (parity runs); otherwise the
-        tail kernel generates eps in-kernel (Philox).  Returns dict(sample, sum_pred_xstart)."""
+        tail kernel generates eps in-kernel (Philox, keyed per call: ``seed`` or a draw from torch's generator).
+        ``snapshots``: optional dict {step count k: None}; after k steps the state x is stored there (NCDHW copy;
+        eager mode) -- drift-versus-step measurements.  Returns dict(sample, sum_pred_xstart)."""
         self.refresh_weights()
         N, T = self.N, diffusion.num_timesteps
         shape = (N, self.C, *self.dims)
@@ -327,21 +359,27 @@ class Plan:
                                  torch.tensor([tmap[i] for i in order], dtype=torch.int32, device=self.dev))
         coef_table, row_of_step = self.tables[tkey]
         self.counter.zero_()
+        self.new_seed(seed)
         if step_noise is not None:
             assert len(step_noise) == T
+            use_graph = False
+        if snapshots:
             use_graph = False
 
         def one_step(eps):
             ops.step_begin(N, self.temb_table, self.cur_add, row_of_step=row_of_step, counter=self.counter,
-                           coef_table=coef_table, cur_coef=self.cur_coef, step_word=self.step_word)
+                           coef_table=coef_table, cur_coef=self.cur_coef, step_word=self.step_word,
+                           err_word=self.err_word)
             self.denoiser_body()
-            self.tail(mode, noise=eps, use_sum=True, seed=seed)
+            self.tail(mode, noise=eps, use_sum=True)
 
         if not use_graph:
             for k in range(T):
-                one_step(None if step_noise is None else step_noise[k].detach().float().contiguous())
+                one_step(None if step_noise is None else step_noise[k].detach().to(self.dev).float().contiguous())
+                if snapshots and (k + 1) in snapshots:
+                    snapshots[k + 1] = ops.from_channels_last(self.x_state, self.C)
         else:
-            key = (tkey, seed)
+            key = tkey
             g = self.graphs.get(key)
             if g is None:
                 # warm-up outside capture (sets kernel attributes, fills caches); state is reset below

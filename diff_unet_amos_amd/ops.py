@@ -198,12 +198,17 @@ def conv3d_k3_wgrad(x, cin, cin_off, dy, cout, cout_off, dw, perm=None, workspac
 
 
 _WGRAD_WS = {}
+_WGRAD_WS_RETIRED = []
 
 
 def _wgrad_ws(nbytes, device):
-    """One grow-only scratch buffer per device for the weight-gradient partial sums (stream-ordered reuse)."""
+    """One grow-only scratch buffer per device for the weight-gradient partial sums (stream-ordered reuse).  A
+    captured training-step graph bakes the buffer's address in, so a buffer that is outgrown is RETIRED, never
+    freed: returning it to the caching allocator would let a replay scribble over whoever owns the memory next."""
     buf = _WGRAD_WS.get(device)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _WGRAD_WS_RETIRED.append(buf)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _WGRAD_WS[device] = buf
     return buf
@@ -319,31 +324,47 @@ def head_bwd(dlogits, u, weight):
     return du, dW, db
 
 
-def seg_loss_reduce(logits, labels):
+LOSS_NAMES = ("mse", "bce", "dice")
+
+
+def seg_loss_reduce(logits, labels, names=LOSS_NAMES, combine="sum"):
     """logits: channels-last [N, D, H, W, Cs] (first C = labels.shape[1] channels); labels fp32 [N, C, D, H, W].
-    Returns (L as a 0-dim fp32 tensor, the fp64 sums the gradient kernel needs)."""
+    Loss of losses/loss.py:25-86 for ``names`` (a subset of mse / bce / dice) combined by "sum" / "mean" / "log".
+    Returns (L as a 0-dim fp32 tensor, the fp64 sums the gradient kernel needs, d L / d (sum of terms) as a 0-dim fp32
+    device tensor -- 1 for "sum", 1/len(names) for "mean", 1/(1 + sum) for "log")."""
     assert logits.is_cuda and logits.is_contiguous() and logits.dim() == 5
     N, Cc = labels.shape[:2]
     V = labels.shape[2] * labels.shape[3] * labels.shape[4]
     assert labels.is_cuda and labels.dtype == torch.float32 and labels.is_contiguous()
     assert tuple(logits.shape[:4]) == (N, *labels.shape[2:]) and logits.shape[-1] >= Cc
+    assert names and all(n_ in LOSS_NAMES for n_ in names) and combine in ("sum", "mean", "log")
     sums = torch.zeros(N * Cc * 4 + 2, dtype=torch.float64, device=logits.device)
     nv.check(nv.lib().dua_seg_loss_reduce(nv.dt_code(logits.dtype), N, Cc, V, nv.ptr(logits), logits.shape[-1], nv.ptr(labels),
                                           nv.ptr(sums), nv.stream_ptr()), "dua_seg_loss_reduce")
     q = sums[:N * Cc * 4].view(N, Cc, 4)
     M = float(N * Cc * V)
-    dice = (1.0 - (2.0 * q[..., 0] + 1e-5) / (q[..., 1] + q[..., 2] + 1e-5)).mean()
-    return (sums[-2] / M + sums[-1] / M + dice).float(), sums
+    terms = {"mse": sums[-2] / M, "bce": sums[-1] / M,
+             "dice": (1.0 - (2.0 * q[..., 0] + 1e-5) / (q[..., 1] + q[..., 2] + 1e-5)).mean()}
+    total = sum(terms[n_] for n_ in names)
+    if len(names) == 1 or combine == "sum":          # loss.py:77-78: a single loss is returned as it is
+        L, dcomb = total, torch.ones((), dtype=torch.float64, device=logits.device)
+    elif combine == "mean":
+        L, dcomb = total / len(names), torch.full((), 1.0 / len(names), dtype=torch.float64, device=logits.device)
+    else:
+        L, dcomb = torch.log(1 + total), 1.0 / (1 + total)
+    return L.float(), sums, dcomb.float()
 
 
-def seg_loss_grad(logits, labels, sums, gscale):
+def seg_loss_grad(logits, labels, sums, gscale, names=LOSS_NAMES):
+    """dlogits = gscale * sum over ``names`` of d term / d logits (``gscale``: 0-dim device tensor or None = 1)."""
     N, Cc = labels.shape[:2]
     V = labels.shape[2] * labels.shape[3] * labels.shape[4]
     out = torch.zeros_like(logits) if logits.shape[-1] > Cc else torch.empty_like(logits)
     g = gscale.detach().float().reshape(1).contiguous() if gscale is not None else None
+    w = [1.0 if n_ in names else 0.0 for n_ in LOSS_NAMES]
     nv.check(nv.lib().dua_seg_loss_grad(nv.dt_code(logits.dtype), N, Cc, V, nv.ptr(logits), logits.shape[-1], nv.ptr(labels),
-                                        nv.ptr(sums), nv.ptr(g), nv.ptr(out), out.shape[-1], nv.stream_ptr()),
-             "dua_seg_loss_grad")
+                                        nv.ptr(sums), nv.ptr(g), w[0], w[1], w[2], nv.ptr(out), out.shape[-1],
+                                        nv.stream_ptr()), "dua_seg_loss_grad")
     return out
 
 
@@ -420,7 +441,9 @@ def state_stride(num_classes):
 
 
 def final_conv_sampler(raw, K, norm, wf, bf, num_classes, mode, coef=None, x_state=None, noise=None,
-                       step_word=None, xin=None, xstart_sum=None, logits=None, xstart=None, seed=0):
+                       step_word=None, xin=None, xstart_sum=None, logits=None, xstart=None, seed=0, seed_dev=None):
+    """``seed_dev``: optional int64[1] device tensor holding the Philox key (read by the kernel at run time, so a
+    captured graph draws a fresh noise field whenever the host rewrites the word); otherwise ``seed`` is the key."""
     _cl_check(raw, "raw")
     N, D, H, W, rs = raw.shape
     vox = D * H * W
@@ -443,7 +466,10 @@ def final_conv_sampler(raw, K, norm, wf, bf, num_classes, mode, coef=None, x_sta
         _cl_check(xin, "xin")
         assert xin.dtype == raw.dtype and tuple(xin.shape[:4]) == (N, D, H, W) and xin.shape[-1] >= num_classes
         xs = xin.shape[-1]
-    d = nv.TailDesc(nv.dt_code(raw.dtype), N, vox, K, rs, num_classes, cx, mode, xs, seed)
+    if seed_dev is not None:
+        assert seed_dev.is_cuda and seed_dev.dtype == torch.int64 and seed_dev.numel() >= 1
+    d = nv.TailDesc(nv.dt_code(raw.dtype), N, vox, K, rs, num_classes, cx, mode, xs, seed,
+                    seed_dev.data_ptr() if seed_dev is not None else None)
     nv.check(nv.lib().dua_final_conv_sampler(C.byref(d), nv.ptr(raw), norm.ref(N, K), nv.ptr(wf),
                                              nv.ptr(bf), nv.ptr(coef), nv.ptr(x_state), nv.ptr(noise),
                                              nv.ptr(step_word), nv.ptr(xin), nv.ptr(xstart_sum), nv.ptr(logits),
@@ -467,9 +493,20 @@ def temb_table(timesteps, freqs, w0, b0, w1, b1, w_cat, b_cat, out=None):
 
 
 def step_begin(N, table, cur_add, rows_per_sample=None, row_of_step=None, counter=None, coef_table=None,
-               cur_coef=None, step_word=None):
-    P = table.shape[1]
+               cur_coef=None, step_word=None, err_word=None):
+    """``err_word`` (int32[1] device, optional): set to 1 by the kernel when a timestep row / step counter read from
+    device memory is outside the tables (the offender is clamped, nothing faults)."""
+    T, P = table.shape
+    assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()
     assert cur_add.numel() >= N * P
-    nv.check(nv.lib().dua_step_begin(N, P, nv.ptr(table), nv.ptr(rows_per_sample), nv.ptr(row_of_step),
+    nsteps = 0
+    if rows_per_sample is not None:
+        assert rows_per_sample.dtype == torch.int32 and rows_per_sample.numel() == N
+    else:
+        assert row_of_step is not None and row_of_step.dtype == torch.int32 and counter is not None
+        nsteps = row_of_step.numel()
+        if coef_table is not None:
+            assert coef_table.numel() >= 8 * nsteps
+    nv.check(nv.lib().dua_step_begin(N, P, nv.ptr(table), T, nv.ptr(rows_per_sample), nv.ptr(row_of_step), nsteps,
                                      nv.ptr(coef_table), nv.ptr(counter), nv.ptr(cur_add), nv.ptr(cur_coef),
-                                     nv.ptr(step_word), nv.stream_ptr()), "dua_step_begin")
+                                     nv.ptr(step_word), nv.ptr(err_word), nv.stream_ptr()), "dua_step_begin")

@@ -1,17 +1,15 @@
-"""Training-side harness for BASELINE config 4 (row 8(f)-2 of the scope table) -- NOT yet native.
+"""Training side of the hot path (BASELINE config 4): ``Trainer.training_step`` of the reference
+(train.py:258-268) = q_sample -> ``model(x=x_t, step=t, image=images, pred_type="denoise")`` under autograd -> loss ->
+backward -> AdamW, one process per GPU with the gradients averaged over RCCL.
 
-The forward kernels of this package are inference-only this round: no backward (dgrad/wgrad, InstanceNorm /
-LeakyReLU / MaxPool / deconv backward) is written yet.  So that ``Trainer.training_step`` (train.py:258-268)
-and a one-process-per-GPU DDP loop over RCCL can already be exercised end to end, this module provides an
-**explicitly labelled PyTorch-autograd fallback** for the *training* branch only: the same parameters, run
-through torch.nn.functional ops on the device (MIOpen/rocBLAS kernels, torch autograd).  Nothing on the
-sampling/inference path ever routes through it, it is opt-in (``DiffUNet.enable_autograd_fallback()``), and
-``uses_native_kernels`` below says False so a harness can report what it measured.  q_sample in the training
-step IS the HIP kernel.
-
-Also here: the loss the reference's configs use (losses/loss.py:25-86 with ``mse,bce,dice`` / ``sum``), restated
-with MONAI DiceLoss(sigmoid=True) defaults, and a DDP step (gradient all-reduce through
-torch.distributed: backend "nccl" is RCCL on ROCm).
+Everything between the parameters and the logits runs on this package's HIP kernels inside ``torch.autograd.Function``s
+(autograd is the tape, not the arithmetic): every 3x3x3 convolution forward / data gradient / weight gradient,
+InstanceNorm + LeakyReLU + temb / embedding adds forward and backward, MaxPool forward and backward, the k2s2
+transposed convolution with its concat in place, the 1x1x1 head, and the fused mse/bce/dice loss.  Activations are
+channels-last [N, D, H, W, C] in the compute dtype (fp16 with fp32 master weights and dynamic loss scaling, or fp32).
+``Diffusion.denoise`` dispatches here whenever grad mode is on, so the reference's training loop runs unchanged through
+``DiffUNet.forward``.  What is still torch: the timestep MLP (two 512-wide Linear layers on a [N, 128] input), the copy
+of the skip half into the concat buffer, AdamW.  There is no torch / MIOpen convolution path in this package.
 """
 from __future__ import annotations
 
@@ -20,22 +18,11 @@ import math
 import torch
 import torch.nn.functional as F
 
-uses_native_kernels = False
-
-
-def _two_conv(block, x, temb):
-    """TwoConv.forward (denoiser.py:63-67 / pretrained/basic_unet.py:28-65) on torch ops."""
-    for i, cb in enumerate((block.conv_0, block.conv_1)):
-        x = F.conv3d(x, cb.conv.weight, cb.conv.bias, padding=1)
-        x = F.instance_norm(x, weight=cb.adn.N.weight, bias=cb.adn.N.bias, eps=1e-5)
-        x = F.leaky_relu(x, 0.1)
-        if i == 0 and temb is not None:
-            s = temb * torch.sigmoid(temb)
-            x = x + F.linear(s, block.temb_proj.weight, block.temb_proj.bias)[:, :, None, None, None]
-    return x
+uses_native_kernels = True
 
 
 def _time_embedding(temb_mod, t):
+    """models/diffusion/utils.py:6-54 (sinusoid -> Linear -> swish -> Linear) on a [N] vector of timesteps."""
     half = temb_mod.embedding_dim // 2
     freq = torch.exp(torch.arange(half, dtype=torch.float32, device=t.device) * -(math.log(10000) / (half - 1)))
     arg = t.float()[:, None] * freq[None, :]
@@ -45,136 +32,34 @@ def _time_embedding(temb_mod, t):
     return F.linear(h, temb_mod.dense[1].weight, temb_mod.dense[1].bias)
 
 
-def autograd_denoise(net, image, x, step):
-    """Diffusion.denoise (diffusion.py:71-84) with torch autograd: encoder + denoiser on torch ops."""
-    enc, den = net.embed_model, net.model
-    emb = [_two_conv(enc.conv_0, image, None)]
-    for d in enc.down:
-        emb.append(_two_conv(d.convs, F.max_pool3d(emb[-1], 2), None))
-    temb = _time_embedding(den.temb, step)
-    h = torch.cat([image, x], dim=1)
-    x0 = _two_conv(den.conv_0, h, temb) + emb[0]
-    x1 = _two_conv(den.down_1.convs, F.max_pool3d(x0, 2), temb) + emb[1]
-    x2 = _two_conv(den.down_2.convs, F.max_pool3d(x1, 2), temb) + emb[2]
-    x3 = _two_conv(den.down_3.convs, F.max_pool3d(x2, 2), temb) + emb[3]
-    x4 = _two_conv(den.down_4.convs, F.max_pool3d(x3, 2), temb) + emb[4]
-
-    def up(block, lo, skip):
-        u = F.conv_transpose3d(lo, block.upsample.deconv.weight, block.upsample.deconv.bias, stride=2)
-        return _two_conv(block.convs, torch.cat([skip, u], dim=1), temb)
-
-    u4 = up(den.upcat_4, x4, x3)
-    u3 = up(den.upcat_3, u4, x2)
-    u2 = up(den.upcat_2, u3, x1)
-    u1 = up(den.upcat_1, u2, x0)
-    return F.conv3d(u1, den.final_conv.weight, den.final_conv.bias)
-
-
-class Loss:
-    """losses/loss.py:25-86 for the names the diffusion configs use: ``mse`` (on sigmoid(pred), :68-69), ``bce``
-    (BCEWithLogits), ``dice`` (MONAI DiceLoss(sigmoid=True): include_background, smooth_nr = smooth_dr = 1e-5,
-    sums over the spatial axes, mean over batch x class); combined by ``sum`` / ``mean`` / ``log``."""
-
-    def __init__(self, losses="mse,bce,dice", loss_combine="sum"):
-        self.names = losses.split(",")
-        for n in self.names:
-            if n not in ("mse", "bce", "dice"):
-                raise NotImplementedError(f"Loss ({n}) is not listed yet")
-        self.loss_combine = loss_combine
-
-    @staticmethod
-    def _dice(pred, target):
-        p = torch.sigmoid(pred)
-        dims = tuple(range(2, pred.dim()))
-        inter = (p * target).sum(dims)
-        denom = p.sum(dims) + target.sum(dims)
-        return (1.0 - (2.0 * inter + 1e-5) / (denom + 1e-5)).mean()
-
-    def __call__(self, preds, labels):
-        out = []
-        for n in self.names:
-            if n == "mse":
-                out.append(F.mse_loss(torch.sigmoid(preds), labels))
-            elif n == "bce":
-                out.append(F.binary_cross_entropy_with_logits(preds, labels))
-            else:
-                out.append(self._dice(preds, labels))
-        if len(out) == 1:
-            return out[0]
-        st = torch.stack(out)
-        if self.loss_combine == "sum":
-            return st.sum()
-        if self.loss_combine == "mean":
-            return st.mean()
-        if self.loss_combine == "log":
-            return torch.log(1 + st.sum())
+def parse_losses(losses="mse,bce,dice", loss_combine="sum"):
+    """losses/loss.py:25-62: comma-separated loss names and the combine rule; the names the HIP loss kernels cover."""
+    names = tuple(losses.split(","))
+    from .ops import LOSS_NAMES
+    for n in names:
+        if n not in LOSS_NAMES:
+            raise NotImplementedError(f"Loss ({n}) is not listed yet")
+    if loss_combine not in ("sum", "mean", "log"):
         raise NotImplementedError("Unsupported value for loss_combine. Please choose from 'sum', 'mean', or 'log'.")
+    return names, loss_combine
 
 
-def training_step(net, images, labels, criterion, noise=None, t=None):
-    """Trainer.training_step (train.py:258-268): x_start = 2*labels - 1 -> q_sample (HIP kernel on a GPU) -> denoise
-    (autograd fallback) -> loss.  ``noise`` / ``t`` can be injected for tests."""
-    x_start = labels * 2 - 1
-    if noise is None and t is None and images.is_cuda:
-        x_t, t, _ = net(x=x_start, pred_type="q_sample")
-    else:
-        noise = torch.randn_like(x_start) if noise is None else noise
-        if t is None:
-            t, _ = net.sampler.sample(x_start.shape[0], x_start.device)
-        d = net.diffusion
-        q = d.q_coef(t).to(x_start.device)
-        x_t = q[:, 0].view(-1, 1, 1, 1, 1) * x_start + q[:, 1].view(-1, 1, 1, 1, 1) * noise
-    preds = autograd_denoise(net, images, x_t, t)
-    return criterion(preds, labels)
-
-
-class DDPTrainer:
-    """One process per GPU; gradients all-reduced by torch DistributedDataParallel (RCCL on a GPU node, gloo in the
-    CPU tests).  InstanceNorm needs no cross-rank statistics (per-sample)."""
-
-    def __init__(self, net, lr=2e-4, weight_decay=1e-4, losses="mse,bce,dice", loss_combine="sum", device_ids=None):
-        import torch.distributed as dist
-        from torch.nn.parallel import DistributedDataParallel
-
-        class _Step(torch.nn.Module):
-            def __init__(self, inner):
-                super().__init__()
-                self.inner = inner
-
-            def forward(self, images, x_t, t):
-                return autograd_denoise(self.inner, images, x_t, t)
-
-        self.net = net
-        self.criterion = Loss(losses, loss_combine)
-        self.wrapped = DistributedDataParallel(_Step(net), device_ids=device_ids) if dist.is_initialized() else _Step(net)
-        self.optimizer = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=weight_decay)     # train.py:121-126
-
-    def step(self, images, labels, noise=None, t=None):
-        x_start = labels * 2 - 1
-        if t is None:
-            t, _ = self.net.sampler.sample(x_start.shape[0], x_start.device)
-        noise = torch.randn_like(x_start) if noise is None else noise
-        if x_start.is_cuda:
-            x_t = self.net.diffusion.q_sample(x_start, t, noise)
-        else:
-            q = self.net.diffusion.q_coef(t)
-            x_t = q[:, 0].view(-1, 1, 1, 1, 1) * x_start + q[:, 1].view(-1, 1, 1, 1, 1) * noise
-        self.optimizer.zero_grad(set_to_none=True)
-        loss = self.criterion(self.wrapped(images, x_t, t), labels)
-        loss.backward()
-        self.optimizer.step()
-        return loss.detach()
+def allreduce_mean_(tensors, group=None):
+    """Average ``tensors`` over the ranks of ``group`` with ONE flat all-reduce (RCCL on a GPU node, gloo in the CPU
+    tests); in place.  No-op outside torch.distributed."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
 
 
 # ------------------------------------------------------------------------------------------------------------
-# Native-convolution training path: every 3x3x3 convolution (forward, data gradient, weight gradient -- >95 % of
-# the step's FLOPs) runs on the HIP kernels of this package inside a torch.autograd.Function; activations are
-# channels-last [N, D, H, W, C] in the compute dtype (fp16 with fp32 master weights and a GradScaler, or fp32).
-# InstanceNorm + LeakyReLU + temb/embedding adds are fused around them (materialize forward, reduce/apply backward).
-# MaxPool comes out of the materialize pass (forward) and a routed-add kernel (backward).  The mse+bce+dice loss is one
-# reduce + one gradient kernel; the 1x1 head is a forward and a one-pass backward kernel; the k2s2 transposed convolution writes/reads its half of the concat buffer in place (forward
-# kernel of the sampler, data- and weight-gradient kernels).  What is still torch: the copy of the skip half into the concat
-# buffer, the timestep MLP, AdamW.
 class _Conv3dK3(torch.autograd.Function):
     """y = conv3d(x, w, b), 3x3x3 / pad 1, channels-last.  forward: dua_conv3d_k3_fwd; backward: the same kernel on
     dy with the weights flipped and transposed (data gradient) + dua_conv3d_k3_wgrad (weight gradient)."""
@@ -358,20 +243,22 @@ class _Head(torch.autograd.Function):
 
 
 class _SegLoss(torch.autograd.Function):
-    """mse + bce + dice ("sum") on channels-last logits: one reduce pass forward, one gradient pass backward."""
+    """losses/loss.py:25-86 for any subset of mse / bce / dice under "sum" / "mean" / "log" on channels-last logits: one
+    reduce pass forward, one gradient pass backward."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, names=("mse", "bce", "dice"), combine="sum"):
         from . import ops
-        L, sums = ops.seg_loss_reduce(logits, labels)
-        ctx.save_for_backward(logits, labels, sums)
+        L, sums, dcomb = ops.seg_loss_reduce(logits, labels, names, combine)
+        ctx.save_for_backward(logits, labels, sums, dcomb)
+        ctx.names = names
         return L
 
     @staticmethod
     def backward(ctx, g):
         from . import ops
-        logits, labels, sums = ctx.saved_tensors
-        return ops.seg_loss_grad(logits, labels, sums, g), None
+        logits, labels, sums, dcomb = ctx.saved_tensors
+        return ops.seg_loss_grad(logits, labels, sums, g * dcomb, ctx.names), None, None, None
 
 
 def native_conv_denoise(net, image, x, step, dtype=torch.float16):
@@ -382,6 +269,10 @@ def native_conv_denoise(net, image, x, step, dtype=torch.float16):
 
 def native_logits_cl(net, image, x, step, dtype=torch.float16):
     """Same network, logits left channels-last [N, D, H, W, C] in the compute dtype (what the fused loss consumes)."""
+    if image.device.type != "cuda":
+        raise RuntimeError("DiffUNet runs on an MI355X (device 'cuda'); there is no CPU path in this package")
+    from . import _native
+    _native.lib()            # fails loudly when libdua_hip.so is missing
     enc, den = net.embed_model, net.model
     img = _cl_pad(image, dtype)
     e, pe = _two_conv_cl(enc.conv_0, img, None, None, True)
@@ -445,8 +336,7 @@ class NativeConvTrainer:
             from torch.nn.parallel import DistributedDataParallel
             dev = next(net.parameters()).device
             self.module = DistributedDataParallel(self.module, device_ids=[dev.index], bucket_cap_mb=32)
-        self.criterion = Loss(losses, loss_combine)
-        self.fused_loss = sorted(losses.split(",")) == ["bce", "dice", "mse"] and loss_combine == "sum"
+        self.loss_names, self.loss_combine = parse_losses(losses, loss_combine)
         self.params = [p for p in net.parameters() if p.requires_grad]
         # graph mode always uses the fused capturable AdamW; ``fused_optimizer`` selects the same kernel for eager steps
         self.optimizer = (torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=True, capturable=True)
@@ -454,16 +344,9 @@ class NativeConvTrainer:
         self.scale, self.good_steps = (init_scale if dtype == torch.float16 else 1.0), 0
 
     def _allreduce(self):
-        import torch.distributed as dist
         if not self.distributed or self.overlap:          # the DDP reducer already averaged them during backward
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in self.params])
-        dist.all_reduce(flat)
-        flat /= dist.get_world_size()
-        off = 0
-        for p in self.params:
-            p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        allreduce_mean_([p.grad for p in self.params])
 
     # ---- whole-step HIP graph (single process): the eager step issues ~3,000 launches and is host-bound once the kernels
     # take < 22 ms; one replay per step removes the host from the loop.  Everything a step decides stays on the device:
@@ -476,7 +359,7 @@ class NativeConvTrainer:
         x_t = ops.q_sample(x_start.contiguous(), g["noise"], g["qtab"][g["t"]].contiguous())
         self.optimizer.zero_grad(set_to_none=True)
         with torch.enable_grad():
-            loss = _SegLoss.apply(self.module(g["images"], x_t, g["t"]), g["labels"])
+            loss = _SegLoss.apply(self.module(g["images"], x_t, g["t"]), g["labels"], self.loss_names, self.loss_combine)
             (loss * g["scale"]).backward()
         grads = [p.grad for p in self.params]
         g["found_inf"].zero_()
@@ -488,7 +371,7 @@ class NativeConvTrainer:
 
     def _build_graph(self, images, labels):
         assert not self.distributed, "graph mode is single-process; use overlap=True under torch.distributed"
-        assert self.fused_loss and labels.dtype == torch.float32
+        assert labels.dtype == torch.float32
         dev = images.device
         d = self.net.diffusion
         self.optimizer = torch.optim.AdamW(self.params, lr=self.lr, weight_decay=self.weight_decay, fused=True, capturable=True)
@@ -546,22 +429,20 @@ class NativeConvTrainer:
         x_t = self.net.diffusion.q_sample(x_start, t, noise)                     # HIP kernel
         self.optimizer.zero_grad(set_to_none=True)
         with torch.enable_grad():
-            if self.fused_loss and labels.dtype == torch.float32:
-                loss = _SegLoss.apply(self.module(images, x_t, t), labels.contiguous())
-            else:
-                loss = self.criterion(self.module(images, x_t, t).permute(0, 4, 1, 2, 3).float(), labels)
+            loss = _SegLoss.apply(self.module(images, x_t, t), labels.float().contiguous(), self.loss_names,
+                                  self.loss_combine)
             (loss * self.scale).backward()
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         self._allreduce()
-        if self.scale != 1.0:
+        if self.dtype == torch.float16:
             # one multi-tensor kernel: grads *= 1/scale, found_inf = any non-finite
             found_inf = torch.zeros(1, dtype=torch.float32, device=self.params[0].device)
             inv = torch.full((1,), 1.0 / self.scale, dtype=torch.float32, device=self.params[0].device)
             torch._amp_foreach_non_finite_check_and_unscale_([p.grad for p in self.params], found_inf, inv)
             if bool(found_inf.item()):                                           # overflow: skip, halve the scale
-                self.scale, self.good_steps = self.scale / 2, 0
+                self.scale, self.good_steps = max(self.scale / 2, 2.0 ** -14), 0
                 return loss.detach()
             self.good_steps += 1
             if self.good_steps >= 200:

@@ -133,24 +133,28 @@ int dua_head_bwd(int dtype, long voxels, int C, int K, const void* dlogits, int 
                  int u_stride, const float* W, void* du, int du_stride, float* dW, float* db, void* workspace,
                  long workspace_bytes, void* stream);
 
-/* Loss of the training step and its gradient (losses/loss.py:25-86, losses "mse,bce,dice" combined by "sum"; MONAI
- * DiceLoss(sigmoid=True) defaults):  L = mean((sigmoid(p)-y)^2) + mean(BCEWithLogits(p,y)) + mean_{n,c}(1 - (2I+e)/(S+Y+e)).
+/* Loss of the training step and its gradient (losses/loss.py:25-86 for the names "mse", "bce", "dice"; MONAI
+ * DiceLoss(sigmoid=True) defaults):  mse = mean((sigmoid(p)-y)^2), bce = mean(BCEWithLogits(p,y)),
+ * dice = mean_{n,c}(1 - (2I+e)/(S+Y+e)); the diffusion configs combine all three by "sum".
  * logits: channels-last [N][voxels][logits_stride] (first C used); labels: fp32 NCDHW [N][C][voxels].
  * reduce: sums (fp64 [N*C*4 + 2], pre-zeroed) += per (n,c) (I = sum s*y, S = sum s, Y = sum y, -), then
- *         (sum (s-y)^2, sum of BCE terms); the caller forms L from them.
- * grad  : dlogits = *gscale * dL/dp (gscale: device fp32 scalar or NULL = 1), same layout as logits. */
+ *         (sum (s-y)^2, sum of BCE terms); the caller forms the selected terms and their combination from them.
+ * grad  : dlogits = *gscale * (w_mse d mse/dp + w_bce d bce/dp + w_dice d dice/dp)  (gscale: device fp32 scalar or
+ *         NULL = 1 -- it carries the loss scale and the derivative of the "mean" / "log" combine; w_*: 1 for the names
+ *         in use, 0 otherwise), same layout as logits. */
 int dua_seg_loss_reduce(int dtype, int N, int C, long voxels, const void* logits, int logits_stride, const float* labels,
                         double* sums, void* stream);
 int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, int logits_stride, const float* labels,
-                      const double* sums, const float* gscale, void* dlogits, int dlogits_stride, void* stream);
+                      const double* sums, const float* gscale, float w_mse, float w_bce, float w_dice, void* dlogits,
+                      int dlogits_stride, void* stream);
 
-/* Tuning/diagnostic switch: key 1 = conv3d_k3 variant (0 auto, 2 = v2 without split-K, 3 = v2 with 2x8x8 tiles,
- * 4 = wave-specialised v4);
+/* Tuning/diagnostic switch: key 1 = conv3d_k3 launch shape (0 automatic policy, 2 = 4x8x8 tiles without split-K,
+ * 3 = 2x8x8 tiles);
  * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid);
- * key 3: ablation mask of the weight-gradient kernel (diagnostic builds, -DDUA_ABLATE); key 4: weight-gradient launch
- * shape (bit 0 = plain block order, bits 1-4 = workgroups per CU over the launch, 0 = default policy; bit 6 = the
- * 6-wave form instead of the 12-wave one, bit 5 = 6 waves with the compiler-scheduled k loop); key 5: workgroups per CU of
- * the v4 convolution in quarters (default 4). */
+ * key 3: ablation mask of the weight-gradient kernel (accepted by diagnostic builds, -DDUA_ABLATE, only);
+ * key 4: weight-gradient launch shape (bit 0 = plain block order, bits 1-4 = workgroups per CU over the launch,
+ * 0 = default policy; bit 6 = the 6-wave form instead of the 12-wave one, bit 5 = 6 waves with the compiler-scheduled
+ * k loop).  Any other key/value is rejected with DUA_ERR_ARG. */
 int dua_set_option(int key, int value);
 
 /* Packs nn.Conv3d weight fp32[Cout][Cin_src][3][3][3] into the kernel's slab order
@@ -215,7 +219,9 @@ typedef struct {
   int C, CX;               /* classes; channel stride of the fp32 sampler state (8/16/24/32) */
   int mode;                /* DUA_MODE_* */
   int xin_stride;          /* channel stride of xin (x_{t-1} goes to channels [0, C)) */
-  unsigned long long seed; /* Philox key when noise == NULL */
+  unsigned long long seed; /* Philox key when noise == NULL and seed_dev == NULL */
+  const unsigned long long* seed_dev; /* optional DEVICE word holding the Philox key: lets a captured graph draw a
+                                         fresh noise field per replay (the host rewrites the word, not the graph) */
 } dua_tail_desc;
 
 /* wf: fp32[C][K], bf: fp32[C].  coef: fp32[N][8] on device.  x_state: fp32[N][voxels][CX] in/out.
@@ -237,12 +243,14 @@ int dua_temb_table(int count, const int* timesteps, const float* freqs, int half
 
 /* Start of one denoiser evaluation: copy the embedding row(s) and sampler coefficients of the
  * current step into the fixed buffers the other kernels read.  Either rows_per_sample
- * (int32[N], training / "denoise") or (row_of_step[], *counter) (sampling loops: uses step
+ * (int32[N], training / "denoise") or (row_of_step[nsteps], *counter) (sampling loops: uses step
  * k = *counter, writes step_word[0] = k, then *counter = k + 1) selects the rows.  Replaces the
- * per-step host work at gaussian_diffusion.py:523,703 and respace.py:123-129. */
-int dua_step_begin(int N, int P, const float* table, const int* rows_per_sample, const int* row_of_step,
-                   const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
-                   void* stream);
+ * per-step host work at gaussian_diffusion.py:523,703 and respace.py:123-129.
+ * Every device-side index is range-checked against table_rows / nsteps: an offender is clamped (no wild
+ * read) and *err_word (may be NULL) is set to 1 for the host to inspect. */
+int dua_step_begin(int N, int P, const float* table, int table_rows, const int* rows_per_sample, const int* row_of_step,
+                   int nsteps, const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
+                   int* err_word, void* stream);
 
 /* ---- layout / packing at the API boundary -------------------------------------------------- */
 /* nn.ConvTranspose3d weight fp32[Cin][Cout][2][2][2] -> [tap][cout_tile][chunk][k-group][64][16 B].

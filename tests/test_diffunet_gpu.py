@@ -4,8 +4,9 @@ the CPU oracle on identical weights, inputs and injected noise.
 Tolerances (stated, per BASELINE.json north_star):
   fp32 mode (exact-fp32 MFMA):   max |d logit| <= 2e-3 after 28 conv + norm layers
   fp16 mode (fp16 operands, fp32 accumulate; the reference's own AMP test envelope):
-                                 max |d logit| <= 0.15, mean <= 0.02 for a single evaluation
-  Dice delta of the binarised sampler output vs the oracle: <= 1e-3 (fp32), reported for fp16.
+                                 max |d logit| <= 1e-2, mean <= 1e-3 for a single evaluation
+                                 (measured 3e-3 / 4e-4 at 32^3 and at 96^3 x 16)
+  Dice delta of the binarised sampler output vs the oracle: <= 1e-3, in fp32 AND in fp16.
 """
 import numpy as np
 import pytest
@@ -56,7 +57,7 @@ def test_selfcheck_fixture_fp32(unet_selfcheck):
     assert d.max() < 2e-3, d.max()
 
 
-@pytest.mark.parametrize("dtype,mx,mean", [(torch.float32, 2e-3, 2e-4), (torch.float16, 0.15, 0.02)])
+@pytest.mark.parametrize("dtype,mx,mean", [(torch.float32, 2e-3, 2e-4), (torch.float16, 1e-2, 1e-3)])
 @pytest.mark.parametrize("kw", [TINY, dict(in_channels=1, out_channels=2)], ids=["tiny", "full-features"])
 def test_denoise_matches_oracle(dtype, mx, mean, kw):
     net, ref = _pair(kw, dtype)
@@ -101,10 +102,9 @@ def test_ddim_sample_matches_oracle(dtype):
     print(f"\n[{dtype}] sum-x0 |d| max {d.max():.3e} mean {d.mean():.3e}; Dice(build, oracle) per class {dice}")
     if dtype == torch.float32:
         assert d.max() < 2e-2 and d.mean() < 1e-3
-        assert min(dice) > 1 - 1e-3
     else:
-        assert d.mean() < 0.1
-        assert min(dice) > 0.98
+        assert d.max() < 0.1 and d.mean() < 1e-2       # a sum of ten predictions: measured 1.7e-2 / 2.7e-3
+    assert min(dice) > 1 - 1e-3                        # north_star: Dice within 1e-3 of the reference, both dtypes
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
@@ -124,7 +124,7 @@ def test_p_sample_loop_matches_oracle(dtype):
                                                  step_noise=[d.cuda() for d in draws]).cpu()
     d = (got - want).abs()
     print(f"\n[{dtype}] x_0 sample |d| max {d.max():.3e} mean {d.mean():.3e}")
-    assert d.mean() < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert d.mean() < (1e-4 if dtype == torch.float32 else 1e-2)
 
 
 def test_generic_callable_path_matches_reference_golden(golden):
@@ -193,7 +193,7 @@ def test_full_size_config2_evaluation_matches_oracle():
         got = net(image=image.cuda(), x=x.cuda(), step=t.cuda(), pred_type="denoise").cpu()
     d = (got - want).abs()
     print(f"\n[96^3 x 16, fp16] |dlogit| max {d.max():.3e} mean {d.mean():.3e} (logit std {want.std():.3f})")
-    assert d.max() < 0.15 and d.mean() < 0.02
+    assert d.max() < 1e-2 and d.mean() < 1e-3
     agree = ((got > 0) == (want > 0)).float().mean()
     print(f"sign agreement of logits (what sigmoid>0.5 keeps): {agree:.6f}")
     assert agree > 0.995
@@ -204,9 +204,11 @@ def test_full_size_config2_evaluation_matches_oracle():
         a = plan.sample_loop(net.sample_diffusion, "ddpm", noise=xT, seed=11)
         s1, x1 = a["sample"].clone(), a["sum_pred_xstart"].clone()
         b = plan.sample_loop(net.sample_diffusion, "ddpm", noise=xT, seed=11)
+        c = plan.sample_loop(net.sample_diffusion, "ddpm", noise=xT)            # key drawn from torch's generator
     assert torch.isfinite(s1).all() and float(x1.abs().max()) <= 10.0 + 1e-4
     dd = (s1 - b["sample"]).abs()
     assert float(dd.mean()) < 2e-3      # same seed, same inputs: equal up to the order of fp64 atomics
+    assert float((s1 - c["sample"]).abs().mean()) > 1e-2      # another key: another noise field
 
 
 def test_batched_ddim_loop_matches_per_sample_oracle():
@@ -225,7 +227,7 @@ def test_batched_ddim_loop_matches_per_sample_oracle():
     assert d.max() < 2e-2 and d.mean() < 1e-3, (float(d.max()), float(d.mean()))
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.float16, 0.15)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.float16, 1e-2)])
 def test_odd_class_count_non_cubic_patch_batch3(dtype, tol):
     """13 classes (BTCV), a 32x48x64 patch (different tile counts per axis, partial tiles at the lower levels),
     batch of 3 with three different timesteps."""
@@ -306,3 +308,189 @@ def test_sharded_sliding_window_with_the_hip_sampler_two_ranks():
     seg_a = inference.binarise(torch.from_numpy(outs[0]))
     seg_b = inference.binarise(torch.from_numpy(want))
     assert (seg_a != seg_b).float().mean().item() < 1e-4
+
+
+# ---- the benchmarked loop length, the seed contract, the timestep guard ----------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_thousand_step_p_sample_loop_matches_oracle(dtype):
+    """BASELINE config 2 is a 1000-step DDPM loop: the fused HIP path (x_t fed back through its fp16 copy in the
+    production dtype) against RefDiffusion.p_sample_loop (gaussian_diffusion.py:441-535 restated) over all 1000 steps
+    of ``diffusion`` with every step's noise injected on both sides; drift reported against the step count."""
+    net, ref = _pair(TINY, dtype)
+    g = torch.Generator().manual_seed(13)
+    shape = (1, 2, 32, 32, 32)
+    image = torch.rand(1, 1, 32, 32, 32, generator=g)
+    xT = torch.randn(*shape, generator=g)
+    T = 1000
+    draws = [torch.randn(*shape, generator=g) for _ in range(T)]
+    marks = (1, 10, 100, 300, 600, 900, 1000)
+    want = {}
+    with torch.no_grad():
+        emb_r = ref.embed_model(image)
+        img = xT
+        for k, i in enumerate(reversed(range(T))):
+            img = ref.diffusion.p_sample(ref.model, img, torch.tensor([i]), draws[k],
+                                         model_kwargs={"image": image, "embeddings": emb_r})["sample"]
+            if k + 1 in marks:
+                want[k + 1] = img.clone()
+        net.embed_model(image.cuda())
+        plan = net._rt.plan(1, (32, 32, 32), torch.device("cuda", 0))
+        snaps = {m: None for m in marks}
+        out = plan.sample_loop(net.diffusion, "ddpm", noise=xT.cuda(), step_noise=draws, snapshots=snaps)
+        via_api = net.diffusion.p_sample_loop(net.model, shape, noise=xT.cuda(), step_noise=[d.cuda() for d in draws[:T]],
+                                              model_kwargs={"image": image.cuda(), "embeddings": net.embed_model(image.cuda())})
+    line = []
+    for m in marks:
+        d = (snaps[m].cpu() - want[m]).abs()
+        line.append(f"{m}: {d.max():.2e}/{d.mean():.2e}")
+    print(f"\n[{dtype}] 1000-step DDPM drift (max/mean |dx| after k steps): " + ", ".join(line))
+    d = (out["sample"].cpu() - want[T]).abs()
+    assert torch.isfinite(out["sample"]).all()
+    if dtype == torch.float32:
+        assert d.max() < 5e-3 and d.mean() < 2e-4, (float(d.max()), float(d.mean()))
+    else:
+        assert d.max() < 0.25 and d.mean() < 1e-2, (float(d.max()), float(d.mean()))
+    from oracle.unet_ref import binarise
+    dice = _dice(binarise(out["sample"].cpu()), binarise(want[T]))
+    assert min(dice) > 1 - 1e-3, dice
+    assert (via_api.cpu() - out["sample"].cpu()).abs().max() < (1e-4 if dtype == torch.float32 else 5e-2)
+
+
+def test_p_mean_variance_matches_reference_golden(golden):
+    """GaussianDiffusion.p_mean_variance (gaussian_diffusion.py:231-326) on the product side against the goldens the
+    reference's own method produced: mean, variance, log_variance, pred_xstart, model_output."""
+    from diff_unet_amos_amd.gaussian_diffusion import make_spaced
+    x = torch.from_numpy(golden["G3_x"]).cuda()
+    stubs = {"half": lambda x, t, **kw: 0.5 * x, "tanh": lambda x, t, **kw: torch.tanh(x) + 1e-3 * t.float().view(-1, 1, 1, 1, 1)}
+    seen = 0
+    for steps, ts in ((10, (0, 1, 5, 9)), (1000, (0, 500, 999))):
+        d = make_spaced(1000, [steps])
+        for name, fn in stubs.items():
+            for t in ts:
+                key = f"G3_s{steps}_{name}_t{t}_pmv"
+                if key + "_mean" not in golden.files:
+                    continue
+                out = d.p_mean_variance(fn, x, torch.tensor([t] * x.shape[0], device="cuda"))
+                for part, tol in (("mean", 1e-6), ("variance", 0.0), ("log_variance", 0.0), ("pred_xstart", 0.0), ("model_output", 1e-6)):
+                    got, want = out[part].cpu().numpy(), golden[f"{key}_{part}"]
+                    assert got.shape == want.shape, (key, part)
+                    if tol == 0.0:
+                        assert np.array_equal(got, want), (key, part)
+                    else:
+                        assert np.allclose(got, want, rtol=tol, atol=tol), (key, part, float(np.abs(got - want).max()))
+                seen += 1
+    assert seen >= 10
+
+
+def test_in_kernel_noise_follows_torch_seed_and_differs_between_calls():
+    """The reference draws a fresh randn_like per step and per call (gaussian_diffusion.py:430); the fused path keys its
+    counter-based generator per call from torch's generator: same torch seed -> same trajectory, next call -> another."""
+    net, _ = _pair(TINY, torch.float32)
+    image = torch.rand(1, 1, 32, 32, 32).cuda()
+    shape = (1, 2, 32, 32, 32)
+    xT = torch.randn(*shape, device="cuda")
+    with torch.no_grad():
+        emb = net.embed_model(image)
+        kw = {"image": image, "embeddings": emb}
+        torch.manual_seed(1234)
+        a = net.sample_diffusion.p_sample_loop(net.model, shape, noise=xT, model_kwargs=kw).clone()
+        b = net.sample_diffusion.p_sample_loop(net.model, shape, noise=xT, model_kwargs=kw).clone()
+        torch.manual_seed(1234)
+        c = net.sample_diffusion.p_sample_loop(net.model, shape, noise=xT, model_kwargs=kw).clone()
+    assert float((a - b).abs().mean()) > 1e-2            # consecutive calls: different noise
+    assert float((a - c).abs().max()) < 1e-3             # same torch seed: same noise (up to the order of fp64 atomics)
+
+
+def test_out_of_range_timestep_is_a_clean_error():
+    net, _ = _pair(TINY, torch.float32)
+    g = torch.Generator().manual_seed(1)
+    image = torch.rand(1, 1, 32, 32, 32, generator=g).cuda()
+    x = torch.randn(1, 2, 32, 32, 32, generator=g).cuda()
+    with torch.no_grad():
+        for bad in (1000, -1, 10 ** 6):
+            with pytest.raises(ValueError, match="timestep out of range"):
+                net(image=image, x=x, step=torch.tensor([bad]), pred_type="denoise")                 # host tensor
+            with pytest.raises(ValueError, match="timestep out of range"):
+                net(image=image, x=x, step=torch.tensor([bad], device="cuda"), pred_type="denoise")   # device tensor
+        ok = net(image=image, x=x, step=torch.tensor([999], device="cuda"), pred_type="denoise")
+    assert torch.isfinite(ok).all()
+
+
+# ---- BASELINE config 3 as a composition: sliding windows -> HIP DDIM sampler -> blend -> binarise -----------------------
+def _seeded_predictor(net, record=None):
+    """x_T comes from the device generator inside the sampler: seed it from the window content so that the oracle can be
+    handed exactly the same x_T (and a window's result does not depend on when it is sampled)."""
+    def predictor(x, **kw):
+        seed = int(x.double().abs().sum().item() * 1e3) % (2 ** 31)
+        torch.manual_seed(seed)
+        if record is not None:
+            record.append(seed)
+        return net(image=x, **kw)
+    return predictor
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_config3_composition_matches_oracle(dtype):
+    """inference.infer (Engine.infer, engine.py:167-182) over 8 overlapping 32^3 windows of a 48x48x40 volume, 16 classes,
+    50-step DDIM through the HIP sampler, against oracle.sliding_window_ref o RefDiffUNet.ddim_sample with the same
+    per-window x_T (eta = 0: no step noise)."""
+    from diff_unet_amos_amd import inference
+    from oracle.sliding_window_ref import sliding_window_ref
+    from oracle.unet_ref import binarise
+    kw = dict(in_channels=1, out_channels=16, features=(8, 8, 16, 32, 64, 8))
+    net, ref = _pair(kw, dtype, sample_steps=50)
+    g = torch.Generator().manual_seed(31)
+    vol = torch.rand(1, 1, 48, 48, 40, generator=g)
+    shape = (1, 16, 32, 32, 32)
+    count = [0]
+
+    def ref_fn(win):          # numpy [1,1,32,32,32] -> [1,16,32,32,32]
+        w = torch.from_numpy(win).float()
+        seed = int(w.cuda().double().abs().sum().item() * 1e3) % (2 ** 31)
+        torch.manual_seed(seed)
+        xT = torch.randn(*shape, device="cuda").cpu()
+        count[0] += 1
+        with torch.no_grad():
+            return ref.ddim_sample(w, x_T=[xT], step_noise=[[torch.zeros(shape)] * 50]).numpy()
+
+    want = torch.from_numpy(sliding_window_ref(vol.numpy(), (32, 32, 32), 0.25, ref_fn)).float()
+    assert count[0] == 8
+    with torch.no_grad():
+        got = inference.sliding_window_inference(vol.cuda(), (32, 32, 32), 1, _seeded_predictor(net), 0.25,
+                                                 pred_type="ddim_sample").cpu()
+        seg = inference.infer(_seeded_predictor(net), vol.cuda(), roi_size=(32, 32, 32), sw_batch_size=1, overlap=0.25).cpu()
+    d = (got - want).abs()
+    dice = _dice(binarise(got), binarise(want))
+    print(f"\n[{dtype}] config-3 composition (8 windows, 16 classes, 50 DDIM steps): blended sum-x0 |d| max {d.max():.3e} "
+          f"mean {d.mean():.3e}; Dice(build, oracle) min over classes {min(dice):.6f}")
+    assert got.shape == (1, 16, 48, 48, 40)
+    if dtype == torch.float32:
+        assert d.max() < 5e-2 and d.mean() < 1e-3
+    else:
+        assert d.mean() < 2e-2
+    assert min(dice) > 1 - 1e-3
+    assert torch.equal(seg, binarise(got))
+
+
+def test_config3_full_size_properties():
+    """256x256x192 volume, 96^3 windows, overlap 0.25 -> 48 windows, 16 classes, default widths, 50-step DDIM, fp16: the
+    output is finite everywhere (every voxel is covered by >= 1 window), bounded by the 50 clamped predictions, and the
+    part of the volume only window 0 covers equals sampling that window on its own with the same x_T."""
+    from diff_unet_amos_amd import inference
+    net, _ = _pair(dict(in_channels=1, out_channels=16), torch.float16, sample_steps=50, affine_noise=False)
+    g = torch.Generator().manual_seed(77)
+    vol = torch.rand(1, 1, 256, 256, 192, generator=g).cuda()
+    seeds = []
+    with torch.no_grad():
+        out = inference.sliding_window_inference(vol, (96, 96, 96), 1, _seeded_predictor(net, seeds), 0.25,
+                                                 pred_type="ddim_sample")
+        assert len(seeds) == 48
+        assert out.shape == (1, 16, 256, 256, 192) and bool(torch.isfinite(out).all())
+        assert float(out.abs().max()) <= 50.0 + 1e-3
+        torch.manual_seed(seeds[0])
+        alone = net(image=vol[:, :, :96, :96, :96], pred_type="ddim_sample")
+    only0 = out[:, :, :72, :72, :72]            # the next windows start at 72 along every axis
+    d = (only0 - alone[:, :, :72, :72, :72]).abs()
+    assert float(d.mean()) < 1e-2, float(d.mean())         # same window, same x_T: equal up to the order of fp64 atomics
+    seg = inference.binarise(out)
+    assert seg.shape == out.shape and set(seg.unique().tolist()) <= {0.0, 1.0}

@@ -99,6 +99,10 @@ def test_forward_dispatch_errors_and_no_cpu_fallback():
     with torch.no_grad():
         with pytest.raises(RuntimeError, match="no CPU path"):
             net(image=torch.zeros(1, 1, 32, 32, 32), x=torch.zeros(1, 2, 32, 32, 32), step=torch.zeros(1).long(), pred_type="denoise")
+    # with grad enabled the same call is the training path (HIP forward + backward kernels): no CPU path there either
     x = torch.zeros(1, 2, 32, 32, 32, requires_grad=True)
-    with pytest.raises(NotImplementedError, match="forward-only"):
+    with pytest.raises(RuntimeError, match="no CPU path"):
         net(image=torch.zeros(1, 1, 32, 32, 32), x=x, step=torch.zeros(1).long(), pred_type="denoise")
+    # the sub-networks on their own run the inference launch plan, which keeps no tape: gradients are refused there
+    with pytest.raises(NotImplementedError, match="pred_type"):
+        net.model(x, torch.zeros(1).long(), image=torch.zeros(1, 1, 32, 32, 32), embeddings=[None] * 5)

@@ -33,19 +33,23 @@ def test_window_count_of_config3():
         _plan(torch.zeros(1, 1, 8, 8, 8), (4, 4, 4), 1.0)
 
 
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]      # the scheduler also runs with device tensors under -m gpu
+
+
+@pytest.mark.parametrize("device", DEVICES)
 @pytest.mark.parametrize("shape,roi,overlap,swb", [
     ((1, 1, 20, 17, 13), (8, 8, 8), 0.25, 4),
     ((2, 1, 9, 16, 16), (8, 8, 8), 0.5, 3),       # batch of 2 volumes
     ((1, 1, 5, 8, 11), (8, 8, 8), 0.8, 1),        # smaller than the roi along D: symmetric zero padding, then crop
     ((1, 1, 8, 8, 8), (8, 8, 8), 0.25, 2),        # exactly one window
 ])
-def test_matches_loop_restatement(shape, roi, overlap, swb):
+def test_matches_loop_restatement(shape, roi, overlap, swb, device):
     g = torch.Generator().manual_seed(sum(shape))
     vol = torch.randn(*shape, generator=g)
-    got = sliding_window_inference(vol, roi, swb, _predictor, overlap, pred_type="ddim_sample")
+    got = sliding_window_inference(vol.to(device), roi, swb, _predictor, overlap, pred_type="ddim_sample")
     want = sliding_window_ref(vol.numpy(), roi, overlap, _predictor_np)
-    assert got.shape == (shape[0], 3, *shape[2:])
-    assert np.allclose(got.numpy(), want, rtol=1e-5, atol=1e-6)
+    assert got.shape == (shape[0], 3, *shape[2:]) and got.device.type == device
+    assert np.allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
 
 
 def _worker(rank, world, port, shape, roi, overlap, swb, gather_dtype, q):
@@ -84,15 +88,16 @@ def test_sharded_equals_single_process(world, shape, overlap):
         assert np.allclose(outs[r], want, rtol=1e-6, atol=1e-6), r
 
 
-def test_binarise_and_dice_match_reference_formulas():
+@pytest.mark.parametrize("device", DEVICES)
+def test_binarise_and_dice_match_reference_formulas(device):
     g = torch.Generator().manual_seed(0)
-    logits = torch.randn(2, 4, 6, 6, 6, generator=g) * 3
-    labels = (torch.rand(2, 4, 6, 6, 6, generator=g) > 0.6).float()
+    logits = (torch.randn(2, 4, 6, 6, 6, generator=g) * 3).to(device)
+    labels = (torch.rand(2, 4, 6, 6, 6, generator=g) > 0.6).float().to(device)
     labels[:, 3] = 0
     logits[:, 3] = -10                                   # class 3 empty on both sides -> dice 0 (metric.py:45-49)
     pred = binarise(logits)
     assert torch.equal(pred, (torch.sigmoid(logits) > 0.5).float())
     got = dice_per_class(pred, labels)
     for c in range(4):
-        assert abs(float(got[c]) - dice_coeff(pred[:, c], labels[:, c])) < 1e-12
+        assert abs(float(got[c]) - dice_coeff(pred[:, c].cpu(), labels[:, c].cpu())) < 1e-12
     assert float(got[3]) == 0.0

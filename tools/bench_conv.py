@@ -41,9 +41,7 @@ def main():
         res = {v: [] for v in variants}
         for rd in range(rounds + 1):
             for v in variants:
-                if v >= 1000:      # 1000 + q: v4 with q/4 workgroups per CU
-                    nv.check(nv.lib().dua_set_option(5, v - 1000), "opt5")
-                nv.check(nv.lib().dua_set_option(1, 4 if v >= 1000 else v), "opt")
+                nv.check(nv.lib().dua_set_option(1, v), "opt")
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):

@@ -1,5 +1,5 @@
-"""Config 4 (training step, batch 2, 96^3, 16 classes) on the torch-autograd FALLBACK (training.py) -- reported
-so the number exists, labelled as not native.  One JSON line.  Usage: python tools/bench_train.py [--steps K]"""
+"""Config 4 (training step, batch 2, 96^3, 16 classes) on the HIP training path (training.NativeConvTrainer): eager or
+as one replayed HIP graph.  One JSON line.  Usage: python tools/bench_train.py [--steps K] [--graph]"""
 import argparse
 import json
 import os
@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diff_unet_amos_amd.diff_unet import DiffUNet          # noqa: E402
-from diff_unet_amos_amd.training import DDPTrainer, NativeConvTrainer         # noqa: E402
+from diff_unet_amos_amd.training import NativeConvTrainer         # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=5)
@@ -18,7 +18,6 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--classes", type=int, default=16)
 ap.add_argument("--size", type=int, default=96)
-ap.add_argument("--path", default="native-conv", choices=["native-conv", "autograd"])
 ap.add_argument("--dtype", default="float16")
 ap.add_argument("--graph", action="store_true", help="replay the whole training step as one HIP graph")
 ap.add_argument("--no-gc", action="store_true", help="disable the Python cyclic GC during the timed loop (diagnosis)")
@@ -27,7 +26,7 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = DiffUNet(in_channels=1, out_channels=a.classes).to(dev)
-tr = NativeConvTrainer(net, dtype=getattr(torch, a.dtype), graph=a.graph) if a.path == "native-conv" else DDPTrainer(net)
+tr = NativeConvTrainer(net, dtype=getattr(torch, a.dtype), graph=a.graph)
 image = torch.rand(a.batch, 1, a.size, a.size, a.size, device=dev)
 labels = (torch.rand(a.batch, a.classes, a.size, a.size, a.size, device=dev) > 0.8).float()
 for _ in range(a.warmup):
@@ -59,8 +58,8 @@ if a.ab_wgrad:
             ts.append(time.perf_counter() - t0)
         ab.setdefault(str(v), []).append(round(sorted(ts)[len(ts) // 2] * 1e3, 2))
     nv.check(nv.lib().dua_set_option(4, 0), "opt")
-print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "median_ms": sorted(per)[len(per) // 2] * 1e3, "per_step_ms": [round(x * 1e3, 2) for x in per], "ab_wgrad_median_ms": ab, "native": a.path == "native-conv",
-                  "path": ("HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; fused loss, pooling, 1x1-head and transposed-conv (in-place concat) kernels; AdamW = torch; " + a.dtype)
-                  if a.path == "native-conv" else "torch autograd fallback (MIOpen/rocBLAS) fp32, q_sample = HIP", "graph": a.graph, "batch": a.batch,
+print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "median_ms": sorted(per)[len(per) // 2] * 1e3, "per_step_ms": [round(x * 1e3, 2) for x in per], "ab_wgrad_median_ms": ab, "native": True,
+                  "path": "HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; fused loss, pooling, 1x1-head and transposed-conv (in-place concat) kernels; AdamW = torch; " + a.dtype,
+                  "graph": a.graph, "batch": a.batch,
                   "size": a.size, "classes": a.classes, "loss": float(loss),
                   "max_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}))

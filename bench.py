@@ -1,29 +1,47 @@
 #!/usr/bin/env python3
-"""Benchmark of the Diff-UNet hot path on MI355X: BASELINE.json config 2.
+"""Benchmark of the Diff-UNet hot path on MI355X.
 
-Workload: DiffUNet(in=1, out=16), one 96^3 patch per GPU, DDPM ancestral sampling
-(`diffusion.p_sample_loop` semantics) -- a "step" is ONE reverse-diffusion step = one denoiser
-evaluation (18 conv3x3x3 + 4 deconv + 1x1 head, 1.0564 TFLOP) + the sampler update, with inputs
-resident in HBM, in-kernel Philox noise, replayed from a captured HIP graph.  The conditioning
-encoder pass (once per patch, 0.28 TFLOP) runs before the timed region like x_T generation.
-Metric: denoised voxel-steps / s  (= N_gpus * 96^3 * K / wall time of K steps).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4]
 
-Multi-GPU (--gpus N under torch.distributed.run): config 2 does not shard (1000 strictly sequential
-steps on one tensor) => N independent replicas, weak scaling, no data-path
-collective; only the timing barrier/all-reduce(MAX) touches RCCL.
+--config 2 (default, the headline: BASELINE.json configs[1]): DiffUNet(in=1, out=16), one 96^3 patch per GPU, DDPM
+  ancestral sampling (`diffusion.p_sample_loop` semantics) -- a "step" is ONE reverse-diffusion step = one denoiser
+  evaluation (18 conv3x3x3 + 4 deconv + 1x1 head, 1.0564 TFLOP) + the sampler update, with inputs resident in HBM,
+  in-kernel Philox noise, replayed from a captured HIP graph.  The conditioning encoder pass (once per patch,
+  0.28 TFLOP) runs before the timed region like x_T generation.  Metric: denoised voxel-steps / s
+  (= N_gpus * 96^3 * K / max-over-ranks wall time of K steps).  Config 2 does not shard (1000 strictly sequential
+  steps on one tensor) => N independent replicas, weak scaling, no data-path collective.
+--config 3 (BASELINE.json configs[2]): sliding-window DDIM inference of a 256x256x192 volume (48 windows of 96^3,
+  50 steps), windows sharded over the ranks, ONE RCCL all_gather_into_tensor of the per-window outputs, identical
+  blend on every rank.  A "step" is one whole volume; reports seconds per volume and the all-gather share.
+--config 4 (BASELINE.json configs[3]): DDP training step (q_sample + denoise + mse/bce/dice + backward + AdamW) on
+  synthetic 96^3 x 16-class batches, 2 samples per GPU, gradients averaged over RCCL (DDP buckets overlapped with
+  backward); reports samples/s and the share a flat all-reduce of the 153.6 MB of gradients would take.
 
-Extra objects in the JSON line:
-  roofline     -- for the dominant kernel (conv3d_k3_v2_kernel, all 18 launches of a step): algorithmic
-                  FLOPs per launch / average launch duration, measured with HIP events on the launch
-                  stream: each of the step's 18 launches replayed back to back between one event pair
-                  (split-K layers without their finish kernel); peak = dense fp16 MFMA.
-  cpu_baseline -- the CPU oracle (oracle/unet_ref.py, "port") timed on this box's host cores on a
-                  bounded sample (1 warm-up + 2 denoiser evaluations at the same 96^3 x 16 shape).
+Launch: with no WORLD_SIZE in the environment and --gpus N > 1 this script starts its own N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) BEFORE touching the GPU
+and relays their output; under torch.distributed.run it is one rank (RANK / LOCAL_RANK / WORLD_SIZE from the env).
+
+Extra objects in the JSON line (config 2, rank 0, N = 1):
+  roofline     -- for the dominant kernel (conv3d_k3_v2_kernel, all 18 launches of a step): algorithmic FLOPs per launch
+                  / average launch duration, measured with HIP events on the launch stream: each of the step's 18
+                  launches replayed back to back between one event pair (split-K layers without their finish kernel);
+                  peak = dense fp16 MFMA (2.5 PFLOP/s nominal: at this part's 1400 W cap the matrix pipes alone sustain
+                  1.5-1.8 PFLOP/s on random data).  traffic = HBM bytes per launch from two
+                  rocprofv3 --pmc child passes of this script (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE),
+                  or null when the profiler is not available.
+  cpu_baseline -- the CPU oracle (oracle/unet_ref.py, "port") timed on this box's host cores on a bounded sample
+                  (1 warm-up + 2 denoiser evaluations at the same 96^3 x 16 shape).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -36,6 +54,7 @@ CLASSES = 16
 FEATURES = (64, 64, 128, 256, 512, 64)
 PEAK_F16_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
+CONV_KERNEL = "conv3d_k3_v2_kernel"
 
 
 def conv3_flops(plan):
@@ -57,7 +76,7 @@ def time_conv_launches(plan, reps):
     """HIP events (torch.cuda.Event on the launch stream) around the conv3d_k3 kernel: one eager denoiser evaluation
     records the arguments of its 18 launches; each launch is then replayed `reps` times back to back between ONE event
     pair (an event pair around a single ~30 us launch reads the command-processor gaps as kernel time).  Split-K layers
-    are replayed without their finish kernel (dua_set_option(2, 1)), so the figure is conv3d_k3_v2_kernel alone, as the
+    are replayed without their finish kernel (dua_set_option(2, 1)), so the figure is the conv kernel alone, as the
     rocprofv3 summary lists it.  Returns (avg ms per launch, launches/step, ms by launch)."""
     from diff_unet_amos_amd import _native as nv
     from diff_unet_amos_amd import ops
@@ -92,6 +111,40 @@ def time_conv_launches(plan, reps):
     return sum(by_launch) / len(by_launch), len(calls), by_launch
 
 
+def measure_traffic(dtype_flag):
+    """HBM bytes per conv launch from the PMC counters, as MI355X_MICROARCH.md (HBM / rocprofv3 sections) prescribes:
+    FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes over a short eager run of this script (a child
+    process: the profiler must start the program itself), FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request),
+    both in KiB; averaged over every launch of the conv kernel.  Returns bytes per launch or None."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="dua_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-graph",
+                   "--no-cpu-baseline", "--no-roofline", "--dtype", dtype_flag]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if CONV_KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            out[counter] = sum(vals) / len(vals)
+        except Exception:       # noqa: BLE001 -- no profiler, no permission, timeout: report null, never fail the bench
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
+
+
 def host_threads():
     """Threads for the CPU baseline: this process's CPU share (a one-GPU box grants 16 cores)."""
     try:
@@ -124,40 +177,66 @@ def cpu_baseline(net_state, threads):
                       f"{dt:.2f} s/step; sampler update excluded (<1%)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--batch", type=int, default=1, help="patches per GPU (BASELINE config 2 is 1)")
-    args = ap.parse_args()
+def self_launch(args):
+    """No WORLD_SIZE and --gpus N > 1: start the N ranks ourselves, before any GPU call in this process (a process that
+    has initialised the GPU must never exec another program; this one only waits for its children)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    # one rank per GPU on a real node.  Rehearsal on a one-GPU box only: DUA_BENCH_BACKEND=gloo lets several ranks
-    # share device 0 (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
-    backend = os.environ.get("DUA_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
 
+class Dist:
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
+        # one rank per GPU on a real node.  Rehearsal on a one-GPU box only: DUA_BENCH_BACKEND=gloo lets several ranks
+        # share device 0 (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
+        self.backend = os.environ.get("DUA_BENCH_BACKEND", "nccl")
+        if self.backend != "nccl":
+            self.local = self.local % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if self.world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def finish(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def run_config2(args, D):
     from diff_unet_amos_amd import _native as nv
     from diff_unet_amos_amd import ops
     from diff_unet_amos_amd.diff_unet import DiffUNet
 
+    dev, rank, world = D.dev, D.rank, D.world
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
     torch.manual_seed(0)
     net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES, compute_dtype=dtype).to(dev).eval()
@@ -180,11 +259,8 @@ def main():
         plan.counter.zero_()
         plan.new_seed(3 + rank)
 
-        def one_step():
-            ops.step_begin(B, plan.temb_table, plan.cur_add, row_of_step=row_of_step, counter=plan.counter,
-                           coef_table=coef_table, cur_coef=plan.cur_coef, step_word=plan.step_word)
-            plan.denoiser_body()
-            plan.tail(nv.MODE_DDPM, noise=None, use_sum=False)
+        def one_step():          # dua_denoiser_step: step begin + 18 conv + 4 deconv + materialise passes + fused tail
+            plan.native_step(nv.MODE_DDPM, row_of_step=row_of_step, coef_table=coef_table, use_sum=False)
 
         assert args.warmup + args.steps + 2 <= T, "the 1000-step process bounds warmup+steps"
         one_step()
@@ -198,24 +274,13 @@ def main():
             run = g.replay
         for _ in range(args.warmup):
             run()
-
-        def barrier():
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        barrier()
+        D.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             run()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        barrier()
+        dt = D.max_over_ranks(time.perf_counter() - t0)
+        D.barrier()
         finite = bool(torch.isfinite(plan.x_state).all())
 
         roof = None
@@ -226,12 +291,8 @@ def main():
             flops_per_launch = sum(fl) / len(fl)
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_F32_TFLOPS
-            traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/), fp16 path only
-            tj = os.path.join(ROOT, "profiles", "r1_conv_traffic.json")
-            if args.dtype == "f16" and os.path.exists(tj):
-                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
-            roof = {"bound": "mfma", "kernel": "conv3d_k3_v2_kernel", "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            roof = {"bound": "mfma", "kernel": CONV_KERNEL, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 2),
                     "conv_ms_per_step": round(avg_ms * per_step, 3),
@@ -239,7 +300,8 @@ def main():
                     "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
                     "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3",
                                        "tflops": round(max(fl) / (by_launch[fl.index(max(fl))] * 1e-3) / 1e12, 2)}}
-
+    if rank == 0 and roof is not None:
+        roof["traffic"] = getattr(args, "traffic", None)   # measured by main() before this process touched the GPU
     if rank == 0:
         ms = dt / args.steps * 1e3
         line = {
@@ -258,9 +320,129 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(state, host_threads())
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()          # rank 0 also ran the instrumented roofline pass: leave together
-        dist.destroy_process_group()
+
+
+def run_config3(args, D):
+    """Sliding-window DDIM inference of one synthetic volume, windows sharded over the ranks, one all-gather."""
+    from diff_unet_amos_amd import inference
+    from diff_unet_amos_amd.diff_unet import DiffUNet
+    dev, rank, world = D.dev, D.rank, D.world
+    torch.manual_seed(0)
+    net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES, sample_steps=50).to(dev).eval()
+    vol = torch.rand(1, 1, 256, 256, 192, generator=torch.Generator().manual_seed(1)).to(dev)      # same volume on every rank
+    nwin = len(inference._plan(vol, (96, 96, 96), 0.25)[4])
+    swb = args.sw_batch
+    timings = {}
+
+    def one_volume():
+        if world > 1:
+            out = inference.sharded_sliding_window_inference(vol, (96, 96, 96), swb, net, 0.25, pred_type="ddim_sample",
+                                                            gather_dtype=torch.float16 if args.gather_fp16 else None,
+                                                            timings=timings)
+        else:
+            out = inference.sliding_window_inference(vol, (96, 96, 96), swb, net, 0.25, pred_type="ddim_sample")
+        return inference.binarise(out)
+
+    with torch.no_grad():
+        net(vol[:, :, :96, :96, :96].contiguous().repeat(swb, 1, 1, 1, 1), pred_type="ddim_sample")   # packs weights, captures the graph
+        for _ in range(args.warmup):
+            one_volume()
+        D.barrier()
+        timings.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            seg = one_volume()
+        torch.cuda.synchronize()
+        dt = D.max_over_ranks(time.perf_counter() - t0)
+        D.barrier()
+    if rank == 0:
+        per = dt / args.steps
+        gather_s = timings.get("all_gather_s", 0.0) / max(1, args.steps)
+        print(json.dumps({
+            "metric": "sliding-window DDIM inference: denoised voxel-steps/sec over a full volume", "value": nwin * VOX * 50 / per,
+            "unit": "voxel-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "AMOS-sized volume 256x256x192, 96^3 windows (overlap 0.25 -> 48), 50-step DDIM, windows "
+                                   "sharded over the ranks, one all_gather_into_tensor of the per-window sums (BASELINE.json configs[2])",
+                       "windows": nwin, "sw_batch_size": swb, "gather_dtype": "f16" if args.gather_fp16 else "f32"},
+            "seconds_per_volume": per, "all_gather_seconds": gather_s, "all_gather_share": gather_s / per if per > 0 else None,
+            "gathered_bytes": timings.get("gathered_bytes"), "foreground_fraction": float(seg.mean())}), flush=True)
+
+
+def run_config4(args, D):
+    """DDP training step on synthetic batches; gradients averaged over RCCL."""
+    from diff_unet_amos_amd.diff_unet import DiffUNet
+    from diff_unet_amos_amd.training import NativeConvTrainer, allreduce_mean_
+    dev, rank, world = D.dev, D.rank, D.world
+    torch.manual_seed(0)
+    net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES).to(dev)
+    B = 2                                          # cfg/amos/train.yaml: batch 10 over 5 GPUs
+    tr = NativeConvTrainer(net, dtype=torch.float16, overlap=not args.flat_allreduce, graph=args.train_graph)
+    g = torch.Generator(device=dev).manual_seed(10 + rank)
+    image = torch.rand(B, 1, 96, 96, 96, device=dev, generator=g)
+    labels = (torch.rand(B, CLASSES, 96, 96, 96, device=dev, generator=g) > 0.8).float()
+    for _ in range(max(1, args.warmup)):
+        tr.step(image, labels)
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(image, labels)
+    torch.cuda.synchronize()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    D.barrier()
+    # what one flat all-reduce of all gradients costs on its own (upper bound of the share when it is not overlapped)
+    grads = [torch.zeros_like(p) for p in net.parameters()]
+    allreduce_mean_(grads)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        allreduce_mean_(grads)
+    torch.cuda.synchronize()
+    ar = D.max_over_ranks((time.perf_counter() - t1) / 5) if world > 1 else 0.0
+    if rank == 0:
+        per = dt / args.steps
+        print(json.dumps({
+            "metric": "DDP training samples/sec on synthetic 96^3 16-class batches", "value": world * B / per, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "q_sample + denoise + mse/bce/dice + backward + AdamW, 96^3, 16 classes, 2 samples per GPU "
+                                   "(BASELINE.json configs[3])", "batch_per_gpu": B,
+                       "gradient_sync": "flat all-reduce after backward" if args.flat_allreduce else "DDP reducer, 32 MB buckets overlapped with backward",
+                       "graph": bool(args.train_graph)},
+            "flat_allreduce_seconds": ar, "flat_allreduce_share": ar / per if per > 0 else None,
+            "gradient_bytes": sum(p.numel() for p in net.parameters()) * 4, "loss": float(loss)}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--batch", type=int, default=1, help="config 2: patches per GPU (BASELINE config 2 is 1)")
+    ap.add_argument("--sw-batch", type=int, default=1, help="config 3: windows per sampler pass")
+    ap.add_argument("--gather-fp16", action="store_true", help="config 3: all-gather the window sums in fp16")
+    ap.add_argument("--flat-allreduce", action="store_true", help="config 4: one flat all-reduce instead of DDP buckets")
+    ap.add_argument("--train-graph", action="store_true", help="config 4: whole step as one HIP graph")
+    args = ap.parse_args()
+    defaults = {2: (200, 20), 3: (1, 0), 4: (5, 2)}[args.config]
+    args.steps = defaults[0] if args.steps is None else args.steps
+    args.warmup = defaults[1] if args.warmup is None else args.warmup
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    if args.config == 2 and args.gpus == 1 and not (args.no_roofline or args.no_traffic):
+        # two short child runs of this script under rocprofv3 --pmc, started before this process initialises the GPU
+        args.traffic = measure_traffic(args.dtype)
+    D = Dist(args)
+    {2: run_config2, 3: run_config3, 4: run_config4}[args.config](args, D)
+    D.finish()
 
 
 if __name__ == "__main__":

@@ -54,6 +54,28 @@ class TailDesc(C.Structure):
 
 
 MODE_LOGITS, MODE_DDPM, MODE_DDIM = 0, 1, 2
+OP_CONV3, OP_MATERIALIZE, OP_DECONV = 1, 2, 3
+
+
+class StepOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("has_norm", C.c_int), ("conv", Conv3Desc), ("mat", MaterializeDesc), ("norm", InNorm),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("stats", C.c_void_p),
+                ("emb", C.c_void_p), ("pooled", C.c_void_p)]
+
+
+class DenoiserPlan(C.Structure):
+    _fields_ = [("N", C.c_int), ("P", C.c_int),
+                ("temb_table", C.c_void_p), ("table_rows", C.c_int),
+                ("rows_per_sample", C.c_void_p),
+                ("row_of_step", C.c_void_p), ("nsteps", C.c_int), ("coef_table", C.c_void_p), ("counter", C.c_void_p),
+                ("cur_add", C.c_void_p), ("cur_coef", C.c_void_p), ("step_word", C.c_void_p), ("err_word", C.c_void_p),
+                ("stat_arena", C.c_void_p), ("stat_bytes", C.c_long),
+                ("ops", C.POINTER(StepOp)), ("n_ops", C.c_int),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
+                ("tail", TailDesc), ("tail_raw", C.c_void_p), ("tail_norm", InNorm), ("wf", C.c_void_p), ("bf", C.c_void_p),
+                ("x_state", C.c_void_p), ("noise", C.c_void_p), ("xin", C.c_void_p), ("xstart_sum", C.c_void_p),
+                ("logits", C.c_void_p), ("xstart", C.c_void_p)]
+
 
 _P = C.c_void_p
 _SIGS = {
@@ -62,6 +84,7 @@ _SIGS = {
     "dua_q_sample": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P]),
     "dua_sampler_step": (C.c_int, [C.c_int, C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dua_final_conv_sampler": (C.c_int, [C.POINTER(TailDesc), _P, C.POINTER(InNorm)] + [_P] * 11),
+    "dua_denoiser_step": (C.c_int, [C.POINTER(DenoiserPlan), _P]),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dua_conv3d_k3_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),

@@ -7,21 +7,15 @@
 //               PRODUCER layer, applied while the halo tile is staged (denoiser.py:63-67);
 //               out-of-volume halo voxels stay literal zeros (padding follows the activation)
 //   epilogue  : + bias, per-(n, c) InstanceNorm statistics of THIS layer's output (sum x and sum x^2 from the
-//               fp32 accumulators, combined per workgroup, then two fp64 atomics per channel into one of 8
-//               replica rows), coalesced 16-byte stores of the raw output.
+//               fp32 accumulators, combined per workgroup, then two fp64 atomics per channel into one
+//               of 8 replica rows), coalesced 16-byte stores of the raw output.
 //
 // GEMM view: M = output voxels, N = Cout, K = 27 taps x Cin.
-// Workgroup (256 threads = 4 waves, two workgroups per CU): a 4x8x8 output tile x 64 output channels; wave w
-// owns depth slice w (64 voxels) as 4 x 4 accumulator blocks of MFMA 16x16 (v_mfma_f32_16x16x32_f16: one
-// instruction consumes a whole 64-byte Cin chunk of a tap; fp32 parity mode: 4 x v_mfma_f32_16x16x4_f32).
-// The 16x16 shape is a measured choice (tools/ubench/mfma_lds_ubench.hip): on random
-// data the chip holds a higher clock on it than on 32x32x16, +10..19 % FLOP/s for the same LDS traffic.
-// Per Cin chunk of 64 bytes/voxel the 6x10x10 halo tile is staged once in LDS (registers in between: the
-// producer's normalisation is applied there); the 9 taps of one kd plane of the packed weights follow it slab
-// by slab, copied global -> LDS by LDS-DMA (global_load_lds, no registers) one slab ahead of the MFMAs.
-// A and B fragments are 16-byte ds_read_b128; the halo row stride (672 B: stride / 16 == 2 mod 4) and the
-// 2x8 row -> voxel map make every fragment read bank-conflict free under the ds_read_b128 lane groups.
-#include <type_traits>
+// Workgroup (256 threads = 4 waves): a 4x8x8 output tile x 64 output channels; wave w owns
+// depth slice w (64 voxels) as 2x2 MFMA 32x32 accumulators.  Per Cin chunk of 64 bytes/voxel
+// the 6x10x10 halo tile is staged once in LDS; the 9 taps of one kd plane of the packed
+// weights follow it slab by slab.  A and B fragments are 16-byte ds_read_b128; the halo row
+// stride (656 B) and the 4x8 row->voxel map make every fragment read bank-conflict free.
 #include "common.hpp"
 #include "../../include/dua_hip.h"
 #include "conv3_args.hpp"
@@ -29,24 +23,15 @@
 namespace dua {
 
 namespace c3 {
-constexpr int TH = 8, TW = 8;
-constexpr int HH = TH + 2, HW = TW + 2;
+constexpr int TD = 4, TH = 8, TW = 8;
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int KG = 4;                      // k-groups (16 B) per chunk
 constexpr int VS = KG * 16;                // 64 B per halo voxel per chunk
-constexpr int RS = HW * VS + 32;           // 672: halo row stride, padded (bank-conflict free for the 16-row A blocks)
-constexpr int PS = HH * RS;                // 6720: halo plane stride
+constexpr int RS = HW * VS + 16;           // 656: halo row stride, padded (bank-conflict free)
+constexpr int PS = HH * RS;                // 6560: halo plane stride
+constexpr int HALO_BYTES = HD * PS;        // 39360
 constexpr int BN = 64;                     // output channels per workgroup
-constexpr int SLAB = 3 * KG * BN * 16;     // 12288: packed weights of one (kd, kh): [kw][k-group][64 couts][16 B]
-constexpr int XF_MAX = 3 * 4 * 1024;       // scale/shift/add tables of the fused input transform (Cin <= 1024)
-constexpr int NSLAB = 3;                   // weight slab ring: the DMA runs two slabs ahead of the MFMAs
-constexpr int lds_main(int td) { return (td + 2) * PS + NSLAB * SLAB; }
 }  // namespace c3
-
-#ifdef DUA_ABLATE      // diagnostic builds only (outputs are wrong): -DDUA_ABLATE=<mask>, 1 = no MFMA, 2 = no fragment
-constexpr int ABL = DUA_ABLATE;   // reads, 4 = no weight staging, 8 = no halo staging, 16 = no epilogue
-#else
-constexpr int ABL = 0;
-#endif
 
 // 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones); 2 forces 4x8x8 tiles without split-K, 3 forces 2x8x8
 int g_conv_variant = 0;
@@ -54,34 +39,31 @@ int g_skip_splitk_finish = 0;   // diagnostics (dua_set_option(2, 1)): time the 
 extern int g_wgrad_abl;
 extern int g_wgrad_variant;
 
+// ------------------------------------------------------------------------------------------------
+// v2: same tile and fragment maps, software-pipelined.  Weights arrive as 12 KB (kd,kh) slabs, loaded to
+// registers one slab ahead of the MFMAs and written into the other half of a double buffer; the next
+// chunk's halo is prefetched into registers during the last slab of the current chunk and written
+// (transformed) to LDS between two barriers.  Operand fragments of k-step t+1 are read from LDS while
+// the MFMAs of step t issue.  One barrier per slab; nothing waits on a global load that was not issued
+// a full MFMA phase earlier.
+namespace c3v2 {
+using namespace c3;
+constexpr int SLAB = 3 * KG * BN * 16;             // 12288
+constexpr int LDS_MAIN = HALO_BYTES + 2 * SLAB;    // 63936
+}  // namespace c3v2
+
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// One K = 32-channel (fp16) / 16-channel (fp32) step of a 16x16 output block.  Lane l = (row/col c = l & 15,
-// k-group kq = l >> 4) holds the 16 bytes of its row (A: voxel) or column (B: output channel) for k-group kq.
-__device__ __forceinline__ void mma16(f32x4& acc, const f16x8& a, const f16x8& b) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
-}
-__device__ __forceinline__ void mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
-  // exact fp32: MFMA j multiplies element j of every lane's k-group, so the four cover the 16 channels once
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
-}
-
-// TDP = tile depth: 4 (4x8x8 voxels, wave = depth slice = four 16-voxel blocks) or 2 (2x8x8 voxels, wave =
-// (depth slice, h half) = two blocks) -- the small tile doubles the workgroup count of the 24^3 layers.
-// Accumulator block (mb, nb) of a wave: voxels = h rows {2 mb, 2 mb + 1} of its slice (16 = 2 x 8), channels
-// nb * 16 .. + 15; lane (c = lane & 15, rq = lane >> 4) holds channel nb * 16 + c of voxels rq * 4 + j, j = 0..3,
-// i.e. h row 2 mb + (rq >> 1), w = (rq & 1) * 4 + j.
+// TDP = tile depth: 4 (4x8x8 voxels, wave = depth slice, two 32-row blocks per wave) or 2 (2x8x8 voxels, wave =
+// (depth slice, h half), one block per wave) -- the small tile doubles the workgroup count of the 24^3 layers.
 template <typename T, int TDP = 4>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
-  using namespace c3;
-  constexpr int TD = TDP, HD = TDP + 2, MB = TDP;       // MB: 16-voxel blocks per wave
-  constexpr int HALO_BYTES = HD * PS, LDS_MAIN = HALO_BYTES + NSLAB * SLAB;
+__global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
+  using namespace c3v2;
+  constexpr int TD = TDP, HD = TDP + 2, MB = TDP / 2;
+  constexpr int HALO_BYTES = HD * PS, LDS_MAIN = HALO_BYTES + 2 * SLAB;
   constexpr int NITEMS = HD * HH * HW * KG, NIT = (NITEMS + 255) / 256;
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
@@ -94,9 +76,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
   float* xad = xsh + a.nchunks * CK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c16 = lane & 15, rq = lane >> 4;
+  const int r = lane & 31, hh = lane >> 5;
   const int dwave = TDP == 4 ? wave : wave >> 1;          // depth slice of this wave
-  const int hbase = TDP == 4 ? 0 : (wave & 1) * 4;        // first h row of this wave's blocks
+  const int hbase = TDP == 4 ? 0 : (wave & 1) * 4;        // first h row of this wave's block(s)
   const int tile = xcd_remap(blockIdx.x, a.ntiles);
   const int ct = blockIdx.y, n = blockIdx.z % a.N;
   const int tw_ = tile % a.tiles_w, th_ = (tile / a.tiles_w) % a.tiles_h, td_ = tile / (a.tiles_w * a.tiles_h);
@@ -104,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
   const bool fused = a.xf.stats != nullptr;
 
   const int kg_t = tid & (KG - 1);
-  int goff[NIT]; int loff[NIT];           // element offset inside the sample (< 2^31, checked by the launcher) / LDS byte offset
+  long goff[NIT]; int loff[NIT];
   const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off;
 #pragma unroll
   for (int j = 0; j < NIT; ++j) {
@@ -113,61 +95,61 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
     int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
     int gd = d0 + hd - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
     bool ok = it < NITEMS && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-    goff[j] = ok ? ((gd * a.H + gh) * a.W + gw) * a.Cin_stride + kg_t * EPG : -1;
+    goff[j] = ok ? (((long)gd * a.H + gh) * a.W + gw) * a.Cin_stride + kg_t * EPG : -1;
     loff[j] = it < NITEMS ? hd * PS + hy * RS + hx * VS + kg_t * 16 : -1;
   }
-  // Weight slabs go global -> LDS by LDS-DMA: 12 pieces of 1 KB per slab, three per wave, destination = wave-uniform
-  // base + lane * 16 (the packed layout is exactly the LDS image).  The ring holds three slabs: slab g+2 is requested at
-  // the start of phase g into the buffer phase g-1 read (every wave is past that phase's barrier), so an L2 round trip
-  // (~1 us under load, about one phase) has two phases to complete.  Vector-memory operations retire in issue order,
-  // so "slab g+1 has landed" is a COUNTED wait at the end of phase g: everything but the youngest operations (the 3
-  // pieces of slab g+2, plus this phase's halo prefetch when it was issued after them) must be done.
-  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB + (wave * 3) * 1024 + lane * 16;
-  auto dma_slab = [&](int g, int gl) {       // g = slab index within the cout tile (chunk * 9 + kd * 3 + kh); gl = g - g0
-    if (ABL & 4) return;
-    const char* src = wsrc + (long)g * SLAB;
-    char* dst = wbuf + (gl % NSLAB) * SLAB + (wave * 3) * 1024;
+  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB;
+  // Weight slabs go global -> registers (issued one slab ahead, 3 x 16 B per thread) -> LDS.  LDS-DMA
+  // (global_load_lds) would save the registers, but with one in flight hipcc (ROCm 7.2) turns every
+  // counted lgkmcnt wait of the fragment pipeline below into lgkmcnt(0).
+  // Two register sets: slab g is loaded during phase g-2 and written to LDS at the end of phase g-1, so
+  // an L2 round trip has two MFMA phases to complete.
+  f32x4 wreg[3][3];   // set = (slab index within chunk) % 3, compile-time (9 slabs per chunk keeps the cycle)
+  auto load_slab = [&](int g, int set) {       // g = global slab index (chunk * 9 + kd * 3 + kh)
+    const char* src = wsrc + (long)g * SLAB + tid * 16;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) glds16(src + j * 1024, dst + j * 1024);
+    for (int j = 0; j < 3; ++j) wreg[set][j] = *(const f32x4*)(src + j * 4096);
+  };
+  auto store_slab = [&](int g, int set) {
+    char* dst = wbuf + (g & 1) * SLAB + tid * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *(f32x4*)(dst + j * 4096) = wreg[set][j];
   };
   Frag hv_[NIT];
-  // Loads are unconditional (an item outside the volume or past Cin reads the sample's first k-group and is zeroed when
-  // it is stored): a load under a lane-dependent branch gets its own basic block and its own wait from hipcc.
   auto load_halo = [&](int ch) {
-    if (ABL & 8) return;
     const bool cok = ch * CK + kg_t * EPG < a.Cin;
 #pragma unroll
-    for (int j = 0; j < NIT; ++j) hv_[j] = *(const Frag*)(xin + ((goff[j] >= 0 && cok) ? goff[j] + ch * CK : 0));
+    for (int j = 0; j < NIT; ++j) {
+      if (goff[j] >= 0 && cok) hv_[j] = *(const Frag*)(xin + goff[j] + ch * CK);
+      else
+#pragma unroll
+        for (int e = 0; e < EPG; ++e) hv_[j][e] = (T)0.f;
+    }
   };
   auto store_halo = [&](int ch) {
-    if (ABL & 8) return;
     const int c0 = ch * CK + kg_t * EPG;
-    const bool cok = c0 < a.Cin;
-    float sc[EPG], sh[EPG], ad[EPG];
-    if (fused && cok) {
+    if (fused && c0 < a.Cin) {
+      float sc[EPG], sh[EPG], ad[EPG];
 #pragma unroll
       for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+#pragma unroll
+      for (int j = 0; j < NIT; ++j)
+        if (goff[j] >= 0) hv_[j] = xform_frag<T>(hv_[j], sc, sh, ad, a.xf.slope);
     }
 #pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      Frag f = hv_[j];
-      if (fused && cok) f = xform_frag<T>(f, sc, sh, ad, a.xf.slope);
-      const bool ok = goff[j] >= 0 && cok;
-#pragma unroll
-      for (int e = 0; e < EPG; ++e) f[e] = ok ? f[e] : (T)0.f;             // padding stays literal zero
-      if (loff[j] >= 0) *(Frag*)(halo + loff[j]) = f;
-    }
+    for (int j = 0; j < NIT; ++j)
+      if (loff[j] >= 0) *(Frag*)(halo + loff[j]) = hv_[j];
   };
 
   // accumulators start at the bias of the lane's output channel (split-K adds it in the finish kernel instead)
-  f32x4 acc[MB][4];
+  f32x16 acc[MB][2];
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-    const float b0 = a.ksplit > 1 ? 0.f : a.bias[ct * BN + nb * 16 + c16];
+  for (int q = 0; q < 2; ++q) {
+    const float b0 = a.ksplit > 1 ? 0.f : a.bias[ct * BN + q * 32 + r];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[m][nb][i] = b0;
+      for (int i = 0; i < 16; ++i) acc[m][q][i] = b0;
   }
 
   // ---- work range: units u = chunk * 3 + kd, three (kd, kh) slabs each ----
@@ -177,148 +159,144 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(Conv3Args a) {
   const int g0 = u0 * 3, g1 = u1 * 3;
 
   // ---- prologue ----
-  dma_slab(g0, 0);
-  if (g0 + 1 < g1) dma_slab(g0 + 1, 1);
+  load_slab(g0, 0);
+  load_slab(g0 + 1, 1);
+  load_slab(g0 + 2, 2);
   load_halo(u0 / 3);
   if (fused) {     // only the Cin chunks this workgroup walks (all of them unless split-K)
     xform_preamble(a.xf, n, min(a.Cin, ((u1 + 2) / 3) * CK), xsc, xsh, xad, (u0 / 3) * CK);
     __syncthreads();
   }
+  store_slab(g0, 0);
   store_halo(u0 / 3);
-  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // slab g0 has landed; slab g0+1 may still be in flight
-  if (g0 + 1 >= g1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  __syncthreads();
 
-  const int a_base = dwave * PS + (hbase + (c16 >> 3)) * RS + (c16 & 7) * VS + rq * 16;
-  const int b_base = (rq * BN + c16) * 16;
-  int ring = 0;                                          // (g - g0) % NSLAB without a division
+  const int a_base = dwave * PS + (hbase + (r >> 3)) * RS + (r & 7) * VS + hh * 16;
+  const int b_base = (hh * BN + r) * 16;
   for (int u = u0; u < u1; ++u) {
     const int kd = u % 3;
     const bool next_chunk = kd == 2 && u + 1 < u1;     // the unit after this one starts a new Cin chunk
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int g = u * 3 + kh;
-      if (g + 2 < g1) dma_slab(g + 2, g + 2 - g0);
-      const bool halo_now = kh == 0 && next_chunk;
-      if (halo_now) load_halo(u / 3 + 1);
+      // slab g+1 (requested two phases ago) goes into the other buffer first, so that the end of the phase is
+      // nothing but the barrier; its register set is then free for slab g+3
+      if (g + 1 < g1) store_slab(g + 1, (kh + 1) % 3);
+      if (g + 3 < g1) load_slab(g + 3, kh);                       // (kh + 3) % 3 == kh
+      if (kh == 0 && next_chunk) load_halo(u / 3 + 1);
       const char* ap = halo + a_base + kd * PS + kh * RS;
-      const char* wb = wbuf + ring * SLAB + b_base;
-      ring = ring == NSLAB - 1 ? 0 : ring + 1;
-      // three k-steps (kw); fragments of step t+1 are in flight while the MFMAs of step t issue
-      Frag fa[2][MB], fb[2][4];
-      auto ld = [&](int kw, int b) {
-        if (ABL & 2) return;
-#pragma unroll
-        for (int m = 0; m < MB; ++m) fa[b][m] = *(const Frag*)(ap + 2 * m * RS + kw * VS);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) fb[b][nb] = *(const Frag*)(wb + (kw * KG * BN + nb * 16) * 16);
+      const char* wb = wbuf + (g & 1) * SLAB + b_base;
+      // six k-steps (kw x ks); fragments of step t+1 are in flight while the MFMAs of step t issue
+      Frag fa0[2], fa1[2], fb0[2], fb1[2];
+      auto ld = [&](int t, int b) {
+        const int kw = t >> 1, ks = t & 1;
+        fa0[b] = *(const Frag*)(ap + kw * VS + ks * 32);
+        fb0[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16);
+        fb1[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16 + 32 * 16);
+        if (MB == 2) fa1[b] = *(const Frag*)(ap + 4 * RS + kw * VS + ks * 32);
       };
       ld(0, 0);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        if (t + 1 < 3) ld(t + 1, (t + 1) & 1);
+      for (int t = 0; t < 6; ++t) {
+        if (t + 1 < 6) ld(t + 1, (t + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
-        if (ABL & 1) {
-#pragma unroll
-          for (int m = 0; m < MB; ++m) asm volatile("" ::"v"(fa[t & 1][m]));
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) asm volatile("" ::"v"(fb[t & 1][nb]));
-        } else {
-#pragma unroll
-          for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) mma16(acc[m][nb], fa[t & 1][m], fb[t & 1][nb]);
+        mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
+        mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
+        if constexpr (MB == 2) {
+          mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
+          mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // slab g+1 must have landed before anyone passes the barrier.  Younger than its pieces: the 3 pieces of slab g+2
-      // (when requested) and, in the phase that prefetches the next halo, those NIT loads -- or fewer, if they have
-      // already been consumed; a count that is too small only waits longer.
-      if (g + 2 < g1) {
-        if (halo_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + NIT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // next slab visible to every wave, and everyone is done with this one
+      __syncthreads();   // next slab visible and everyone is done with this one
     }
     if (next_chunk) {
       store_halo(u / 3 + 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      __syncthreads();
     }
   }
-  __syncthreads();     // the epilogue reuses the halo and weight buffers
-
-  if (ABL & 16) {
-    if (acc[0][0][0] == 123.f && acc[0][1][1] == 5.f) ((float*)a.y)[0] = 1.f;
-    return;
-  }
-  // ---- epilogue, one 32-channel half (nb pair) at a time: the wave's 16*MB voxels x 32 channels go through an LDS
-  // staging tile so that global stores are 16 bytes per lane and whole 64-byte (fp16) runs per voxel ----
-  const int gd = d0 + dwave;
-  const bool dok = gd < a.D;
-  const bool full = d0 + TD <= a.D && h0 + TH <= a.H && w0 + TW <= a.W;
-  const bool partial_out = a.ksplit > 1;        // split-K: fp32 partial tile to part[ks][n][voxel][cout_pad], no statistics
-  constexpr int NV = 16 * MB;                   // voxels per wave
-  auto stage_and_store = [&](auto* out_base, int out_stride, int q, bool want_stats, float* ex) {
-    using OT = typename std::remove_pointer<decltype(out_base)>::type;
-    constexpr int OEPG = 16 / (int)sizeof(OT);
-    constexpr int OS = 32 * (int)sizeof(OT) + 16;
-    char* ot = smem + wave * NV * OS;
+  if (a.ksplit > 1) {
+    // ---- split-K: this workgroup's fp32 partial tile goes to part[ks][n][voxel][cout_pad] ----
+    constexpr int OSF = 32 * 4 + 16;
+    char* otf = smem + wave * (32 * MB) * OSF;
+    const int gdz = d0 + dwave;
+    float* pout = a.part + ((long)(ks_id * a.N + n) * a.D * a.H * a.W) * a.cout_pad + ct * BN;
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      const int nb = 2 * q + h2;
-      float s = 0.f, ss = 0.f;
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
       for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int vw = m * 16 + rq * 4 + i;            // voxel within the wave: h = hbase + (vw >> 3), w = vw & 7
-          float v = acc[m][nb][i];
-          if (!full) {
-            const bool ok = dok && (h0 + hbase + (vw >> 3) < a.H) && (w0 + (vw & 7) < a.W);
-            v = ok ? v : 0.f;
-          }
-          s += v;
-          ss = fmaf(v, v, ss);
-          *(OT*)(ot + vw * OS + (h2 * 16 + c16) * (int)sizeof(OT)) = (OT)v;
-        }
-      if (want_stats) {
-        s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
-        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-        if (rq == 0) { ex[(wave * BN + nb * 16 + c16) * 2] = s; ex[(wave * BN + nb * 16 + c16) * 2 + 1] = ss; }
-      }
-    }
-    __syncthreads();
-    if (dok) {
-      constexpr int GPV = 32 / OEPG;            // 16-byte groups per voxel in this half
-      constexpr int VPI = 64 / GPV;
-      typedef OT OFrag __attribute__((ext_vector_type(OEPG)));
+        for (int i = 0; i < 16; ++i) *(float*)(otf + (m * 32 + acc_row(i, hh)) * OSF + r * 4) = acc[m][q][i];
+      __syncthreads();
+      if (gdz < a.D) {
 #pragma unroll
-      for (int it = 0; it < NV / VPI; ++it) {
-        const int v = it * VPI + lane / GPV, cg = lane % GPV;
-        const int gh = h0 + hbase + (v >> 3), gw = w0 + (v & 7);
-        if ((full || (gh < a.H && gw < a.W)) && (partial_out || ct * BN + q * 32 + cg * OEPG < a.Cout))
-          *(OFrag*)(out_base + (((long)gd * a.H + gh) * a.W + gw) * out_stride + q * 32 + cg * OEPG) =
-              *(const OFrag*)(ot + v * OS + cg * 16);
+        for (int it = 0; it < 4 * MB; ++it) {
+          const int v = it * 8 + (lane >> 3), cg = lane & 7;
+          const int gh = h0 + hbase + (v >> 3), gw = w0 + (v & 7);
+          if (gh < a.H && gw < a.W)
+            *(f32x4*)(pout + (((long)gdz * a.H + gh) * a.W + gw) * a.cout_pad + q * 32 + cg * 4) =
+                *(const f32x4*)(otf + v * OSF + cg * 16);
+        }
       }
+      if (q == 0) __syncthreads();
     }
-  };
-  if (partial_out) {
-    float* pout = a.part + ((long)(ks_id * a.N + n) * a.D * a.H * a.W) * a.cout_pad + ct * BN;
-    stage_and_store(pout, a.cout_pad, 0, false, (float*)nullptr);
-    __syncthreads();
-    stage_and_store(pout, a.cout_pad, 1, false, (float*)nullptr);
     return;
   }
-  float* ex = (float*)(smem + 4 * NV * (32 * 4 + 16));   // [4 waves][64 couts][2], behind the largest staging tile
+  // ---- epilogue, one 32-channel half at a time (fits fp32 too) ----
+  // Statistics are taken from the fp32 accumulators (sum x, sum x^2 per lane over its 32 voxels, then fp64);
+  // tiles that lie fully inside the volume -- all of them at 96/48/24^3 -- skip the per-voxel masks.
+  constexpr int OS = 32 * (int)sizeof(T) + 16;
+  char* ot = smem + wave * (32 * MB) * OS;
+  float* ex = (float*)(smem + 4 * (32 * MB) * OS);   // [4 waves][64 couts][2]
+  const int gd = d0 + dwave;
+  const bool dok = gd < a.D;
+  const bool full = d0 + TD <= a.D && h0 + TH <= a.H && w0 + TW <= a.W;
   T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
-  stage_and_store(yout, a.Cout_stride, 0, true, ex);
-  __syncthreads();               // staging tile is reused by the second half
-  stage_and_store(yout, a.Cout_stride, 1, true, ex);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int co = q * 32 + r;
+    float s = 0.f, ss = 0.f;
+    if (full) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[m][q][i];
+          s += v;
+          ss = fmaf(v, v, ss);
+          *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = (T)v;
+        }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int hl = hbase + 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
+          const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
+          const float v = ok ? acc[m][q][i] : 0.f;
+          s += v;
+          ss = fmaf(v, v, ss);
+          *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = (T)v;
+        }
+    }
+    s += __shfl_xor(s, 32);
+    ss += __shfl_xor(ss, 32);
+    if (hh == 0) { ex[(wave * BN + co) * 2] = s; ex[(wave * BN + co) * 2 + 1] = ss; }
+    __syncthreads();
+    if (dok) {
+      constexpr int GPV = 32 / EPG;            // 16-byte groups per voxel in this half
+      constexpr int VPI = 64 / GPV;
+#pragma unroll
+      for (int it = 0; it < (32 * MB) / VPI; ++it) {
+        const int v = it * VPI + lane / GPV, cg = lane % GPV;
+        const int gh = h0 + hbase + (v >> 3), gw = w0 + (v & 7);
+        if ((full || (gh < a.H && gw < a.W)) && ct * BN + q * 32 + cg * EPG < a.Cout)
+          *(Frag*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + q * 32 + cg * EPG) =
+              *(const Frag*)(ot + v * OS + cg * 16);
+      }
+    }
+    if (q == 0) __syncthreads();               // staging tile is reused by the second half
+  }
   if (wave == 0) {
     double S = 0, Q = 0;
 #pragma unroll
@@ -404,11 +382,11 @@ static int ensure_lds_attr() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DUA_ERR_ARG;
   if (done[dev]) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     c3::lds_main(4) + c3::XF_MAX);
+  hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     c3v2::LDS_MAIN + 3 * 4 * 1024);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)conv3d_k3_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            c3::lds_main(2) + c3::XF_MAX);
+    e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            c3v2::LDS_MAIN + 3 * 4 * 1024);
   if (e != hipSuccess) return (int)e;
   done[dev] = true;
   return 0;
@@ -419,7 +397,6 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
                         const dua_in_norm* in, void* y, double* stats, float* ws, long ws_bytes, hipStream_t s) {
   using namespace c3;
   constexpr int CK = KG * Elem<T>::EPG;
-  constexpr int TD = 4;
   Conv3Args a;
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
   a.xf = make_xform(in, d->Cin);
@@ -434,10 +411,9 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   a.cout_pad = nct * BN;
   a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = nullptr;
   if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
-  const long vox = (long)d->D * d->H * d->W;
-  if (vox * d->Cin_stride >= (1L << 31)) return DUA_ERR_ARG;       // per-sample element offsets are 32-bit in the kernel
   const int xf_bytes = in && in->stats ? 3 * 4 * a.nchunks * CK : 0;
   if (int e = ensure_lds_attr<T>()) return e;
+  const long vox = (long)d->D * d->H * d->W;
   if (ws != nullptr && g_conv_variant == 0) {
     int ks, ups;
     choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups);
@@ -448,12 +424,13 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     const int td2 = (d->D + 1) / 2;
     a.ntiles = td2 * a.tiles_h * a.tiles_w;
     dim3 grid2(a.ntiles, nct, d->N);
-    hipLaunchKernelGGL((conv3d_k3_kernel<T, 2>), grid2, dim3(256), lds_main(2) + xf_bytes, s, a);
+    constexpr int LDS2 = 4 * c3::HH * c3::RS + 2 * c3v2::SLAB;
+    hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2>), grid2, dim3(256), LDS2 + xf_bytes, s, a);
     return (int)hipGetLastError();
   }
   dim3 grid(a.ntiles, nct, d->N * a.ksplit);
-  hipLaunchKernelGGL((conv3d_k3_kernel<T, 4>), grid, dim3(256), lds_main(4) + xf_bytes, s, a);
   if (a.ksplit > 1) {
+    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
     if (g_skip_splitk_finish) return (int)hipGetLastError();
     const int G = a.cout_pad / 4 > 256 ? 256 : a.cout_pad / 4;       // channel groups handled per block pass
     if (a.cout_pad / 4 > 256) return DUA_ERR_ARG;
@@ -463,7 +440,9 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     dim3 fgrid((unsigned)((vox + (long)VL * ITER - 1) / ((long)VL * ITER)), d->N);
     hipLaunchKernelGGL(splitk_finish_kernel<T>, fgrid, dim3(256), 0, s, (const float*)ws, a.ksplit, d->N, vox, a.cout_pad,
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
+    return (int)hipGetLastError();
   }
+  hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
   return (int)hipGetLastError();
 }
 
@@ -486,7 +465,7 @@ long dua_conv3d_k3_workspace(const dua_conv3_desc* d) {
   if (!d || (d->dtype != DUA_F16 && d->dtype != DUA_F32)) return DUA_ERR_ARG;
   const int ck = 4 * (d->dtype == DUA_F16 ? 8 : 4);
   const int nch = (d->Cin + ck - 1) / ck, nct = (d->Cout + BN - 1) / BN;
-  const int tiles = ((d->D + 3) / 4) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
+  const int tiles = ((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
   int ks, ups;
   dua::choose_split(tiles * nct * d->N, nch * 3, &ks, &ups);
   return ks > 1 ? (long)ks * d->N * d->D * d->H * d->W * nct * BN * 4 : 0;

@@ -256,11 +256,14 @@ class Plan:
             ops.to_channels_last(e.detach().float().contiguous(), self.emb[l], 0, self.f[l])
         self.emb_token += 1
 
-    def denoiser_body(self):
+    def denoiser_body(self, zero_stats=True):
         """BasicUNetRDenoiser.forward from the staged input (self.xin) up to the raw output of the
-        last decoder block; self.cur_add must hold the embedding rows of this evaluation."""
+        last decoder block; self.cur_add must hold the embedding rows of this evaluation.  This method is the ONE
+        place the launch sequence is written down: called directly it launches kernel by kernel (instrumented
+        passes); under ops.recording it fills the op list dua_denoiser_step executes (native_step)."""
         f = self.f
-        self.den_stats.zero_()
+        if zero_stats:
+            self.den_stats.zero_()
         x, cin = self.xin, self.cin0
         for l in range(5):
             a, b = self.den[l]
@@ -309,6 +312,51 @@ class Plan:
         self.seed_word.fill_(int(seed) & (2 ** 63 - 1))
         return seed
 
+    # ---- the evaluation as one C-ABI call -------------------------------------------------------------------
+    def native_step(self, mode, rows_per_sample=None, row_of_step=None, coef_table=None, noise=None, logits=None,
+                    xstart=None, use_sum=False):
+        """step begin + denoiser + tail through dua_denoiser_step (include/dua_hip.h).  The op list is recorded from
+        denoiser_body once per weight packing; per call only the step's rows / noise / outputs are filled in."""
+        if getattr(self, "_step_ops_version", None) != self.weights_version:
+            rec = []
+            with ops.recording(rec):
+                last = self.denoiser_body(zero_stats=False)
+            self._step_ops = (nv.StepOp * len(rec))(*rec)
+            self._step_last = last
+            self._step_ops_version = self.weights_version
+        last = self._step_last
+        tnorm = self._norm(last, 0)
+        tn = tnorm.c
+        N, vox = self.N, self.dims[0] * self.dims[1] * self.dims[2]
+        ptr = lambda t: t.data_ptr() if t is not None else None          # noqa: E731
+        sampling = mode != nv.MODE_LOGITS
+        if noise is not None:
+            assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous() and noise.numel() == N * self.C * vox
+        for t in (logits, xstart):
+            if t is not None:
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == N * self.C * vox
+        nsteps = 0
+        if rows_per_sample is not None:
+            assert rows_per_sample.dtype == torch.int32 and rows_per_sample.numel() == N and rows_per_sample.is_cuda
+        else:
+            assert row_of_step is not None and row_of_step.dtype == torch.int32 and coef_table is not None
+            nsteps = row_of_step.numel()
+            assert coef_table.numel() >= 8 * nsteps
+        tail = nv.TailDesc(nv.dt_code(self.dtype), N, vox, last.cout, self.uB[0].shape[-1], self.C, self.cx, mode,
+                           self.xin.shape[-1] if sampling else 0, 0, self.seed_word.data_ptr())
+        p = nv.DenoiserPlan(
+            N, self.P, self.temb_table.data_ptr(), self.temb_table.shape[0], ptr(rows_per_sample),
+            ptr(row_of_step), nsteps, ptr(coef_table), self.counter.data_ptr(),
+            self.cur_add.data_ptr(), self.cur_coef.data_ptr(), self.step_word.data_ptr(), self.err_word.data_ptr(),
+            self.den_stats.data_ptr(), self.den_stats.numel() * 8,
+            self._step_ops, len(self._step_ops), self.splitk_ws.data_ptr(), self.splitk_ws.numel() * 4,
+            tail, self.uB[0].data_ptr(), nv.InNorm(tn.stats, tn.gamma, tn.beta, tn.add, tn.add_stride, tn.c_pad, tn.inv_count, tn.eps, tn.slope),
+            self.wf.data_ptr(), self.bf.data_ptr(), self.x_state.data_ptr(), ptr(noise),
+            self.xin.data_ptr() if sampling else None, self.x_sum.data_ptr() if (use_sum and sampling) else None,
+            ptr(logits), ptr(xstart))
+        self._step_keep = (p, noise, logits, xstart, rows_per_sample, row_of_step, coef_table)
+        ops.denoiser_step(p)
+
     # ---- public operations ------------------------------------------------------------------------
     def denoise(self, x, t):
         """logits = model(x, t, image, embeddings) for already-encoded image (denoiser.py:284-312)."""
@@ -323,10 +371,8 @@ class Plan:
         rows = t.detach().to(device=self.dev, dtype=torch.int32).contiguous()
         if not on_host:
             self.err_word.zero_()
-        ops.step_begin(N, self.temb_table, self.cur_add, rows_per_sample=rows, err_word=self.err_word)
-        self.denoiser_body()
         out = torch.empty((N, self.C, *self.dims), dtype=torch.float32, device=self.dev)
-        self.tail(nv.MODE_LOGITS, logits=out)
+        self.native_step(nv.MODE_LOGITS, rows_per_sample=rows, logits=out)
         if not on_host and int(self.err_word.item()):     # device-resident t: the kernel clamped it, say so
             raise ValueError(f"timestep out of range: the model was built for 0 <= t < {T}")
         return out
@@ -367,11 +413,7 @@ class Plan:
             use_graph = False
 
         def one_step(eps):
-            ops.step_begin(N, self.temb_table, self.cur_add, row_of_step=row_of_step, counter=self.counter,
-                           coef_table=coef_table, cur_coef=self.cur_coef, step_word=self.step_word,
-                           err_word=self.err_word)
-            self.denoiser_body()
-            self.tail(mode, noise=eps, use_sum=True)
+            self.native_step(mode, row_of_step=row_of_step, coef_table=coef_table, noise=eps, use_sum=True)
 
         if not use_graph:
             for k in range(T):

@@ -106,10 +106,11 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
 
 def sharded_sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int, predictor: Callable,
                                      overlap: float = 0.25, group=None, gather_dtype: torch.dtype = None,
-                                     **kwargs) -> torch.Tensor:
+                                     timings: dict = None, **kwargs) -> torch.Tensor:
     """One process per GPU: windows dealt round-robin over the ranks of ``group``, one all-gather of the
     per-window outputs (fp32, or ``gather_dtype`` to halve the xGMI bytes), identical blend on every rank.
-    ``inputs`` must be the same on all ranks."""
+    ``inputs`` must be the same on all ranks.  ``timings`` (optional dict): accumulates the wall time of the
+    collective under "all_gather_s" (device synchronised around it) and records "gathered_bytes"."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     spatial, roi, padded, pad, starts = _plan(inputs, roi_size, overlap)
@@ -129,7 +130,17 @@ def sharded_sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_si
         probe = predictor(_window(x, 0, nwin, starts, roi), **kwargs)
         local = torch.zeros((per_rank, *probe.shape[1:]), dtype=gather_dtype or probe.dtype, device=probe.device)
     flat = torch.empty((world * per_rank, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    if timings is not None:
+        import time
+        if local.is_cuda:
+            torch.cuda.synchronize(local.device)
+        t0 = time.perf_counter()
     dist.all_gather_into_tensor(flat, local, group=group)
+    if timings is not None:
+        if local.is_cuda:
+            torch.cuda.synchronize(local.device)
+        timings["all_gather_s"] = timings.get("all_gather_s", 0.0) + time.perf_counter() - t0
+        timings["gathered_bytes"] = flat.numel() * flat.element_size()
     gathered = flat.view(world, per_rank, *local.shape[1:])
     results = []
     for r in range(world):

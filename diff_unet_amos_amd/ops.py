@@ -14,6 +14,41 @@ import torch
 from . import _native as nv
 
 
+# When a list is installed here (engine.Plan building its dua_denoiser_plan), conv3d_k3 / materialize / deconv_k2s2
+# validate their arguments as usual but APPEND a filled nv.StepOp instead of launching: the launch sequence is written
+# once, in Python, and executed by dua_denoiser_step.
+_RECORD = None
+
+
+class recording:
+    def __init__(self, sink):
+        self.sink = sink
+
+    def __enter__(self):
+        global _RECORD
+        assert _RECORD is None
+        _RECORD = self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        global _RECORD
+        _RECORD = None
+        return False
+
+
+def _norm_value(norm, N, Cc):
+    """(has_norm, nv.InNorm by value) for a StepOp."""
+    if norm is None:
+        return 0, nv.InNorm()
+    norm.ref(N, Cc)
+    c = norm.c
+    return 1, nv.InNorm(c.stats, c.gamma, c.beta, c.add, c.add_stride, c.c_pad, c.inv_count, c.eps, c.slope)
+
+
+def _addr(t):
+    return t.data_ptr() if t is not None else None
+
+
 def _cl_check(t, name):
     assert t.is_cuda and t.is_contiguous() and t.dim() == 5, f"{name}: need a contiguous channels-last [N,D,H,W,C] device tensor"
     assert t.shape[-1] % 8 == 0, f"{name}: channel stride must be a multiple of 8"
@@ -163,6 +198,11 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
     assert bias_pad.numel() == nct * 64 and bias_pad.dtype == torch.float32
     assert out_stats.dtype == torch.float64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, nct * 64, 2)
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
+    if _RECORD is not None:
+        has, nval = _norm_value(norm, N, cin)
+        _RECORD.append(nv.StepOp(nv.OP_CONV3, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),
+                                 _addr(y), _addr(out_stats), None, None))
+        return
     ws_bytes = 0
     if workspace is not None:
         assert workspace.is_cuda and workspace.is_contiguous()
@@ -385,6 +425,11 @@ def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None):
         assert tuple(pooled.shape[:4]) == (N, D // 2, H // 2, W // 2) and pooled.dtype == raw.dtype and pooled.shape[-1] >= Cc
         ps = pooled.shape[-1]
     d = nv.MaterializeDesc(nv.dt_code(raw.dtype), N, D, H, W, Cc, rs, es, out.shape[-1], out_off, ps)
+    if _RECORD is not None:
+        has, nval = _norm_value(norm, N, Cc)
+        _RECORD.append(nv.StepOp(nv.OP_MATERIALIZE, has, nv.Conv3Desc(), d, nval, _addr(raw), None, None, _addr(out), None,
+                                 _addr(emb), _addr(pooled)))
+        return
     nv.check(nv.lib().dua_materialize(C.byref(d), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(emb), nv.ptr(out),
                                       nv.ptr(pooled), nv.stream_ptr()), "dua_materialize")
 
@@ -401,6 +446,11 @@ def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=Non
     assert nch * ck <= 1024
     assert w_packed.numel() == 8 * nct * nch * 4 * 64 * 16 and bias_pad.numel() == nct * 64
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
+    if _RECORD is not None:
+        has, nval = _norm_value(norm, N, cin)
+        _RECORD.append(nv.StepOp(nv.OP_DECONV, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),
+                                 _addr(y), None, None, None))
+        return
     nv.check(nv.lib().dua_deconv_k2s2_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),
                                           nv.ptr(y), nv.stream_ptr()), "dua_deconv_k2s2_fwd")
 
@@ -510,3 +560,8 @@ def step_begin(N, table, cur_add, rows_per_sample=None, row_of_step=None, counte
     nv.check(nv.lib().dua_step_begin(N, P, nv.ptr(table), T, nv.ptr(rows_per_sample), nv.ptr(row_of_step), nsteps,
                                      nv.ptr(coef_table), nv.ptr(counter), nv.ptr(cur_add), nv.ptr(cur_coef),
                                      nv.ptr(step_word), nv.ptr(err_word), nv.stream_ptr()), "dua_step_begin")
+
+
+def denoiser_step(plan_struct):
+    """dua_denoiser_step: the whole evaluation + tail described by an nv.DenoiserPlan, on the current stream."""
+    nv.check(nv.lib().dua_denoiser_step(C.byref(plan_struct), nv.stream_ptr()), "dua_denoiser_step")

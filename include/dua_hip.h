@@ -252,6 +252,52 @@ int dua_step_begin(int N, int P, const float* table, int table_rows, const int* 
                    int nsteps, const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
                    int* err_word, void* stream);
 
+/* ---- one denoiser evaluation as ONE entry point -----------------------------------------------------------------
+ * BasicUNetRDenoiser.forward (models/basic_unet/denoiser.py:284-312) + the sampler update that consumes it
+ * (guided_diffusion/gaussian_diffusion.py:395-439 / 537-586; models/diffusion/diffusion.py:94-98), i.e. the loop body
+ * of p_sample_loop_progressive / ddim_sample_loop_progressive (gaussian_diffusion.py:487-535, 667-716) for the HIP
+ * denoiser: step begin -> zero the statistics arena -> the fixed sequence of convolution / materialise /
+ * transposed-convolution launches -> fused final_conv + sampler tail.  The caller describes the sequence once (the
+ * buffers are resident, only the step's rows / noise / outputs change) and may capture the call into a hipGraph and
+ * replay it per step.  Enqueues on `stream`, never allocates, never synchronises; the first failing launch's code is
+ * returned. */
+#define DUA_OP_CONV3 1        /* dua_conv3d_k3_fwd(conv, x, w, bias, norm?, y, stats, workspace) */
+#define DUA_OP_MATERIALIZE 2  /* dua_materialize(mat, raw = x, norm, emb, out = y, pooled) */
+#define DUA_OP_DECONV 3       /* dua_deconv_k2s2_fwd(conv, x, w, bias, norm?, y) */
+typedef struct {
+  int kind;                /* DUA_OP_* */
+  int has_norm;            /* norm below describes the producer of x (fused InstanceNorm + LeakyReLU + add) */
+  dua_conv3_desc conv;
+  dua_materialize_desc mat;
+  dua_in_norm norm;
+  const void* x;           /* input (raw tensor for MATERIALIZE) */
+  const void* w;           /* packed weights (CONV3 / DECONV) */
+  const float* bias;       /* padded bias (CONV3 / DECONV) */
+  void* y;                 /* output */
+  double* stats;           /* CONV3: this layer's statistics rows inside the arena */
+  const void* emb;         /* MATERIALIZE: encoder feature map added after the activation, or NULL */
+  void* pooled;            /* MATERIALIZE: MaxPool3d(2) output, or NULL */
+} dua_step_op;
+
+typedef struct {
+  int N, P;                         /* batch; length of one timestep-embedding row */
+  /* step begin (dua_step_begin) */
+  const float* temb_table; int table_rows;
+  const int* rows_per_sample;       /* "denoise": one row per sample ... */
+  const int* row_of_step; int nsteps; const float* coef_table; int* counter;   /* ... or the sampling loop's tables */
+  float* cur_add; float* cur_coef; int* step_word; int* err_word;
+  /* statistics arena of all CONV3 ops, zeroed at the start of the evaluation */
+  double* stat_arena; long stat_bytes;
+  /* the launch sequence */
+  const dua_step_op* ops; int n_ops;
+  void* workspace; long workspace_bytes;     /* split-K scratch shared by the CONV3 ops */
+  /* tail (dua_final_conv_sampler) */
+  dua_tail_desc tail; const void* tail_raw; dua_in_norm tail_norm; const float* wf; const float* bf;
+  float* x_state; const float* noise; void* xin; float* xstart_sum; float* logits; float* xstart;
+} dua_denoiser_plan;
+
+int dua_denoiser_step(const dua_denoiser_plan* plan, void* stream);
+
 /* ---- layout / packing at the API boundary -------------------------------------------------- */
 /* nn.ConvTranspose3d weight fp32[Cin][Cout][2][2][2] -> [tap][cout_tile][chunk][k-group][64][16 B].
  * Returns bytes needed when w_packed is NULL. */

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """A/B timing of conv3d_k3 variants on the layer shapes of the 96^3 x 16-class denoiser
-(interleaved rounds in one process, HIP events on the launch stream)."""
+(interleaved rounds in one process, HIP events on the launch stream).
+usage: bench_conv.py <variants> [shape indices] [rounds]
+  variants: comma list of dua_set_option(1, v) values for this build, and/or "lib:<path>" = the same entry point of ANOTHER
+  build of libdua_hip.so loaded beside it (same-box, same-process comparison of two kernel generations; box-to-box
+  spread is +-10 %, so nothing else ranks two builds)."""
+import ctypes
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,12 +21,21 @@ SHAPES = [  # (S, Cin, Cout, fused prologue)
 
 
 def main():
-    variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "2"])]
+    variants = [v if v.startswith("lib:") else int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
+    main_lib = nv.lib()
+    alts = {}
+    for v in variants:
+        if isinstance(v, str):
+            L = ctypes.CDLL(os.path.abspath(v[4:]))
+            for name in ("dua_conv3d_k3_fwd", "dua_set_option"):
+                fn = getattr(L, name)
+                fn.restype, fn.argtypes = nv._SIGS[name]
+            alts[v] = L
     only = [int(i) for i in sys.argv[2].split(",")] if len(sys.argv) > 2 else None
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     dt = torch.float16
     dev = "cuda"
-    print(f"{'shape':>22} " + " ".join(f"{'v%d us' % v:>9} {'TF':>7}" for v in variants))
+    print(f"{'shape':>22} " + " ".join(f"{(os.path.basename(v)[-12:] if isinstance(v, str) else 'v%d' % v) + ' us':>15} {'TF':>7}" for v in variants))
     for idx, (S, cin, cout, fused) in enumerate(SHAPES):
         if only is not None and idx not in only:
             continue
@@ -41,7 +55,11 @@ def main():
         res = {v: [] for v in variants}
         for rd in range(rounds + 1):
             for v in variants:
-                nv.check(nv.lib().dua_set_option(1, v), "opt")
+                if isinstance(v, str):
+                    nv._lib = alts[v]
+                else:
+                    nv._lib = main_lib
+                    nv.check(main_lib.dua_set_option(1, v), "opt")
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
@@ -54,7 +72,8 @@ def main():
         out = []
         for v in variants:
             us = sorted(res[v])[len(res[v]) // 2]
-            out.append(f"{us:9.1f} {fl / us / 1e6:7.1f}")
+            out.append(f"{us:15.1f} {fl / us / 1e6:7.1f}")
+        nv._lib = main_lib
         print(f"{S:>3}^3 {cin:>4}->{cout:<4} {'fused' if fused else '     '} " + " ".join(out), flush=True)
 
 

@@ -26,7 +26,7 @@ class NativeLibraryMissing(RuntimeError):
 class Conv3Desc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("Cin", C.c_int), ("Cin_stride", C.c_int), ("Cin_off", C.c_int),
-                ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int)]
+                ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int), ("tap_channel_plus1", C.c_int)]
 
 
 class InNorm(C.Structure):
@@ -92,6 +92,7 @@ _SIGS = {
     "dua_conv3d_k3_wgrad_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_wgrad": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.c_int, _P, _P, C.c_long, _P]),
     "dua_pack_conv3_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "dua_pack_conv3_weights_tap": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "dua_pack_conv3_weights_dgrad": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_instnorm_finalize": (C.c_int, [C.c_int, C.c_int, C.POINTER(InNorm), _P, _P, _P]),
     "dua_instnorm_bwd_reduce": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P]),

@@ -14,6 +14,7 @@ struct Conv3Args {
   int nchunks, ntiles, tiles_h, tiles_w, cout_pad;
   int ksplit, units_per_split;      // split-K over (chunk, kd) units; partial tiles go to `part` in fp32
   float* part;
+  int tap_ch;                       // single-channel tap form: packed index of that channel, else -1
 };
 
 }  // namespace dua

@@ -59,7 +59,14 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 
 // TDP = tile depth: 4 (4x8x8 voxels, wave = depth slice, two 32-row blocks per wave) or 2 (2x8x8 voxels, wave =
 // (depth slice, h half), one block per wave) -- the small tile doubles the workgroup count of the 24^3 layers.
-template <typename T, int TDP = 4>
+// NKS = k-steps of 16 channels taken per tap and chunk (2 = the whole 32-channel chunk).  NKS < 2 is the SINGLE-CHANNEL
+// TAP form for first layers (fp16, one Cin chunk): the packed input holds 16 * NKS ordinary channels followed by ONE
+// more real channel (the conditioning image of DiffUNet: torch.cat([image, x]) at models/basic_unet/denoiser.py:298; the
+// encoder's only input channel) and zero padding.  Contracting that channel as part of a padded 16-wide k-step spends
+// 27 MFMA k-steps on one channel; here its 27 taps are gathered from the halo into a [voxel][32] tile (im2col of one
+// channel) and contracted in TWO k-steps against a [32 taps][64 couts] weight block that dua_pack_conv3_weights_tap
+// appends to the packed weights: 27 + 2 k-steps per tile instead of 54 for DiffUNet's 17-channel first layer.
+template <typename T, int TDP = 4, int NKS = 2>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   using namespace c3v2;
   constexpr int TD = TDP, HD = TDP + 2, MB = TDP / 2;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   // ---- work range: units u = chunk * 3 + kd, three (kd, kh) slabs each ----
   const int ks_id = blockIdx.z / a.N;
   const int u0 = ks_id * a.units_per_split;
-  const int u1 = min(a.nchunks * 3, u0 + a.units_per_split);
+  const int u1 = NKS == 0 ? u0 : min(a.nchunks * 3, u0 + a.units_per_split);   // NKS 0: the tap channel is the whole input
   const int g0 = u0 * 3, g1 = u1 * 3;
 
   // ---- prologue ----
@@ -169,6 +176,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   }
   store_slab(g0, 0);
   store_halo(u0 / 3);
+  if constexpr (NKS < 2) {       // tap block of this cout tile: [4 k-groups of 8 taps][64 couts][16 B], behind the slabs
+    const char* wt = (const char*)a.w + (long)gridDim.y * a.nchunks * 9 * SLAB + (long)ct * 4096;
+    *(f32x4*)(smem + LDS_MAIN + tid * 16) = *(const f32x4*)(wt + tid * 16);
+  }
   __syncthreads();
 
   const int a_base = dwave * PS + (hbase + (r >> 3)) * RS + (r & 7) * VS + hh * 16;
@@ -186,27 +197,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
       if (kh == 0 && next_chunk) load_halo(u / 3 + 1);
       const char* ap = halo + a_base + kd * PS + kh * RS;
       const char* wb = wbuf + (g & 1) * SLAB + b_base;
-      // six k-steps (kw x ks); fragments of step t+1 are in flight while the MFMAs of step t issue
-      Frag fa0[2], fa1[2], fb0[2], fb1[2];
-      auto ld = [&](int t, int b) {
-        const int kw = t >> 1, ks = t & 1;
-        fa0[b] = *(const Frag*)(ap + kw * VS + ks * 32);
-        fb0[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16);
-        fb1[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16 + 32 * 16);
-        if (MB == 2) fa1[b] = *(const Frag*)(ap + 4 * RS + kw * VS + ks * 32);
-      };
-      ld(0, 0);
+      // 3 * NKS k-steps (kw x ks); fragments of step t+1 are in flight while the MFMAs of step t issue
+      if constexpr (NKS > 0) {
+        constexpr int NT = 3 * NKS;
+        Frag fa0[2], fa1[2], fb0[2], fb1[2];
+        auto ld = [&](int t, int b) {
+          const int kw = t / NKS, ks = t % NKS;
+          fa0[b] = *(const Frag*)(ap + kw * VS + ks * 32);
+          fb0[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16);
+          fb1[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16 + 32 * 16);
+          if (MB == 2) fa1[b] = *(const Frag*)(ap + 4 * RS + kw * VS + ks * 32);
+        };
+        ld(0, 0);
 #pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        if (t + 1 < 6) ld(t + 1, (t + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
-        mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
-        mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
-        if constexpr (MB == 2) {
-          mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
-          mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
+        for (int t = 0; t < NT; ++t) {
+          if (t + 1 < NT) ld(t + 1, (t + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
+          mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
+          mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
+          if constexpr (MB == 2) {
+            mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
+            mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();   // next slab visible and everyone is done with this one
     }
@@ -214,6 +228,42 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
       store_halo(u / 3 + 1);
       __syncthreads();
     }
+  }
+  if constexpr (NKS < 2) {
+    // ---- the tap channel: im2col of ONE input channel into the (now free) weight buffers, then two k-steps ----
+    // thread tid <-> output voxel (d = tid >> 6, h = (tid >> 3) & 7, w = tid & 7) = MFMA row (tid & 31) of block
+    // (tid >> 5) & 1 of wave tid >> 6: row = [27 taps | 5 zeros] fp16, 64 B + 16 B pad (80-byte stride: the 16-lane
+    // groups of ds_read_b128 then touch 16 different 16-byte slots).
+    constexpr int IS = 80;
+    static_assert(sizeof(T) == 2 && TDP == 4, "the tap form is fp16, 4x8x8 tiles");
+    const char* hp = halo + (tid >> 6) * PS + ((tid >> 3) & 7) * RS + (tid & 7) * VS + a.tap_ch * 2;
+    f16 tv[32];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) tv[t] = *(const f16*)(hp + (t / 9) * PS + ((t / 3) % 3) * RS + (t % 3) * VS);
+#pragma unroll
+    for (int t = 27; t < 32; ++t) tv[t] = (f16)0.f;
+    char* im = wbuf + tid * IS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = tv[g * 8 + e];
+      *(f16x8*)(im + g * 16) = o;
+    }
+    __syncthreads();
+    const char* wt = smem + LDS_MAIN;
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const f16x8 b0 = *(const f16x8*)(wt + ((2 * sidx + hh) * BN + r) * 16);
+      const f16x8 b1 = *(const f16x8*)(wt + ((2 * sidx + hh) * BN + 32 + r) * 16);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const f16x8 av = *(const f16x8*)(wbuf + (wave * 64 + m * 32 + r) * IS + (2 * sidx + hh) * 16);
+        mma32(acc[m][0], av, b0);
+        mma32(acc[m][1], av, b1);
+      }
+    }
+    __syncthreads();     // the epilogue's staging tile reuses the halo; nobody may still be gathering from it
   }
   if (a.ksplit > 1) {
     // ---- split-K: this workgroup's fp32 partial tile goes to part[ks][n][voxel][cout_pad] ----
@@ -384,6 +434,12 @@ static int ensure_lds_attr() {
   if (done[dev]) return 0;
   hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      c3v2::LDS_MAIN + 3 * 4 * 1024);
+  if constexpr (sizeof(T) == 2) {
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 4096);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 4096);
+  }
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             c3v2::LDS_MAIN + 3 * 4 * 1024);
@@ -409,11 +465,24 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   a.ntiles = td * a.tiles_h * a.tiles_w;
   const int nct = (d->Cout + BN - 1) / BN;
   a.cout_pad = nct * BN;
-  a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = nullptr;
+  a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = nullptr; a.tap_ch = -1;
   if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
   const int xf_bytes = in && in->stats ? 3 * 4 * a.nchunks * CK : 0;
   if (int e = ensure_lds_attr<T>()) return e;
   const long vox = (long)d->D * d->H * d->W;
+  if (d->tap_channel_plus1 > 0) {
+    // single-channel tap form (see the kernel): fp16, one Cin chunk, no fused input transform, 16 * NKS ordinary
+    // channels in front of the tap channel, zero padding behind it; weights from dua_pack_conv3_weights_tap
+    a.tap_ch = d->tap_channel_plus1 - 1;
+    if constexpr (sizeof(T) != 2) return DUA_ERR_ARG;
+    else {
+      if (a.nchunks != 1 || (in && in->stats) || (a.tap_ch != 0 && a.tap_ch != 16) || d->Cin != a.tap_ch + 8) return DUA_ERR_ARG;
+      dim3 grid(a.ntiles, nct, d->N);
+      if (a.tap_ch == 16) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 1>), grid, dim3(256), c3v2::LDS_MAIN + 4096, s, a);
+      else hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 0>), grid, dim3(256), c3v2::LDS_MAIN + 4096, s, a);
+      return (int)hipGetLastError();
+    }
+  }
   if (ws != nullptr && g_conv_variant == 0) {
     int ks, ups;
     choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups);

@@ -10,9 +10,11 @@
 namespace dua {
 
 // ---- conv3 weights: [Cout][Cin_src][27] fp32 -> [ct][chunk][kd][t9][kg][64][EPG] ----
+// zero_cp: packed input channel whose slab weights are forced to zero (the single-channel tap form keeps that channel's
+// weights in its own block), or -1.
 template <typename T>
 __global__ void pack_conv3_kernel(int Cout, int Cin_src, int nchunks, const float* __restrict__ w,
-                                  const int* __restrict__ perm, T* __restrict__ out, long total) {
+                                  const int* __restrict__ perm, T* __restrict__ out, long total, int zero_cp) {
   constexpr int EPG = Elem<T>::EPG;
   constexpr int CK = 4 * EPG;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -27,7 +29,19 @@ __global__ void pack_conv3_kernel(int Cout, int Cin_src, int nchunks, const floa
     const int cp = ch * CK + kg * EPG + e;            // packed input channel
     const int ci = perm ? perm[cp] : cp;
     float v = 0.f;
-    if (co < Cout && ci >= 0 && ci < Cin_src) v = w[((long)co * Cin_src + ci) * 27 + kd * 9 + t9];
+    if (co < Cout && ci >= 0 && ci < Cin_src && cp != zero_cp) v = w[((long)co * Cin_src + ci) * 27 + kd * 9 + t9];
+    out[i] = (T)v;
+  }
+}
+
+// ---- single-channel tap block: [ct][4 groups of 8 taps][64 couts][8] = w[co][ci][tap], taps 27..31 zero ----
+template <typename T>
+__global__ void pack_conv3_tap_kernel(int Cout, int Cin_src, int ci, const float* __restrict__ w, T* __restrict__ out, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int e = (int)(i % 8), co_l = (int)((i / 8) % 64), g = (int)((i / 512) % 4), ct = (int)(i / 2048);
+    const int co = ct * 64 + co_l, tap = g * 8 + e;
+    float v = 0.f;
+    if (co < Cout && tap < 27 && ci >= 0 && ci < Cin_src) v = w[((long)co * Cin_src + ci) * 27 + tap];
     out[i] = (T)v;
   }
 }
@@ -108,22 +122,42 @@ static inline unsigned nblocks(long total) {
 
 extern "C" {
 
+static long pack_conv3_common(int dtype, int Cout, int Cin_src, int Cin_packed, int tap_channel, const float* w,
+                              const int* in_perm, int tap_src, void* w_packed, void* stream);
+
 long dua_pack_conv3_weights(int dtype, int Cout, int Cin_src, int Cin_packed, const float* w, const int* in_perm,
                             void* w_packed, void* stream) {
+  return pack_conv3_common(dtype, Cout, Cin_src, Cin_packed, -1, w, in_perm, -1, w_packed, stream);
+}
+
+long dua_pack_conv3_weights_tap(int dtype, int Cout, int Cin_src, int Cin_packed, int tap_channel, int tap_src_channel,
+                                const float* w, const int* in_perm, void* w_packed, void* stream) {
+  if (dtype != DUA_F16 || Cin_packed > 32 || tap_channel < 0 || tap_channel >= Cin_packed || tap_src_channel < 0 ||
+      tap_src_channel >= Cin_src)
+    return DUA_ERR_ARG;
+  return pack_conv3_common(dtype, Cout, Cin_src, Cin_packed, tap_channel, w, in_perm, tap_src_channel, w_packed, stream);
+}
+
+static long pack_conv3_common(int dtype, int Cout, int Cin_src, int Cin_packed, int tap_channel, const float* w,
+                              const int* in_perm, int tap_src, void* w_packed, void* stream) {
   const int epg = dtype == DUA_F16 ? 8 : 4, ck = 4 * epg;
   if ((dtype != DUA_F16 && dtype != DUA_F32) || Cout <= 0 || Cin_src <= 0 || Cin_packed <= 0) return DUA_ERR_ARG;
   const int nchunks = (Cin_packed + ck - 1) / ck, nct = (Cout + 63) / 64;
   const long total = (long)nct * nchunks * 27 * 4 * 64 * epg;
-  const long bytes = total * (dtype == DUA_F16 ? 2 : 4);
+  const long tap_total = tap_channel >= 0 ? (long)nct * 4 * 64 * 8 : 0;
+  const long bytes = (total + tap_total) * (dtype == DUA_F16 ? 2 : 4);
   if (!w_packed) return bytes;
   if (!w) return DUA_ERR_ARG;
+  if (tap_channel >= 0)
+    hipLaunchKernelGGL(dua::pack_conv3_tap_kernel<dua::f16>, dim3(dua::nblocks(tap_total)), dim3(256), 0, (hipStream_t)stream,
+                       Cout, Cin_src, tap_src, w, (dua::f16*)w_packed + total, tap_total);
   // in_perm must cover nchunks*ck entries when given
   if (dtype == DUA_F16)
     hipLaunchKernelGGL(dua::pack_conv3_kernel<dua::f16>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
-                       Cout, Cin_src, nchunks, w, in_perm, (dua::f16*)w_packed, total);
+                       Cout, Cin_src, nchunks, w, in_perm, (dua::f16*)w_packed, total, tap_channel);
   else
     hipLaunchKernelGGL(dua::pack_conv3_kernel<float>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
-                       Cout, Cin_src, nchunks, w, in_perm, (float*)w_packed, total);
+                       Cout, Cin_src, nchunks, w, in_perm, (float*)w_packed, total, tap_channel);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? bytes : -(long)e;
 }

@@ -101,9 +101,11 @@ class Plan:
         self.tables = {}
 
     # ---- parameter binding -------------------------------------------------------------------
-    def _mk(self, name, block, cin_packed=None, perm=None):
+    def _mk(self, name, block, cin_packed=None, perm=None, tap=None):
         c = _Conv()
         c.name = name
+        # single-channel tap form of the first layers (fp16 only; ops.conv3d_k3): packed index of the lone image channel
+        c.tap = tap if (tap in (0, 16) and self.dtype == torch.float16 and cin_packed == (tap or 0) + 8) else None
         c.w, c.b = block.conv.weight, block.conv.bias
         c.gamma, c.beta = block.adn.N.weight, block.adn.N.bias
         c.cout, c.cin = c.w.shape[0], c.w.shape[1]
@@ -134,13 +136,13 @@ class Plan:
     def _bind(self):
         net = self.net
         enc, den = net.embed_model, net.model
-        self.enc = [(self._mk("e0a", enc.conv_0.conv_0, cin_packed=8, perm=[0] + [-1] * 7), self._mk("e0b", enc.conv_0.conv_1))]
+        self.enc = [(self._mk("e0a", enc.conv_0.conv_0, cin_packed=8, perm=[0] + [-1] * 7, tap=0), self._mk("e0b", enc.conv_0.conv_1))]
         for i in range(4):
             tc = enc.down[i].convs
             self.enc.append((self._mk(f"e{i+1}a", tc.conv_0), self._mk(f"e{i+1}b", tc.conv_1)))
         C = self.C
         perm0 = list(range(1, C + 1)) + [0] + [-1] * (self.cin0 - C - 1)   # packed [x_t | image | pad] -> source [image | x_t]
-        self.den = [(self._mk("d0a", den.conv_0.conv_0, cin_packed=self.cin0, perm=perm0), self._mk("d0b", den.conv_0.conv_1))]
+        self.den = [(self._mk("d0a", den.conv_0.conv_0, cin_packed=self.cin0, perm=perm0, tap=C), self._mk("d0b", den.conv_0.conv_1))]
         for i, blk in enumerate((den.down_1, den.down_2, den.down_3, den.down_4)):
             self.den.append((self._mk(f"d{i+1}a", blk.convs.conv_0), self._mk(f"d{i+1}b", blk.convs.conv_1)))
         ups = (den.upcat_1, den.upcat_2, den.upcat_3, den.upcat_4)          # index = level the block outputs at
@@ -174,7 +176,7 @@ class Plan:
             for pair in self.enc + self.den + self.dec:
                 for c in pair:
                     c.wp, c.bp = ops.pack_conv3_weights(c.w.detach().float().contiguous(), c.b.detach(), dt,
-                                                        cin_packed=c.cin_packed, perm=c.perm)
+                                                        cin_packed=c.cin_packed, perm=c.perm, tap_channel=c.tap)
                     c.gamma_c = c.gamma.detach().float().contiguous()
                     c.beta_c = c.beta.detach().float().contiguous()
                     c.norm = c.norm_add = None       # rebuilt lazily against the new gamma/beta
@@ -214,7 +216,7 @@ class Plan:
 
     def _conv(self, c, x, cin, y, level, xform_from=None, add_key=None):
         norm = None if xform_from is None else self._norm(xform_from, level, add_key)
-        ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, c.stats, norm=norm, workspace=self.splitk_ws)
+        ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, c.stats, norm=norm, workspace=self.splitk_ws, tap_channel=c.tap)
 
     def run_encoder(self, image):
         """BasicUNetEncoder.forward: fills self.emb[0..4] (channels-last)."""

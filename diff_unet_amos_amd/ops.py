@@ -84,8 +84,9 @@ def from_channels_last(src, C_, c_off=0, out=None):
     return out
 
 
-def pack_conv3_weights(w, bias, dtype, cin_packed=None, perm=None):
-    """nn.Conv3d parameters -> (packed weights as a byte tensor, bias padded to a multiple of 64)."""
+def pack_conv3_weights(w, bias, dtype, cin_packed=None, perm=None, tap_channel=None):
+    """nn.Conv3d parameters -> (packed weights as a byte tensor, bias padded to a multiple of 64).
+    ``tap_channel``: packed index of the channel handled by conv3d_k3(tap_channel=...) (single-channel tap form)."""
     assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
     w = w.contiguous()
     cout, cin = w.shape[:2]
@@ -98,10 +99,19 @@ def pack_conv3_weights(w, bias, dtype, cin_packed=None, perm=None):
         perm_t = torch.tensor(p, dtype=torch.int32, device=w.device)
     L = nv.lib()
     code = nv.dt_code(dtype)
-    nbytes = L.dua_pack_conv3_weights(code, cout, cin, cin_packed, None, None, None, None)
-    assert nbytes > 0
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    rc = L.dua_pack_conv3_weights(code, cout, cin, cin_packed, nv.ptr(w), nv.ptr(perm_t), nv.ptr(buf), nv.stream_ptr())
+    if tap_channel is None:
+        nbytes = L.dua_pack_conv3_weights(code, cout, cin, cin_packed, None, None, None, None)
+        assert nbytes > 0
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        rc = L.dua_pack_conv3_weights(code, cout, cin, cin_packed, nv.ptr(w), nv.ptr(perm_t), nv.ptr(buf), nv.stream_ptr())
+    else:
+        src = tap_channel if perm is None else perm[tap_channel]
+        assert dtype == torch.float16 and cin_packed <= 32 and 0 <= src < cin
+        nbytes = L.dua_pack_conv3_weights_tap(code, cout, cin, cin_packed, tap_channel, src, None, None, None, None)
+        assert nbytes > 0
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        rc = L.dua_pack_conv3_weights_tap(code, cout, cin, cin_packed, tap_channel, src, nv.ptr(w), nv.ptr(perm_t), nv.ptr(buf),
+                                          nv.stream_ptr())
     if rc != nbytes:
         raise RuntimeError(f"dua_pack_conv3_weights failed ({rc})")
     cpad = -(-cout // 64) * 64
@@ -182,9 +192,12 @@ def conv3_workspace_bytes(dtype, N, D, H, W, cin, cout):
     return int(nv.lib().dua_conv3d_k3_workspace(C.byref(d)))
 
 
-def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None, workspace=None):
+def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None, workspace=None, tap_channel=None):
     """Raw 3x3x3 convolution (+bias); ``norm`` = producer descriptor of x (fused IN+LeakyReLU+add);
-    accumulates this layer's InstanceNorm sums into ``out_stats`` (must be zero on entry)."""
+    accumulates this layer's InstanceNorm sums into ``out_stats`` (must be zero on entry).
+    ``tap_channel`` (0 or 16, fp16, cin == tap_channel + 8): the single-channel tap form for first layers -- that packed
+    channel is the last real input channel and is contracted as two k-steps over its 27 taps (weights packed with the
+    same ``tap_channel``)."""
     _cl_check(x, "x"); _cl_check(y, "y")
     assert x.dtype == y.dtype and x.device == y.device
     N, D, H, W, cs_in = x.shape
@@ -194,10 +207,15 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
     ck = chunk_elems(x.dtype)
     nch, nct = -(-cin // ck), -(-cout // 64)
     assert nch * ck <= 1024
-    assert w_packed.numel() == nct * nch * 27 * 4 * 64 * 16, "packed weights do not match (Cin, Cout, dtype)"
+    tap_bytes = 0
+    if tap_channel is not None:
+        assert x.dtype == torch.float16 and tap_channel in (0, 16) and cin == tap_channel + 8 and norm is None
+        tap_bytes = nct * 4096
+    assert w_packed.numel() == nct * nch * 27 * 4 * 64 * 16 + tap_bytes, "packed weights do not match (Cin, Cout, dtype)"
     assert bias_pad.numel() == nct * 64 and bias_pad.dtype == torch.float32
     assert out_stats.dtype == torch.float64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, nct * 64, 2)
-    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
+    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off,
+                     0 if tap_channel is None else tap_channel + 1)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, cin)
         _RECORD.append(nv.StepOp(nv.OP_CONV3, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),

@@ -51,6 +51,10 @@ typedef struct {
   int N, D, H, W;
   int Cin, Cin_stride, Cin_off;    /* all multiples of 8 */
   int Cout, Cout_stride, Cout_off; /* all multiples of 8 */
+  int tap_channel_plus1;           /* 0 = ordinary convolution.  k > 0 (dua_conv3d_k3_fwd only, DUA_F16, Cin <= 32, no fused
+                                      producer): packed input channel k-1 (0 or 16) is the LAST real channel (Cin = k-1 + 8,
+                                      channels behind it are zero padding); its 27 taps are contracted as two 16-wide k-steps
+                                      instead of 27 padded ones.  Needs weights from dua_pack_conv3_weights_tap. */
 } dua_conv3_desc;
 
 /* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32[ceil(Cout/64)*64].  in: NULL or the
@@ -163,6 +167,13 @@ int dua_set_option(int key, int value);
  * channel.  Returns bytes needed when w_packed is NULL. */
 long dua_pack_conv3_weights(int dtype, int Cout, int Cin_src, int Cin_packed, const float* w, const int* in_perm,
                             void* w_packed, void* stream);
+
+/* The same packing for the single-channel tap form of dua_conv3_desc.tap_channel_plus1 (DUA_F16, Cin_packed <= 32): the
+ * slab weights of packed channel tap_channel are zeroed and a block [cout_tile][4 groups of 8 taps][64 couts][8] (taps
+ * 27..31 zero) holding the 27 weights of SOURCE channel tap_src_channel per output channel is appended.  Returns bytes
+ * needed when w_packed is NULL. */
+long dua_pack_conv3_weights_tap(int dtype, int Cout, int Cin_src, int Cin_packed, int tap_channel, int tap_src_channel,
+                                const float* w, const int* in_perm, void* w_packed, void* stream);
 
 /* ---- InstanceNorm3d statistics -> per-(n,c) scale/shift (inspection / tests) -----------------------
  * The same arithmetic every consumer runs in its preamble, written out: scale, shift = fp32 [N][C]. */

@@ -179,6 +179,36 @@ def test_conv3_fused_input_transform_and_channel_slices(dtype, conv_variant):
     assert float((ybuf[..., :8].float() + 5).abs().max()) == 0 and float((ybuf[..., 48:].float() + 5).abs().max()) == 0
 
 
+@pytest.mark.parametrize("classes,shape", [(16, (1, 16, 24, 8)), (16, (2, 10, 9, 13)), (0, (1, 8, 16, 16))])
+def test_conv3_single_channel_tap_form(classes, shape):
+    """First layers: the lone image channel behind 16 (denoiser) or 0 (encoder) ordinary channels contracted as two
+    k-steps over its 27 taps; against torch conv3d on the fp16-rounded operands and against the ordinary form."""
+    ops = _ops()
+    N, D, H, W = shape
+    cin_src, cout, cin_p = classes + 1, 64, classes + 8
+    g = torch.Generator().manual_seed(classes + D)
+    x = torch.randn(N, cin_src, D, H, W, generator=g)                    # reference channel order [image | x_t]
+    w = torch.randn(cout, cin_src, 3, 3, 3, generator=g) / (27 * cin_src) ** 0.5
+    b = torch.randn(cout, generator=g)
+    perm = list(range(1, classes + 1)) + [0] + [-1] * 7                  # packed [x_t | image | pad]
+    xp = torch.zeros(N, D, H, W, cin_p, dtype=torch.float16, device="cuda")
+    xp[..., :classes] = x[:, 1:].permute(0, 2, 3, 4, 1).half()
+    xp[..., classes] = x[:, 0].half()
+    outs = []
+    for tap in (None, classes):
+        wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), torch.float16, cin_packed=cin_p, perm=perm, tap_channel=tap)
+        y = torch.zeros(N, D, H, W, cout, dtype=torch.float16, device="cuda")
+        st = ops.stats_buffer(N, cout, "cuda")
+        ops.conv3d_k3(xp, cin_p, 0, wp, bp, cout, y, 0, st, tap_channel=tap)
+        outs.append((ops.from_channels_last(y, cout).cpu(), st.sum(1).cpu()))
+    want = F.conv3d(x.half().float(), w.half().float(), b, padding=1)
+    for got, st in outs:
+        assert (got - want).abs().max() < 2e-2, float((got - want).abs().max())
+        gd = got.double().permute(1, 0, 2, 3, 4).reshape(cout, N, -1).permute(1, 0, 2)
+        assert torch.allclose(st[..., 0], gd.sum(-1), rtol=1e-5, atol=2e-2)
+    assert (outs[0][0] - outs[1][0]).abs().max() < 4e-3      # same products, different summation order
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_conv3_permuted_padded_input_channels(dtype):
     """First denoiser layer: torch.cat([image, x_t]) (denoiser.py:298) stored as [x_t | image | 0-pad]."""

@@ -1,0 +1,165 @@
+// Windowed multi-head self-attention core of the Swin blocks (BASELINE config 5).
+//
+// Reference: models/swin_unetr/attention.py:97-120 (WindowAttention.forward) between the two Linear layers:
+//   q, k, v = qkv.reshape(b, n, 3, heads, hd).permute(2, 0, 3, 1, 4);  attn = (q * hd^-0.5) @ k^T
+//   attn += relative_position_bias[heads, n, n];  attn += mask[window, n, n] (shifted windows, -100 entries,
+//   attention.py:123-160);  attn = softmax(attn, -1);  x = (attn @ v).transpose(1, 2).reshape(b, n, C)
+// for windows of n = wd*wh*ww tokens (7^3 = 343; 216 at the coarsest level) and head dimension 16 (feature_size 48:
+// 48/3 = 96/6 = 192/12 = 384/24).  The qkv and proj Linear layers stay library GEMMs.
+//
+// One workgroup (4 waves) per (window, head); K and V of the window live in LDS, a wave owns blocks of 32 queries.
+// Both products run on MFMA 32x32x16 with fp16 operands and fp32 accumulation, "transposed" so that a query is a LANE:
+//   S^T[32 keys][32 queries] = K_blk [32 x 16] . Q^T [16 x 32]           (one instruction per block: K = head dim = 16)
+// leaves the whole score row of a query in the registers of two lanes (l, l + 32): bias, mask, max, exp and the sum are
+// plain register arithmetic + one exchange between the halves -- no LDS, no shuffles per element.  The accumulator
+// tile is then the B operand of the second product as it stands (cdna_hip_programming.md, "An accumulator tile as the
+// next MFMA's operand"):
+//   O^T[dims][32 queries] += V^T_blk [dims x 32 keys, keys in the accumulator's row order] . P^T_blk [32 keys x 32 queries]
+// (rows 16..31 of the 32-row output are padding: the price of a 16-wide head on a 32-row instruction).  V is written
+// to LDS already in that permuted key order, so its operand fragment is one 16-byte read.
+// Bias and mask arrive TRANSPOSED ([head][key][query], [window][key][query], fp32) so that the 32 lanes of a half read
+// 128 contiguous bytes per key.
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+
+namespace dua {
+
+namespace wa {
+constexpr int HD = 16;          // head dimension
+constexpr int MAXB = 11;        // 32-token blocks per window (n <= 352)
+}  // namespace wa
+
+struct WinAttnArgs {
+  const void* qkv; const float* bias_t; const float* mask_t; void* out;
+  int n, heads, nw;             // tokens per window, heads, windows per image (mask index = window % nw)
+  float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void window_attention_kernel(WinAttnArgs a) {
+  using namespace wa;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f16* Kl = (f16*)smem;                           // [nb*32][16]
+  f16* Ql = Kl + MAXB * 32 * HD;                  // [nb*32][16]
+  f16* Vp = Ql + MAXB * 32 * HD;                  // [nb][2 s][2 hh][32 rows (dims, 16 real)][8 keys]  (permuted V^T)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int win = blockIdx.x, head = blockIdx.y;
+  const int n = a.n, nb = (n + 31) >> 5, C = a.heads * HD;
+  const T* base = (const T*)a.qkv + (long)win * n * 3 * C + head * HD;
+  // ---- stage Q, K (row major) and V (permuted, zero padded) ----
+  for (int i = tid; i < nb * 32 * 2; i += 256) {          // (token, half of the 16 dims)
+    const int tok = i >> 1, half = i & 1;
+    f16x8 q, k;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { q[e] = (f16)0.f; k[e] = (f16)0.f; }
+    if (tok < n) {
+      const T* p = base + (long)tok * 3 * C + half * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { q[e] = (f16)(float)p[e]; k[e] = (f16)(float)p[C + e]; }
+    }
+    *(f16x8*)(Ql + tok * HD + half * 8) = q;
+    *(f16x8*)(Kl + tok * HD + half * 8) = k;
+  }
+  // Vp[kb][s][h2][row][j] = V[key = kb*32 + 16 s + 8 (j >> 2) + 4 h2 + (j & 3)][dim = row]  (row >= 16: 0)
+  for (int i = tid; i < nb * 2 * 2 * 32; i += 256) {
+    const int row = i & 31, h2 = (i >> 5) & 1, s = (i >> 6) & 1, kb = i >> 7;
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = kb * 32 + 16 * s + 8 * (j >> 2) + 4 * h2 + (j & 3);
+      v[j] = (row < HD && key < n) ? (f16)(float)base[(long)key * 3 * C + 2 * C + row] : (f16)0.f;
+    }
+    *(f16x8*)(Vp + (long)i * 8) = v;
+  }
+  __syncthreads();
+
+  const float* bias = a.bias_t + (long)head * n * n;
+  const float* mask = a.mask_t ? a.mask_t + (long)(win % a.nw) * n * n : nullptr;
+  T* outp = (T*)a.out + (long)win * n * C + head * HD;
+  for (int qb = wave; qb < nb; qb += 4) {
+    const int q = qb * 32 + r;                     // this lane's query
+    const bool qok = q < n;
+    const int qc = qok ? q : 0;
+    const f16x8 qf = *(const f16x8*)(Ql + (qb * 32 + r) * HD + hh * 8);      // B operand: Q^T[dims 8hh..][query r]
+    f32x16 S[MAXB];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kb = 0; kb < MAXB; ++kb) {
+      if (kb < nb) {
+        const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
+        f32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, z, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kb * 32 + acc_row(i, hh);
+          float v = -3.0e38f;                     // padding keys never win the max and exponentiate to 0
+          if (key < n) {
+            v = z[i] * a.scale + bias[(long)key * n + qc];
+            if (mask) v += mask[(long)key * n + qc];
+          }
+          z[i] = v;
+          mx = fmaxf(mx, v);
+        }
+        S[kb] = z;
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));            // the other half of the keys of the same query
+    float sum = 0.f;
+    f32x16 O;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[i] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < MAXB; ++kb) {
+      if (kb < nb) {
+        f16x8 p[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float e = __expf(S[kb][i] - mx);
+          sum += e;
+          p[i >> 3][i & 7] = (f16)e;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const f16x8 vf = *(const f16x8*)(Vp + ((long)((kb * 2 + s) * 2 + hh) * 32 + r) * 8);
+          O = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, p[s], O, 0, 0, 0);
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+    // O^T rows = dims: register i of half hh holds dim (i & 3) + 8 (i >> 2) + 4 hh; dims < 16 are i = 0..7
+    if (qok) {
+      T* o = outp + (long)q * C;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        typedef T TV4 __attribute__((ext_vector_type(4)));
+        TV4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (T)(O[4 * g + e] * inv);
+        *(TV4*)(o + 8 * g + 4 * hh) = w;
+      }
+    }
+  }
+}
+
+}  // namespace dua
+
+extern "C" int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image,
+                                        const void* qkv, const float* bias_t, const float* mask_t, float scale, void* out,
+                                        void* stream) {
+  using namespace dua;
+  if (!qkv || !bias_t || !out || windows <= 0 || heads <= 0 || tokens <= 0 || tokens > wa::MAXB * 32) return DUA_ERR_ARG;
+  if (mask_t && (windows_per_image <= 0 || windows % windows_per_image)) return DUA_ERR_ARG;
+  WinAttnArgs a;
+  a.qkv = qkv; a.bias_t = bias_t; a.mask_t = mask_t; a.out = out;
+  a.n = tokens; a.heads = heads; a.nw = mask_t ? windows_per_image : 1; a.scale = scale;
+  const int lds = wa::MAXB * 32 * wa::HD * 2 * 2 + wa::MAXB * 2 * 2 * 32 * 8 * 2;     // Q + K + permuted V^T
+  dim3 grid(windows, heads);
+  if (dtype == DUA_F16) hipLaunchKernelGGL(window_attention_kernel<f16>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  else if (dtype == DUA_F32) hipLaunchKernelGGL(window_attention_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  else return DUA_ERR_ARG;
+  return (int)hipGetLastError();
+}

@@ -156,9 +156,62 @@ def pack_deconv_weights(w, bias, dtype):
 STAT_REPLICAS = 8
 
 
+class ZeroArena:
+    """Bump allocator over ONE device buffer that is zeroed by ONE fill per training step.
+
+    A training step needs ~280 small zero-initialised buffers (weight-gradient accumulators, statistics rows, reduction
+    scratch); as separate torch.zeros calls they were ~280 fill kernels and >1 ms of a 20 ms step.  While an arena is
+    active (``with arena:``), ``ops.zeros`` hands out views of it; ``reset()`` re-zeroes everything with one kernel.
+    Views must not outlive the step (gradients are consumed by the optimizer and dropped by zero_grad(set_to_none))."""
+
+    def __init__(self, nbytes, device):
+        self.buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        self.off = 0
+        self.overflow = 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.off = 0
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        start = (self.off + 255) & ~255
+        if start + nbytes > self.buf.numel():
+            self.overflow += nbytes
+            return None
+        self.off = start + nbytes
+        return self.buf[start:start + nbytes].view(dtype).view(tuple(shape))
+
+    def __enter__(self):
+        global _ARENA
+        self._prev = _ARENA
+        _ARENA = self
+        return self
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = self._prev
+        return False
+
+
+_ARENA = None
+
+
+def zeros(shape, dtype, device):
+    """torch.zeros, or a view of the active ZeroArena (same device) when one is installed."""
+    if _ARENA is not None and torch.device(device) == _ARENA.buf.device:
+        t = _ARENA.take(tuple(shape) if not isinstance(shape, int) else (shape,), dtype)
+        if t is not None:
+            return t
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
 def stats_buffer(N, cout, device):
     """Zeroed fp64 [N][8][ceil(cout/64)*64][2] accumulator a convolution adds (sum x, sum x^2) into."""
-    return torch.zeros((N, STAT_REPLICAS, -(-cout // 64) * 64, 2), dtype=torch.float64, device=device)
+    return zeros((N, STAT_REPLICAS, -(-cout // 64) * 64, 2), torch.float64, device)
 
 
 class Norm:
@@ -292,7 +345,7 @@ def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0):
     assert Cc % 8 == 0 and Cc <= raw.shape[-1] and da_off % 8 == 0 and da_off + Cc <= dA.shape[-1]
     assert dy_off % 8 == 0 and dy_off + Cc <= dY.shape[-1]
     cpad = norm.keep[0].shape[2]
-    sums = torch.zeros((N, STAT_REPLICAS, cpad, 4), dtype=torch.float64, device=raw.device)
+    sums = zeros((N, STAT_REPLICAS, cpad, 4), torch.float64, raw.device)
     d = nv.NormBwdDesc(nv.dt_code(raw.dtype), N, vox, Cc, dA.shape[-1], da_off, raw.shape[-1], 0, dY.shape[-1], dy_off)
     L = nv.lib()
     nv.check(L.dua_instnorm_bwd_reduce(C.byref(d), nv.ptr(dA), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(sums), nv.stream_ptr()),
@@ -343,7 +396,7 @@ def deconv_k2s2_bwd(x, cin, cin_off, dy, cout, cout_off, w, need_dx=True, need_d
         d_in = nv.Conv3Desc(code, N, D, H, W, cin, cs_in, cin_off, cout, dy.shape[-1], cout_off)
         ws_bytes = int(L.dua_deconv_k2s2_bwd_workspace(C.byref(d_in)))
         ws = _wgrad_ws(ws_bytes, x.device)
-        dw = torch.zeros_like(w)
+        dw = zeros(tuple(w.shape), w.dtype, w.device)
         nv.check(L.dua_deconv_k2s2_bwd(C.byref(d_in), nv.ptr(x), nv.ptr(dy), None, None, nv.ptr(dw), nv.ptr(ws), ws.numel(),
                                        nv.stream_ptr()), "dua_deconv_k2s2_bwd(dw)")
     return dx, dw
@@ -372,8 +425,8 @@ def head_bwd(dlogits, u, weight):
     assert dlogits.is_cuda and dlogits.is_contiguous() and dlogits.dtype == u.dtype and dlogits.shape[-1] == K
     assert tuple(dlogits.shape[:4]) == tuple(u.shape[:4]) and u.shape[-1] == Cc
     du = torch.empty_like(u)
-    dW = torch.zeros((K, Cc), dtype=torch.float32, device=u.device)
-    db = torch.zeros(K, dtype=torch.float32, device=u.device)
+    dW = zeros((K, Cc), torch.float32, u.device)
+    db = zeros((K,), torch.float32, u.device)
     vox = u.numel() // Cc
     ws = _wgrad_ws(int(nv.lib().dua_head_bwd_workspace(vox)), u.device)         # shared grow-only scratch (stream-ordered)
     nv.check(nv.lib().dua_head_bwd(nv.dt_code(u.dtype), vox, Cc, K, nv.ptr(dlogits), K, nv.ptr(u), Cc, nv.ptr(weight),
@@ -396,7 +449,7 @@ def seg_loss_reduce(logits, labels, names=LOSS_NAMES, combine="sum"):
     assert labels.is_cuda and labels.dtype == torch.float32 and labels.is_contiguous()
     assert tuple(logits.shape[:4]) == (N, *labels.shape[2:]) and logits.shape[-1] >= Cc
     assert names and all(n_ in LOSS_NAMES for n_ in names) and combine in ("sum", "mean", "log")
-    sums = torch.zeros(N * Cc * 4 + 2, dtype=torch.float64, device=logits.device)
+    sums = zeros((N * Cc * 4 + 2,), torch.float64, logits.device)
     nv.check(nv.lib().dua_seg_loss_reduce(nv.dt_code(logits.dtype), N, Cc, V, nv.ptr(logits), logits.shape[-1], nv.ptr(labels),
                                           nv.ptr(sums), nv.stream_ptr()), "dua_seg_loss_reduce")
     q = sums[:N * Cc * 4].view(N, Cc, 4)
@@ -417,7 +470,7 @@ def seg_loss_grad(logits, labels, sums, gscale, names=LOSS_NAMES):
     """dlogits = gscale * sum over ``names`` of d term / d logits (``gscale``: 0-dim device tensor or None = 1)."""
     N, Cc = labels.shape[:2]
     V = labels.shape[2] * labels.shape[3] * labels.shape[4]
-    out = torch.zeros_like(logits) if logits.shape[-1] > Cc else torch.empty_like(logits)
+    out = zeros(tuple(logits.shape), logits.dtype, logits.device) if logits.shape[-1] > Cc else torch.empty_like(logits)
     g = gscale.detach().float().reshape(1).contiguous() if gscale is not None else None
     w = [1.0 if n_ in names else 0.0 for n_ in LOSS_NAMES]
     nv.check(nv.lib().dua_seg_loss_grad(nv.dt_code(logits.dtype), N, Cc, V, nv.ptr(logits), logits.shape[-1], nv.ptr(labels),

@@ -100,7 +100,7 @@ class _Conv3dK3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _Conv3dK3._dgrad(dy, weight.detach().float().contiguous(), x.shape[-1])
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+            dw = ops.zeros((cout, cin, 3, 3, 3), torch.float32, x.device)
             ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dy, cout, 0, dw)
             dw = dw.to(weight.dtype)
         if ctx.needs_input_grad[2]:
@@ -206,9 +206,9 @@ class _ConvNormAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1])
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            dw = ops.zeros(tuple(weight.shape), torch.float32, x.device)
             ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dY, cout, 0, dw)
-        db = torch.zeros(cout, dtype=torch.float32, device=x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
+        db = ops.zeros((cout,), torch.float32, x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
         dgamma, dbeta = sums[:, :, 2].sum(0).float(), sums[:, :, 1].sum(0).float()
         dadd = sums[:, :, 0].float() if ctx.has_add else None
         return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None
@@ -321,17 +321,20 @@ class NativeConvTrainer:
     """One-process-per-GPU trainer on the native-convolution path: fp32 master weights, fp16 activations and gradients
     with dynamic loss scaling (or plain fp32), AdamW as train.py:121-126.  Under torch.distributed the gradients are
     averaged by torch's DDP reducer (``overlap=True``: 32 MB buckets all-reduced while the rest of backward still
-    runs; RCCL on a GPU node) or by one flat all-reduce after backward (``overlap=False``)."""
+    runs; RCCL on a GPU node) or by one flat all-reduce after backward (``overlap=False``).
+    ``graph=True`` replays the step from HIP graphs: one graph single-process; under torch.distributed TWO graphs
+    (forward + backward | unscale + AdamW + loss-scale update) with the flat gradient all-reduce between them -- the
+    collective stays an ordinary call, so any backend works (RCCL on a node, gloo in the tests)."""
 
     def __init__(self, net, lr=2e-4, weight_decay=1e-4, losses="mse,bce,dice", loss_combine="sum",
                  dtype=torch.float16, init_scale=2.0 ** 12, overlap=True, graph=False, fused_optimizer=False):
         import torch.distributed as dist
         self.net, self.dtype = net, dtype
         self.lr, self.weight_decay, self.init_scale = lr, weight_decay, init_scale
-        self.use_graph, self._graph = graph, None
+        self.use_graph, self._graph, self._graph2 = graph, None, None
         self.module = _NativeModule(net, dtype)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.overlap = overlap and self.distributed
+        self.overlap = overlap and self.distributed and not graph        # the DDP reducer's hooks cannot be captured
         if self.overlap:
             from torch.nn.parallel import DistributedDataParallel
             dev = next(net.parameters()).device
@@ -342,6 +345,11 @@ class NativeConvTrainer:
         self.optimizer = (torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=True, capturable=True)
                           if fused_optimizer else torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay))
         self.scale, self.good_steps = (init_scale if dtype == torch.float16 else 1.0), 0
+        # every zero-initialised buffer of a step (weight-gradient accumulators, statistics rows, reduction scratch) comes
+        # out of one arena that a single fill re-zeroes: gradients are 4 bytes per parameter, the rest is small
+        from . import ops
+        dev = self.params[0].device
+        self.arena = ops.ZeroArena(sum(p.numel() for p in self.params) * 4 + (96 << 20), dev) if dev.type == "cuda" else None
 
     def _allreduce(self):
         if not self.distributed or self.overlap:          # the DDP reducer already averaged them during backward
@@ -352,25 +360,36 @@ class NativeConvTrainer:
     # take < 22 ms; one replay per step removes the host from the loop.  Everything a step decides stays on the device:
     # the timestep -> (sqrt(a_bar), sqrt(1 - a_bar)) gather, the fp16 overflow check (found_inf feeds the fused AdamW,
     # which skips the update itself) and the loss-scale update (torch._amp_update_scale_).
-    def _graph_body(self):
+    def _graph_fwd_bwd(self):
         from . import ops
         g = self._g
-        x_start = g["labels"] * 2 - 1
-        x_t = ops.q_sample(x_start.contiguous(), g["noise"], g["qtab"][g["t"]].contiguous())
-        self.optimizer.zero_grad(set_to_none=True)
-        with torch.enable_grad():
-            loss = _SegLoss.apply(self.module(g["images"], x_t, g["t"]), g["labels"], self.loss_names, self.loss_combine)
-            (loss * g["scale"]).backward()
+        self.arena.reset()
+        with self.arena:
+            x_start = g["labels"] * 2 - 1
+            x_t = ops.q_sample(x_start.contiguous(), g["noise"], g["qtab"][g["t"]].contiguous())
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.enable_grad():
+                loss = _SegLoss.apply(self.module(g["images"], x_t, g["t"]), g["labels"], self.loss_names, self.loss_combine)
+                (loss * g["scale"]).backward()
+        return loss.detach()
+
+    def _graph_update(self):
+        g = self._g
         grads = [p.grad for p in self.params]
         g["found_inf"].zero_()
         torch._amp_foreach_non_finite_check_and_unscale_(grads, g["found_inf"], g["scale"].reciprocal())
         self.optimizer.grad_scale, self.optimizer.found_inf = None, g["found_inf"]
         self.optimizer.step()
         torch._amp_update_scale_(g["scale"], g["growth"], g["found_inf"], 2.0, 0.5, 200)
-        return loss.detach()
+
+    def _graph_body(self):
+        loss = self._graph_fwd_bwd()
+        if self.distributed:
+            allreduce_mean_([p.grad for p in self.params])
+        self._graph_update()
+        return loss
 
     def _build_graph(self, images, labels):
-        assert not self.distributed, "graph mode is single-process; use overlap=True under torch.distributed"
         assert labels.dtype == torch.float32
         dev = images.device
         d = self.net.diffusion
@@ -389,10 +408,19 @@ class NativeConvTrainer:
                 self._g["noise"].normal_()
                 self._graph_body()
         torch.cuda.current_stream().wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self._graph):
-            self._g["loss"] = self._graph_body()
+        if not self.distributed:
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._g["loss"] = self._graph_body()
+        else:
+            # two graphs sharing one memory pool; the gradients allocated while capturing the first stay alive (p.grad)
+            # and are what the eager all-reduce and the second graph see on every replay
+            self._graph, self._graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._g["loss"] = self._graph_fwd_bwd()
+            with torch.cuda.graph(self._graph2, pool=self._graph.pool()):
+                self._graph_update()
         # the warm-up steps were real updates: put weights, Adam moments/step counter and the loss scale back
         with torch.no_grad():
             for p, q in zip(self.params, saved):
@@ -417,6 +445,9 @@ class NativeConvTrainer:
         else:
             g["noise"].copy_(noise)
         self._graph.replay()
+        if self._graph2 is not None:
+            allreduce_mean_([p.grad for p in self.params])
+            self._graph2.replay()
         return g["loss"]
 
     def step(self, images, labels, noise=None, t=None):
@@ -428,7 +459,10 @@ class NativeConvTrainer:
         noise = torch.randn_like(x_start) if noise is None else noise
         x_t = self.net.diffusion.q_sample(x_start, t, noise)                     # HIP kernel
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.enable_grad():
+        import contextlib
+        if self.arena is not None:
+            self.arena.reset()
+        with (self.arena if self.arena is not None else contextlib.nullcontext()), torch.enable_grad():
             loss = _SegLoss.apply(self.module(images, x_t, t), labels.float().contiguous(), self.loss_names,
                                   self.loss_combine)
             (loss * self.scale).backward()

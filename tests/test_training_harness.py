@@ -262,7 +262,7 @@ def test_native_conv_trainer_learns():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
-def _native_ddp_worker(rank, world, port, q, overlap=True):
+def _native_ddp_worker(rank, world, port, q, overlap=True, graph=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share cuda:0; gloo moves CUDA tensors via the host
     try:
@@ -270,7 +270,7 @@ def _native_ddp_worker(rank, world, port, q, overlap=True):
         dev = torch.device("cuda:0")
         torch.manual_seed(0)
         net = DiffUNet(**KW).to(dev)
-        tr = NativeConvTrainer(net, lr=1e-3, dtype=torch.float32, overlap=overlap)
+        tr = NativeConvTrainer(net, lr=1e-3, dtype=torch.float32, overlap=overlap, graph=graph)
         image, labels, noise, t = _data(2, 7)
         sl = slice(rank, rank + 1)
         loss = tr.step(image[sl].to(dev), labels[sl].to(dev), noise=noise[sl].to(dev), t=t[sl].to(dev))
@@ -281,15 +281,16 @@ def _native_ddp_worker(rank, world, port, q, overlap=True):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("overlap", [True, False])
-def test_native_trainer_two_ranks_equal_union_batch(overlap):
+@pytest.mark.parametrize("overlap,graph", [(True, False), (False, False), (False, True)], ids=["ddp-buckets", "flat", "flat-graph"])
+def test_native_trainer_two_ranks_equal_union_batch(overlap, graph):
     """Two processes (one GPU, gloo) each train on their own sample; the gradient averaging (DDP reducer buckets
-    overlapped with backward, or one flat all-reduce after it) must leave both with the parameters single-process
-    training on the two-sample batch produces (oracle autograd, CPU)."""
+    overlapped with backward, one flat all-reduce after it, or the flat all-reduce between the two HIP graphs of graph
+    mode) must leave both with the parameters single-process training on the two-sample batch produces (oracle
+    autograd, CPU; graph mode uses the fused AdamW, whose arithmetic differs from the foreach one in the last bits)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() + 177) % 2000
-    procs = [ctx.Process(target=_native_ddp_worker, args=(r, 2, port + int(overlap), q, overlap)) for r in range(2)]
+    procs = [ctx.Process(target=_native_ddp_worker, args=(r, 2, port + int(overlap) + 2 * int(graph), q, overlap, graph)) for r in range(2)]
     for p in procs:
         p.start()
     outs = {r: (l, sd) for r, l, sd in (q.get(timeout=300) for _ in range(2))}
@@ -304,7 +305,7 @@ def test_native_trainer_two_ranks_equal_union_batch(overlap):
         if k.endswith("conv.bias"):       # zero true gradient: Adam turns rounding noise into +-lr steps on both sides
             continue
         worst = max(worst, float(np.abs(outs[0][1][k] - v.detach().numpy()).max()))
-    assert worst < 2e-4, worst
+    assert worst < (2e-4 if not graph else 5e-4), worst
 
 
 @pytest.mark.gpu

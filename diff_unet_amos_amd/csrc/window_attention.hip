@@ -36,7 +36,7 @@ struct WinAttnArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 1) void window_attention_kernel(WinAttnArgs a) {
+__global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   using namespace wa;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f16* Kl = (f16*)smem;                           // [nb*32][16]
@@ -82,50 +82,52 @@ __global__ __launch_bounds__(256, 1) void window_attention_kernel(WinAttnArgs a)
     const bool qok = q < n;
     const int qc = qok ? q : 0;
     const f16x8 qf = *(const f16x8*)(Ql + (qb * 32 + r) * HD + hh * 8);      // B operand: Q^T[dims 8hh..][query r]
-    f32x16 S[MAXB];
-    float mx = -3.0e38f;
+    // score tile of key block kb for this lane's query: scale * <q, k> + bias + mask (padding keys: -3e38)
+    auto scores = [&](int kb) {
+      const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
+      f32x16 z;
 #pragma unroll
-    for (int kb = 0; kb < MAXB; ++kb) {
-      if (kb < nb) {
-        const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
-        f32x16 z;
+      for (int i = 0; i < 16; ++i) z[i] = 0.f;
+      z = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, z, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) z[i] = 0.f;
-        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, z, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = kb * 32 + acc_row(i, hh);
-          float v = -3.0e38f;                     // padding keys never win the max and exponentiate to 0
-          if (key < n) {
-            v = z[i] * a.scale + bias[(long)key * n + qc];
-            if (mask) v += mask[(long)key * n + qc];
-          }
-          z[i] = v;
-          mx = fmaxf(mx, v);
+      for (int i = 0; i < 16; ++i) {
+        const int key = kb * 32 + acc_row(i, hh);
+        float v = -3.0e38f;                     // padding keys never win the max and exponentiate to 0
+        if (key < n) {
+          v = z[i] * a.scale + bias[(long)key * n + qc];
+          if (mask) v += mask[(long)key * n + qc];
         }
-        S[kb] = z;
+        z[i] = v;
       }
+      return z;
+    };
+    // pass 1: the row maximum (the score tiles are cheap to recompute -- one MFMA each -- and 11 of them would not
+    // fit the register file next to the output tile)
+    float mx = -3.0e38f;
+    for (int kb = 0; kb < nb; ++kb) {
+      const f32x16 z = scores(kb);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, z[i]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));            // the other half of the keys of the same query
+    // pass 2: exponentials, their sum, and P^T as the B operand of the second product
     float sum = 0.f;
     f32x16 O;
 #pragma unroll
     for (int i = 0; i < 16; ++i) O[i] = 0.f;
+    for (int kb = 0; kb < nb; ++kb) {
+      const f32x16 z = scores(kb);
+      f16x8 p[2];
 #pragma unroll
-    for (int kb = 0; kb < MAXB; ++kb) {
-      if (kb < nb) {
-        f16x8 p[2];
+      for (int i = 0; i < 16; ++i) {
+        const float e = __expf(z[i] - mx);
+        sum += e;
+        p[i >> 3][i & 7] = (f16)e;
+      }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float e = __expf(S[kb][i] - mx);
-          sum += e;
-          p[i >> 3][i & 7] = (f16)e;
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const f16x8 vf = *(const f16x8*)(Vp + ((long)((kb * 2 + s) * 2 + hh) * 32 + r) * 8);
-          O = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, p[s], O, 0, 0, 0);
-        }
+      for (int s = 0; s < 2; ++s) {
+        const f16x8 vf = *(const f16x8*)(Vp + ((long)((kb * 2 + s) * 2 + hh) * 32 + r) * 8);
+        O = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, p[s], O, 0, 0, 0);
       }
     }
     sum += __shfl_xor(sum, 32);

@@ -636,3 +636,21 @@ def step_begin(N, table, cur_add, rows_per_sample=None, row_of_step=None, counte
 def denoiser_step(plan_struct):
     """dua_denoiser_step: the whole evaluation + tail described by an nv.DenoiserPlan, on the current stream."""
     nv.check(nv.lib().dua_denoiser_step(C.byref(plan_struct), nv.stream_ptr()), "dua_denoiser_step")
+
+
+def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1):
+    """Softmax attention inside windows (models/swin_unetr/attention.py:97-120 between the qkv and proj Linear layers).
+    qkv: [windows, tokens, 3 * heads * 16] (fp16 or fp32, contiguous); bias_t: fp32 [heads, tokens, tokens] = bias[h].T;
+    mask_t: fp32 [windows_per_image, tokens, tokens] = mask[w].T or None.  Returns [windows, tokens, heads * 16]."""
+    assert qkv.is_cuda and qkv.is_contiguous() and qkv.dim() == 3 and qkv.dtype in (torch.float16, torch.float32)
+    Wn, n, c3 = qkv.shape
+    assert c3 == 3 * heads * 16 and n <= 352, "head dimension 16, at most 352 tokens per window"
+    _f32c(bias_t, "bias_t")
+    assert tuple(bias_t.shape) == (heads, n, n)
+    if mask_t is not None:
+        _f32c(mask_t, "mask_t")
+        assert tuple(mask_t.shape) == (windows_per_image, n, n) and Wn % windows_per_image == 0
+    out = torch.empty((Wn, n, heads * 16), dtype=qkv.dtype, device=qkv.device)
+    nv.check(nv.lib().dua_window_attention_fwd(nv.dt_code(qkv.dtype), Wn, n, heads, windows_per_image, nv.ptr(qkv), nv.ptr(bias_t),
+                                               nv.ptr(mask_t), 16 ** -0.5, nv.ptr(out), nv.stream_ptr()), "dua_window_attention_fwd")
+    return out

@@ -309,6 +309,17 @@ typedef struct {
 
 int dua_denoiser_step(const dua_denoiser_plan* plan, void* stream);
 
+/* ---- windowed multi-head self-attention (DiffSwinUNETR, BASELINE config 5) -------------------------------------------
+ * The core of WindowAttention.forward (models/swin_unetr/attention.py:97-120) between its two Linear layers:
+ *   out[w, q, h*16 + d] = sum_k softmax_k( scale * <Q[w,h,q,:], K[w,h,k,:]> + bias[h,q,k] + mask[w % wpi, q,k] ) V[w,h,k,d]
+ * qkv: [windows][tokens][3][heads][16] (the qkv Linear's output as it stands), element type = dtype; out:
+ * [windows][tokens][heads*16].  bias_t: fp32 [heads][tokens(key)][tokens(query)] = relative_position_bias_table gathered
+ * by relative_position_index (attention.py:103-106), TRANSPOSED; mask_t: fp32 [windows_per_image][key][query] from
+ * compute_mask (attention.py:123-160; 0 / -100), transposed, or NULL for unshifted blocks.  tokens <= 352, head
+ * dimension 16 (feature_size 48).  fp16 MFMA operands, fp32 softmax and accumulation. */
+int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image, const void* qkv,
+                             const float* bias_t, const float* mask_t, float scale, void* out, void* stream);
+
 /* ---- layout / packing at the API boundary -------------------------------------------------- */
 /* nn.ConvTranspose3d weight fp32[Cin][Cout][2][2][2] -> [tap][cout_tile][chunk][k-group][64][16 B].
  * Returns bytes needed when w_packed is NULL. */

@@ -1,0 +1,130 @@
+// Memory-bound pieces of the diff_swin_unetr variant (BASELINE config 5).
+//
+//  patch_merge_norm : PatchMerging.forward up to (not including) the reduction Linear
+//                     (models/swin_unetr/patch.py:44-61 and the legacy 3-D gather :70-91): zero-pad odd extents, gather
+//                     the 2x2x2 neighbourhood of every second voxel into an 8C vector, LayerNorm(8C).  The LEGACY
+//                     gather reads corner (0,1,0) twice and (0,0,1) twice (x5 == x2, x6 == x3) and never reads
+//                     (1,1,0) / (0,1,1); it is what the reference's default PatchMerging computes, so it is reproduced.
+//  residual_norm_act: the tail of UnetResBlock.forward (models/swin_unetr/blocks.py:308-316):
+//                     out = LeakyReLU( InstanceNorm(conv2 raw) + residual ), residual = the block input, or
+//                     InstanceNorm(conv3 raw) when the block changes the channel count (conv3 = 1x1x1).
+// Both are one streaming pass over their tensors (HBM bound); tokens / voxels are channels-last, as the reference's
+// Swin tensors already are ([b, d, h, w, c]).
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+
+namespace dua {
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// one wave per output token; lanes stride over the 8C gathered elements (two passes: moments, then normalise + store)
+template <typename T>
+__global__ __launch_bounds__(256) void patch_merge_norm_kernel(const T* __restrict__ x, int B, int D, int H, int W, int C,
+                                                               int legacy, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, T* __restrict__ out) {
+  const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const long ntok = (long)B * D2 * H2 * W2;
+  const int lane = threadIdx.x & 63;
+  const long tok = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (tok >= ntok) return;
+  const int w2 = (int)(tok % W2), h2 = (int)((tok / W2) % H2), d2 = (int)((tok / ((long)W2 * H2)) % D2), b = (int)(tok / ((long)W2 * H2 * D2));
+  // corner k of the gathered vector -> (di, dj, dk); V2: itertools.product order; legacy: patch.py:82-89
+  const int leg[8] = {0, 4, 2, 1, 5, 2, 1, 7};          // bit 2 = d offset, bit 1 = h offset, bit 0 = w offset
+  const int E = 8 * C;
+  auto fetch = [&](int e) -> float {
+    const int k = e / C, c = e - k * C;
+    const int code = legacy ? leg[k] : k;
+    const int d = 2 * d2 + (code >> 2), h = 2 * h2 + ((code >> 1) & 1), w = 2 * w2 + (code & 1);
+    if (d >= D || h >= H || w >= W) return 0.f;          // F.pad(..., value 0) of odd extents
+    return (float)x[((((long)b * D + d) * H + h) * W + w) * C + c];
+  };
+  float s = 0.f, ss = 0.f;
+  for (int e = lane; e < E; e += 64) { const float v = fetch(e); s += v; ss = fmaf(v, v, ss); }
+  s = wave_sum64(s); ss = wave_sum64(ss);
+  const float mean = s / (float)E;
+  float var = ss / (float)E - mean * mean;
+  var = var > 0.f ? var : 0.f;
+  const float rstd = rsqrtf(var + eps);
+  T* o = out + tok * E;
+  for (int e = lane; e < E; e += 64) o[e] = (T)((fetch(e) - mean) * rstd * gamma[e] + beta[e]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void residual_norm_act_kernel(const T* __restrict__ raw, int raw_stride, InXform xf,
+                                                                const T* __restrict__ res, int res_stride, InXform rf,
+                                                                int has_rf, long vox, int C, T* __restrict__ out,
+                                                                int out_stride, int out_off, float slope) {
+  extern __shared__ float tbl[];      // scale, shift of raw; scale, shift of the residual
+  const int n = blockIdx.y;
+  float* sc = tbl; float* sh = tbl + C; float* rsc = tbl + 2 * C; float* rsh = tbl + 3 * C; float* dump = tbl + 4 * C;
+  xform_preamble(xf, n, C, sc, sh, dump);
+  if (has_rf) xform_preamble(rf, n, C, rsc, rsh, dump);
+  __syncthreads();
+  constexpr int EPG = Elem<T>::EPG;
+  using Frag = typename Elem<T>::Frag;
+  const int groups = C / EPG;
+  const long items = vox * groups;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < items; i += (long)gridDim.x * 256) {
+    const long v = i / groups;
+    const int g = (int)(i - v * groups), c0 = g * EPG;
+    const Frag a = *(const Frag*)(raw + ((long)n * vox + v) * raw_stride + c0);
+    const Frag r = *(const Frag*)(res + ((long)n * vox + v) * res_stride + c0);
+    Frag o;
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) {
+      float y = fmaf((float)a[e], sc[c0 + e], sh[c0 + e]);
+      const float rr = has_rf ? fmaf((float)r[e], rsc[c0 + e], rsh[c0 + e]) : (float)r[e];
+      y += rr;
+      o[e] = (T)(y > 0.f ? y : y * slope);
+    }
+    *(Frag*)(out + ((long)n * vox + v) * out_stride + out_off + c0) = o;
+  }
+}
+
+}  // namespace dua
+
+extern "C" {
+
+int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legacy, const void* x, const float* gamma,
+                         const float* beta, float eps, void* out, void* stream) {
+  if (!x || !gamma || !beta || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return DUA_ERR_ARG;
+  const long ntok = (long)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
+  dim3 grid((unsigned)((ntok + 3) / 4));
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::patch_merge_norm_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)x, B, D,
+                       H, W, C, legacy, gamma, beta, eps, (dua::f16*)out);
+  else if (dtype == DUA_F32)
+    hipLaunchKernelGGL(dua::patch_merge_norm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, B, D, H, W,
+                       C, legacy, gamma, beta, eps, (float*)out);
+  else return DUA_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+int dua_residual_norm_act(int dtype, int N, long voxels, int C, const void* raw, int raw_stride, const dua_in_norm* in,
+                          const void* res, int res_stride, const dua_in_norm* res_in, void* out, int out_stride, int out_off,
+                          float slope, void* stream) {
+  if (!raw || !in || !in->stats || !res || !out || N <= 0 || voxels <= 0 || C <= 0 || C % 8 || raw_stride % 8 ||
+      res_stride % 8 || out_stride % 8 || out_off % 8 || C > 2048)
+    return DUA_ERR_ARG;
+  if (res_in && !res_in->stats) return DUA_ERR_ARG;
+  const dua::InXform xf = dua::make_xform(in, C), rf = dua::make_xform(res_in, C);
+  long b = (voxels * (C / 8) + 255) / 256;
+  dim3 grid((unsigned)(b > 4096 ? 4096 : b), N);
+  const size_t lds = (size_t)5 * C * sizeof(float);
+  if (dtype == DUA_F16)
+    hipLaunchKernelGGL(dua::residual_norm_act_kernel<dua::f16>, grid, dim3(256), lds, (hipStream_t)stream, (const dua::f16*)raw,
+                       raw_stride, xf, (const dua::f16*)res, res_stride, rf, res_in ? 1 : 0, voxels, C, (dua::f16*)out,
+                       out_stride, out_off, slope);
+  else if (dtype == DUA_F32)
+    hipLaunchKernelGGL(dua::residual_norm_act_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)raw,
+                       raw_stride, xf, (const float*)res, res_stride, rf, res_in ? 1 : 0, voxels, C, (float*)out, out_stride,
+                       out_off, slope);
+  else return DUA_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

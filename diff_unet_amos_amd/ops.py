@@ -654,3 +654,32 @@ def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1):
     nv.check(nv.lib().dua_window_attention_fwd(nv.dt_code(qkv.dtype), Wn, n, heads, windows_per_image, nv.ptr(qkv), nv.ptr(bias_t),
                                                nv.ptr(mask_t), 16 ** -0.5, nv.ptr(out), nv.stream_ptr()), "dua_window_attention_fwd")
     return out
+
+
+def patch_merge_norm(x, gamma, beta, legacy=True, eps=1e-5):
+    """PatchMerging.forward up to its reduction Linear (models/swin_unetr/patch.py:44-91): x [B, D, H, W, C] ->
+    LayerNorm_8C of the gathered 2x2x2 neighbourhoods, [B, ceil(D/2), ceil(H/2), ceil(W/2), 8C]."""
+    assert x.is_cuda and x.is_contiguous() and x.dim() == 5 and x.dtype in (torch.float16, torch.float32)
+    B, D, H, W, Cc = x.shape
+    _f32c(gamma, "gamma"); _f32c(beta, "beta")
+    assert gamma.numel() == beta.numel() == 8 * Cc
+    out = torch.empty((B, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, 8 * Cc), dtype=x.dtype, device=x.device)
+    nv.check(nv.lib().dua_patch_merge_norm(nv.dt_code(x.dtype), B, D, H, W, Cc, 1 if legacy else 0, nv.ptr(x), nv.ptr(gamma),
+                                           nv.ptr(beta), eps, nv.ptr(out), nv.stream_ptr()), "dua_patch_merge_norm")
+    return out
+
+
+def residual_norm_act(raw, norm, res, res_norm=None, slope=0.01, out=None, out_off=0):
+    """out = LeakyReLU(IN(raw) + residual) (UnetResBlock tail, models/swin_unetr/blocks.py:308-316); ``res_norm`` normalises
+    the residual (conv3 + norm3 of channel-changing blocks)."""
+    _cl_check(raw, "raw"); _cl_check(res, "res")
+    N, D, H, W, Cc = raw.shape
+    assert tuple(res.shape[:4]) == (N, D, H, W) and res.shape[-1] >= Cc and res.dtype == raw.dtype
+    if out is None:
+        out = torch.empty_like(raw)
+    _cl_check(out, "out")
+    assert tuple(out.shape[:4]) == (N, D, H, W) and out_off % 8 == 0 and out_off + Cc <= out.shape[-1]
+    nv.check(nv.lib().dua_residual_norm_act(nv.dt_code(raw.dtype), N, D * H * W, Cc, nv.ptr(raw), raw.shape[-1], norm.ref(N, Cc),
+                                            nv.ptr(res), res.shape[-1], _norm_ref(res_norm, N, Cc), nv.ptr(out), out.shape[-1],
+                                            out_off, slope, nv.stream_ptr()), "dua_residual_norm_act")
+    return out

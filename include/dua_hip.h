@@ -320,6 +320,19 @@ int dua_denoiser_step(const dua_denoiser_plan* plan, void* stream);
 int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image, const void* qkv,
                              const float* bias_t, const float* mask_t, float scale, void* out, void* stream);
 
+/* PatchMerging.forward up to the reduction Linear (models/swin_unetr/patch.py:44-61; legacy != 0: the 3-D gather of
+ * :70-91 with its duplicated corners): x [B][D][H][W][C] -> out [B][ceil(D/2)][ceil(H/2)][ceil(W/2)][8C] = LayerNorm_8C(gather),
+ * odd extents zero padded.  gamma, beta: fp32 [8C]. */
+int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legacy, const void* x, const float* gamma,
+                         const float* beta, float eps, void* out, void* stream);
+
+/* Tail of UnetResBlock.forward (models/swin_unetr/blocks.py:308-316): out = LeakyReLU(IN(raw) + residual), raw = conv2's raw
+ * output with its statistics in `in` (no add), residual = res as it is (res_in == NULL) or IN(res) with res_in (conv3 +
+ * norm3).  Channels-last slices like everywhere else; C a multiple of 8. */
+int dua_residual_norm_act(int dtype, int N, long voxels, int C, const void* raw, int raw_stride, const dua_in_norm* in,
+                          const void* res, int res_stride, const dua_in_norm* res_in, void* out, int out_stride, int out_off,
+                          float slope, void* stream);
+
 /* ---- layout / packing at the API boundary -------------------------------------------------- */
 /* nn.ConvTranspose3d weight fp32[Cin][Cout][2][2][2] -> [tap][cout_tile][chunk][k-group][64][16 B].
  * Returns bytes needed when w_packed is NULL. */

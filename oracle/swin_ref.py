@@ -140,3 +140,38 @@ class RefPatchMerging(nn.Module):
 
     def forward(self, x):
         return self.reduction(self.norm(patch_merging_gather(x, self.legacy)))
+
+
+def nonlinearity(x):
+    """models/diffusion/utils.py:27-29 (swish), applied to the time embedding before every t_proj."""
+    return x * torch.sigmoid(x)
+
+
+class RefUnetResBlock(nn.Module):
+    """models/swin_unetr/blocks.py:219-316 for 3-D, kernel 3, stride 1, instance norm:
+        conv1 -> norm1 -> LeakyReLU(0.01) -> + t_proj(swish(t)) -> conv2 -> norm2 -> (+ norm3(conv3(inp)) | + inp) -> LeakyReLU
+    MONAI's get_conv_layer(..., act=None, norm=None, conv_only=False) is restated as a bias-free Conv3d with "same"
+    padding (its documented default bias=False), get_norm_layer(("instance", {"affine": True})) as
+    InstanceNorm3d(affine=True) -- the norm_name the reference passes (swin_unetr/denoiser.py) -- PARITY UNPINNED."""
+
+    def __init__(self, in_channels, out_channels, embedding_size=512, affine=True):
+        super().__init__()
+        self.conv1 = nn.Conv3d(in_channels, out_channels, 3, 1, 1, bias=False)
+        self.t_proj = nn.Linear(embedding_size, out_channels)
+        self.conv2 = nn.Conv3d(out_channels, out_channels, 3, 1, 1, bias=False)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.01)
+        self.norm1 = nn.InstanceNorm3d(out_channels, affine=affine)
+        self.norm2 = nn.InstanceNorm3d(out_channels, affine=affine)
+        self.downsample = in_channels != out_channels
+        if self.downsample:
+            self.conv3 = nn.Conv3d(in_channels, out_channels, 1, 1, 0, bias=False)
+            self.norm3 = nn.InstanceNorm3d(out_channels, affine=affine)
+
+    def forward(self, inp, t):
+        residual = inp
+        out = self.lrelu(self.norm1(self.conv1(inp)))
+        out = out + self.t_proj(nonlinearity(t))[:, :, None, None, None]
+        out = self.norm2(self.conv2(out))
+        if self.downsample:
+            residual = self.norm3(self.conv3(residual))
+        return self.lrelu(out + residual)

@@ -77,6 +77,11 @@ class DenoiserPlan(C.Structure):
                 ("logits", C.c_void_p), ("xstart", C.c_void_p)]
 
 
+class WindowGeom(C.Structure):
+    """dua_window_geom."""
+    _fields_ = [(n, C.c_int) for n in ("B", "D", "H", "W", "C", "wd", "wh", "ww", "sd", "sh", "sw")]
+
+
 _P = C.c_void_p
 _SIGS = {
     "dua_set_option": (C.c_int, [C.c_int, C.c_int]),
@@ -84,10 +89,17 @@ _SIGS = {
     "dua_q_sample": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P]),
     "dua_sampler_step": (C.c_int, [C.c_int, C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dua_final_conv_sampler": (C.c_int, [C.POINTER(TailDesc), _P, C.POINTER(InNorm)] + [_P] * 11),
-    "dua_window_attention_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P, _P]),
-    "dua_patch_merge_norm": (C.c_int, [C.c_int] * 7 + [_P, _P, _P, C.c_float, _P, _P]),
+    "dua_window_attention_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P]),
+    "dua_patch_merge_norm": (C.c_int, [C.c_int] * 7 + [_P, _P, _P, _P, C.c_float, _P, _P]),
     "dua_residual_norm_act": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.POINTER(InNorm), _P, C.c_int,
-                                        C.POINTER(InNorm), _P, C.c_int, C.c_int, C.c_float, _P]),
+                                        C.POINTER(InNorm), _P, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_int,
+                                        C.c_int, _P]),
+    "dua_window_gather_norm": (C.c_int, [C.c_int, C.POINTER(WindowGeom), _P, _P, _P, _P, C.c_float, _P, _P]),
+    "dua_window_scatter_add_norm": (C.c_int, [C.c_int, C.POINTER(WindowGeom), _P, _P, _P, _P, C.c_float, _P, _P]),
+    "dua_stage_out": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, _P, C.c_int, C.c_float, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "dua_patch_embed": (C.c_int, [C.c_int] * 8 + [_P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "dua_instnorm_stats": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "dua_gelu": (C.c_int, [C.c_int, C.c_long, _P, _P]),
     "dua_denoiser_step": (C.c_int, [C.POINTER(DenoiserPlan), _P]),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),

@@ -7,7 +7,9 @@
 //                     (1,1,0) / (0,1,1); it is what the reference's default PatchMerging computes, so it is reproduced.
 //  residual_norm_act: the tail of UnetResBlock.forward (models/swin_unetr/blocks.py:308-316):
 //                     out = LeakyReLU( InstanceNorm(conv2 raw) + residual ), residual = the block input, or
-//                     InstanceNorm(conv3 raw) when the block changes the channel count (conv3 = 1x1x1).
+//                     InstanceNorm(conv3 raw) when the block changes the channel count (conv3 = 1x1x1); then the two adds
+//                     of SwinUNETRDenoiser.forward on a block's output (swin_unetr/denoiser.py:370-399): + embeddings[k]
+//                     for the encoder blocks, + reverse_attention(skip) = skip * (1 - sigmoid(skip)) for the decoders.
 // Both are one streaming pass over their tensors (HBM bound); tokens / voxels are channels-last, as the reference's
 // Swin tensors already are ([b, d, h, w, c]).
 #include "common.hpp"
@@ -22,9 +24,11 @@ __device__ __forceinline__ float wave_sum64(float v) {
 }
 
 // one wave per output token; lanes stride over the 8C gathered elements (two passes: moments, then normalise + store)
+// x is the fp32 token stream of the stage; y (optional, T) is the last block's MLP output still to be added to it
+// (transformer.py:477-480) -- the sum is formed on the fly, the stream itself is dead after the merge.
 template <typename T>
-__global__ __launch_bounds__(256) void patch_merge_norm_kernel(const T* __restrict__ x, int B, int D, int H, int W, int C,
-                                                               int legacy, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void patch_merge_norm_kernel(const float* __restrict__ x, const T* __restrict__ y, int B, int D,
+                                                               int H, int W, int C, int legacy, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, T* __restrict__ out) {
   const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   const long ntok = (long)B * D2 * H2 * W2;
@@ -40,7 +44,8 @@ __global__ __launch_bounds__(256) void patch_merge_norm_kernel(const T* __restri
     const int code = legacy ? leg[k] : k;
     const int d = 2 * d2 + (code >> 2), h = 2 * h2 + ((code >> 1) & 1), w = 2 * w2 + (code & 1);
     if (d >= D || h >= H || w >= W) return 0.f;          // F.pad(..., value 0) of odd extents
-    return (float)x[((((long)b * D + d) * H + h) * W + w) * C + c];
+    const long i = ((((long)b * D + d) * H + h) * W + w) * C + c;
+    return y ? x[i] + (float)y[i] : x[i];
   };
   float s = 0.f, ss = 0.f;
   for (int e = lane; e < E; e += 64) { const float v = fetch(e); s += v; ss = fmaf(v, v, ss); }
@@ -57,7 +62,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void residual_norm_act_kernel(const T* __restrict__ raw, int raw_stride, InXform xf,
                                                                 const T* __restrict__ res, int res_stride, InXform rf,
                                                                 int has_rf, long vox, int C, T* __restrict__ out,
-                                                                int out_stride, int out_off, float slope) {
+                                                                int out_stride, int out_off, float slope,
+                                                                const T* __restrict__ post, int post_stride, int post_off,
+                                                                const T* __restrict__ ra, int ra_stride, int ra_off) {
   extern __shared__ float tbl[];      // scale, shift of raw; scale, shift of the residual
   const int n = blockIdx.y;
   float* sc = tbl; float* sh = tbl + C; float* rsc = tbl + 2 * C; float* rsh = tbl + 3 * C; float* dump = tbl + 4 * C;
@@ -73,13 +80,18 @@ __global__ __launch_bounds__(256) void residual_norm_act_kernel(const T* __restr
     const int g = (int)(i - v * groups), c0 = g * EPG;
     const Frag a = *(const Frag*)(raw + ((long)n * vox + v) * raw_stride + c0);
     const Frag r = *(const Frag*)(res + ((long)n * vox + v) * res_stride + c0);
-    Frag o;
+    Frag o, pa, rs;
+    if (post) pa = *(const Frag*)(post + ((long)n * vox + v) * post_stride + post_off + c0);
+    if (ra) rs = *(const Frag*)(ra + ((long)n * vox + v) * ra_stride + ra_off + c0);
 #pragma unroll
     for (int e = 0; e < EPG; ++e) {
       float y = fmaf((float)a[e], sc[c0 + e], sh[c0 + e]);
       const float rr = has_rf ? fmaf((float)r[e], rsc[c0 + e], rsh[c0 + e]) : (float)r[e];
       y += rr;
-      o[e] = (T)(y > 0.f ? y : y * slope);
+      y = y > 0.f ? y : y * slope;
+      if (post) y += (float)pa[e];                                       // + embeddings[k]   (denoiser.py:370-383)
+      if (ra) { const float s = (float)rs[e]; y += s * (1.f - 1.f / (1.f + __expf(-s))); }   // + reverse_attention(skip) (:405-408)
+      o[e] = (T)y;
     }
     *(Frag*)(out + ((long)n * vox + v) * out_stride + out_off + c0) = o;
   }
@@ -89,16 +101,16 @@ __global__ __launch_bounds__(256) void residual_norm_act_kernel(const T* __restr
 
 extern "C" {
 
-int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legacy, const void* x, const float* gamma,
-                         const float* beta, float eps, void* out, void* stream) {
+int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legacy, const float* x, const void* y,
+                         const float* gamma, const float* beta, float eps, void* out, void* stream) {
   if (!x || !gamma || !beta || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return DUA_ERR_ARG;
   const long ntok = (long)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
   dim3 grid((unsigned)((ntok + 3) / 4));
   if (dtype == DUA_F16)
-    hipLaunchKernelGGL(dua::patch_merge_norm_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)x, B, D,
+    hipLaunchKernelGGL(dua::patch_merge_norm_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, x, (const dua::f16*)y, B, D,
                        H, W, C, legacy, gamma, beta, eps, (dua::f16*)out);
   else if (dtype == DUA_F32)
-    hipLaunchKernelGGL(dua::patch_merge_norm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, B, D, H, W,
+    hipLaunchKernelGGL(dua::patch_merge_norm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (const float*)y, B, D, H, W,
                        C, legacy, gamma, beta, eps, (float*)out);
   else return DUA_ERR_ARG;
   return (int)hipGetLastError();
@@ -106,11 +118,14 @@ int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legac
 
 int dua_residual_norm_act(int dtype, int N, long voxels, int C, const void* raw, int raw_stride, const dua_in_norm* in,
                           const void* res, int res_stride, const dua_in_norm* res_in, void* out, int out_stride, int out_off,
-                          float slope, void* stream) {
+                          float slope, const void* post_add, int post_stride, int post_off, const void* ra_src,
+                          int ra_stride, int ra_off, void* stream) {
   if (!raw || !in || !in->stats || !res || !out || N <= 0 || voxels <= 0 || C <= 0 || C % 8 || raw_stride % 8 ||
       res_stride % 8 || out_stride % 8 || out_off % 8 || C > 2048)
     return DUA_ERR_ARG;
   if (res_in && !res_in->stats) return DUA_ERR_ARG;
+  if (post_add && (post_stride % 8 || post_off % 8 || post_stride < post_off + C)) return DUA_ERR_ARG;
+  if (ra_src && (ra_stride % 8 || ra_off % 8 || ra_stride < ra_off + C)) return DUA_ERR_ARG;
   const dua::InXform xf = dua::make_xform(in, C), rf = dua::make_xform(res_in, C);
   long b = (voxels * (C / 8) + 255) / 256;
   dim3 grid((unsigned)(b > 4096 ? 4096 : b), N);
@@ -118,11 +133,12 @@ int dua_residual_norm_act(int dtype, int N, long voxels, int C, const void* raw,
   if (dtype == DUA_F16)
     hipLaunchKernelGGL(dua::residual_norm_act_kernel<dua::f16>, grid, dim3(256), lds, (hipStream_t)stream, (const dua::f16*)raw,
                        raw_stride, xf, (const dua::f16*)res, res_stride, rf, res_in ? 1 : 0, voxels, C, (dua::f16*)out,
-                       out_stride, out_off, slope);
+                       out_stride, out_off, slope, (const dua::f16*)post_add, post_stride, post_off, (const dua::f16*)ra_src,
+                       ra_stride, ra_off);
   else if (dtype == DUA_F32)
     hipLaunchKernelGGL(dua::residual_norm_act_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)raw,
                        raw_stride, xf, (const float*)res, res_stride, rf, res_in ? 1 : 0, voxels, C, (float*)out, out_stride,
-                       out_off, slope);
+                       out_off, slope, (const float*)post_add, post_stride, post_off, (const float*)ra_src, ra_stride, ra_off);
   else return DUA_ERR_ARG;
   return (int)hipGetLastError();
 }

@@ -18,7 +18,9 @@
 // (rows 16..31 of the 32-row output are padding: the price of a 16-wide head on a 32-row instruction).  V is written
 // to LDS already in that permuted key order, so its operand fragment is one 16-byte read.
 // Bias and mask arrive TRANSPOSED ([head][key][query], [window][key][query], fp32) so that the 32 lanes of a half read
-// 128 contiguous bytes per key.
+// 128 contiguous bytes per key.  The shifted-window mask can instead be given as what compute_mask builds it from: one
+// region id per token of every window ([windows per image][tokens], uint8; attention.py:135-157) -- 343 bytes per window
+// instead of 343 x 343 floats (161 MB per image at 48^3 tokens); the kernel adds -100 where the ids of query and key differ.
 #include "common.hpp"
 #include "../../include/dua_hip.h"
 
@@ -30,7 +32,7 @@ constexpr int MAXB = 11;        // 32-token blocks per window (n <= 352)
 }  // namespace wa
 
 struct WinAttnArgs {
-  const void* qkv; const float* bias_t; const float* mask_t; void* out;
+  const void* qkv; const float* bias_t; const float* mask_t; const unsigned char* region; void* out;
   int n, heads, nw;             // tokens per window, heads, windows per image (mask index = window % nw)
   float scale;
 };
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   f16* Kl = (f16*)smem;                           // [nb*32][16]
   f16* Ql = Kl + MAXB * 32 * HD;                  // [nb*32][16]
   f16* Vp = Ql + MAXB * 32 * HD;                  // [nb][2 s][2 hh][32 rows (dims, 16 real)][8 keys]  (permuted V^T)
+  unsigned char* regl = (unsigned char*)(Vp + MAXB * 2 * 2 * 32 * 8);     // [nb*32] region id of every token of the window
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int win = blockIdx.x, head = blockIdx.y;
@@ -72,9 +75,12 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     }
     *(f16x8*)(Vp + (long)i * 8) = v;
   }
+  if (a.region)
+    for (int i = tid; i < nb * 32; i += 256) regl[i] = i < n ? a.region[(long)(win % a.nw) * n + i] : (unsigned char)255;
   __syncthreads();
 
   const float* bias = a.bias_t + (long)head * n * n;
+  const bool has_region = a.region != nullptr;
   const float* mask = a.mask_t ? a.mask_t + (long)(win % a.nw) * n * n : nullptr;
   T* outp = (T*)a.out + (long)win * n * C + head * HD;
   for (int qb = wave; qb < nb; qb += 4) {
@@ -82,6 +88,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     const bool qok = q < n;
     const int qc = qok ? q : 0;
     const f16x8 qf = *(const f16x8*)(Ql + (qb * 32 + r) * HD + hh * 8);      // B operand: Q^T[dims 8hh..][query r]
+    const unsigned char rq = has_region ? regl[qb * 32 + r] : (unsigned char)0;
     // score tile of key block kb for this lane's query: scale * <q, k> + bias + mask (padding keys: -3e38)
     auto scores = [&](int kb) {
       const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
         if (key < n) {
           v = z[i] * a.scale + bias[(long)key * n + qc];
           if (mask) v += mask[(long)key * n + qc];
+          if (has_region && regl[key] != rq) v += -100.f;      // compute_mask's 0 / -100 from the region ids
         }
         z[i] = v;
       }
@@ -150,15 +158,15 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 }  // namespace dua
 
 extern "C" int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image,
-                                        const void* qkv, const float* bias_t, const float* mask_t, float scale, void* out,
-                                        void* stream) {
+                                        const void* qkv, const float* bias_t, const float* mask_t,
+                                        const unsigned char* region_ids, float scale, void* out, void* stream) {
   using namespace dua;
   if (!qkv || !bias_t || !out || windows <= 0 || heads <= 0 || tokens <= 0 || tokens > wa::MAXB * 32) return DUA_ERR_ARG;
-  if (mask_t && (windows_per_image <= 0 || windows % windows_per_image)) return DUA_ERR_ARG;
+  if ((mask_t || region_ids) && (windows_per_image <= 0 || windows % windows_per_image)) return DUA_ERR_ARG;
   WinAttnArgs a;
-  a.qkv = qkv; a.bias_t = bias_t; a.mask_t = mask_t; a.out = out;
-  a.n = tokens; a.heads = heads; a.nw = mask_t ? windows_per_image : 1; a.scale = scale;
-  const int lds = wa::MAXB * 32 * wa::HD * 2 * 2 + wa::MAXB * 2 * 2 * 32 * 8 * 2;     // Q + K + permuted V^T
+  a.qkv = qkv; a.bias_t = bias_t; a.mask_t = mask_t; a.region = region_ids; a.out = out;
+  a.n = tokens; a.heads = heads; a.nw = (mask_t || region_ids) ? windows_per_image : 1; a.scale = scale;
+  const int lds = wa::MAXB * 32 * wa::HD * 2 * 2 + wa::MAXB * 2 * 2 * 32 * 8 * 2 + wa::MAXB * 32;   // Q + K + permuted V^T + regions
   dim3 grid(windows, heads);
   if (dtype == DUA_F16) hipLaunchKernelGGL(window_attention_kernel<f16>, grid, dim3(256), lds, (hipStream_t)stream, a);
   else if (dtype == DUA_F32) hipLaunchKernelGGL(window_attention_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -26,20 +26,21 @@ class _FusedAdapter:
 
 
 class _Runtime:
-    """Launch plans of one DiffUNet, keyed by (batch, patch shape, device, dtype)."""
+    """Launch plans of one network pair, keyed by (batch, patch shape, device, dtype)."""
 
-    def __init__(self, net):
+    def __init__(self, net, plan_cls=Plan):
         self.net = net
+        self.plan_cls = plan_cls
         self.plans = {}
 
     def plan(self, N, dims, device):
         device = torch.device(device)
         if device.type != "cuda":
-            raise RuntimeError("DiffUNet runs on an MI355X (device 'cuda'); there is no CPU path in this package")
+            raise RuntimeError(f"{type(self.net).__name__} runs on an MI355X (device 'cuda'); there is no CPU path in this package")
         key = (N, tuple(dims), device.index, self.net.compute_dtype)
         p = self.plans.get(key)
         if p is None:
-            p = Plan(self.net, N, *dims, self.net.compute_dtype, device)
+            p = self.plan_cls(self.net, N, *dims, self.net.compute_dtype, device)
             self.plans[key] = p
         return p
 

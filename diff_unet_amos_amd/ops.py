@@ -149,7 +149,8 @@ def pack_deconv_weights(w, bias, dtype):
         raise RuntimeError(f"dua_pack_deconv_weights failed ({rc})")
     cpad = -(-cout // 64) * 64
     b = torch.zeros(cpad, dtype=torch.float32, device=w.device)
-    b[:cout] = bias.detach().float()
+    if bias is not None:
+        b[:cout] = bias.detach().float()
     return buf, b
 
 
@@ -405,16 +406,18 @@ def deconv_k2s2_bwd(x, cin, cin_off, dy, cout, cout_off, w, need_dx=True, need_d
 HEAD_MAX_K, HEAD_MAX_C = 16, 64
 
 
-def head_fwd(u, weight, bias):
+def head_fwd(u, weight, bias, out=None):
     """logits [N, D, H, W, K] = 1x1x1 convolution of the channels-last activation ``u`` (weight fp32 [K, C], bias fp32 [K])."""
     _cl_check(u, "u")
     K, Cc = weight.shape
     assert K <= HEAD_MAX_K and Cc <= HEAD_MAX_C and Cc % 8 == 0 and Cc <= u.shape[-1]
     assert weight.dtype == torch.float32 and weight.is_contiguous() and bias.dtype == torch.float32 and bias.numel() == K
-    out = torch.empty((*u.shape[:4], K), dtype=u.dtype, device=u.device)
+    if out is None:
+        out = torch.empty((*u.shape[:4], K), dtype=u.dtype, device=u.device)
+    assert out.is_contiguous() and out.dtype == u.dtype and tuple(out.shape[:4]) == tuple(u.shape[:4]) and out.shape[-1] >= K
     vox = u.numel() // u.shape[-1]
     nv.check(nv.lib().dua_head_fwd(nv.dt_code(u.dtype), vox, Cc, K, nv.ptr(u), u.shape[-1], nv.ptr(weight), nv.ptr(bias),
-                                   nv.ptr(out), K, nv.stream_ptr()), "dua_head_fwd")
+                                   nv.ptr(out), out.shape[-1], nv.stream_ptr()), "dua_head_fwd")
     return out
 
 
@@ -638,48 +641,159 @@ def denoiser_step(plan_struct):
     nv.check(nv.lib().dua_denoiser_step(C.byref(plan_struct), nv.stream_ptr()), "dua_denoiser_step")
 
 
-def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1):
+def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1, region_ids=None, out=None):
     """Softmax attention inside windows (models/swin_unetr/attention.py:97-120 between the qkv and proj Linear layers).
     qkv: [windows, tokens, 3 * heads * 16] (fp16 or fp32, contiguous); bias_t: fp32 [heads, tokens, tokens] = bias[h].T;
-    mask_t: fp32 [windows_per_image, tokens, tokens] = mask[w].T or None.  Returns [windows, tokens, heads * 16]."""
+    the shifted-window mask either as mask_t: fp32 [windows_per_image, tokens, tokens] = mask[w].T, or as region_ids:
+    uint8 [windows_per_image, tokens] (what compute_mask derives it from).  Returns [windows, tokens, heads * 16]."""
     assert qkv.is_cuda and qkv.is_contiguous() and qkv.dim() == 3 and qkv.dtype in (torch.float16, torch.float32)
     Wn, n, c3 = qkv.shape
     assert c3 == 3 * heads * 16 and n <= 352, "head dimension 16, at most 352 tokens per window"
     _f32c(bias_t, "bias_t")
     assert tuple(bias_t.shape) == (heads, n, n)
+    assert mask_t is None or region_ids is None
     if mask_t is not None:
         _f32c(mask_t, "mask_t")
         assert tuple(mask_t.shape) == (windows_per_image, n, n) and Wn % windows_per_image == 0
-    out = torch.empty((Wn, n, heads * 16), dtype=qkv.dtype, device=qkv.device)
+    if region_ids is not None:
+        assert region_ids.is_cuda and region_ids.dtype == torch.uint8 and region_ids.is_contiguous()
+        assert tuple(region_ids.shape) == (windows_per_image, n) and Wn % windows_per_image == 0
+    if out is None:
+        out = torch.empty((Wn, n, heads * 16), dtype=qkv.dtype, device=qkv.device)
+    assert out.is_contiguous() and out.dtype == qkv.dtype and out.numel() == Wn * n * heads * 16
     nv.check(nv.lib().dua_window_attention_fwd(nv.dt_code(qkv.dtype), Wn, n, heads, windows_per_image, nv.ptr(qkv), nv.ptr(bias_t),
-                                               nv.ptr(mask_t), 16 ** -0.5, nv.ptr(out), nv.stream_ptr()), "dua_window_attention_fwd")
+                                               nv.ptr(mask_t), nv.ptr(region_ids), 16 ** -0.5, nv.ptr(out), nv.stream_ptr()),
+             "dua_window_attention_fwd")
     return out
 
 
-def patch_merge_norm(x, gamma, beta, legacy=True, eps=1e-5):
-    """PatchMerging.forward up to its reduction Linear (models/swin_unetr/patch.py:44-91): x [B, D, H, W, C] ->
-    LayerNorm_8C of the gathered 2x2x2 neighbourhoods, [B, ceil(D/2), ceil(H/2), ceil(W/2), 8C]."""
-    assert x.is_cuda and x.is_contiguous() and x.dim() == 5 and x.dtype in (torch.float16, torch.float32)
+def patch_merge_norm(x, gamma, beta, legacy=True, eps=1e-5, y=None, dtype=None, out=None):
+    """PatchMerging.forward up to its reduction Linear (models/swin_unetr/patch.py:44-91): the fp32 token stream
+    x [B, D, H, W, C] (+ y, the last block's MLP output in ``dtype``) -> LayerNorm_8C of the gathered 2x2x2 neighbourhoods,
+    [B, ceil(D/2), ceil(H/2), ceil(W/2), 8C] in ``dtype``."""
+    assert x.is_cuda and x.is_contiguous() and x.dim() == 5 and x.dtype == torch.float32
     B, D, H, W, Cc = x.shape
+    dtype = dtype or (y.dtype if y is not None else torch.float32)
+    if y is not None:
+        assert y.is_contiguous() and y.dtype == dtype and y.numel() == x.numel()
     _f32c(gamma, "gamma"); _f32c(beta, "beta")
     assert gamma.numel() == beta.numel() == 8 * Cc
-    out = torch.empty((B, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, 8 * Cc), dtype=x.dtype, device=x.device)
-    nv.check(nv.lib().dua_patch_merge_norm(nv.dt_code(x.dtype), B, D, H, W, Cc, 1 if legacy else 0, nv.ptr(x), nv.ptr(gamma),
-                                           nv.ptr(beta), eps, nv.ptr(out), nv.stream_ptr()), "dua_patch_merge_norm")
+    shape = (B, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, 8 * Cc)
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=x.device)
+    assert out.is_contiguous() and out.dtype == dtype and out.numel() == B * shape[1] * shape[2] * shape[3] * 8 * Cc
+    nv.check(nv.lib().dua_patch_merge_norm(nv.dt_code(dtype), B, D, H, W, Cc, 1 if legacy else 0, nv.ptr(x), nv.ptr(y),
+                                           nv.ptr(gamma), nv.ptr(beta), eps, nv.ptr(out), nv.stream_ptr()), "dua_patch_merge_norm")
     return out
 
 
-def residual_norm_act(raw, norm, res, res_norm=None, slope=0.01, out=None, out_off=0):
-    """out = LeakyReLU(IN(raw) + residual) (UnetResBlock tail, models/swin_unetr/blocks.py:308-316); ``res_norm`` normalises
-    the residual (conv3 + norm3 of channel-changing blocks)."""
+def residual_norm_act(raw, norm, res, res_norm=None, slope=0.01, out=None, out_off=0, post_add=None, post_off=0,
+                      ra_src=None, ra_off=0, res_off=0):
+    """out = LeakyReLU(IN(raw) + residual) [+ post_add] [+ reverse_attention(ra_src)] (UnetResBlock tail,
+    models/swin_unetr/blocks.py:308-316, and the adds of swin_unetr/denoiser.py:370-399); ``res_norm`` normalises the
+    residual (conv3 + norm3 of channel-changing blocks)."""
     _cl_check(raw, "raw"); _cl_check(res, "res")
     N, D, H, W, Cc = raw.shape
-    assert tuple(res.shape[:4]) == (N, D, H, W) and res.shape[-1] >= Cc and res.dtype == raw.dtype
+    assert tuple(res.shape[:4]) == (N, D, H, W) and res.shape[-1] >= res_off + Cc and res.dtype == raw.dtype and res_off % 8 == 0
     if out is None:
         out = torch.empty_like(raw)
     _cl_check(out, "out")
     assert tuple(out.shape[:4]) == (N, D, H, W) and out_off % 8 == 0 and out_off + Cc <= out.shape[-1]
+    for t_, o_ in ((post_add, post_off), (ra_src, ra_off)):
+        if t_ is not None:
+            _cl_check(t_, "add")
+            assert tuple(t_.shape[:4]) == (N, D, H, W) and t_.dtype == raw.dtype and o_ % 8 == 0 and o_ + Cc <= t_.shape[-1]
+    res_ptr = C.c_void_p(res.data_ptr() + res_off * res.element_size())
     nv.check(nv.lib().dua_residual_norm_act(nv.dt_code(raw.dtype), N, D * H * W, Cc, nv.ptr(raw), raw.shape[-1], norm.ref(N, Cc),
-                                            nv.ptr(res), res.shape[-1], _norm_ref(res_norm, N, Cc), nv.ptr(out), out.shape[-1],
-                                            out_off, slope, nv.stream_ptr()), "dua_residual_norm_act")
+                                            res_ptr, res.shape[-1], _norm_ref(res_norm, N, Cc), nv.ptr(out), out.shape[-1],
+                                            out_off, slope, nv.ptr(post_add), post_add.shape[-1] if post_add is not None else 0,
+                                            post_off, nv.ptr(ra_src), ra_src.shape[-1] if ra_src is not None else 0, ra_off,
+                                            nv.stream_ptr()), "dua_residual_norm_act")
     return out
+
+
+def window_geom(B, dims, C_, window, shift):
+    """dua_window_geom for a [B, *dims, C] token stream; ``window`` / ``shift`` already clipped (get_window_size)."""
+    return nv.WindowGeom(B, dims[0], dims[1], dims[2], C_, window[0], window[1], window[2], shift[0], shift[1], shift[2])
+
+
+def window_gather_norm(x, geom, gamma, beta, out, y=None, eps=1e-5):
+    """[x += y] -> norm1 -> pad -> roll(-shift) -> window_partition (transformer.py:378-417).  x: fp32 [B, D, H, W, C]
+    (updated in place when y is given); out: [B * windows, tokens, C] in the compute dtype."""
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and out.is_contiguous()
+    assert y is None or (y.is_contiguous() and y.dtype == out.dtype and y.numel() == x.numel())
+    _f32c(gamma, "gamma"); _f32c(beta, "beta")
+    nv.check(nv.lib().dua_window_gather_norm(nv.dt_code(out.dtype), C.byref(geom), nv.ptr(x), nv.ptr(y), nv.ptr(gamma), nv.ptr(beta),
+                                             eps, nv.ptr(out), nv.stream_ptr()), "dua_window_gather_norm")
+    return out
+
+
+def window_scatter_add_norm(x, geom, yw, gamma, beta, out, eps=1e-5):
+    """x += crop(roll(+shift)(window_reverse(yw))); out = norm2(x) (transformer.py:417-434, 475-476)."""
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and yw.is_contiguous() and out.is_contiguous()
+    assert yw.dtype == out.dtype and out.numel() == x.numel()
+    _f32c(gamma, "gamma"); _f32c(beta, "beta")
+    nv.check(nv.lib().dua_window_scatter_add_norm(nv.dt_code(out.dtype), C.byref(geom), nv.ptr(x), nv.ptr(yw), nv.ptr(gamma),
+                                                  nv.ptr(beta), eps, nv.ptr(out), nv.stream_ptr()), "dua_window_scatter_add_norm")
+    return out
+
+
+def stage_out(y, B, Cc, out, out_off=0, tadd=None, emb=None, x=None, eps=1e-5):
+    """x = y + tadd[b]; out[..., out_off:out_off + C] = layer_norm(x) (no affine) + emb (transformer.py:277-312,
+    swin_unetr/denoiser.py:367-368).  y: [B * tokens, C]; tadd: fp32 [B, >= C] (a column slice of a wider table is fine)."""
+    assert y.is_cuda and y.is_contiguous() and y.numel() % (B * Cc) == 0 and out.dtype == y.dtype and out.is_contiguous()
+    per = y.numel() // (B * Cc)
+    ts = 0
+    if tadd is not None:
+        assert tadd.dtype == torch.float32 and tadd.dim() == 2 and tadd.shape[0] == B and tadd.stride(1) == 1
+        ts = tadd.stride(0)
+    if emb is not None:
+        assert emb.is_contiguous() and emb.dtype == y.dtype and emb.numel() == y.numel()
+    if x is not None:
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.numel() == y.numel()
+    assert out.numel() == B * per * out.shape[-1]
+    nv.check(nv.lib().dua_stage_out(nv.dt_code(y.dtype), B, per, Cc, nv.ptr(y), nv.ptr(tadd), ts, eps, nv.ptr(emb), nv.ptr(x),
+                                    nv.ptr(out), out.shape[-1], out_off, nv.stream_ptr()), "dua_stage_out")
+    return out
+
+
+def pack_patch_embed_weights(w, cin_packed, perm=None):
+    """Conv3d(k2, s2) weight fp32 [E, Cin, 2, 2, 2] -> fp32 [8 taps (kd, kh, kw), cin_packed, E]; packed channel p reads
+    source channel perm[p] (default: p), channels beyond the source are zero."""
+    E, Cin = w.shape[:2]
+    perm = list(range(Cin)) if perm is None else list(perm)
+    wp = torch.zeros(8, cin_packed, E, dtype=torch.float32, device=w.device)
+    wp[:, :len(perm)] = w.detach().float()[:, perm].permute(2, 3, 4, 1, 0).reshape(8, len(perm), E)
+    return wp.contiguous()
+
+
+def patch_embed(xin, cin_packed, w_packed, bias, out, out_off=0, tadd=None, emb=None, x=None, eps=1e-5):
+    """PatchEmbed conv + bias (+ tadd[b]) -> x (fp32 stream), layer_norm(x) (+ emb) -> out slice (transformer.py:271-275)."""
+    _cl_check(xin, "xin")
+    B, D, H, W, Cs = xin.shape
+    E = w_packed.shape[-1]
+    _f32c(w_packed, "w_packed"); _f32c(bias, "bias")
+    ts = 0
+    if tadd is not None:
+        assert tadd.dtype == torch.float32 and tadd.dim() == 2 and tadd.shape[0] == B and tadd.stride(1) == 1
+        ts = tadd.stride(0)
+    nv.check(nv.lib().dua_patch_embed(nv.dt_code(xin.dtype), B, D, H, W, Cs, cin_packed, E, nv.ptr(xin), nv.ptr(w_packed),
+                                      nv.ptr(bias), nv.ptr(tadd), ts, eps, nv.ptr(emb), nv.ptr(x), nv.ptr(out), out.shape[-1],
+                                      out_off, nv.stream_ptr()), "dua_patch_embed")
+    return out
+
+
+def instnorm_stats(x, Cc, stats, c_off=0):
+    """Accumulate per-(n, c) sum / sum of squares of a channels-last slice into a (zeroed) statistics buffer."""
+    _cl_check(x, "x")
+    N, D, H, W, Cs = x.shape
+    nv.check(nv.lib().dua_instnorm_stats(nv.dt_code(x.dtype), N, D * H * W, Cc, nv.ptr(x), Cs, c_off, nv.ptr(stats),
+                                         stats.shape[2], nv.stream_ptr()), "dua_instnorm_stats")
+    return stats
+
+
+def gelu_(x):
+    """Exact GELU in place (MONAI MLPBlock act "GELU")."""
+    assert x.is_cuda and x.is_contiguous() and x.numel() % 8 == 0
+    nv.check(nv.lib().dua_gelu(nv.dt_code(x.dtype), x.numel(), nv.ptr(x), nv.stream_ptr()), "dua_gelu")
+    return x

@@ -1,0 +1,399 @@
+"""Launch plan of the two Swin-UNETR networks (diff_swin_unetr variant, BASELINE config 5) on one MI355X.
+
+Owns, per (batch, patch shape, dtype): packed weights, resident workspaces, the timestep table of all fifteen
+``t_proj(swish(t_embedder(t)))`` projections, and the fixed kernel sequence of one encoder pass and one denoiser
+evaluation.  Replaces SwinUNETREncoder.forward (models/swin_unetr/encoder.py:212-219) and SwinUNETRDenoiser.forward
+(models/swin_unetr/denoiser.py:353-403).
+
+Data layout
+  * voxels / tokens are channels-last everywhere ([N, D, H, W, C]); a Swin token map IS a channels-last feature map, so
+    the hidden states feed the convolutions without a transpose (the reference rearranges "b c d h w" <-> "b d h w c"
+    around every stage, transformer.py:97,109).
+  * the residual token stream of a stage is fp32; every GEMM / convolution operand is the compute dtype.
+  * torch.cat((up, skip)) of UnetrUpBlock (blocks.py:90) is a buffer both producers write their half of.
+
+What runs where
+  * hand-written HIP: 3x3x3 convolutions + InstanceNorm statistics (conv3d_igemm.hip), the transposed convolutions
+    (deconv.hip), windowed attention (window_attention.hip), norm1 + pad + roll + window partition and its inverse with
+    the residual add and norm2 (swin_tokens.hip), patch embedding, patch-merging gather + LayerNorm, the stage adds,
+    GELU, the UnetResBlock tail with the embedding / reverse-attention adds (swin_ops.hip), the 1x1x1 output head.
+  * library GEMMs (torch.nn.functional.linear -> hipBLASLt): qkv / proj / MLP / patch-merging reduction Linear layers and
+    the 1x1x1 conv3 of channel-changing UnetResBlocks.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _native as nv
+from . import ops
+from .swin_unetr import HEADS, WINDOW
+
+SLOPE = 0.01         # get_act_layer(("leakyrelu", {"negative_slope": 0.01})), blocks.py:247
+EPS = 1e-5
+
+
+def clip_window(dims, window, shift):
+    """attention.py:225-251 get_window_size."""
+    ws, ss = list(window), list(shift)
+    for i in range(3):
+        if dims[i] <= window[i]:
+            ws[i], ss[i] = dims[i], 0
+    return tuple(ws), tuple(ss)
+
+
+def region_ids(dims_padded, window, shift):
+    """The image compute_mask (attention.py:123-160) partitions into windows: region id 0..26 per token,
+    uint8 [windows, tokens]."""
+    d, h, w = dims_padded
+    img = torch.zeros((d, h, w), dtype=torch.uint8)
+    cnt = 0
+    for sd in (slice(-window[0]), slice(-window[0], -shift[0]), slice(-shift[0], None)):
+        for sh in (slice(-window[1]), slice(-window[1], -shift[1]), slice(-shift[1], None)):
+            for sw in (slice(-window[2]), slice(-window[2], -shift[2]), slice(-shift[2], None)):
+                img[sd, sh, sw] = cnt
+                cnt += 1
+    wd, wh, ww = window
+    x = img.view(d // wd, wd, h // wh, wh, w // ww, ww).permute(0, 2, 4, 1, 3, 5)
+    return x.reshape(-1, wd * wh * ww).contiguous()
+
+
+class _Res:
+    """One UnetResBlock bound to its packed weights and statistics."""
+
+
+class SwinEmbeddings(list):
+    """What embed_model(image) returns: [hidden_states_out (5 tensors), enc0, enc1, enc2, enc3] like the reference
+    (NCDHW fp32, converted on first access) while the denoiser reads the channels-last device buffers."""
+
+    def __init__(self, plan, token):
+        super().__init__([None] * 5)
+        self.plan, self.token = plan, token
+
+    def __getitem__(self, i):
+        v = super().__getitem__(i)
+        if v is None:
+            p = self.plan
+            assert p.emb_token == self.token, "embeddings were overwritten by a later encoder pass"
+            if i == 0:
+                v = [ops.from_channels_last(p.e_hs[k], p.e_hs[k].shape[-1]) for k in range(5)]
+            else:
+                v = ops.from_channels_last(p.e_enc[i - 1], p.e_enc[i - 1].shape[-1])
+            super().__setitem__(i, v)
+        return v
+
+    def __iter__(self):
+        return (self[i] for i in range(5))
+
+
+class SwinPlan:
+    """Buffers + launch sequences for one (N, D, H, W, dtype)."""
+
+    def __init__(self, net, N, D, H, W, dtype, device):
+        assert D % 32 == 0 and H % 32 == 0 and W % 32 == 0, \
+            "input image size (image_size) should be divisible by stage-wise image resolution."      # denoiser.py:110-113
+        assert min(D, H, W) >= 64, "InstanceNorm3d needs more than one voxel at the 1/32 level"
+        self.net, self.N, self.dims, self.dtype, self.dev = net, N, (D, H, W), dtype, device
+        self.C = net.num_classes
+        f = net.feature_size
+        self.f = f
+        self.cin0 = -(-(self.C + 1) // 8) * 8                 # [image | x_t (C) | zero pad]
+        S = [(D >> l, H >> l, W >> l) for l in range(6)]    # S[0] voxels, S[1..5] token maps x0..x4
+        self.S = S
+        self.tok_c = [f * 2 ** i for i in range(5)]           # channels of x0..x4
+        z = lambda l, c, dt=dtype: torch.zeros((N, *S[l], c), dtype=dt, device=device)  # noqa: E731
+        # ---- conditioning encoder: inputs, outputs
+        self.img_in = z(0, 8)
+        self.e_hs = [z(i + 1, self.tok_c[i]) for i in range(5)]
+        self.e_enc = [z(0, f), z(1, f), z(2, 2 * f), z(3, 4 * f)]
+        self.emb_token = 0
+        # ---- denoiser
+        self.xin = z(0, self.cin0)
+        self.hs = [z(1, f), z(2, 2 * f), z(3, 4 * f), None, z(5, 16 * f)]      # hs[3] lives in cat[4]
+        self.cat = [z(0, 2 * f), z(1, 2 * f), z(2, 4 * f), z(3, 8 * f), z(4, 16 * f)]   # (up | skip) of decoder1..5
+        self.dec = [z(0, f), z(1, f), z(2, 2 * f), z(3, 4 * f), z(4, 8 * f), z(5, 16 * f)]   # out, dec0..dec4
+        self.logits_cl = z(0, -(-self.C // 8) * 8)
+        # ---- shared scratch (the two networks never run concurrently)
+        big = max(N * S[l][0] * S[l][1] * S[l][2] * c for l, c in ((0, f), (1, f), (2, 2 * f), (3, 4 * f), (4, 8 * f), (5, 16 * f)))
+        self.raw1 = torch.zeros(big, dtype=dtype, device=device)
+        self.raw2 = torch.zeros(big, dtype=dtype, device=device)
+        self.res3 = torch.zeros(big, dtype=dtype, device=device)
+        self.stream = [torch.zeros((N, *S[i + 1], self.tok_c[i]), dtype=torch.float32, device=device) for i in range(5)]
+        self.geo = []
+        tok_max = 0
+        for i in range(4):
+            dims = S[i + 1]
+            ws, ss = clip_window(dims, WINDOW, tuple(w // 2 for w in WINDOW))
+            pad = tuple(-(-dims[k] // ws[k]) * ws[k] for k in range(3))
+            nw = (pad[0] // ws[0]) * (pad[1] // ws[1]) * (pad[2] // ws[2])
+            n = ws[0] * ws[1] * ws[2]
+            reg = region_ids(pad, ws, ss).to(device) if any(ss) else None
+            self.geo.append(dict(dims=dims, ws=ws, ss=ss, nw=nw, n=n, region=reg,
+                                 g0=ops.window_geom(N, dims, self.tok_c[i], ws, (0, 0, 0)),
+                                 g1=ops.window_geom(N, dims, self.tok_c[i], ws, ss)))
+            tok_max = max(tok_max, N * nw * n * self.tok_c[i])
+        self.win = torch.zeros(tok_max, dtype=dtype, device=device)           # window-partitioned LN1(x)
+        self.att = torch.zeros(tok_max, dtype=dtype, device=device)           # attention output
+        self.ln2 = torch.zeros(tok_max, dtype=dtype, device=device)
+        self.merged = torch.zeros(tok_max, dtype=dtype, device=device)        # gathered + normalised 8C tokens (= tokens * C)
+        self.logits = torch.zeros((N, self.C, *S[0]), dtype=torch.float32, device=device)
+        self._bind()
+        self.weights_version = None
+
+    # ---- parameter binding -------------------------------------------------------------------
+    def _res(self, name, block, level, cin_packed=None, perm=None):
+        r = _Res()
+        r.name, r.block, r.level = name, block, level
+        r.cout, r.cin = block.conv1.conv.weight.shape[:2]
+        r.cin_packed = cin_packed or r.cin
+        r.perm = perm
+        r.has3 = hasattr(block, "conv3")
+        r.t_off = None
+        return r
+
+    def _bind(self):
+        enc, den = self.net.embed_model, self.net.model
+        self.e_res = [self._res("e1", enc.encoder1.layer, 0, cin_packed=8), self._res("e2", enc.encoder2.layer, 1),
+                      self._res("e3", enc.encoder3.layer, 2), self._res("e4", enc.encoder4.layer, 3)]
+        self.d_res = [self._res("d1", den.encoder1.layer, 0, cin_packed=self.cin0), self._res("d2", den.encoder2.layer, 1),
+                      self._res("d3", den.encoder3.layer, 2), self._res("d4", den.encoder4.layer, 3),
+                      self._res("d10", den.encoder10.layer, 5)]
+        ups = [den.decoder1, den.decoder2, den.decoder3, den.decoder4, den.decoder5]
+        self.u_res = [self._res(f"u{k + 1}", ups[k].conv_block, k) for k in range(5)]
+        self.ups = ups
+        # one fp64 arena for the InstanceNorm sums, zeroed by one memset per pass
+        sizes, blocks = [], self.e_res + self.d_res + self.u_res
+        for r in blocks:
+            sizes.append(self.N * ops.STAT_REPLICAS * (-(-r.cout // 64) * 64) * 2)
+        self.stat_arena = torch.zeros(3 * sum(sizes), dtype=torch.float64, device=self.dev)
+        o = 0
+        for r, n in zip(blocks, sizes):
+            r.st = [self.stat_arena[o + k * n:o + (k + 1) * n].view(self.N, ops.STAT_REPLICAS, -1, 2) for k in range(3)]
+            o += 3 * n
+        n_enc = 3 * sum(sizes[:len(self.e_res)])
+        self.enc_stats, self.den_stats = self.stat_arena[:n_enc], self.stat_arena[n_enc:]
+        # timestep table columns: swinViT.t_proj[0..4], then every UnetResBlock's t_proj
+        self.t_lin = [den.swinViT.t_proj[i] for i in range(5)] + [r.block.t_proj for r in self.d_res + self.u_res]
+        offs, o = [], 0
+        for lin in self.t_lin:
+            offs.append(o)
+            o += -(-lin.weight.shape[0] // 8) * 8
+        self.P = o
+        self.vit_t_off = offs[:5]
+        for r, off in zip(self.d_res + self.u_res, offs[5:]):
+            r.t_off = off
+        self.cur_add = torch.zeros((self.N, self.P), dtype=torch.float32, device=self.dev)
+        need = 0
+        for r in blocks:
+            dims = self.S[r.level]
+            for cin in (-(-r.cin_packed // 8) * 8, r.cout):
+                need = max(need, ops.conv3_workspace_bytes(self.dtype, self.N, *dims, cin, r.cout))
+        self.splitk_ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=self.dev)
+
+    def _pack_vit(self, vit, cin_packed):
+        dt = self.dtype
+        f32 = lambda p: p.detach().float().contiguous()  # noqa: E731
+        out = dict(pe_w=ops.pack_patch_embed_weights(vit.patch_embed.proj.weight.detach(), cin_packed),
+                   pe_b=f32(vit.patch_embed.proj.bias), stages=[])
+        for i, layer in enumerate(vit.stages()):
+            n = self.geo[i]["n"]
+            blocks = []
+            for blk in layer.blocks:
+                a = blk.attn
+                idx = a.relative_position_index[:n, :n].reshape(-1)
+                bias = a.relative_position_bias_table.detach().float()[idx].reshape(n, n, -1)     # [query, key, head]
+                blocks.append(dict(g1=f32(blk.norm1.weight), b1=f32(blk.norm1.bias), g2=f32(blk.norm2.weight), b2=f32(blk.norm2.bias),
+                                   bias_t=bias.permute(2, 1, 0).contiguous(),                    # [head, key, query]
+                                   wqkv=a.qkv.weight.detach().to(dt).contiguous(), bqkv=a.qkv.bias.detach().to(dt).contiguous(),
+                                   wproj=a.proj.weight.detach().to(dt).contiguous(), bproj=a.proj.bias.detach().to(dt).contiguous(),
+                                   w1=blk.mlp.linear1.weight.detach().to(dt).contiguous(), bb1=blk.mlp.linear1.bias.detach().to(dt).contiguous(),
+                                   w2=blk.mlp.linear2.weight.detach().to(dt).contiguous(), bb2=blk.mlp.linear2.bias.detach().to(dt).contiguous()))
+            out["stages"].append(dict(blocks=blocks, gm=f32(layer.downsample.norm.weight), bm=f32(layer.downsample.norm.bias),
+                                      wred=layer.downsample.reduction.weight.detach().to(dt).contiguous()))
+        return out
+
+    def refresh_weights(self):
+        """Re-pack when any parameter changed (load_state_dict, optimizer step)."""
+        ver = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        if ver == self.weights_version:
+            return
+        dt, dev = self.dtype, self.dev
+        with torch.no_grad():
+            for r in self.e_res + self.d_res + self.u_res:
+                b = r.block
+                r.w1, r.b1 = ops.pack_conv3_weights(b.conv1.conv.weight.detach().float().contiguous(), None, dt,
+                                                    cin_packed=r.cin_packed if r.cin_packed != r.cin else None)
+                r.w2, r.b2 = ops.pack_conv3_weights(b.conv2.conv.weight.detach().float().contiguous(), None, dt)
+                if r.has3:
+                    w3 = torch.zeros((r.cout, r.cin_packed), dtype=dt, device=dev)
+                    w3[:, :r.cin] = b.conv3.conv.weight.detach().reshape(r.cout, r.cin).to(dt)
+                    r.w3 = w3
+                r.ones = torch.ones(r.cout, dtype=torch.float32, device=dev)
+                r.zeros = torch.zeros(r.cout, dtype=torch.float32, device=dev)
+                r.norms = None
+            self.up_packed = [ops.pack_deconv_weights(u.transp_conv.conv.weight.detach().float().contiguous(), None, dt)
+                              for u in self.ups]
+            enc, den = self.net.embed_model, self.net.model
+            self.e_vit = self._pack_vit(enc.swinViT, 8)
+            self.d_vit = self._pack_vit(den.swinViT, self.cin0)
+            self.wf = den.out.conv.conv.weight.detach().float().reshape(self.C, -1).contiguous()
+            self.bf = den.out.conv.conv.bias.detach().float().contiguous()
+            # t_proj(swish(t_embedder(t))) of every projection, for every original timestep (depends on weights only)
+            T = self.net.timesteps
+            te = den.t_embedder
+            half = te.embedding_dim // 2
+            freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(dev)
+            wcat = torch.zeros((self.P, te.dense[1].weight.shape[0]), dtype=torch.float32, device=dev)
+            bcat = torch.zeros(self.P, dtype=torch.float32, device=dev)
+            o = 0
+            for lin in self.t_lin:
+                c = lin.weight.shape[0]
+                wcat[o:o + c] = lin.weight.detach().float()
+                bcat[o:o + c] = lin.bias.detach().float()
+                o += -(-c // 8) * 8
+            ts = torch.arange(T, dtype=torch.int32, device=dev)
+            f32 = lambda p: p.detach().float().contiguous()  # noqa: E731
+            self.temb_table = ops.temb_table(ts, freqs, f32(te.dense[0].weight), f32(te.dense[0].bias), f32(te.dense[1].weight),
+                                             f32(te.dense[1].bias), wcat, bcat)
+        self.weights_version = ver
+
+    # ---- building blocks ------------------------------------------------------------------------
+    def _view(self, flat, level, c):
+        n = self.N * self.S[level][0] * self.S[level][1] * self.S[level][2] * c
+        return flat[:n].view(self.N, *self.S[level], c)
+
+    def _tadd(self, off, c):
+        return None if off is None else self.cur_add[:, off:off + c]
+
+    def _res_block(self, r, x, cin, out, out_off=0, post_add=None, ra=None, ra_off=0):
+        """UnetResBlock.forward (blocks.py:298-316) on channels [0, cin) of ``x`` -> channels [out_off, ...) of ``out``."""
+        l, N = r.level, self.N
+        count = self.S[l][0] * self.S[l][1] * self.S[l][2]
+        raw1, raw2 = self._view(self.raw1, l, r.cout), self._view(self.raw2, l, r.cout)
+        if r.norms is None:
+            add = None if r.t_off is None else self.cur_add.view(-1)[r.t_off:]
+            r.norms = (ops.Norm(r.st[0], r.ones, r.zeros, count, add=add, add_stride=self.P if add is not None else 0,
+                                slope=SLOPE, eps=EPS),
+                       ops.Norm(r.st[1], r.ones, r.zeros, count, slope=SLOPE, eps=EPS),
+                       ops.Norm(r.st[2], r.ones, r.zeros, count, slope=SLOPE, eps=EPS))
+        n1, n2, n3 = r.norms
+        ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=self.splitk_ws)
+        ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=self.splitk_ws)
+        if r.has3:
+            res = self._view(self.res3, l, r.cout)
+            torch.matmul(x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin), r.w3.t(),
+                         out=res.view(-1, r.cout))                                  # 1x1x1 conv3 = library GEMM
+            ops.instnorm_stats(res, r.cout, r.st[2])
+            ops.residual_norm_act(raw2, n2, res, n3, slope=SLOPE, out=out, out_off=out_off, post_add=post_add, ra_src=ra,
+                                  ra_off=ra_off)
+        else:
+            ops.residual_norm_act(raw2, n2, x, None, slope=SLOPE, out=out, out_off=out_off, post_add=post_add, ra_src=ra,
+                                  ra_off=ra_off)
+
+    def _swin(self, vit, xin, cin_packed, t_offs, emb, outs):
+        """SwinTransformer.forward (transformer.py:270-316): patch embedding, four stages, the adds between them.
+        ``outs[i]`` = (buffer, channel offset) receiving hidden_states_out[i] (+ emb[i])."""
+        N, dt = self.N, self.dtype
+        tadd = lambda i: None if t_offs is None else self._tadd(t_offs[i], self.tok_c[i])  # noqa: E731
+        ops.patch_embed(xin, cin_packed, vit["pe_w"], vit["pe_b"], outs[0][0], outs[0][1], tadd=tadd(0),
+                        emb=None if emb is None else emb[0], x=self.stream[0])
+        for i in range(4):
+            g, st, C_ = self.geo[i], vit["stages"][i], self.tok_c[i]
+            x = self.stream[i]
+            ntok_w = N * g["nw"] * g["n"]
+            ntok = x.numel() // C_
+            win = self.win[:ntok_w * C_].view(N * g["nw"], g["n"], C_)
+            att = self.att[:ntok_w * C_].view(N * g["nw"], g["n"], C_)
+            ln2 = self.ln2[:ntok * C_].view(ntok, C_)
+            y = None
+            for k, b in enumerate(st["blocks"]):
+                shifted = k % 2 == 1 and any(g["ss"])
+                geom = g["g1"] if shifted else g["g0"]
+                ops.window_gather_norm(x, geom, b["g1"], b["b1"], win, y=y)
+                qkv = F.linear(win, b["wqkv"], b["bqkv"])
+                ops.window_attention(qkv, HEADS[i], b["bias_t"], region_ids=g["region"] if shifted else None,
+                                     windows_per_image=g["nw"], out=att)
+                po = F.linear(att, b["wproj"], b["bproj"])
+                ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)
+                h = F.linear(ln2, b["w1"], b["bb1"])
+                ops.gelu_(h)
+                y = F.linear(h, b["w2"], b["bb2"])
+            dims = g["dims"]
+            mshape = (N, (dims[0] + 1) // 2, (dims[1] + 1) // 2, (dims[2] + 1) // 2, 8 * C_)
+            merged = self.merged[:mshape[0] * mshape[1] * mshape[2] * mshape[3] * mshape[4]].view(mshape)
+            ops.patch_merge_norm(x, st["gm"], st["bm"], legacy=True, y=y, dtype=dt, out=merged)
+            red = F.linear(merged.view(-1, 8 * C_), st["wred"])
+            ops.stage_out(red, N, 2 * C_, outs[i + 1][0], outs[i + 1][1], tadd=tadd(i + 1),
+                          emb=None if emb is None else emb[i + 1], x=self.stream[i + 1] if i < 3 else None)
+
+    # ---- the two networks ---------------------------------------------------------------------------
+    def run_encoder(self, image):
+        """SwinUNETREncoder.forward (encoder.py:212-219): fills e_hs[0..4], e_enc[0..3] (channels-last)."""
+        self.refresh_weights()
+        N = self.N
+        assert tuple(image.shape) == (N, 1, *self.dims), f"image shape {tuple(image.shape)} != plan {(N, 1, *self.dims)}"
+        img = image.detach().float().contiguous()
+        ops.to_channels_last(img, self.img_in, 0, 8)
+        ops.to_channels_last(img, self.xin, 0, 1)               # conditioning channel of the denoiser input
+        self.enc_stats.zero_()
+        self._swin(self.e_vit, self.img_in, 8, None, None, [(self.e_hs[i], 0) for i in range(5)])
+        srcs = [(self.img_in, 8), (self.e_hs[0], self.f), (self.e_hs[1], 2 * self.f), (self.e_hs[2], 4 * self.f)]
+        for r, (x, cin), out in zip(self.e_res, srcs, self.e_enc):
+            self._res_block(r, x, cin, out)
+        self.emb_token += 1
+        return SwinEmbeddings(self, self.emb_token)
+
+    def stage_condition(self, image, embeddings):
+        """Make sure the denoiser's conditioning (image channel of xin, the nine encoder maps) is resident."""
+        if isinstance(embeddings, SwinEmbeddings) and embeddings.plan is self and embeddings.token == self.emb_token:
+            return
+        img = image.detach().float().contiguous()
+        assert tuple(img.shape) == (self.N, 1, *self.dims)
+        ops.to_channels_last(img, self.xin, 0, 1)
+        for k in range(5):
+            e = embeddings[0][k]
+            ops.to_channels_last(e.detach().float().contiguous(), self.e_hs[k], 0, e.shape[1])
+        for k in range(4):
+            e = embeddings[k + 1]
+            ops.to_channels_last(e.detach().float().contiguous(), self.e_enc[k], 0, e.shape[1])
+        self.emb_token += 1
+
+    def denoiser_body(self):
+        """SwinUNETRDenoiser.forward from the staged input (self.xin) to channels-last logits; self.cur_add holds the
+        t_proj rows of this evaluation."""
+        f = self.f
+        self.den_stats.zero_()
+        cat, dec, hs = self.cat, self.dec, self.hs
+        outs = [(hs[0], 0), (hs[1], 0), (hs[2], 0), (cat[4], 8 * f), (hs[4], 0)]
+        self._swin(self.d_vit, self.xin, self.cin0, self.vit_t_off, self.e_hs, outs)
+        # enc_k = encoder_k(...) + embeddings[k + 1] lands in the skip half of its decoder's concat buffer
+        self._res_block(self.d_res[0], self.xin, self.cin0, cat[0], f, post_add=self.e_enc[0])
+        self._res_block(self.d_res[1], hs[0], f, cat[1], f, post_add=self.e_enc[1])
+        self._res_block(self.d_res[2], hs[1], 2 * f, cat[2], 2 * f, post_add=self.e_enc[2])
+        self._res_block(self.d_res[3], hs[2], 4 * f, cat[3], 4 * f, post_add=self.e_enc[3])
+        self._res_block(self.d_res[4], hs[4], 16 * f, dec[5])                     # dec4 = encoder10(hs[4])
+        src = dec[5]
+        for k in (4, 3, 2, 1, 0):                                                  # decoder5 .. decoder1
+            cout = cat[k].shape[-1] // 2
+            wp, bp = self.up_packed[k]
+            ops.deconv_k2s2(src, src.shape[-1], 0, wp, bp, cout, cat[k], 0)
+            ra = cat[k] if k < 4 else None                                         # + r_k (not for decoder5: skip = hs[3])
+            self._res_block(self.u_res[k], cat[k], 2 * cout, dec[k], 0, ra=ra, ra_off=cout)
+            src = dec[k]
+        ops.head_fwd(dec[0], self.wf, self.bf, out=self.logits_cl)
+
+    def denoise(self, x, t):
+        """logits = model(x, t, image, embeddings) for an already-staged image (denoiser.py:353-403)."""
+        self.refresh_weights()
+        N = self.N
+        assert tuple(x.shape) == (N, self.C, *self.dims) and t.numel() == N
+        T = self.temb_table.shape[0]
+        rows = t.detach().to(device=self.dev, dtype=torch.int64).reshape(-1)
+        if not t.is_cuda and not bool(((t >= 0) & (t < T)).all()):
+            raise ValueError(f"timestep out of range: the model was built for 0 <= t < {T}, got {t.tolist()}")
+        ops.to_channels_last(x.detach().float().contiguous(), self.xin, 1, self.cin0 - 1)
+        torch.index_select(self.temb_table, 0, rows.clamp(0, T - 1), out=self.cur_add)
+        self.denoiser_body()
+        return ops.from_channels_last(self.logits_cl, self.C)

@@ -316,22 +316,65 @@ int dua_denoiser_step(const dua_denoiser_plan* plan, void* stream);
  * [windows][tokens][heads*16].  bias_t: fp32 [heads][tokens(key)][tokens(query)] = relative_position_bias_table gathered
  * by relative_position_index (attention.py:103-106), TRANSPOSED; mask_t: fp32 [windows_per_image][key][query] from
  * compute_mask (attention.py:123-160; 0 / -100), transposed, or NULL for unshifted blocks.  tokens <= 352, head
- * dimension 16 (feature_size 48).  fp16 MFMA operands, fp32 softmax and accumulation. */
+ * dimension 16 (feature_size 48).  fp16 MFMA operands, fp32 softmax and accumulation.
+ * region_ids (or NULL): the same mask in the form compute_mask derives it from -- uint8 [windows_per_image][tokens], the
+ * shift region (0..26) of every token; the kernel adds -100 where query and key regions differ.  Give one of the two. */
 int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image, const void* qkv,
-                             const float* bias_t, const float* mask_t, float scale, void* out, void* stream);
+                             const float* bias_t, const float* mask_t, const unsigned char* region_ids, float scale,
+                             void* out, void* stream);
 
 /* PatchMerging.forward up to the reduction Linear (models/swin_unetr/patch.py:44-61; legacy != 0: the 3-D gather of
  * :70-91 with its duplicated corners): x [B][D][H][W][C] -> out [B][ceil(D/2)][ceil(H/2)][ceil(W/2)][8C] = LayerNorm_8C(gather),
- * odd extents zero padded.  gamma, beta: fp32 [8C]. */
-int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legacy, const void* x, const float* gamma,
-                         const float* beta, float eps, void* out, void* stream);
+ * odd extents zero padded.  x: the fp32 token stream; y (or NULL): the last block's MLP output in `dtype`, added on the fly.
+ * gamma, beta: fp32 [8C]. */
+int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legacy, const float* x, const void* y,
+                         const float* gamma, const float* beta, float eps, void* out, void* stream);
 
 /* Tail of UnetResBlock.forward (models/swin_unetr/blocks.py:308-316): out = LeakyReLU(IN(raw) + residual), raw = conv2's raw
  * output with its statistics in `in` (no add), residual = res as it is (res_in == NULL) or IN(res) with res_in (conv3 +
- * norm3).  Channels-last slices like everywhere else; C a multiple of 8. */
+ * norm3).  Then the adds SwinUNETRDenoiser.forward applies to a block's output (swin_unetr/denoiser.py:370-399):
+ * + post_add (embeddings[k]; NULL = none) and + ra_src * (1 - sigmoid(ra_src)) (reverse_attention of the skip, :405-408;
+ * NULL = none).  Channels-last slices like everywhere else; C a multiple of 8. */
 int dua_residual_norm_act(int dtype, int N, long voxels, int C, const void* raw, int raw_stride, const dua_in_norm* in,
                           const void* res, int res_stride, const dua_in_norm* res_in, void* out, int out_stride, int out_off,
-                          float slope, void* stream);
+                          float slope, const void* post_add, int post_stride, int post_off, const void* ra_src,
+                          int ra_stride, int ra_off, void* stream);
+
+/* ---- Swin token stream (models/swin_unetr/transformer.py) ------------------------------------
+ * The residual stream x of a stage is fp32 [B][D][H][W][C]; GEMM / convolution operands are written in `dtype`.
+ * C in {48, 96, 192, 384, 768} (feature_size 48). */
+typedef struct dua_window_geom {
+  int B, D, H, W, C;
+  int wd, wh, ww;     /* window, already clipped to the map (attention.py:225-251 get_window_size) */
+  int sd, sh, sw;     /* shift; 0 on clipped axes and in unshifted blocks */
+} dua_window_geom;
+
+/* SwinTransformerBlock.forward_part1 up to the attention (transformer.py:378-417): [x += y (the previous block's MLP
+ * output, transformer.py:477-480; NULL = none)] -> norm1 -> zero pad to a window multiple -> roll(-shift) ->
+ * window_partition.  out: [B * windows][tokens][C]. */
+int dua_window_gather_norm(int dtype, const dua_window_geom* geom, float* x, const void* y, const float* gamma,
+                           const float* beta, float eps, void* out, void* stream);
+/* The way back (transformer.py:417-431, 475-476, 433): x += crop(roll(+shift)(window_reverse(yw)));  out = norm2(x)
+ * ([B][D][H][W][C] in `dtype`) for the MLP. */
+int dua_window_scatter_add_norm(int dtype, const dua_window_geom* geom, float* x, const void* yw, const float* gamma,
+                                const float* beta, float eps, void* out, void* stream);
+/* Between stages (transformer.py:277-312): x = y + tadd[b] (t_proj[i](swish(t)), fp32 [B][tadd_stride]; NULL = none; x may
+ * be NULL after the last stage), out = layer_norm(x) without affine (proj_out, :253-268) + emb (the encoder's feature map,
+ * swin_unetr/denoiser.py:367-368; NULL = none), written to channels [out_off, out_off + C) of a channels-last buffer. */
+int dua_stage_out(int dtype, int B, long tokens_per_sample, int C, const void* y, const float* tadd, int tadd_stride,
+                  float eps, const void* emb, float* x, void* out, int out_stride, int out_off, void* stream);
+/* PatchEmbed (Conv3d k = s = 2, bias; transformer.py:185-191) on a channels-last input slice [B][D][H][W][Cin_stride]
+ * (first Cin_packed channels), fused with the stage-0 adds above.  w_packed: fp32 [8 taps (kd, kh, kw)][Cin_packed][E],
+ * E = 48. */
+int dua_patch_embed(int dtype, int B, int D, int H, int W, int Cin_stride, int Cin_packed, int E, const void* in,
+                    const float* w_packed, const float* bias, const float* tadd, int tadd_stride, float eps, const void* emb,
+                    float* x, void* out, int out_stride, int out_off, void* stream);
+/* Sum / sum of squares per (n, c) of a channels-last slice, accumulated into a dua_in_norm statistics buffer (zeroed by
+ * the caller): the statistics of UnetResBlock's 1x1x1 conv3 (blocks.py:286-296), whose GEMM is a library call. */
+int dua_instnorm_stats(int dtype, int N, long voxels, int C, const void* x, int x_stride, int x_off, double* stats,
+                       int c_pad, void* stream);
+/* Exact (erf) GELU in place between the two MLP GEMMs (MONAI MLPBlock act "GELU"). */
+int dua_gelu(int dtype, long elems, void* x, void* stream);
 
 /* ---- layout / packing at the API boundary -------------------------------------------------- */
 /* nn.ConvTranspose3d weight fp32[Cin][Cout][2][2][2] -> [tap][cout_tile][chunk][k-group][64][16 B].

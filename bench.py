@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the Diff-UNet hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
 
 --config 2 (default, the headline: BASELINE.json configs[1]): DiffUNet(in=1, out=16), one 96^3 patch per GPU, DDPM
   ancestral sampling (`diffusion.p_sample_loop` semantics) -- a "step" is ONE reverse-diffusion step = one denoiser
@@ -16,6 +16,10 @@
 --config 4 (BASELINE.json configs[3]): DDP training step (q_sample + denoise + mse/bce/dice + backward + AdamW) on
   synthetic 96^3 x 16-class batches, 2 samples per GPU, gradients averaged over RCCL (DDP buckets overlapped with
   backward); reports samples/s and the share a flat all-reduce of the 153.6 MB of gradients would take.
+--config 5 (BASELINE.json configs[4]): the diff_swin_unetr variant -- DiffSwinUNETR(in=1, out=16, feature_size 48), one
+  96^3 patch per GPU; a "step" is one reverse-diffusion step = one SwinUNETRDenoiser evaluation (8 shifted-window
+  attention blocks, 4 patch mergings, 10 UnetResBlocks, 5 transposed convolutions, 1x1x1 head) + the sampler update,
+  replayed from a captured HIP graph; same metric as config 2.
 
 Launch: with no WORLD_SIZE in the environment and --gpus N > 1 this script starts its own N ranks
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) BEFORE touching the GPU
@@ -413,12 +417,76 @@ def run_config4(args, D):
             "gradient_bytes": sum(p.numel() for p in net.parameters()) * 4, "loss": float(loss)}), flush=True)
 
 
+def run_config5(args, D):
+    """DiffSwinUNETR reverse-diffusion steps (replicas only, like config 2)."""
+    from diff_unet_amos_amd import _native as nv
+    from diff_unet_amos_amd import ops
+    from diff_unet_amos_amd.diff_swin_unetr import DiffSwinUNETR
+    dev, rank, world = D.dev, D.rank, D.world
+    dtype = torch.float16 if args.dtype == "f16" else torch.float32
+    torch.manual_seed(0)
+    net = DiffSwinUNETR(in_channels=1, out_channels=CLASSES, feature_size=48, compute_dtype=dtype).to(dev).eval()
+    B = args.batch
+    image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    plan = net._rt.plan(B, (96, 96, 96), dev)
+    diffusion = net.diffusion
+    with torch.no_grad():
+        net.embed_model(image)                     # encoder once per patch (not in the timed region)
+        x_T = torch.randn(B, CLASSES, 96, 96, 96, device=dev)
+        ops.to_channels_last(x_T, plan.x_state, 0, plan.cx)
+        ops.to_channels_last(x_T, plan.xin, 0, plan.C)
+        T = diffusion.num_timesteps
+        order = list(range(T))[::-1]
+        coef_table = diffusion.ddpm_coef(torch.tensor(order)).to(dev).contiguous()
+        row_of_step = torch.tensor(order, dtype=torch.int32, device=dev)
+        plan.counter.zero_()
+        plan.new_seed(3 + rank)
+
+        def one_step():
+            ops.step_begin(B, plan.temb_table, plan.cur_add, row_of_step=row_of_step, counter=plan.counter,
+                           coef_table=coef_table, cur_coef=plan.cur_coef, step_word=plan.step_word, err_word=plan.err_word)
+            plan.denoiser_body()
+            plan.tail(nv.MODE_DDPM)
+
+        assert args.warmup + args.steps + 2 <= T
+        one_step()
+        torch.cuda.synchronize()
+        if args.no_graph:
+            run = one_step
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step()
+            run = g.replay
+        for _ in range(args.warmup):
+            run()
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        dt = D.max_over_ranks(time.perf_counter() - t0)
+        D.barrier()
+        finite = bool(torch.isfinite(plan.x_state).all())
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        print(json.dumps({
+            "metric": "denoised voxel-steps/sec on 96^3 16-class AMOS patches", "value": world * B * VOX * args.steps / dt,
+            "unit": "voxel-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "DiffSwinUNETR (feature_size 48) 96^3 patch, 16 classes, DDPM p_sample steps of the 1000-step "
+                                   "process (BASELINE.json configs[4]); one patch per GPU, replicas only",
+                       "patch": [96, 96, 96], "classes": CLASSES, "batch_per_gpu": B, "graph_replay": not args.no_graph,
+                       "noise": "in-kernel Philox4x32-10", "weights": "torch.manual_seed(0) default init"},
+            "finite": finite}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4])
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -430,7 +498,7 @@ def main():
     ap.add_argument("--flat-allreduce", action="store_true", help="config 4: one flat all-reduce instead of DDP buckets")
     ap.add_argument("--train-graph", action="store_true", help="config 4: whole step as one HIP graph")
     args = ap.parse_args()
-    defaults = {2: (200, 20), 3: (1, 0), 4: (5, 2)}[args.config]
+    defaults = {2: (200, 20), 3: (1, 0), 4: (5, 2), 5: (100, 10)}[args.config]
     args.steps = defaults[0] if args.steps is None else args.steps
     args.warmup = defaults[1] if args.warmup is None else args.warmup
 
@@ -441,7 +509,7 @@ def main():
         # two short child runs of this script under rocprofv3 --pmc, started before this process initialises the GPU
         args.traffic = measure_traffic(args.dtype)
     D = Dist(args)
-    {2: run_config2, 3: run_config3, 4: run_config4}[args.config](args, D)
+    {2: run_config2, 3: run_config3, 4: run_config4, 5: run_config5}[args.config](args, D)
     D.finish()
 
 

@@ -77,6 +77,11 @@ struct InXform {
 __device__ __forceinline__ void xform_preamble(const InXform& xf, int n, int C, float* sc, float* sh, float* ad,
                                                int c_begin = 0) {
   for (int c = c_begin + threadIdx.x; c < C; c += blockDim.x) {
+    if (!xf.stats) {                      // no producer statistics: the input is already materialised (identity)
+      sc[c] = 1.f; sh[c] = 0.f;
+      ad[c] = xf.add ? xf.add[(long)n * xf.add_stride + c] : 0.f;
+      continue;
+    }
     double S = 0, Q = 0;
 #pragma unroll
     for (int r = 0; r < STAT_REPLICAS; ++r) {

@@ -348,14 +348,18 @@ int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in
                            const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
                            const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
                            void* stream) {
-  if (!d || !raw || !in || !in->stats || !in->gamma || !in->beta || !wf || !bf || in->c_pad < d->K) return DUA_ERR_ARG;
+  if (!d || !raw || !wf || !bf) return DUA_ERR_ARG;
+  const bool identity = !in || !in->stats;        // raw is an already materialised activation (Swin-UNETR's decoder1 output)
+  if (!identity && (!in->gamma || !in->beta || in->c_pad < d->K)) return DUA_ERR_ARG;
   if (d->K % 8 || d->raw_stride % 8 || d->K > d->raw_stride || d->C <= 0 || d->C > d->CX || d->K > 512) return DUA_ERR_ARG;
   if (d->mode == DUA_MODE_LOGITS) { if (!logits) return DUA_ERR_ARG; }
   else if (d->mode == DUA_MODE_DDPM || d->mode == DUA_MODE_DDIM) { if (!coef || !x_state) return DUA_ERR_ARG; }
   else return DUA_ERR_ARG;
   if (xin && d->xin_stride % 8) return DUA_ERR_ARG;
   dua::TailArgs a;
-  a.raw = raw; a.xf = dua::make_xform(in, d->K); a.wf = wf; a.bf = bf; a.coef = coef; a.x_state = x_state;
+  a.raw = raw; a.xf = dua::make_xform(identity ? nullptr : in, d->K);
+  if (identity) a.xf.slope = 1.f;
+  a.wf = wf; a.bf = bf; a.coef = coef; a.x_state = x_state;
   a.noise = noise; a.step_word = step_word; a.xin = xin; a.xsum = xstart_sum; a.logits = logits; a.xstart = xstart;
   a.vox = d->voxels; a.K = d->K; a.raw_stride = d->raw_stride; a.C = d->C; a.xin_stride = d->xin_stride;
   a.mode = d->mode;

@@ -17,7 +17,13 @@
 //   O^T[dims][32 queries] += V^T_blk [dims x 32 keys, keys in the accumulator's row order] . P^T_blk [32 keys x 32 queries]
 // (rows 16..31 of the 32-row output are padding: the price of a 16-wide head on a 32-row instruction).  V is written
 // to LDS already in that permuted key order, so its operand fragment is one 16-byte read.
-// Bias and mask arrive TRANSPOSED ([head][key][query], [window][key][query], fp32) so that the 32 lanes of a half read
+// The relative-position bias is either dense and TRANSPOSED (bias_t) or -- the production form -- the reference's own
+// table: bias[h][q][k] = table[relative_position_index[q][k]][h] (attention.py:103-106), and the index is a function of
+// the coordinate difference of q and k inside the table's (2gd-1)(2gh-1)(2gw-1) grid (attention.py:56-73), so the kernel
+// keeps the 2197-entry column of its head in LDS (8.8 KB instead of 343 x 343 floats from L2) and looks up
+// table[off(q) - off(k) + centre].  Token -> coordinate uses the TABLE's grid (7, 7, 7) even for clipped windows: the
+// reference slices relative_position_index[:n, :n] of the 7^3 index (attention.py:104).
+// Bias and mask otherwise arrive TRANSPOSED ([head][key][query], [window][key][query], fp32) so that the 32 lanes of a half read
 // 128 contiguous bytes per key.  The shifted-window mask can instead be given as what compute_mask builds it from: one
 // region id per token of every window ([windows per image][tokens], uint8; attention.py:135-157) -- 343 bytes per window
 // instead of 343 x 343 floats (161 MB per image at 48^3 tokens); the kernel adds -100 where the ids of query and key differ.
@@ -29,10 +35,13 @@ namespace dua {
 namespace wa {
 constexpr int HD = 16;          // head dimension
 constexpr int MAXB = 11;        // 32-token blocks per window (n <= 352)
+constexpr int MAXTAB = 2208;    // (2*7-1)^3 = 2197 table entries per head, padded
 }  // namespace wa
 
 struct WinAttnArgs {
   const void* qkv; const float* bias_t; const float* mask_t; const unsigned char* region; void* out;
+  const float* table;           // [heads][tab_len] or null (then bias_t)
+  int gd, gh, gw, tab_len;      // grid the relative-position index was built for
   int n, heads, nw;             // tokens per window, heads, windows per image (mask index = window % nw)
   float scale;
 };
@@ -42,27 +51,40 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   using namespace wa;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f16* Kl = (f16*)smem;                           // [nb*32][16]
-  f16* Ql = Kl + MAXB * 32 * HD;                  // [nb*32][16]
-  f16* Vp = Ql + MAXB * 32 * HD;                  // [nb][2 s][2 hh][32 rows (dims, 16 real)][8 keys]  (permuted V^T)
-  unsigned char* regl = (unsigned char*)(Vp + MAXB * 2 * 2 * 32 * 8);     // [nb*32] region id of every token of the window
+  f16* Ql = Kl + MAXB * 32 * HD;                  // [4*32][16]   the four query blocks of this workgroup
+  f16* Vp = Ql + 4 * 32 * HD;                     // [nb][2 s][2 hh][32 rows (dims, 16 real)][8 keys]  (permuted V^T)
+  float* tab = (float*)(Vp + MAXB * 2 * 2 * 32 * 8);                // [MAXTAB] bias table column of this head
+  short* koff = (short*)(tab + MAXTAB);                              // [nb*32] coordinate offset of every token
+  unsigned char* regl = (unsigned char*)(koff + MAXB * 32);          // [nb*32] region id of every token of the window
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int win = blockIdx.x, head = blockIdx.y;
+  const int win = blockIdx.x, head = blockIdx.y, qb0 = blockIdx.z * 4;
   const int n = a.n, nb = (n + 31) >> 5, C = a.heads * HD;
   const T* base = (const T*)a.qkv + (long)win * n * 3 * C + head * HD;
-  // ---- stage Q, K (row major) and V (permuted, zero padded) ----
+  // ---- stage K (row major), this workgroup's Q blocks and V (permuted, zero padded) ----
   for (int i = tid; i < nb * 32 * 2; i += 256) {          // (token, half of the 16 dims)
     const int tok = i >> 1, half = i & 1;
-    f16x8 q, k;
+    f16x8 k;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { q[e] = (f16)0.f; k[e] = (f16)0.f; }
+    for (int e = 0; e < 8; ++e) k[e] = (f16)0.f;
+    if (tok < n) {
+      const T* p = base + (long)tok * 3 * C + C + half * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) k[e] = (f16)(float)p[e];
+    }
+    *(f16x8*)(Kl + tok * HD + half * 8) = k;
+  }
+  {
+    const int tok = qb0 * 32 + (tid >> 1), half = tid & 1;  // 128 tokens x 2 halves = 256 threads
+    f16x8 q;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = (f16)0.f;
     if (tok < n) {
       const T* p = base + (long)tok * 3 * C + half * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { q[e] = (f16)(float)p[e]; k[e] = (f16)(float)p[C + e]; }
+      for (int e = 0; e < 8; ++e) q[e] = (f16)(float)p[e];
     }
-    *(f16x8*)(Ql + tok * HD + half * 8) = q;
-    *(f16x8*)(Kl + tok * HD + half * 8) = k;
+    *(f16x8*)(Ql + (tid >> 1) * HD + half * 8) = q;
   }
   // Vp[kb][s][h2][row][j] = V[key = kb*32 + 16 s + 8 (j >> 2) + 4 h2 + (j & 3)][dim = row]  (row >= 16: 0)
   for (int i = tid; i < nb * 2 * 2 * 32; i += 256) {
@@ -75,82 +97,106 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     }
     *(f16x8*)(Vp + (long)i * 8) = v;
   }
-  if (a.region)
+  const bool has_table = a.table != nullptr;
+  const int sh_ = 2 * a.gw - 1, sd_ = (2 * a.gh - 1) * sh_;         // strides of the (dd, dh, dw) difference grid
+  if (has_table) {
+    for (int i = tid; i < a.tab_len; i += 256) tab[i] = a.table[(long)head * a.tab_len + i];
+    for (int i = tid; i < nb * 32; i += 256) {
+      const int t = i < n ? i : 0;
+      koff[i] = (short)((t / (a.gh * a.gw)) * sd_ + ((t / a.gw) % a.gh) * sh_ + t % a.gw);
+    }
+  }
+  const bool has_region = a.region != nullptr;
+  if (has_region)
     for (int i = tid; i < nb * 32; i += 256) regl[i] = i < n ? a.region[(long)(win % a.nw) * n + i] : (unsigned char)255;
   __syncthreads();
 
-  const float* bias = a.bias_t + (long)head * n * n;
-  const bool has_region = a.region != nullptr;
+  const int qb = qb0 + wave;
+  if (qb >= nb) return;
+  const float* bias = has_table ? nullptr : a.bias_t + (long)head * n * n;
   const float* mask = a.mask_t ? a.mask_t + (long)(win % a.nw) * n * n : nullptr;
   T* outp = (T*)a.out + (long)win * n * C + head * HD;
-  for (int qb = wave; qb < nb; qb += 4) {
-    const int q = qb * 32 + r;                     // this lane's query
-    const bool qok = q < n;
-    const int qc = qok ? q : 0;
-    const f16x8 qf = *(const f16x8*)(Ql + (qb * 32 + r) * HD + hh * 8);      // B operand: Q^T[dims 8hh..][query r]
-    const unsigned char rq = has_region ? regl[qb * 32 + r] : (unsigned char)0;
-    // score tile of key block kb for this lane's query: scale * <q, k> + bias + mask (padding keys: -3e38)
-    auto scores = [&](int kb) {
-      const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
-      f32x16 z;
+  const int q = qb * 32 + r;                     // this lane's query
+  const bool qok = q < n;
+  const int qc = qok ? q : 0;
+  const f16x8 qf = *(const f16x8*)(Ql + (wave * 32 + r) * HD + hh * 8);      // B operand: Q^T[dims 8hh..][query r]
+  const unsigned char rq = has_region ? regl[qb * 32 + r] : (unsigned char)0;
+  const int qoff = has_table ? (int)koff[qc] + (a.gd - 1) * sd_ + (a.gh - 1) * sh_ + (a.gw - 1) : 0;
+  // score tile of key block kb for this lane's query: scale * <q, k> + bias + mask (padding keys: -3e38)
+  auto scores = [&](int kb) {
+    const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
+    f32x16 z;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) z[i] = 0.f;
-      z = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, z, 0, 0, 0);
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, z, 0, 0, 0);
+    if (has_table) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) z[i] = fmaf(z[i], a.scale, tab[qoff - (int)koff[kb * 32 + acc_row(i, hh)]]);
+    } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = kb * 32 + acc_row(i, hh);
-        float v = -3.0e38f;                     // padding keys never win the max and exponentiate to 0
-        if (key < n) {
-          v = z[i] * a.scale + bias[(long)key * n + qc];
-          if (mask) v += mask[(long)key * n + qc];
-          if (has_region && regl[key] != rq) v += -100.f;      // compute_mask's 0 / -100 from the region ids
-        }
-        z[i] = v;
+        z[i] = fmaf(z[i], a.scale, bias[(long)(key < n ? key : 0) * n + qc]);
       }
-      return z;
-    };
-    // pass 1: the row maximum (the score tiles are cheap to recompute -- one MFMA each -- and 11 of them would not
-    // fit the register file next to the output tile)
-    float mx = -3.0e38f;
-    for (int kb = 0; kb < nb; ++kb) {
-      const f32x16 z = scores(kb);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, z[i]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));            // the other half of the keys of the same query
-    // pass 2: exponentials, their sum, and P^T as the B operand of the second product
-    float sum = 0.f;
-    f32x16 O;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) O[i] = 0.f;
-    for (int kb = 0; kb < nb; ++kb) {
-      const f32x16 z = scores(kb);
-      f16x8 p[2];
+    if (mask) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float e = __expf(z[i] - mx);
-        sum += e;
-        p[i >> 3][i & 7] = (f16)e;
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const f16x8 vf = *(const f16x8*)(Vp + ((long)((kb * 2 + s) * 2 + hh) * 32 + r) * 8);
-        O = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, p[s], O, 0, 0, 0);
+        const int key = kb * 32 + acc_row(i, hh);
+        z[i] += mask[(long)(key < n ? key : 0) * n + qc];
       }
     }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.f / sum;
-    // O^T rows = dims: register i of half hh holds dim (i & 3) + 8 (i >> 2) + 4 hh; dims < 16 are i = 0..7
-    if (qok) {
-      T* o = outp + (long)q * C;
+    if (has_region) {                             // compute_mask's 0 / -100 from the region ids
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        typedef T TV4 __attribute__((ext_vector_type(4)));
-        TV4 w;
+      for (int i = 0; i < 16; ++i) z[i] += regl[kb * 32 + acc_row(i, hh)] != rq ? -100.f : 0.f;
+    }
+    if (kb == nb - 1) {                           // only the last block holds padding keys: they never win the max
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = (T)(O[4 * g + e] * inv);
-        *(TV4*)(o + 8 * g + 4 * hh) = w;
-      }
+      for (int i = 0; i < 16; ++i) z[i] = kb * 32 + acc_row(i, hh) < n ? z[i] : -3.0e38f;
+    }
+    return z;
+  };
+  // pass 1: the row maximum (the score tiles are cheap to recompute -- one MFMA each -- and 11 of them would not
+  // fit the register file next to the output tile)
+  float mx = -3.0e38f;
+  for (int kb = 0; kb < nb; ++kb) {
+    const f32x16 z = scores(kb);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, z[i]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));            // the other half of the keys of the same query
+  // pass 2: exponentials, their sum, and P^T as the B operand of the second product
+  float sum = 0.f;
+  f32x16 O;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) O[i] = 0.f;
+  for (int kb = 0; kb < nb; ++kb) {
+    const f32x16 z = scores(kb);
+    f16x8 p[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float e = __expf(z[i] - mx);
+      sum += e;
+      p[i >> 3][i & 7] = (f16)e;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const f16x8 vf = *(const f16x8*)(Vp + ((long)((kb * 2 + s) * 2 + hh) * 32 + r) * 8);
+      O = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, p[s], O, 0, 0, 0);
+    }
+  }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.f / sum;
+  // O^T rows = dims: register i of half hh holds dim (i & 3) + 8 (i >> 2) + 4 hh; dims < 16 are i = 0..7
+  if (qok) {
+    T* o = outp + (long)q * C;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      typedef T TV4 __attribute__((ext_vector_type(4)));
+      TV4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (T)(O[4 * g + e] * inv);
+      *(TV4*)(o + 8 * g + 4 * hh) = w;
     }
   }
 }
@@ -159,15 +205,25 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 
 extern "C" int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image,
                                         const void* qkv, const float* bias_t, const float* mask_t,
-                                        const unsigned char* region_ids, float scale, void* out, void* stream) {
+                                        const unsigned char* region_ids, const float* bias_table, int grid_d, int grid_h,
+                                        int grid_w, float scale, void* out, void* stream) {
   using namespace dua;
-  if (!qkv || !bias_t || !out || windows <= 0 || heads <= 0 || tokens <= 0 || tokens > wa::MAXB * 32) return DUA_ERR_ARG;
+  if (!qkv || (!bias_t && !bias_table) || !out || windows <= 0 || heads <= 0 || tokens <= 0 || tokens > wa::MAXB * 32)
+    return DUA_ERR_ARG;
   if ((mask_t || region_ids) && (windows_per_image <= 0 || windows % windows_per_image)) return DUA_ERR_ARG;
   WinAttnArgs a;
-  a.qkv = qkv; a.bias_t = bias_t; a.mask_t = mask_t; a.region = region_ids; a.out = out;
+  a.qkv = qkv; a.bias_t = bias_table ? nullptr : bias_t; a.mask_t = mask_t; a.region = region_ids; a.out = out;
+  a.table = bias_table; a.gd = grid_d; a.gh = grid_h; a.gw = grid_w; a.tab_len = 0;
+  if (bias_table) {
+    if (grid_d <= 0 || grid_h <= 0 || grid_w <= 0 || tokens > grid_d * grid_h * grid_w) return DUA_ERR_ARG;
+    a.tab_len = (2 * grid_d - 1) * (2 * grid_h - 1) * (2 * grid_w - 1);
+    if (a.tab_len > wa::MAXTAB) return DUA_ERR_ARG;
+  }
   a.n = tokens; a.heads = heads; a.nw = (mask_t || region_ids) ? windows_per_image : 1; a.scale = scale;
-  const int lds = wa::MAXB * 32 * wa::HD * 2 * 2 + wa::MAXB * 2 * 2 * 32 * 8 * 2 + wa::MAXB * 32;   // Q + K + permuted V^T + regions
-  dim3 grid(windows, heads);
+  const int nb = (tokens + 31) / 32;
+  const int lds = wa::MAXB * 32 * wa::HD * 2 + 4 * 32 * wa::HD * 2 + wa::MAXB * 2 * 2 * 32 * 8 * 2 +      // K, Q, V^T
+                  wa::MAXTAB * 4 + wa::MAXB * 32 * 2 + wa::MAXB * 32;                                        // table, offsets, regions
+  dim3 grid(windows, heads, (nb + 3) / 4);
   if (dtype == DUA_F16) hipLaunchKernelGGL(window_attention_kernel<f16>, grid, dim3(256), lds, (hipStream_t)stream, a);
   else if (dtype == DUA_F32) hipLaunchKernelGGL(window_attention_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
   else return DUA_ERR_ARG;

@@ -1,7 +1,7 @@
 """DiffSwinUNETR (models/diff_swin_unetr.py:7-47): SwinUNETREncoder + SwinUNETRDenoiser behind Diffusion -- BASELINE
 config 5.  Same constructor arguments as the reference; ``pred_type="ddim_sample"`` / ``"denoise"`` under
-``torch.no_grad()`` run the HIP launch plan (swin_engine.SwinPlan), the sampling loops the generic per-step form of
-gaussian_diffusion.py (model call + fused sampler-step kernel)."""
+``torch.no_grad()`` run the HIP launch plan (swin_engine.SwinPlan); the sampling loops replay one captured HIP graph per
+reverse step (SwinPlan.sample_loop, reached through the denoiser's ``fused_engine`` hook like DiffUNet's)."""
 from __future__ import annotations
 
 from typing import Sequence
@@ -24,7 +24,6 @@ class DiffSwinUNETR(Diffusion):
                          timesteps=timesteps, mode=mode, sample_steps=sample_steps)
         self.feature_size = feature_size
         self.compute_dtype = compute_dtype
-        self.batched_sampling = False        # the generic loop follows the reference's per-sample walk (diffusion.py:88-101)
         self.embed_model = SwinUNETREncoder(image_size, in_channels, spatial_dims=spatial_dims, feature_size=feature_size,
                                             drop_rate=dropout)
         self.model = SwinUNETRDenoiser(image_size, out_channels + 1, out_channels, spatial_dims=spatial_dims,

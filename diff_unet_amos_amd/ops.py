@@ -594,7 +594,7 @@ def final_conv_sampler(raw, K, norm, wf, bf, num_classes, mode, coef=None, x_sta
         assert seed_dev.is_cuda and seed_dev.dtype == torch.int64 and seed_dev.numel() >= 1
     d = nv.TailDesc(nv.dt_code(raw.dtype), N, vox, K, rs, num_classes, cx, mode, xs, seed,
                     seed_dev.data_ptr() if seed_dev is not None else None)
-    nv.check(nv.lib().dua_final_conv_sampler(C.byref(d), nv.ptr(raw), norm.ref(N, K), nv.ptr(wf),
+    nv.check(nv.lib().dua_final_conv_sampler(C.byref(d), nv.ptr(raw), _norm_ref(norm, N, K), nv.ptr(wf),
                                              nv.ptr(bf), nv.ptr(coef), nv.ptr(x_state), nv.ptr(noise),
                                              nv.ptr(step_word), nv.ptr(xin), nv.ptr(xstart_sum), nv.ptr(logits),
                                              nv.ptr(xstart), nv.stream_ptr()), "dua_final_conv_sampler")
@@ -641,16 +641,24 @@ def denoiser_step(plan_struct):
     nv.check(nv.lib().dua_denoiser_step(C.byref(plan_struct), nv.stream_ptr()), "dua_denoiser_step")
 
 
-def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1, region_ids=None, out=None):
+def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1, region_ids=None, out=None, bias_table=None,
+                     table_grid=(7, 7, 7)):
     """Softmax attention inside windows (models/swin_unetr/attention.py:97-120 between the qkv and proj Linear layers).
     qkv: [windows, tokens, 3 * heads * 16] (fp16 or fp32, contiguous); bias_t: fp32 [heads, tokens, tokens] = bias[h].T;
     the shifted-window mask either as mask_t: fp32 [windows_per_image, tokens, tokens] = mask[w].T, or as region_ids:
-    uint8 [windows_per_image, tokens] (what compute_mask derives it from).  Returns [windows, tokens, heads * 16]."""
+    uint8 [windows_per_image, tokens] (what compute_mask derives it from).  ``bias_table`` (instead of bias_t): the
+    reference's relative_position_bias_table transposed, fp32 [heads, (2gd-1)(2gh-1)(2gw-1)] for ``table_grid`` -- the
+    kernel evaluates relative_position_index itself.  Returns [windows, tokens, heads * 16]."""
     assert qkv.is_cuda and qkv.is_contiguous() and qkv.dim() == 3 and qkv.dtype in (torch.float16, torch.float32)
     Wn, n, c3 = qkv.shape
     assert c3 == 3 * heads * 16 and n <= 352, "head dimension 16, at most 352 tokens per window"
-    _f32c(bias_t, "bias_t")
-    assert tuple(bias_t.shape) == (heads, n, n)
+    if bias_table is not None:
+        _f32c(bias_table, "bias_table")
+        gd, gh, gw = table_grid
+        assert bias_t is None and tuple(bias_table.shape) == (heads, (2 * gd - 1) * (2 * gh - 1) * (2 * gw - 1)) and n <= gd * gh * gw
+    else:
+        _f32c(bias_t, "bias_t")
+        assert tuple(bias_t.shape) == (heads, n, n)
     assert mask_t is None or region_ids is None
     if mask_t is not None:
         _f32c(mask_t, "mask_t")
@@ -662,7 +670,8 @@ def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1, regio
         out = torch.empty((Wn, n, heads * 16), dtype=qkv.dtype, device=qkv.device)
     assert out.is_contiguous() and out.dtype == qkv.dtype and out.numel() == Wn * n * heads * 16
     nv.check(nv.lib().dua_window_attention_fwd(nv.dt_code(qkv.dtype), Wn, n, heads, windows_per_image, nv.ptr(qkv), nv.ptr(bias_t),
-                                               nv.ptr(mask_t), nv.ptr(region_ids), 16 ** -0.5, nv.ptr(out), nv.stream_ptr()),
+                                               nv.ptr(mask_t), nv.ptr(region_ids), nv.ptr(bias_table), table_grid[0], table_grid[1],
+                                               table_grid[2], 16 ** -0.5, nv.ptr(out), nv.stream_ptr()),
              "dua_window_attention_fwd")
     return out
 

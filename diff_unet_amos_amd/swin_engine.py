@@ -99,7 +99,9 @@ class SwinPlan:
         self.C = net.num_classes
         f = net.feature_size
         self.f = f
-        self.cin0 = -(-(self.C + 1) // 8) * 8                 # [image | x_t (C) | zero pad]
+        self.cin0 = -(-(self.C + 1) // 8) * 8                 # [x_t (C) | image | zero pad]: the sampler tail writes x_{t-1}
+        self.cx = ops.state_stride(self.C)                    # into channels [0, C) of the next evaluation's input
+        self.perm0 = list(range(1, self.C + 1)) + [0]         # packed channel p of xin = channel perm0[p] of cat([image, x])
         S = [(D >> l, H >> l, W >> l) for l in range(6)]    # S[0] voxels, S[1..5] token maps x0..x4
         self.S = S
         self.tok_c = [f * 2 ** i for i in range(5)]           # channels of x0..x4
@@ -114,7 +116,6 @@ class SwinPlan:
         self.hs = [z(1, f), z(2, 2 * f), z(3, 4 * f), None, z(5, 16 * f)]      # hs[3] lives in cat[4]
         self.cat = [z(0, 2 * f), z(1, 2 * f), z(2, 4 * f), z(3, 8 * f), z(4, 16 * f)]   # (up | skip) of decoder1..5
         self.dec = [z(0, f), z(1, f), z(2, 2 * f), z(3, 4 * f), z(4, 8 * f), z(5, 16 * f)]   # out, dec0..dec4
-        self.logits_cl = z(0, -(-self.C // 8) * 8)
         # ---- shared scratch (the two networks never run concurrently)
         big = max(N * S[l][0] * S[l][1] * S[l][2] * c for l, c in ((0, f), (1, f), (2, 2 * f), (3, 4 * f), (4, 8 * f), (5, 16 * f)))
         self.raw1 = torch.zeros(big, dtype=dtype, device=device)
@@ -138,9 +139,18 @@ class SwinPlan:
         self.att = torch.zeros(tok_max, dtype=dtype, device=device)           # attention output
         self.ln2 = torch.zeros(tok_max, dtype=dtype, device=device)
         self.merged = torch.zeros(tok_max, dtype=dtype, device=device)        # gathered + normalised 8C tokens (= tokens * C)
-        self.logits = torch.zeros((N, self.C, *S[0]), dtype=torch.float32, device=device)
+        # ---- sampler state
+        self.x_state = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
+        self.x_sum = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
+        self.cur_coef = torch.zeros((N, 8), dtype=torch.float32, device=device)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self.step_word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.err_word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.seed_word = torch.zeros(1, dtype=torch.int64, device=device)
         self._bind()
         self.weights_version = None
+        self.graphs = {}
+        self.tables = {}
 
     # ---- parameter binding -------------------------------------------------------------------
     def _res(self, name, block, level, cin_packed=None, perm=None):
@@ -157,7 +167,8 @@ class SwinPlan:
         enc, den = self.net.embed_model, self.net.model
         self.e_res = [self._res("e1", enc.encoder1.layer, 0, cin_packed=8), self._res("e2", enc.encoder2.layer, 1),
                       self._res("e3", enc.encoder3.layer, 2), self._res("e4", enc.encoder4.layer, 3)]
-        self.d_res = [self._res("d1", den.encoder1.layer, 0, cin_packed=self.cin0), self._res("d2", den.encoder2.layer, 1),
+        self.d_res = [self._res("d1", den.encoder1.layer, 0, cin_packed=self.cin0, perm=self.perm0),
+                      self._res("d2", den.encoder2.layer, 1),
                       self._res("d3", den.encoder3.layer, 2), self._res("d4", den.encoder4.layer, 3),
                       self._res("d10", den.encoder10.layer, 5)]
         ups = [den.decoder1, den.decoder2, den.decoder3, den.decoder4, den.decoder5]
@@ -192,20 +203,18 @@ class SwinPlan:
                 need = max(need, ops.conv3_workspace_bytes(self.dtype, self.N, *dims, cin, r.cout))
         self.splitk_ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=self.dev)
 
-    def _pack_vit(self, vit, cin_packed):
+    def _pack_vit(self, vit, cin_packed, perm=None):
         dt = self.dtype
         f32 = lambda p: p.detach().float().contiguous()  # noqa: E731
-        out = dict(pe_w=ops.pack_patch_embed_weights(vit.patch_embed.proj.weight.detach(), cin_packed),
+        out = dict(pe_w=ops.pack_patch_embed_weights(vit.patch_embed.proj.weight.detach(), cin_packed, perm),
                    pe_b=f32(vit.patch_embed.proj.bias), stages=[])
         for i, layer in enumerate(vit.stages()):
             n = self.geo[i]["n"]
             blocks = []
             for blk in layer.blocks:
                 a = blk.attn
-                idx = a.relative_position_index[:n, :n].reshape(-1)
-                bias = a.relative_position_bias_table.detach().float()[idx].reshape(n, n, -1)     # [query, key, head]
                 blocks.append(dict(g1=f32(blk.norm1.weight), b1=f32(blk.norm1.bias), g2=f32(blk.norm2.weight), b2=f32(blk.norm2.bias),
-                                   bias_t=bias.permute(2, 1, 0).contiguous(),                    # [head, key, query]
+                                   table=a.relative_position_bias_table.detach().float().t().contiguous(),     # [head, 13^3]
                                    wqkv=a.qkv.weight.detach().to(dt).contiguous(), bqkv=a.qkv.bias.detach().to(dt).contiguous(),
                                    wproj=a.proj.weight.detach().to(dt).contiguous(), bproj=a.proj.bias.detach().to(dt).contiguous(),
                                    w1=blk.mlp.linear1.weight.detach().to(dt).contiguous(), bb1=blk.mlp.linear1.bias.detach().to(dt).contiguous(),
@@ -224,11 +233,11 @@ class SwinPlan:
             for r in self.e_res + self.d_res + self.u_res:
                 b = r.block
                 r.w1, r.b1 = ops.pack_conv3_weights(b.conv1.conv.weight.detach().float().contiguous(), None, dt,
-                                                    cin_packed=r.cin_packed if r.cin_packed != r.cin else None)
+                                                    cin_packed=r.cin_packed if r.cin_packed != r.cin else None, perm=r.perm)
                 r.w2, r.b2 = ops.pack_conv3_weights(b.conv2.conv.weight.detach().float().contiguous(), None, dt)
                 if r.has3:
                     w3 = torch.zeros((r.cout, r.cin_packed), dtype=dt, device=dev)
-                    w3[:, :r.cin] = b.conv3.conv.weight.detach().reshape(r.cout, r.cin).to(dt)
+                    w3[:, :r.cin] = b.conv3.conv.weight.detach().reshape(r.cout, r.cin)[:, r.perm or list(range(r.cin))].to(dt)
                     r.w3 = w3
                 r.ones = torch.ones(r.cout, dtype=torch.float32, device=dev)
                 r.zeros = torch.zeros(r.cout, dtype=torch.float32, device=dev)
@@ -237,7 +246,7 @@ class SwinPlan:
                               for u in self.ups]
             enc, den = self.net.embed_model, self.net.model
             self.e_vit = self._pack_vit(enc.swinViT, 8)
-            self.d_vit = self._pack_vit(den.swinViT, self.cin0)
+            self.d_vit = self._pack_vit(den.swinViT, self.cin0, self.perm0)
             self.wf = den.out.conv.conv.weight.detach().float().reshape(self.C, -1).contiguous()
             self.bf = den.out.conv.conv.bias.detach().float().contiguous()
             # t_proj(swish(t_embedder(t))) of every projection, for every original timestep (depends on weights only)
@@ -258,6 +267,7 @@ class SwinPlan:
             self.temb_table = ops.temb_table(ts, freqs, f32(te.dense[0].weight), f32(te.dense[0].bias), f32(te.dense[1].weight),
                                              f32(te.dense[1].bias), wcat, bcat)
         self.weights_version = ver
+        self.graphs.clear()
 
     # ---- building blocks ------------------------------------------------------------------------
     def _view(self, flat, level, c):
@@ -313,8 +323,8 @@ class SwinPlan:
                 geom = g["g1"] if shifted else g["g0"]
                 ops.window_gather_norm(x, geom, b["g1"], b["b1"], win, y=y)
                 qkv = F.linear(win, b["wqkv"], b["bqkv"])
-                ops.window_attention(qkv, HEADS[i], b["bias_t"], region_ids=g["region"] if shifted else None,
-                                     windows_per_image=g["nw"], out=att)
+                ops.window_attention(qkv, HEADS[i], None, region_ids=g["region"] if shifted else None,
+                                     windows_per_image=g["nw"], out=att, bias_table=b["table"], table_grid=WINDOW)
                 po = F.linear(att, b["wproj"], b["bproj"])
                 ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)
                 h = F.linear(ln2, b["w1"], b["bb1"])
@@ -336,7 +346,7 @@ class SwinPlan:
         assert tuple(image.shape) == (N, 1, *self.dims), f"image shape {tuple(image.shape)} != plan {(N, 1, *self.dims)}"
         img = image.detach().float().contiguous()
         ops.to_channels_last(img, self.img_in, 0, 8)
-        ops.to_channels_last(img, self.xin, 0, 1)               # conditioning channel of the denoiser input
+        ops.to_channels_last(img, self.xin, self.C, self.cin0 - self.C)     # conditioning channel of the denoiser input
         self.enc_stats.zero_()
         self._swin(self.e_vit, self.img_in, 8, None, None, [(self.e_hs[i], 0) for i in range(5)])
         srcs = [(self.img_in, 8), (self.e_hs[0], self.f), (self.e_hs[1], 2 * self.f), (self.e_hs[2], 4 * self.f)]
@@ -351,7 +361,7 @@ class SwinPlan:
             return
         img = image.detach().float().contiguous()
         assert tuple(img.shape) == (self.N, 1, *self.dims)
-        ops.to_channels_last(img, self.xin, 0, 1)
+        ops.to_channels_last(img, self.xin, self.C, self.cin0 - self.C)
         for k in range(5):
             e = embeddings[0][k]
             ops.to_channels_last(e.detach().float().contiguous(), self.e_hs[k], 0, e.shape[1])
@@ -382,7 +392,27 @@ class SwinPlan:
             ra = cat[k] if k < 4 else None                                         # + r_k (not for decoder5: skip = hs[3])
             self._res_block(self.u_res[k], cat[k], 2 * cout, dec[k], 0, ra=ra, ra_off=cout)
             src = dec[k]
-        ops.head_fwd(dec[0], self.wf, self.bf, out=self.logits_cl)
+
+    def tail(self, mode, noise=None, logits=None, use_sum=False):
+        """UnetOutBlock (1x1x1, denoiser.py:399-400) fused with the sampler update (engine.Plan.tail's kernel, fed the
+        materialised decoder1 output)."""
+        ops.final_conv_sampler(self.dec[0], self.f, None, self.wf, self.bf, self.C, mode, coef=self.cur_coef,
+                               x_state=self.x_state, noise=noise, step_word=self.step_word,
+                               xin=self.xin if mode != nv.MODE_LOGITS else None,
+                               xstart_sum=self.x_sum if use_sum else None, logits=logits, seed_dev=self.seed_word)
+
+    def new_seed(self, seed=None):
+        """Philox key of this call's in-kernel noise (engine.Plan.new_seed)."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    seed ^= (dist.get_rank() + 1) * 0x9E3779B97F4A7C15 & (2 ** 62 - 1)
+            except Exception:       # pragma: no cover - torch.distributed not built
+                pass
+        self.seed_word.fill_(int(seed) & (2 ** 63 - 1))
+        return seed
 
     def denoise(self, x, t):
         """logits = model(x, t, image, embeddings) for an already-staged image (denoiser.py:353-403)."""
@@ -390,10 +420,75 @@ class SwinPlan:
         N = self.N
         assert tuple(x.shape) == (N, self.C, *self.dims) and t.numel() == N
         T = self.temb_table.shape[0]
-        rows = t.detach().to(device=self.dev, dtype=torch.int64).reshape(-1)
-        if not t.is_cuda and not bool(((t >= 0) & (t < T)).all()):
+        on_host = not t.is_cuda
+        if on_host and not bool(((t >= 0) & (t < T)).all()):
             raise ValueError(f"timestep out of range: the model was built for 0 <= t < {T}, got {t.tolist()}")
-        ops.to_channels_last(x.detach().float().contiguous(), self.xin, 1, self.cin0 - 1)
-        torch.index_select(self.temb_table, 0, rows.clamp(0, T - 1), out=self.cur_add)
+        rows = t.detach().to(device=self.dev, dtype=torch.int32).contiguous()
+        if not on_host:
+            self.err_word.zero_()
+        ops.to_channels_last(x.detach().float().contiguous(), self.xin, 0, self.C)
+        ops.step_begin(N, self.temb_table, self.cur_add, rows_per_sample=rows, err_word=self.err_word)
         self.denoiser_body()
-        return ops.from_channels_last(self.logits_cl, self.C)
+        out = torch.empty((N, self.C, *self.dims), dtype=torch.float32, device=self.dev)
+        self.tail(nv.MODE_LOGITS, logits=out)
+        if not on_host and int(self.err_word.item()):
+            raise ValueError(f"timestep out of range: the model was built for 0 <= t < {T}")
+        return out
+
+    def sample_loop(self, diffusion, kind, noise=None, step_noise=None, eta=0.0, use_graph=True, seed=None):
+        """T reverse steps from ``noise`` (x_T, NCDHW) or a fresh draw: the loop bodies of p_sample_loop_progressive /
+        ddim_sample_loop_progressive (gaussian_diffusion.py:487-535, 667-716) around SwinUNETRDenoiser.forward, one
+        captured HIP graph replayed per step.  Returns dict(sample, sum_pred_xstart)."""
+        self.refresh_weights()
+        N, T = self.N, diffusion.num_timesteps
+        shape = (N, self.C, *self.dims)
+        if noise is None:
+            noise = torch.randn(*shape, device=self.dev)
+        assert tuple(noise.shape) == shape
+        x_T = noise.detach().float().contiguous()
+
+        def reset():
+            ops.to_channels_last(x_T, self.x_state, 0, self.cx)
+            ops.to_channels_last(x_T, self.xin, 0, self.C)
+            self.x_sum.zero_()
+            self.counter.zero_()
+
+        reset()
+        mode = nv.MODE_DDPM if kind == "ddpm" else nv.MODE_DDIM
+        tkey = (id(diffusion), kind, float(eta))
+        if tkey not in self.tables:
+            order = list(range(T))[::-1]
+            tt = torch.tensor(order)
+            coef = diffusion.ddpm_coef(tt) if kind == "ddpm" else diffusion.ddim_coef(tt, eta)
+            tmap = diffusion.model_timesteps()
+            self.tables[tkey] = (coef.to(self.dev).contiguous(),
+                                 torch.tensor([tmap[i] for i in order], dtype=torch.int32, device=self.dev))
+        coef_table, row_of_step = self.tables[tkey]
+        self.new_seed(seed)
+        if step_noise is not None:
+            assert len(step_noise) == T
+            use_graph = False
+
+        def one_step(eps):
+            ops.step_begin(N, self.temb_table, self.cur_add, row_of_step=row_of_step, counter=self.counter,
+                           coef_table=coef_table, cur_coef=self.cur_coef, step_word=self.step_word, err_word=self.err_word)
+            self.denoiser_body()
+            self.tail(mode, noise=eps, use_sum=True)
+
+        if not use_graph:
+            for k in range(T):
+                one_step(None if step_noise is None else step_noise[k].detach().to(self.dev).float().contiguous())
+        else:
+            g = self.graphs.get(tkey)
+            if g is None:
+                one_step(None)                    # warm-up outside capture (kernel attributes, GEMM workspaces)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    one_step(None)
+                self.graphs[tkey] = g
+                reset()
+            for _ in range(T):
+                g.replay()
+        return {"sample": ops.from_channels_last(self.x_state, self.C),
+                "sum_pred_xstart": ops.from_channels_last(self.x_sum, self.C)}

@@ -218,3 +218,13 @@ class SwinUNETRDenoiser(nn.Module):
         plan = rt.plan_for(x)
         plan.stage_condition(image, embeddings)
         return plan.denoise(x, t)
+
+    def fused_engine(self, shape, model_kwargs):
+        """Hook used by GaussianDiffusion loops: a launch plan for ``shape`` with the conditioning staged."""
+        rt = self._rt
+        if rt is None:
+            return None
+        image = model_kwargs["image"]
+        plan = rt.plan(shape[0], tuple(shape[2:]), image.device)
+        plan.stage_condition(image, model_kwargs["embeddings"])
+        return rt.adapter(plan)

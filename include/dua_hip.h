@@ -238,7 +238,9 @@ typedef struct {
 /* wf: fp32[C][K], bf: fp32[C].  coef: fp32[N][8] on device.  x_state: fp32[N][voxels][CX] in/out.
  * noise: fp32 NCDHW [N][C][voxels] or NULL (in-kernel Philox4x32-10 + Box-Muller, counter =
  * (element, *step_word)).  xin, xstart_sum ([N][voxels][CX]), logits and xstart (NCDHW fp32) may be
- * NULL.  In DUA_MODE_LOGITS only logits is written. */
+ * NULL.  In DUA_MODE_LOGITS only logits is written.
+ * in == NULL (or in->stats == NULL): raw is an already materialised activation and goes to the 1x1x1 convolution as it
+ * is -- the tail of SwinUNETRDenoiser.forward (`out` UnetOutBlock, models/swin_unetr/denoiser.py:399-400). */
 int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in_norm* in,
                            const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
                            const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
@@ -318,10 +320,15 @@ int dua_denoiser_step(const dua_denoiser_plan* plan, void* stream);
  * compute_mask (attention.py:123-160; 0 / -100), transposed, or NULL for unshifted blocks.  tokens <= 352, head
  * dimension 16 (feature_size 48).  fp16 MFMA operands, fp32 softmax and accumulation.
  * region_ids (or NULL): the same mask in the form compute_mask derives it from -- uint8 [windows_per_image][tokens], the
- * shift region (0..26) of every token; the kernel adds -100 where query and key regions differ.  Give one of the two. */
+ * shift region (0..26) of every token; the kernel adds -100 where query and key regions differ.  Give one of the two.
+ * bias_table (or NULL): the relative-position bias in the form the reference stores it, transposed to
+ * fp32 [heads][(2 grid_d - 1)(2 grid_h - 1)(2 grid_w - 1)] (attention.py:49-54 relative_position_bias_table; grid = the
+ * window the index was built for, (7, 7, 7), also when the window itself is clipped); the kernel evaluates
+ * relative_position_index (attention.py:56-73) from the token coordinates.  Takes precedence over bias_t. */
 int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image, const void* qkv,
-                             const float* bias_t, const float* mask_t, const unsigned char* region_ids, float scale,
-                             void* out, void* stream);
+                             const float* bias_t, const float* mask_t, const unsigned char* region_ids,
+                             const float* bias_table, int grid_d, int grid_h, int grid_w, float scale, void* out,
+                             void* stream);
 
 /* PatchMerging.forward up to the reduction Linear (models/swin_unetr/patch.py:44-61; legacy != 0: the 3-D gather of
  * :70-91 with its duplicated corners): x [B][D][H][W][C] -> out [B][ceil(D/2)][ceil(H/2)][ceil(W/2)][8C] = LayerNorm_8C(gather),

@@ -260,6 +260,32 @@ def test_patch_embed_stage_out_gelu_kernels_match_oracle(dtype, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("heads,table_ws,ws,dims", [(3, (7, 7, 7), (7, 7, 7), (7, 14, 7)), (24, (7, 7, 7), (6, 6, 6), (6, 6, 6)),
+                                                    (6, (7, 7, 7), (2, 2, 2), (2, 2, 2))])
+def test_window_attention_bias_table_form_equals_dense_bias(heads, table_ws, ws, dims):
+    """bias_table + in-kernel relative_position_index == the dense bias the oracle gathers (attention.py:103-106), also
+    for clipped windows, where the reference slices the 7^3 index to [:n, :n]."""
+    from diff_unet_amos_amd import ops
+    torch.manual_seed(heads)
+    att = RefWindowAttention(heads * 16, heads, table_ws, qkv_bias=True)
+    with torch.no_grad():
+        att.relative_position_bias_table.normal_(0, 0.5)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, *dims, heads * 16, generator=g)
+    xw = window_partition(x, ws)
+    n = xw.shape[1]
+    with torch.no_grad():
+        qkv = att.qkv(xw)
+        want = att.attention_core(qkv, None)
+    qd = qkv.half().cuda().contiguous()
+    dense = ops.window_attention(qd, heads, att.bias(n).detach().transpose(1, 2).contiguous().cuda())
+    table = ops.window_attention(qd, heads, None, bias_table=att.relative_position_bias_table.detach().t().contiguous().cuda(),
+                                 table_grid=table_ws)
+    assert torch.equal(dense, table)
+    assert (table.float().cpu() - want).abs().max() < 2e-3 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
 def test_window_attention_region_ids_equal_the_dense_mask():
     from diff_unet_amos_amd import ops
     from diff_unet_amos_amd.swin_engine import region_ids
@@ -343,3 +369,35 @@ def test_diff_swin_unetr_ddim_sample_matches_oracle():
     d = (got - want).abs()
     print(f"ddim x3 sum of x0: max |d| {d.max():.2e} mean {d.mean():.2e}")
     assert d.max() < 5e-4 and d.mean() < 2e-5             # measured 1.8e-5 / 2e-6
+
+
+@pytest.mark.gpu
+def test_diff_swin_unetr_graph_replay_equals_eager_and_full_size_runs():
+    """The captured-graph sampling loop equals the eager launch sequence (DDIM, eta 0: no noise enters), a second call
+    reuses the graph, and the BASELINE config-5 shape (96^3, 16 classes, fp16) runs to finite, bounded output."""
+    net, _ = _swin_pair(2, torch.float16, seed=6)
+    from diff_unet_amos_amd.gaussian_diffusion import make_spaced
+    net.sample_diffusion = make_spaced(1000, [4])
+    g = torch.Generator().manual_seed(8)
+    image = torch.randn(1, 1, 64, 64, 64, generator=g).cuda()
+    xT = torch.randn(1, 2, 64, 64, 64, generator=g).cuda()
+    with torch.no_grad():
+        emb = net.embed_model(image)
+        plan = net._rt.plan(1, (64, 64, 64), image.device)
+        a = plan.sample_loop(net.sample_diffusion, "ddim", noise=xT, use_graph=False)
+        b = plan.sample_loop(net.sample_diffusion, "ddim", noise=xT, use_graph=True)
+        c = plan.sample_loop(net.sample_diffusion, "ddim", noise=xT, use_graph=True)
+    assert len(plan.graphs) == 1
+    for k in ("sample", "sum_pred_xstart"):
+        assert torch.equal(a[k], b[k]) and torch.equal(b[k], c[k]), k
+    assert float(a["sum_pred_xstart"].abs().max()) <= 4.0 + 1e-6          # four clamped x0 predictions
+    del net, plan, emb
+    torch.cuda.empty_cache()
+    from diff_unet_amos_amd.diff_swin_unetr import DiffSwinUNETR
+    torch.manual_seed(0)
+    big = DiffSwinUNETR(in_channels=1, out_channels=16, feature_size=48, sample_steps=3).cuda().eval()
+    img = torch.rand(2, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        out = big(image=img, pred_type="ddim_sample")
+    assert tuple(out.shape) == (2, 16, 96, 96, 96) and bool(torch.isfinite(out).all()) and float(out.abs().max()) <= 3.0 + 1e-6
+    assert not torch.equal(out[0], out[1])

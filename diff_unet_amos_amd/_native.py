@@ -82,6 +82,17 @@ class WindowGeom(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "D", "H", "W", "C", "wd", "wh", "ww", "sd", "sh", "sw")]
 
 
+class TokenLinearDesc(C.Structure):
+    """dua_token_linear_desc."""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("M", C.c_long), ("K", C.c_int), ("N", C.c_int),
+                ("W", C.c_void_p), ("bias", C.c_void_p), ("mode", C.c_int), ("samples", C.c_int),
+                ("out", C.c_void_p), ("ldc", C.c_int), ("out_off", C.c_int), ("x", C.c_void_p),
+                ("stats", C.c_void_p), ("c_pad", C.c_int), ("geom", WindowGeom), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("eps", C.c_float), ("ln_out", C.c_void_p)]
+
+
+TOKLIN_PLAIN, TOKLIN_GELU, TOKLIN_STATS, TOKLIN_RESIDUAL, TOKLIN_SCATTER = range(5)
+
 _P = C.c_void_p
 _SIGS = {
     "dua_set_option": (C.c_int, [C.c_int, C.c_int]),
@@ -101,6 +112,7 @@ _SIGS = {
     "dua_patch_embed": (C.c_int, [C.c_int] * 8 + [_P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, C.c_int, C.c_int, _P]),
     "dua_instnorm_stats": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
     "dua_gelu": (C.c_int, [C.c_int, C.c_long, _P, _P]),
+    "dua_token_linear": (C.c_int, [C.POINTER(TokenLinearDesc), _P]),
     "dua_denoiser_step": (C.c_int, [C.POINTER(DenoiserPlan), _P]),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),

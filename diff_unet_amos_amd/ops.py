@@ -806,3 +806,48 @@ def gelu_(x):
     assert x.is_cuda and x.is_contiguous() and x.numel() % 8 == 0
     nv.check(nv.lib().dua_gelu(nv.dt_code(x.dtype), x.numel(), nv.ptr(x), nv.stream_ptr()), "dua_gelu")
     return x
+
+
+def token_linear(A, W, bias=None, mode="plain", out=None, out_off=0, x=None, stats=None, samples=1, geom=None, gamma=None,
+                 beta=None, ln_out=None, eps=1e-5):
+    """dua_token_linear: fp16 A [tokens, K] (row stride A.stride(0)) times the nn.Linear weight W [N, K] with one fused
+    epilogue -- "plain" / "gelu" (-> out[:, out_off:out_off+N]), "stats" (raw out + per-(sample, channel) sums into
+    ``stats``), "residual" (x += result, fp32 stream) or "scatter" (window order -> voxel order, x += result,
+    ln_out = LayerNorm(x) * gamma + beta).  Layers wider than 192 outputs are split by rows of W."""
+    assert A.is_cuda and A.dtype == torch.float16 and A.dim() == 2 and A.stride(1) == 1
+    assert W.is_cuda and W.dtype == torch.float16 and W.is_contiguous() and W.dim() == 2 and W.shape[1] == A.shape[1]
+    M, K = A.shape
+    N = W.shape[0]
+    code = {"plain": nv.TOKLIN_PLAIN, "gelu": nv.TOKLIN_GELU, "stats": nv.TOKLIN_STATS, "residual": nv.TOKLIN_RESIDUAL,
+            "scatter": nv.TOKLIN_SCATTER}[mode]
+    if bias is not None:
+        _f32c(bias, "bias")
+        assert bias.numel() == N
+    if N > 192:
+        assert mode in ("plain", "gelu")
+        for n0 in range(0, N, 192):
+            n1 = min(N, n0 + 192)
+            token_linear(A, W[n0:n1], None if bias is None else bias[n0:n1], mode, out, out_off + n0)
+        return out
+    d = nv.TokenLinearDesc()
+    d.A, d.lda, d.M, d.K, d.N, d.W, d.bias = A.data_ptr(), A.stride(0), M // samples, K, N, W.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.mode, d.samples = code, samples
+    if mode in ("plain", "gelu", "stats"):
+        assert out is not None and out.is_cuda and out.dtype == torch.float16 and out.is_contiguous()
+        ldc = out.shape[-1]
+        assert out.numel() == M * ldc and out_off + N <= ldc
+        d.out, d.ldc, d.out_off = out.data_ptr(), ldc, out_off
+    if mode == "stats":
+        assert stats is not None and stats.dtype == torch.float64 and stats.is_contiguous() and stats.shape[0] == samples and M % samples == 0
+        d.stats, d.c_pad = stats.data_ptr(), stats.shape[2]
+    if mode in ("residual", "scatter"):
+        assert x is not None and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        d.x = x.data_ptr()
+    if mode == "residual":
+        assert x.numel() == M * N
+    if mode == "scatter":
+        _f32c(gamma, "gamma"); _f32c(beta, "beta")
+        assert ln_out is not None and ln_out.dtype == torch.float16 and ln_out.is_contiguous() and ln_out.numel() == x.numel()
+        d.geom, d.gamma, d.beta, d.eps, d.ln_out = geom, gamma.data_ptr(), beta.data_ptr(), eps, ln_out.data_ptr()
+    nv.check(nv.lib().dua_token_linear(C.byref(d), nv.stream_ptr()), "dua_token_linear")
+    return out if mode in ("plain", "gelu", "stats") else x

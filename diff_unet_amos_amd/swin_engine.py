@@ -139,6 +139,11 @@ class SwinPlan:
         self.att = torch.zeros(tok_max, dtype=dtype, device=device)           # attention output
         self.ln2 = torch.zeros(tok_max, dtype=dtype, device=device)
         self.merged = torch.zeros(tok_max, dtype=dtype, device=device)        # gathered + normalised 8C tokens (= tokens * C)
+        self.fused_linear = dtype == torch.float16                            # swin_gemm.hip is an fp16-operand kernel
+        if self.fused_linear:
+            self.qkv_buf = torch.zeros(3 * tok_max, dtype=dtype, device=device)
+            self.hid_buf = torch.zeros(4 * tok_max, dtype=dtype, device=device)
+            self.red_buf = torch.zeros(tok_max // 4 + 8, dtype=dtype, device=device)
         # ---- sampler state
         self.x_state = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
         self.x_sum = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
@@ -218,7 +223,8 @@ class SwinPlan:
                                    wqkv=a.qkv.weight.detach().to(dt).contiguous(), bqkv=a.qkv.bias.detach().to(dt).contiguous(),
                                    wproj=a.proj.weight.detach().to(dt).contiguous(), bproj=a.proj.bias.detach().to(dt).contiguous(),
                                    w1=blk.mlp.linear1.weight.detach().to(dt).contiguous(), bb1=blk.mlp.linear1.bias.detach().to(dt).contiguous(),
-                                   w2=blk.mlp.linear2.weight.detach().to(dt).contiguous(), bb2=blk.mlp.linear2.bias.detach().to(dt).contiguous()))
+                                   w2=blk.mlp.linear2.weight.detach().to(dt).contiguous(), bb2=blk.mlp.linear2.bias.detach().to(dt).contiguous(),
+                                   fqkv=f32(a.qkv.bias), fproj=f32(a.proj.bias), f1=f32(blk.mlp.linear1.bias), f2=f32(blk.mlp.linear2.bias)))
             out["stages"].append(dict(blocks=blocks, gm=f32(layer.downsample.norm.weight), bm=f32(layer.downsample.norm.bias),
                                       wred=layer.downsample.reduction.weight.detach().to(dt).contiguous()))
         return out
@@ -293,9 +299,12 @@ class SwinPlan:
         ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=self.splitk_ws)
         if r.has3:
             res = self._view(self.res3, l, r.cout)
-            torch.matmul(x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin), r.w3.t(),
-                         out=res.view(-1, r.cout))                                  # 1x1x1 conv3 = library GEMM
-            ops.instnorm_stats(res, r.cout, r.st[2])
+            x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
+            if self.fused_linear and r.cout <= 64 and cin <= 384:
+                ops.token_linear(x2, r.w3, None, "stats", out=res.view(-1, r.cout), stats=r.st[2], samples=N)   # conv3 + norm3 sums
+            else:
+                torch.matmul(x2, r.w3.t(), out=res.view(-1, r.cout))                 # 1x1x1 conv3 = library GEMM
+                ops.instnorm_stats(res, r.cout, r.st[2])
             ops.residual_norm_act(raw2, n2, res, n3, slope=SLOPE, out=out, out_off=out_off, post_add=post_add, ra_src=ra,
                                   ra_off=ra_off)
         else:
@@ -318,23 +327,40 @@ class SwinPlan:
             att = self.att[:ntok_w * C_].view(N * g["nw"], g["n"], C_)
             ln2 = self.ln2[:ntok * C_].view(ntok, C_)
             y = None
+            fused = self.fused_linear and C_ <= 96          # tall token GEMMs with fused epilogues (swin_gemm.hip)
+            if fused:
+                qkv_buf = self.qkv_buf[:ntok_w * 3 * C_].view(N * g["nw"], g["n"], 3 * C_)
+                hid = self.hid_buf[:ntok * 4 * C_].view(ntok, 4 * C_)
             for k, b in enumerate(st["blocks"]):
                 shifted = k % 2 == 1 and any(g["ss"])
                 geom = g["g1"] if shifted else g["g0"]
                 ops.window_gather_norm(x, geom, b["g1"], b["b1"], win, y=y)
-                qkv = F.linear(win, b["wqkv"], b["bqkv"])
+                if fused:
+                    qkv = ops.token_linear(win.view(-1, C_), b["wqkv"], b["fqkv"], "plain", out=qkv_buf)
+                else:
+                    qkv = F.linear(win, b["wqkv"], b["bqkv"])
                 ops.window_attention(qkv, HEADS[i], None, region_ids=g["region"] if shifted else None,
                                      windows_per_image=g["nw"], out=att, bias_table=b["table"], table_grid=WINDOW)
-                po = F.linear(att, b["wproj"], b["bproj"])
-                ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)
-                h = F.linear(ln2, b["w1"], b["bb1"])
-                ops.gelu_(h)
-                y = F.linear(h, b["w2"], b["bb2"])
+                if fused:
+                    ops.token_linear(att.view(-1, C_), b["wproj"], b["fproj"], "scatter", x=x, geom=geom, gamma=b["g2"],
+                                     beta=b["b2"], ln_out=ln2)
+                    ops.token_linear(ln2, b["w1"], b["f1"], "gelu", out=hid)
+                    ops.token_linear(hid, b["w2"], b["f2"], "residual", x=x)       # x + mlp(norm2(x)) lands in the stream
+                else:
+                    po = F.linear(att, b["wproj"], b["bproj"])
+                    ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)
+                    h = F.linear(ln2, b["w1"], b["bb1"])
+                    ops.gelu_(h)
+                    y = F.linear(h, b["w2"], b["bb2"])
             dims = g["dims"]
             mshape = (N, (dims[0] + 1) // 2, (dims[1] + 1) // 2, (dims[2] + 1) // 2, 8 * C_)
             merged = self.merged[:mshape[0] * mshape[1] * mshape[2] * mshape[3] * mshape[4]].view(mshape)
             ops.patch_merge_norm(x, st["gm"], st["bm"], legacy=True, y=y, dtype=dt, out=merged)
-            red = F.linear(merged.view(-1, 8 * C_), st["wred"])
+            if fused and 8 * C_ <= 384:
+                red = ops.token_linear(merged.view(-1, 8 * C_), st["wred"], None, "plain",
+                                       out=self.red_buf[:merged.numel() // 4].view(-1, 2 * C_))
+            else:
+                red = F.linear(merged.view(-1, 8 * C_), st["wred"])
             ops.stage_out(red, N, 2 * C_, outs[i + 1][0], outs[i + 1][1], tadd=tadd(i + 1),
                           emb=None if emb is None else emb[i + 1], x=self.stream[i + 1] if i < 3 else None)
 

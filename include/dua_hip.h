@@ -380,6 +380,33 @@ int dua_patch_embed(int dtype, int B, int D, int H, int W, int Cin_stride, int C
  * the caller): the statistics of UnetResBlock's 1x1x1 conv3 (blocks.py:286-296), whose GEMM is a library call. */
 int dua_instnorm_stats(int dtype, int N, long voxels, int C, const void* x, int x_stride, int x_off, double* stats,
                        int c_pad, void* stream);
+/* Token GEMM with a fused epilogue for the tall / skinny Linear layers of the fine Swin stages and the 1x1x1 conv3 of
+ * UnetResBlock: out[token][n] = sum_k A[token][k] W[n][k] (+ bias[n]), fp16 operands (A: [samples * M][lda], W: the
+ * nn.Linear weight [N][K] as it is), fp32 accumulation.  K <= 384, N <= 192 per call (callers split wider layers by rows of
+ * W).  Modes:
+ *   PLAIN    out[token][out_off + n] (fp16, row stride ldc)                              qkv, proj, reduction
+ *   GELU     the same after exact GELU                                                   MLPBlock linear1 + act
+ *   STATS    PLAIN without bias, and stats[sample][replica][c][2] += (sum, sum^2) of the ROUNDED outputs (N <= 64; M = voxels
+ *            per sample, `samples` grid rows)                                            conv3 + norm3 statistics
+ *   RESIDUAL x[token][n] += out + bias on the fp32 stream                                x + mlp(norm2(x)), transformer.py:477-480
+ *   SCATTER  token = window order: x[voxel(token)] += out + bias, ln_out[voxel] = LayerNorm(x)*gamma+beta; padding tokens
+ *            dropped (window_reverse, roll back, crop, shortcut add, norm2: transformer.py:417-434, 475-476) */
+#define DUA_TOKLIN_PLAIN 0
+#define DUA_TOKLIN_GELU 1
+#define DUA_TOKLIN_STATS 2
+#define DUA_TOKLIN_RESIDUAL 3
+#define DUA_TOKLIN_SCATTER 4
+typedef struct dua_token_linear_desc {
+  const void* A; int lda; long M; int K, N;
+  const void* W; const float* bias;
+  int mode, samples;
+  void* out; int ldc, out_off;
+  float* x;
+  double* stats; int c_pad;
+  dua_window_geom geom; const float* gamma; const float* beta; float eps; void* ln_out;
+} dua_token_linear_desc;
+int dua_token_linear(const dua_token_linear_desc* d, void* stream);
+
 /* Exact (erf) GELU in place between the two MLP GEMMs (MONAI MLPBlock act "GELU"). */
 int dua_gelu(int dtype, long elems, void* x, void* stream);
 

@@ -401,3 +401,65 @@ def test_diff_swin_unetr_graph_replay_equals_eager_and_full_size_runs():
         out = big(image=img, pred_type="ddim_sample")
     assert tuple(out.shape) == (2, 16, 96, 96, 96) and bool(torch.isfinite(out).all()) and float(out.abs().max()) <= 3.0 + 1e-6
     assert not torch.equal(out[0], out[1])
+
+
+@pytest.mark.gpu
+def test_token_linear_kernel_epilogues_match_torch():
+    """dua_token_linear against torch.nn.functional on the same fp16 operands: plain / GELU (also split over 288 and 384
+    outputs), conv3 + statistics, residual add on the fp32 stream, window scatter + shortcut + LayerNorm."""
+    import torch.nn.functional as F
+    from diff_unet_amos_amd import ops
+    g = torch.Generator().manual_seed(21)
+    dev = "cuda"
+    for M, K, N, mode in ((1000, 48, 144, "plain"), (777, 96, 288, "plain"), (513, 384, 96, "plain"), (300, 48, 192, "gelu"),
+                          (260, 96, 384, "gelu"), (129, 24, 48, "plain"), (2000, 192, 48, "plain")):
+        A = torch.randn(M, K, generator=g).half().to(dev)
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+        b = torch.randn(N, generator=g).to(dev)
+        out = torch.zeros(M, N + 8, dtype=torch.float16, device=dev)
+        ops.token_linear(A, W, b, mode, out=out, out_off=8)
+        want = F.linear(A.float(), W.float(), b)
+        want = F.gelu(want) if mode == "gelu" else want
+        assert float(out[:, :8].abs().max()) == 0.0
+        assert (out[:, 8:].float() - want).abs().max() < 4e-3 * max(1.0, float(want.abs().max())), (M, K, N, mode)
+    # conv3 + norm3 statistics: two samples, a channel slice of a wider buffer as input
+    B, V, K, N = 2, 1500, 96, 48
+    buf = torch.randn(B * V, K + 16, generator=g).half().to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+    out = torch.empty(B * V, N, dtype=torch.float16, device=dev)
+    st = ops.stats_buffer(B, N, dev)
+    ops.token_linear(buf[:, :K], W, None, "stats", out=out, stats=st, samples=B)
+    want = F.linear(buf[:, :K].float(), W.float())
+    assert (out.float() - want).abs().max() < 4e-3 * max(1.0, float(want.abs().max()))
+    o = out.float().view(B, V, N)
+    assert torch.allclose(st[:, :, :N, 0].sum(1), o.sum(1).double(), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[:, :, :N, 1].sum(1), (o * o).sum(1).double(), rtol=1e-4, atol=1e-2)
+    # residual
+    for M, K, N in ((900, 192, 48), (450, 384, 96)):
+        A = torch.randn(M, K, generator=g).half().to(dev)
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+        b = torch.randn(N, generator=g).to(dev)
+        x = torch.randn(M, N, generator=g).to(dev)
+        want = x + F.linear(A.float(), W.float(), b)
+        ops.token_linear(A, W, b, "residual", x=x)
+        assert (x - want).abs().max() < 2e-3 * max(1.0, float(want.abs().max()))
+    # scatter + shortcut + LayerNorm == window_scatter_add_norm after a library GEMM
+    for dims, C_, ws, ss in (((9, 8, 10), 48, (7, 7, 7), (3, 3, 3)), ((8, 14, 7), 96, (7, 7, 7), (3, 3, 0))):
+        Bn = 2
+        geom = ops.window_geom(Bn, dims, C_, ws, ss)
+        nwin = 1
+        for k in range(3):
+            nwin *= -(-dims[k] // ws[k])
+        Mw = Bn * nwin * ws[0] * ws[1] * ws[2]
+        A = torch.randn(Mw, C_, generator=g).half().to(dev)
+        W = (torch.randn(C_, C_, generator=g) / C_ ** 0.5).half().to(dev)
+        b = torch.randn(C_, generator=g).to(dev)
+        gm, bt = torch.randn(C_, generator=g).to(dev), torch.randn(C_, generator=g).to(dev)
+        x0 = torch.randn(Bn, *dims, C_, generator=g).to(dev)
+        xa, xb = x0.clone(), x0.clone()
+        la, lb = torch.empty(Bn, *dims, C_, dtype=torch.float16, device=dev), torch.empty(Bn, *dims, C_, dtype=torch.float16, device=dev)
+        po = F.linear(A, W, b.half())
+        ops.window_scatter_add_norm(xa, geom, po, gm, bt, la)
+        ops.token_linear(A, W, b, "scatter", x=xb, geom=geom, gamma=gm, beta=bt, ln_out=lb)
+        assert (xa - xb).abs().max() < 4e-3 * max(1.0, float(xa.abs().max()))
+        assert (la.float() - lb.float()).abs().max() < 8e-3 * max(1.0, float(la.float().abs().max()))

@@ -12,11 +12,13 @@
 //   SCATTER   window token -> voxel (window_reverse, roll back, crop), x += out + bias, ln_out = norm2(x)
 //                                                                    (transformer.py:417-434, 475-476)
 //
-// Mapping: the weights are the A operand of MFMA 32x32x16 (rows = output channels, resident in LDS for the whole launch:
-// persistent workgroups), a wave's 32 tokens are the B operand, read straight from global memory (one 16-byte k-group per
-// lane and k-step; a token row is consumed completely by its two lanes).  The accumulator then holds, per LANE = TOKEN,
-// four consecutive output channels per register quad: epilogues are per-token register arithmetic (LayerNorm = in-lane sum +
-// one exchange with lane ^ 32) and 8 / 16-byte stores.
+// Mapping: the weights are the A operand of MFMA 32x32x16 (rows = output channels, resident in LDS for the whole launch),
+// a wave's 32 tokens are the B operand.  A tile of 128 token rows comes in with coalesced 16-byte loads (consecutive lanes =
+// consecutive bytes of a row; one row per lane, the direct operand load, costs one address per lane: 97 us instead of 54 for
+// the library GEMM on the 96^3 conv3, profiles/r2_swin_*), is read back as operand fragments from padded LDS rows, and the
+// result leaves the same way: accumulators (per LANE = TOKEN, four consecutive output channels per register quad -- bias,
+// GELU and the statistics are register arithmetic) -> LDS tile -> coalesced rows.  The scatter epilogue walks the tile
+// with 16 lanes per token (LayerNorm = a 16-lane butterfly), like window_scatter_add_norm.
 #include "common.hpp"
 #include "../../include/dua_hip.h"
 #include "swin_geom.hpp"
@@ -36,186 +38,201 @@ struct TokLinArgs {
   float* x;
   double* stats; int c_pad;
   WinGeom g; const float* gamma; const float* beta; float eps; f16* ln_out;
-  int row_bytes;                // LDS row stride of W
+  int w_row, a_row, o_row, w_bytes;   // LDS row strides (bytes) of W, the A tile, the output tile; size of the W region
 };
 
-__device__ __forceinline__ float gelu_erf(float a) { return 0.5f * a * (1.f + erff(a * 0.70710678118654752f)); }
+// LDS row stride for rows of `bytes` payload read 16 bytes per lane with one row per lane: an odd number of 16-byte units
+// keeps the 16 lanes of a read phase on distinct bank groups.
+static inline int padded_row(int bytes) { return (bytes / 16) & 1 ? bytes : bytes + 16; }
 
 template <int MODE, int NB>
 __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
   using namespace tg;
-  constexpr int MAXNB = NB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;                       // [NB*32][w_row]   weights, resident
+  char* At = smem + a.w_bytes;           // [128][a_row]     activation tile (one K chunk), then the output tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-  const int K = a.K, N = a.N, RS = a.row_bytes, kg = K >> 3;
+  const int K = a.K, N = a.N, kg = K >> 3;
   for (int i = tid; i < NB * 32 * kg; i += 256) {
     const int n = i / kg, g8 = i - n * kg;
     f16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
     if (n < N) v = *(const f16x8*)(a.W + (long)n * K + g8 * 8);
-    *(f16x8*)(smem + n * RS + g8 * 16) = v;
+    *(f16x8*)(Wl + n * a.w_row + g8 * 16) = v;
   }
-  __syncthreads();
   const int sample = blockIdx.y;                                  // STATS: one grid row per sample
   const f16* A = a.A + (long)sample * a.M * a.lda;
-  float ssum[MODE == DUA_TOKLIN_STATS ? 2 : 1][16], ssq[MODE == DUA_TOKLIN_STATS ? 2 : 1][16];                                  // STATS (N <= 64): per-lane partial sums over this workgroup's tiles
+  constexpr int SNB = MODE == DUA_TOKLIN_STATS ? (NB < 2 ? NB : 2) : 1;
+  float ssum[SNB][16], ssq[SNB][16];                              // STATS (N <= 64): per-lane partial sums over this workgroup's tiles
   if (MODE == DUA_TOKLIN_STATS) {
 #pragma unroll
-    for (int nb = 0; nb < (NB < 2 ? NB : 2); ++nb)
+    for (int nb = 0; nb < SNB; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) { ssum[nb][i] = 0.f; ssq[nb][i] = 0.f; }
   }
   const long tiles = (a.M + 127) / 128;
   for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const long tok = tile * 128 + wave * 32 + r;
-    const bool valid = tok < a.M;
-    const f16* arow = A + (valid ? tok : a.M - 1) * a.lda;
-    f32x16 acc[MAXNB];
+    const long tok0 = tile * 128;
+    f32x16 acc[NB];
 #pragma unroll
-    for (int nb = 0; nb < MAXNB; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
     for (int k0 = 0; k0 < K; k0 += 16 * KSTEPS) {
-      f16x8 bf[KSTEPS];
+      const int kc = K - k0 < 16 * KSTEPS ? K - k0 : 16 * KSTEPS, cpr = kc >> 3;
+      __syncthreads();                                            // W staged / the previous tile's copy-out is done
+      for (int c = tid; c < 128 * cpr; c += 256) {                // coalesced: consecutive lanes, consecutive 16 bytes of a row
+        const int row = c / cpr, col = c - row * cpr;
+        f16x8 v;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int kk = k0 + 16 * ks + 8 * hh;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bf[ks][e] = (f16)0.f;
-        if (kk < K) bf[ks] = *(const f16x8*)(arow + kk);
+        for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
+        if (tok0 + row < a.M) v = *(const f16x8*)(A + (tok0 + row) * a.lda + k0 + col * 8);
+        *(f16x8*)(At + row * a.a_row + col * 16) = v;
       }
+      __syncthreads();
+      const char* arow = At + (wave * 32 + r) * a.a_row;
+      for (int ks = 0; ks * 16 < kc; ++ks) {
+        const int kk = 16 * ks + 8 * hh;
+        f16x8 bf;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        if (k0 + 16 * ks < K) {
+        for (int e = 0; e < 8; ++e) bf[e] = (f16)0.f;
+        if (kk < kc) bf = *(const f16x8*)(arow + kk * 2);
 #pragma unroll
-          for (int nb = 0; nb < MAXNB; ++nb)
-            if (nb < NB) {
-              const f16x8 af = *(const f16x8*)(smem + (nb * 32 + r) * RS + (k0 + 16 * ks + 8 * hh) * 2);
-              acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[ks], acc[nb], 0, 0, 0);
-            }
+        for (int nb = 0; nb < NB; ++nb) {
+          const f16x8 af = *(const f16x8*)(Wl + (nb * 32 + r) * a.w_row + (k0 + kk) * 2);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nb], 0, 0, 0);
         }
       }
     }
-    // ---- epilogues: register quad j of block nb = channels nb*32 + 8j + 4hh + (0..3) of this lane's token ----
-    if (MODE == DUA_TOKLIN_PLAIN || MODE == DUA_TOKLIN_GELU || MODE == DUA_TOKLIN_STATS) {
-      f16* orow = a.out + ((long)sample * a.M + tok) * a.ldc + a.out_off;
+    __syncthreads();                                              // every wave is done reading the A tile: reuse it for the output
+    // ---- registers -> output tile in LDS.  Register quad j of block nb = channels nb*32 + 8j + 4hh + (0..3) of token r ----
+    const long tok = tok0 + wave * 32 + r;
+    const bool valid = tok < a.M;
+    char* orow = At + (wave * 32 + r) * a.o_row;
 #pragma unroll
-      for (int nb = 0; nb < MAXNB; ++nb)
-        if (nb < NB) {
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c0 = nb * 32 + 8 * j + 4 * hh;
-            if (c0 < N) {
-              f16x4 o;
+      for (int j = 0; j < 4; ++j) {
+        const int c0 = nb * 32 + 8 * j + 4 * hh;
+        if (c0 < N) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[nb][4 * j + e] + (a.bias ? a.bias[c0 + e] : 0.f);
+            if (MODE == DUA_TOKLIN_GELU) v[e] = gelu_erf(v[e]);
+          }
+          if (MODE == DUA_TOKLIN_RESIDUAL || MODE == DUA_TOKLIN_SCATTER) {
+            *(f32x4*)(orow + c0 * 4) = f32x4{v[0], v[1], v[2], v[3]};
+          } else {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+            *(f16x4*)(orow + c0 * 2) = o;
+            if (MODE == DUA_TOKLIN_STATS && valid && nb < SNB) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                float v = acc[nb][4 * j + e] + (a.bias ? a.bias[c0 + e] : 0.f);
-                if (MODE == DUA_TOKLIN_GELU) v = gelu_erf(v);
-                o[e] = (f16)v;
-                if (MODE == DUA_TOKLIN_STATS && valid && nb < 2) {
-                  const float q = (float)o[e];                   // statistics of what the consumer will read
-                  ssum[nb][4 * j + e] += q; ssq[nb][4 * j + e] = fmaf(q, q, ssq[nb][4 * j + e]);
-                }
+                const float q = (float)o[e];                     // statistics of what the consumer will read
+                ssum[nb < SNB ? nb : 0][4 * j + e] += q;
+                ssq[nb < SNB ? nb : 0][4 * j + e] = fmaf(q, q, ssq[nb < SNB ? nb : 0][4 * j + e]);
               }
-              if (valid) *(f16x4*)(orow + c0) = o;
             }
           }
         }
-    } else if (MODE == DUA_TOKLIN_RESIDUAL) {
-      if (valid) {
-        float* xr = a.x + tok * N;
-#pragma unroll
-        for (int nb = 0; nb < MAXNB; ++nb)
-          if (nb < NB) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int c0 = nb * 32 + 8 * j + 4 * hh;
-              if (c0 < N) {
-                f32x4 xv = *(f32x4*)(xr + c0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xv[e] += acc[nb][4 * j + e] + (a.bias ? a.bias[c0 + e] : 0.f);
-                *(f32x4*)(xr + c0) = xv;
-              }
-            }
-          }
       }
-    } else {                                                       // DUA_TOKLIN_SCATTER
+    }
+    __syncthreads();
+    // ---- output tile -> global memory, coalesced ----
+    if (MODE == DUA_TOKLIN_PLAIN || MODE == DUA_TOKLIN_GELU || MODE == DUA_TOKLIN_STATS) {
+      const int cpr = N >> 3;
+      for (int c = tid; c < 128 * cpr; c += 256) {
+        const int row = c / cpr, col = c - row * cpr;
+        if (tok0 + row < a.M)
+          *(f16x8*)(a.out + ((long)sample * a.M + tok0 + row) * a.ldc + a.out_off + col * 8) = *(const f16x8*)(At + row * a.o_row + col * 16);
+      }
+    } else if (MODE == DUA_TOKLIN_RESIDUAL) {
+      const int cpr = N >> 2;
+      for (int c = tid; c < 128 * cpr; c += 256) {
+        const int row = c / cpr, col = c - row * cpr;
+        if (tok0 + row < a.M) {
+          float* xp = a.x + (tok0 + row) * N + col * 4;
+          f32x4 xv = *(const f32x4*)xp;
+          const f32x4 dv = *(const f32x4*)(At + row * a.o_row + col * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[e] += dv[e];
+          *(f32x4*)xp = xv;
+        }
+      }
+    } else {                                                       // DUA_TOKLIN_SCATTER: 16 lanes per token, channel = i*16 + j
       const WinGeom& g = a.g;
-      const long tk = valid ? tok : 0;
-      const int t = (int)(tk % g.n), wi = (int)((tk / g.n) % g.nw), b = (int)(tk / ((long)g.n * g.nw));
-      int d, h, w;
-      const bool real = window_to_voxel(g, wi, t, d, h, w) && valid;
-      const long dst = ((((long)b * g.D + d) * g.H + h) * g.W + w) * N;
-      float s = 0.f;
+      const int jl = tid & 15;
+      constexpr int CPL = NB * 2;                                  // N = 32 NB ... but N is 48 or 96: channels per lane = N / 16
+      for (int row = tid >> 4; row < 128; row += 16) {
+        const long tk = tok0 + row;
+        const bool inb = tk < a.M;
+        const long tkc = inb ? tk : 0;
+        const int t = (int)(tkc % g.n), wi = (int)((tkc / g.n) % g.nw), b = (int)(tkc / ((long)g.n * g.nw));
+        int d, h, w;
+        const bool real = window_to_voxel(g, wi, t, d, h, w) && inb;
+        const long dst = ((((long)b * g.D + d) * g.H + h) * g.W + w) * N;
+        const int cpl = N >> 4;
+        float v[CPL];
+        float s = 0.f;
 #pragma unroll
-      for (int nb = 0; nb < MAXNB; ++nb)
-        if (nb < NB) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c0 = nb * 32 + 8 * j + 4 * hh;
-            if (c0 < N) {
-              f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-              if (real) xv = *(const f32x4*)(a.x + dst + c0);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float v = xv[e] + acc[nb][4 * j + e] + (a.bias ? a.bias[c0 + e] : 0.f);
-                acc[nb][4 * j + e] = v;
-                s += v;
-              }
-              if (real) *(f32x4*)(a.x + dst + c0) = f32x4{acc[nb][4 * j], acc[nb][4 * j + 1], acc[nb][4 * j + 2], acc[nb][4 * j + 3]};
-            }
+        for (int i = 0; i < CPL; ++i) {
+          v[i] = 0.f;
+          if (i < cpl) {
+            const int c = i * 16 + jl;
+            v[i] = *(const float*)(At + row * a.o_row + c * 4) + (real ? a.x[dst + c] : 0.f);
+            s += v[i];
           }
         }
-      s += __shfl_xor(s, 32);
-      const float mean = s / (float)N;
-      float q = 0.f;
 #pragma unroll
-      for (int nb = 0; nb < MAXNB; ++nb)
-        if (nb < NB) {
+        for (int o2 = 8; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2);
+        const float mean = s / (float)N;
+        float q = 0.f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (nb * 32 + 8 * j + 4 * hh < N) {
+        for (int i = 0; i < CPL; ++i)
+          if (i < cpl) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { const float dl = acc[nb][4 * j + e] - mean; q = fmaf(dl, dl, q); }
+        for (int o2 = 8; o2 > 0; o2 >>= 1) q += __shfl_xor(q, o2);
+        const float rstd = rsqrtf(q / (float)N + a.eps);
+        if (real) {
+#pragma unroll
+          for (int i = 0; i < CPL; ++i)
+            if (i < cpl) {
+              const int c = i * 16 + jl;
+              a.x[dst + c] = v[i];
+              a.ln_out[dst + c] = (f16)((v[i] - mean) * rstd * a.gamma[c] + a.beta[c]);
             }
         }
-      q += __shfl_xor(q, 32);
-      const float rstd = rsqrtf(q / (float)N + a.eps);
-      if (real) {
-#pragma unroll
-        for (int nb = 0; nb < MAXNB; ++nb)
-          if (nb < NB) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int c0 = nb * 32 + 8 * j + 4 * hh;
-              if (c0 < N) {
-                f16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (f16)((acc[nb][4 * j + e] - mean) * rstd * a.gamma[c0 + e] + a.beta[c0 + e]);
-                *(f16x4*)(a.ln_out + dst + c0) = o;
-              }
-            }
-          }
       }
     }
   }
   if (MODE == DUA_TOKLIN_STATS) {
+    // Lanes -> waves -> one pair of WIDE atomic instructions per workgroup (consecutive lanes = consecutive channels).
+    // Two active lanes per atomic instruction, 32 instructions per wave, cost 100 us at 768 workgroups: the memory side
+    // handles one instruction's lanes together, so the number of atomic INSTRUCTIONS is what counts.
+    __syncthreads();
+    float* red = (float*)At;                                       // [4 waves][64 channels][2]
 #pragma unroll
-    for (int nb = 0; nb < (NB < 2 ? NB : 2); ++nb)
-      if (nb < NB) {
+    for (int nb = 0; nb < SNB; ++nb) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float s = ssum[nb][i], ss = ssq[nb][i];
+      for (int i = 0; i < 16; ++i) {
+        float s = ssum[nb][i], ss = ssq[nb][i];
 #pragma unroll
-          for (int o2 = 16; o2 > 0; o2 >>= 1) { s += __shfl_xor(s, o2); ss += __shfl_xor(ss, o2); }
-          const int c = nb * 32 + 8 * (i >> 2) + 4 * hh + (i & 3);
-          if (r == 0 && c < N) {
-            double* p = a.stats + (((long)sample * STAT_REPLICAS + (blockIdx.x % STAT_REPLICAS)) * a.c_pad + c) * 2;
-            unsafeAtomicAdd(p, (double)s); unsafeAtomicAdd(p + 1, (double)ss);
-          }
-        }
+        for (int o2 = 16; o2 > 0; o2 >>= 1) { s += __shfl_xor(s, o2); ss += __shfl_xor(ss, o2); }
+        const int c = nb * 32 + 8 * (i >> 2) + 4 * hh + (i & 3);
+        if (r == 0) { red[(wave * 64 + c) * 2] = s; red[(wave * 64 + c) * 2 + 1] = ss; }
       }
+    }
+    __syncthreads();
+    if (tid < N) {
+      double S = 0, Q = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { S += red[(w * 64 + tid) * 2]; Q += red[(w * 64 + tid) * 2 + 1]; }
+      stats_add(a.stats, sample, a.c_pad, blockIdx.x % STAT_REPLICAS, tid, S, Q);
+    }
   }
 }
 
@@ -233,26 +250,32 @@ extern "C" int dua_token_linear(const dua_token_linear_desc* d, void* stream) {
   int samples = 1;
   switch (d->mode) {
     case DUA_TOKLIN_PLAIN: case DUA_TOKLIN_GELU:
-      if (!d->out || d->ldc % 4 || d->out_off % 4 || d->ldc < d->out_off + d->N || d->samples != 1) return DUA_ERR_ARG;
+      if (!d->out || d->ldc % 8 || d->out_off % 8 || d->ldc < d->out_off + d->N || d->samples != 1) return DUA_ERR_ARG;
       break;
     case DUA_TOKLIN_STATS:
-      if (!d->out || !d->stats || d->N > 64 || d->c_pad < d->N || d->ldc % 4 || d->out_off % 4 || d->ldc < d->out_off + d->N) return DUA_ERR_ARG;
+      if (!d->out || !d->stats || d->N > 64 || d->c_pad < d->N || d->ldc % 8 || d->out_off % 8 || d->ldc < d->out_off + d->N) return DUA_ERR_ARG;
       samples = d->samples;
       break;
     case DUA_TOKLIN_RESIDUAL:
       if (!d->x || d->samples != 1) return DUA_ERR_ARG;
       break;
     case DUA_TOKLIN_SCATTER:
-      if (!d->x || !d->ln_out || !d->gamma || !d->beta || !geom_ok(&d->geom) || d->geom.C != d->N || d->samples != 1) return DUA_ERR_ARG;
+      if (!d->x || !d->ln_out || !d->gamma || !d->beta || !geom_ok(&d->geom) || d->geom.C != d->N || d->N % 16 || d->samples != 1) return DUA_ERR_ARG;
       a.g = make_geom(&d->geom);
       if ((long)a.g.B * a.g.nw * a.g.n != d->M) return DUA_ERR_ARG;
       break;
     default: return DUA_ERR_ARG;
   }
-  const int units = d->K * 2 / 16;
-  a.row_bytes = d->K * 2 + ((units & 1) ? 0 : 16);
   const int NB = (d->N + 31) / 32;
-  const int lds = NB * 32 * a.row_bytes + 16;
+  const int kc = d->K < 16 * tg::KSTEPS ? d->K : 16 * tg::KSTEPS;
+  const bool f32_tile = d->mode == DUA_TOKLIN_RESIDUAL || d->mode == DUA_TOKLIN_SCATTER;
+  a.w_row = padded_row(d->K * 2);
+  a.a_row = padded_row(((kc + 15) / 16) * 32);
+  a.o_row = padded_row(d->N * (f32_tile ? 4 : 2));
+  a.w_bytes = NB * 32 * a.w_row + 16;
+  const int tile_bytes = 128 * (a.a_row > a.o_row ? a.a_row : a.o_row);
+  const int lds = a.w_bytes + tile_bytes;
+  if (lds > 160 * 1024) return DUA_ERR_ARG;
   using Kern = void (*)(TokLinArgs);
 #define ROW(M_) {token_linear_kernel<M_, 1>, token_linear_kernel<M_, 2>, token_linear_kernel<M_, 3>, token_linear_kernel<M_, 4>, \
                  token_linear_kernel<M_, 5>, token_linear_kernel<M_, 6>}
@@ -267,7 +290,7 @@ extern "C" int dua_token_linear(const dua_token_linear_desc* d, void* stream) {
     hipGetDevice(&dev);
     if (attr_dev != dev) { for (auto& row : raised) for (bool& b : row) b = false; attr_dev = dev; }
     if (!raised[d->mode][NB - 1]) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return DUA_ERR_ARG;
       raised[d->mode][NB - 1] = true;
     }

@@ -26,10 +26,13 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // one wave per output token; lanes stride over the 8C gathered elements (two passes: moments, then normalise + store)
 // x is the fp32 token stream of the stage; y (optional, T) is the last block's MLP output still to be added to it
 // (transformer.py:477-480) -- the sum is formed on the fly, the stream itself is dead after the merge.
+// One wave per output token: lane l owns elements l, l + 64, ... of the 8C gathered vector (8C is a multiple of 64), held in
+// registers between the moments and the normalisation; corner and channel of an element advance incrementally (no division).
 template <typename T>
 __global__ __launch_bounds__(256) void patch_merge_norm_kernel(const float* __restrict__ x, const T* __restrict__ y, int B, int D,
                                                                int H, int W, int C, int legacy, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, T* __restrict__ out) {
+  constexpr int MAXV = 48;                               // 8C / 64 values per lane, C <= 384
   const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   const long ntok = (long)B * D2 * H2 * W2;
   const int lane = threadIdx.x & 63;
@@ -38,24 +41,38 @@ __global__ __launch_bounds__(256) void patch_merge_norm_kernel(const float* __re
   const int w2 = (int)(tok % W2), h2 = (int)((tok / W2) % H2), d2 = (int)((tok / ((long)W2 * H2)) % D2), b = (int)(tok / ((long)W2 * H2 * D2));
   // corner k of the gathered vector -> (di, dj, dk); V2: itertools.product order; legacy: patch.py:82-89
   const int leg[8] = {0, 4, 2, 1, 5, 2, 1, 7};          // bit 2 = d offset, bit 1 = h offset, bit 0 = w offset
-  const int E = 8 * C;
-  auto fetch = [&](int e) -> float {
-    const int k = e / C, c = e - k * C;
-    const int code = legacy ? leg[k] : k;
-    const int d = 2 * d2 + (code >> 2), h = 2 * h2 + ((code >> 1) & 1), w = 2 * w2 + (code & 1);
-    if (d >= D || h >= H || w >= W) return 0.f;          // F.pad(..., value 0) of odd extents
-    const long i = ((((long)b * D + d) * H + h) * W + w) * C + c;
-    return y ? x[i] + (float)y[i] : x[i];
-  };
-  float s = 0.f, ss = 0.f;
-  for (int e = lane; e < E; e += 64) { const float v = fetch(e); s += v; ss = fmaf(v, v, ss); }
-  s = wave_sum64(s); ss = wave_sum64(ss);
+  const int E = 8 * C, nper = E >> 6;
+  float v[MAXV];
+  float s = 0.f;
+  int k = 0, c = lane;
+  while (c >= C) { c -= C; ++k; }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    v[i] = 0.f;
+    if (i < nper) {
+      const int code = legacy ? leg[k] : k;
+      const int d = 2 * d2 + (code >> 2), h = 2 * h2 + ((code >> 1) & 1), w = 2 * w2 + (code & 1);
+      if (d < D && h < H && w < W) {                     // F.pad(..., value 0) of odd extents
+        const long idx = ((((long)b * D + d) * H + h) * W + w) * C + c;
+        v[i] = y ? x[idx] + (float)y[idx] : x[idx];
+      }
+      s += v[i];
+      c += 64;
+      while (c >= C) { c -= C; ++k; }
+    }
+  }
+  s = wave_sum64(s);
   const float mean = s / (float)E;
-  float var = ss / (float)E - mean * mean;
-  var = var > 0.f ? var : 0.f;
-  const float rstd = rsqrtf(var + eps);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nper) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
+  q = wave_sum64(q);
+  const float rstd = rsqrtf(q / (float)E + eps);
   T* o = out + tok * E;
-  for (int e = lane; e < E; e += 64) o[e] = (T)((fetch(e) - mean) * rstd * gamma[e] + beta[e]);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nper) { const int e = lane + 64 * i; o[e] = (T)((v[i] - mean) * rstd * gamma[e] + beta[e]); }
 }
 
 template <typename T>
@@ -103,7 +120,7 @@ extern "C" {
 
 int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legacy, const float* x, const void* y,
                          const float* gamma, const float* beta, float eps, void* out, void* stream) {
-  if (!x || !gamma || !beta || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return DUA_ERR_ARG;
+  if (!x || !gamma || !beta || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C > 384) return DUA_ERR_ARG;
   const long ntok = (long)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
   dim3 grid((unsigned)((ntok + 3) / 4));
   if (dtype == DUA_F16)

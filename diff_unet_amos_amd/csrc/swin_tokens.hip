@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(T* __restrict__ x, long group
 #pragma unroll
     for (int e = 0; e < EPG; ++e) {
       const float a = (float)f[e];
-      f[e] = (T)(0.5f * a * (1.f + erff(a * 0.70710678118654752f)));
+      f[e] = (T)gelu_erf(a);
     }
     *(Frag*)(x + i * EPG) = f;
   }

@@ -10,8 +10,8 @@
 // One workgroup (4 waves) per (window, head); K and V of the window live in LDS, a wave owns blocks of 32 queries.
 // Both products run on MFMA 32x32x16 with fp16 operands and fp32 accumulation, "transposed" so that a query is a LANE:
 //   S^T[32 keys][32 queries] = K_blk [32 x 16] . Q^T [16 x 32]           (one instruction per block: K = head dim = 16)
-// leaves the whole score row of a query in the registers of two lanes (l, l + 32): bias, mask, max, exp and the sum are
-// plain register arithmetic + one exchange between the halves -- no LDS, no shuffles per element.  The accumulator
+// leaves the whole score row of a query in the registers of two lanes (l, l + 32): bias, mask, the running max, exp and the
+// sum are plain register arithmetic + one exchange between the halves per key block -- no shuffles per element.  The accumulator
 // tile is then the B operand of the second product as it stands (cdna_hip_programming.md, "An accumulator tile as the
 // next MFMA's operand"):
 //   O^T[dims][32 queries] += V^T_blk [dims x 32 keys, keys in the accumulator's row order] . P^T_blk [32 keys x 32 queries]
@@ -131,7 +131,12 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, z, 0, 0, 0);
     if (has_table) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) z[i] = fmaf(z[i], a.scale, tab[qoff - (int)koff[kb * 32 + acc_row(i, hh)]]);
+      for (int j = 0; j < 4; ++j) {               // register quad j = keys kb*32 + 8j + 4hh + (0..3): one 8-byte read of offsets
+        typedef short short4v __attribute__((ext_vector_type(4)));
+        const short4v ko = *(const short4v*)(koff + kb * 32 + 8 * j + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[4 * j + e] = fmaf(z[4 * j + e], a.scale, tab[qoff - (int)ko[e]]);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -148,7 +153,11 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     }
     if (has_region) {                             // compute_mask's 0 / -100 from the region ids
 #pragma unroll
-      for (int i = 0; i < 16; ++i) z[i] += regl[kb * 32 + acc_row(i, hh)] != rq ? -100.f : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const unsigned rk = *(const unsigned*)(regl + kb * 32 + 8 * j + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[4 * j + e] += ((rk >> (8 * e)) & 255u) != (unsigned)rq ? -100.f : 0.f;
+      }
     }
     if (kb == nb - 1) {                           // only the last block holds padding keys: they never win the max
 #pragma unroll
@@ -156,26 +165,30 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     }
     return z;
   };
-  // pass 1: the row maximum (the score tiles are cheap to recompute -- one MFMA each -- and 11 of them would not
-  // fit the register file next to the output tile)
-  float mx = -3.0e38f;
-  for (int kb = 0; kb < nb; ++kb) {
-    const f32x16 z = scores(kb);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, z[i]);
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));            // the other half of the keys of the same query
-  // pass 2: exponentials, their sum, and P^T as the B operand of the second product
-  float sum = 0.f;
+  // One pass with a running maximum (the 11 score tiles of a query would not fit the register file next to the output
+  // tile, and recomputing them costs as much as the softmax itself): when a block raises the maximum, the sum and the
+  // eight live registers of O^T are rescaled by exp(old - new).  Both halves of a query's keys feed the same MFMA
+  // contraction, so they share one maximum per block (one exchange with lane ^ 32).
+  float mx = -3.0e38f, sum = 0.f;
   f32x16 O;
 #pragma unroll
   for (int i = 0; i < 16; ++i) O[i] = 0.f;
   for (int kb = 0; kb < nb; ++kb) {
     const f32x16 z = scores(kb);
+    float bm = z[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) bm = fmaxf(bm, z[i]);
+    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    const float mnew = fmaxf(mx, bm);
+    const float alpha = __expf(mx - mnew);
+    mx = mnew;
+    sum *= alpha;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) O[i] *= alpha;    // rows 16..31 of O^T are padding (zero V rows): registers 8..15 stay 0
     f16x8 p[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float e = __expf(z[i] - mx);
+      const float e = __expf(z[i] - mnew);
       sum += e;
       p[i >> 3][i & 7] = (f16)e;
     }

@@ -115,7 +115,9 @@ class SwinPlan:
         self.xin = z(0, self.cin0)
         self.hs = [z(1, f), z(2, 2 * f), z(3, 4 * f), None, z(5, 16 * f)]      # hs[3] lives in cat[4]
         self.cat = [z(0, 2 * f), z(1, 2 * f), z(2, 4 * f), z(3, 8 * f), z(4, 16 * f)]   # (up | skip) of decoder1..5
-        self.dec = [z(0, f), z(1, f), z(2, 2 * f), z(3, 4 * f), z(4, 8 * f), z(5, 16 * f)]   # out, dec0..dec4
+        self.tail_k = -(-f // 32) * 32                      # decoder1's output keeps a 64-channel stride (48 real, the rest zero)
+        self.dec = [z(0, self.tail_k), z(1, f), z(2, 2 * f), z(3, 4 * f), z(4, 8 * f), z(5, 16 * f)]   # out, dec0..dec4
+                                                            # so that the fused head + sampler tail runs its MFMA form
         # ---- shared scratch (the two networks never run concurrently)
         big = max(N * S[l][0] * S[l][1] * S[l][2] * c for l, c in ((0, f), (1, f), (2, 2 * f), (3, 4 * f), (4, 8 * f), (5, 16 * f)))
         self.raw1 = torch.zeros(big, dtype=dtype, device=device)
@@ -253,7 +255,8 @@ class SwinPlan:
             enc, den = self.net.embed_model, self.net.model
             self.e_vit = self._pack_vit(enc.swinViT, 8)
             self.d_vit = self._pack_vit(den.swinViT, self.cin0, self.perm0)
-            self.wf = den.out.conv.conv.weight.detach().float().reshape(self.C, -1).contiguous()
+            self.wf = torch.zeros((self.C, self.tail_k), dtype=torch.float32, device=dev)
+            self.wf[:, :self.f] = den.out.conv.conv.weight.detach().float().reshape(self.C, -1)
             self.bf = den.out.conv.conv.bias.detach().float().contiguous()
             # t_proj(swish(t_embedder(t))) of every projection, for every original timestep (depends on weights only)
             T = self.net.timesteps
@@ -422,7 +425,7 @@ class SwinPlan:
     def tail(self, mode, noise=None, logits=None, use_sum=False):
         """UnetOutBlock (1x1x1, denoiser.py:399-400) fused with the sampler update (engine.Plan.tail's kernel, fed the
         materialised decoder1 output)."""
-        ops.final_conv_sampler(self.dec[0], self.f, None, self.wf, self.bf, self.C, mode, coef=self.cur_coef,
+        ops.final_conv_sampler(self.dec[0], self.tail_k, None, self.wf, self.bf, self.C, mode, coef=self.cur_coef,
                                x_state=self.x_state, noise=noise, step_word=self.step_word,
                                xin=self.xin if mode != nv.MODE_LOGITS else None,
                                xstart_sum=self.x_sum if use_sum else None, logits=logits, seed_dev=self.seed_word)

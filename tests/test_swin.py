@@ -70,7 +70,7 @@ def test_window_attention_kernel_matches_oracle(dtype, tol, heads, ws, dims, shi
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 4e-3)])
-@pytest.mark.parametrize("shape,legacy", [((2, 6, 8, 10, 48), True), ((1, 5, 7, 6, 96), True), ((1, 4, 4, 4, 16), False)])
+@pytest.mark.parametrize("shape,legacy", [((2, 6, 8, 10, 48), True), ((1, 5, 7, 6, 96), True), ((1, 4, 4, 4, 16), False), ((1, 2, 2, 2, 384), True)])
 def test_patch_merge_norm_kernel_matches_oracle(dtype, tol, shape, legacy):
     """Gather (legacy duplicates, zero padding of odd extents) + LayerNorm(8C); the reduction Linear stays a GEMM."""
     from diff_unet_amos_amd import ops
@@ -256,7 +256,7 @@ def test_patch_embed_stage_out_gelu_kernels_match_oracle(dtype, tol):
         assert torch.allclose(st.cpu().view(B, 10, C_), xs, atol=1e-5)
         assert (o2[:, 8:].float().cpu() - want2).abs().max() < tol * max(1.0, float(want2.abs().max())), C_
     h = torch.randn(4096, generator=g).to(dtype) * 3
-    assert (ops.gelu_(h.clone().cuda()).float().cpu() - F.gelu(h.float())).abs().max() < (1e-6 if dtype == torch.float32 else 2e-3)
+    assert (ops.gelu_(h.clone().cuda()).float().cpu() - F.gelu(h.float())).abs().max() < (3e-6 if dtype == torch.float32 else 2e-3)
 
 
 @pytest.mark.gpu

@@ -158,11 +158,15 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(net_state, threads):
+def cpu_baseline(net_state, threads, swin=False):
     """Oracle (CPU restatement of the reference path) on the host cores: bounded sample."""
-    from oracle.unet_ref import RefDiffUNet
     torch.set_num_threads(threads)
-    ref = RefDiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES).eval()
+    if swin:
+        from oracle.swin_ref import make_ref_diff_swin_unetr
+        ref = make_ref_diff_swin_unetr(1, CLASSES, 48).eval()
+    else:
+        from oracle.unet_ref import RefDiffUNet
+        ref = RefDiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES).eval()
     ref.load_state_dict(net_state)
     g = torch.Generator().manual_seed(1)
     image = torch.rand(1, 1, 96, 96, 96, generator=g)
@@ -426,6 +430,7 @@ def run_config5(args, D):
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
     torch.manual_seed(0)
     net = DiffSwinUNETR(in_channels=1, out_channels=CLASSES, feature_size=48, compute_dtype=dtype).to(dev).eval()
+    state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     B = args.batch
     image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     plan = net._rt.plan(B, (96, 96, 96), dev)
@@ -470,7 +475,7 @@ def run_config5(args, D):
         finite = bool(torch.isfinite(plan.x_state).all())
     if rank == 0:
         ms = dt / args.steps * 1e3
-        print(json.dumps({
+        line = {
             "metric": "denoised voxel-steps/sec on 96^3 16-class AMOS patches", "value": world * B * VOX * args.steps / dt,
             "unit": "voxel-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -478,7 +483,10 @@ def run_config5(args, D):
                                    "process (BASELINE.json configs[4]); one patch per GPU, replicas only",
                        "patch": [96, 96, 96], "classes": CLASSES, "batch_per_gpu": B, "graph_replay": not args.no_graph,
                        "noise": "in-kernel Philox4x32-10", "weights": "torch.manual_seed(0) default init"},
-            "finite": finite}), flush=True)
+            "finite": finite}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(state, host_threads(), swin=True)
+        print(json.dumps(line), flush=True)
 
 
 def main():

@@ -123,6 +123,10 @@ class SwinPlan:
         self.raw1 = torch.zeros(big, dtype=dtype, device=device)
         self.raw2 = torch.zeros(big, dtype=dtype, device=device)
         self.res3 = torch.zeros(big, dtype=dtype, device=device)
+        self.raw1b, self.raw2b, self.res3b = (torch.zeros(big, dtype=dtype, device=device) for _ in range(3))   # side stream
+        self.side_stream = torch.cuda.Stream(device=device)
+        self.two_streams = True
+        self.enc_done = [torch.cuda.Event() for _ in range(4)]
         self.stream = [torch.zeros((N, *S[i + 1], self.tok_c[i]), dtype=torch.float32, device=device) for i in range(5)]
         self.geo = []
         tok_max = 0
@@ -209,6 +213,7 @@ class SwinPlan:
             for cin in (-(-r.cin_packed // 8) * 8, r.cout):
                 need = max(need, ops.conv3_workspace_bytes(self.dtype, self.N, *dims, cin, r.cout))
         self.splitk_ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=self.dev)
+        self.splitk_ws_b = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=self.dev)
 
     def _pack_vit(self, vit, cin_packed, perm=None):
         dt = self.dtype
@@ -286,11 +291,13 @@ class SwinPlan:
     def _tadd(self, off, c):
         return None if off is None else self.cur_add[:, off:off + c]
 
-    def _res_block(self, r, x, cin, out, out_off=0, post_add=None, ra=None, ra_off=0):
-        """UnetResBlock.forward (blocks.py:298-316) on channels [0, cin) of ``x`` -> channels [out_off, ...) of ``out``."""
+    def _res_block(self, r, x, cin, out, out_off=0, post_add=None, ra=None, ra_off=0, side=False):
+        """UnetResBlock.forward (blocks.py:298-316) on channels [0, cin) of ``x`` -> channels [out_off, ...) of ``out``.
+        ``side``: use the second set of scratch buffers (blocks running on the side stream, see denoiser_body)."""
         l, N = r.level, self.N
         count = self.S[l][0] * self.S[l][1] * self.S[l][2]
-        raw1, raw2 = self._view(self.raw1, l, r.cout), self._view(self.raw2, l, r.cout)
+        b1, b2, b3, ws = (self.raw1b, self.raw2b, self.res3b, self.splitk_ws_b) if side else (self.raw1, self.raw2, self.res3, self.splitk_ws)
+        raw1, raw2 = self._view(b1, l, r.cout), self._view(b2, l, r.cout)
         if r.norms is None:
             add = None if r.t_off is None else self.cur_add.view(-1)[r.t_off:]
             r.norms = (ops.Norm(r.st[0], r.ones, r.zeros, count, add=add, add_stride=self.P if add is not None else 0,
@@ -298,10 +305,10 @@ class SwinPlan:
                        ops.Norm(r.st[1], r.ones, r.zeros, count, slope=SLOPE, eps=EPS),
                        ops.Norm(r.st[2], r.ones, r.zeros, count, slope=SLOPE, eps=EPS))
         n1, n2, n3 = r.norms
-        ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=self.splitk_ws)
-        ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=self.splitk_ws)
+        ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws)
+        ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=ws)
         if r.has3:
-            res = self._view(self.res3, l, r.cout)
+            res = self._view(b3, l, r.cout)
             x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
             if self.fused_linear and r.cout <= 64 and cin <= 384:
                 ops.token_linear(x2, r.w3, None, "stats", out=res.view(-1, r.cout), stats=r.st[2], samples=N)   # conv3 + norm3 sums
@@ -314,13 +321,16 @@ class SwinPlan:
             ops.residual_norm_act(raw2, n2, x, None, slope=SLOPE, out=out, out_off=out_off, post_add=post_add, ra_src=ra,
                                   ra_off=ra_off)
 
-    def _swin(self, vit, xin, cin_packed, t_offs, emb, outs):
+    def _swin(self, vit, xin, cin_packed, t_offs, emb, outs, ready=None):
         """SwinTransformer.forward (transformer.py:270-316): patch embedding, four stages, the adds between them.
-        ``outs[i]`` = (buffer, channel offset) receiving hidden_states_out[i] (+ emb[i])."""
+        ``outs[i]`` = (buffer, channel offset) receiving hidden_states_out[i] (+ emb[i]); ``ready(i)`` is called once the
+        launch producing it has been enqueued."""
         N, dt = self.N, self.dtype
         tadd = lambda i: None if t_offs is None else self._tadd(t_offs[i], self.tok_c[i])  # noqa: E731
         ops.patch_embed(xin, cin_packed, vit["pe_w"], vit["pe_b"], outs[0][0], outs[0][1], tadd=tadd(0),
                         emb=None if emb is None else emb[0], x=self.stream[0])
+        if ready is not None:
+            ready(0)
         for i in range(4):
             g, st, C_ = self.geo[i], vit["stages"][i], self.tok_c[i]
             x = self.stream[i]
@@ -366,6 +376,8 @@ class SwinPlan:
                 red = F.linear(merged.view(-1, 8 * C_), st["wred"])
             ops.stage_out(red, N, 2 * C_, outs[i + 1][0], outs[i + 1][1], tadd=tadd(i + 1),
                           emb=None if emb is None else emb[i + 1], x=self.stream[i + 1] if i < 3 else None)
+            if ready is not None:
+                ready(i + 1)
 
     # ---- the two networks ---------------------------------------------------------------------------
     def run_encoder(self, image):
@@ -406,18 +418,40 @@ class SwinPlan:
         self.den_stats.zero_()
         cat, dec, hs = self.cat, self.dec, self.hs
         outs = [(hs[0], 0), (hs[1], 0), (hs[2], 0), (cat[4], 8 * f), (hs[4], 0)]
-        self._swin(self.d_vit, self.xin, self.cin0, self.vit_t_off, self.e_hs, outs)
-        # enc_k = encoder_k(...) + embeddings[k + 1] lands in the skip half of its decoder's concat buffer
-        self._res_block(self.d_res[0], self.xin, self.cin0, cat[0], f, post_add=self.e_enc[0])
-        self._res_block(self.d_res[1], hs[0], f, cat[1], f, post_add=self.e_enc[1])
-        self._res_block(self.d_res[2], hs[1], 2 * f, cat[2], 2 * f, post_add=self.e_enc[2])
-        self._res_block(self.d_res[3], hs[2], 4 * f, cat[3], 4 * f, post_add=self.e_enc[3])
+        # Two streams.  The coarse Swin stages (12^3 and 6^3 tokens), encoder10 and decoder5..3 are a chain of ~150 launches of
+        # 5-20 us that leave most of the chip idle; encoder1..4 (denoiser.py:370-383) depend only on the input and on
+        # hidden_states_out[0..2] and are needed late (by decoder1..4, denoiser.py:388-397) -- with the two 96^3
+        # convolutions of encoder1 needed last.  They go to a side stream once stage 1 has run (stages 0-1 fill the chip by
+        # themselves: overlapping those only slows both), smallest first, and each decoder waits for its skip only.
+        # enc_k = encoder_k(...) + embeddings[k + 1] lands in the skip half of its decoder's concat buffer.
+        main, side = torch.cuda.current_stream(), self.side_stream
+        two = self.two_streams
+        srcs = [(self.xin, self.cin0), (hs[0], f), (hs[1], 2 * f), (hs[2], 4 * f)]
+
+        def enc(k):
+            r = self.d_res[k]
+            self._res_block(r, srcs[k][0], srcs[k][1], cat[k], r.cout, post_add=self.e_enc[k], side=two)
+
+        def ready(i):                                   # hidden_states_out[i] has been enqueued on the main stream
+            if i == 2 and two:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    for k in (3, 2, 1, 0):
+                        enc(k)
+                        self.enc_done[k].record(side)
+
+        self._swin(self.d_vit, self.xin, self.cin0, self.vit_t_off, self.e_hs, outs, ready)
+        if not two:
+            for k in range(4):
+                enc(k)
         self._res_block(self.d_res[4], hs[4], 16 * f, dec[5])                     # dec4 = encoder10(hs[4])
         src = dec[5]
         for k in (4, 3, 2, 1, 0):                                                  # decoder5 .. decoder1
             cout = cat[k].shape[-1] // 2
             wp, bp = self.up_packed[k]
             ops.deconv_k2s2(src, src.shape[-1], 0, wp, bp, cout, cat[k], 0)
+            if two and k < 4:
+                main.wait_event(self.enc_done[k])                                  # the skip half of cat[k]
             ra = cat[k] if k < 4 else None                                         # + r_k (not for decoder5: skip = hs[3])
             self._res_block(self.u_res[k], cat[k], 2 * cout, dec[k], 0, ra=ra, ra_off=cout)
             src = dec[k]

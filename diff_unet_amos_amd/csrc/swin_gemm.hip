@@ -236,6 +236,144 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
   }
 }
 
+// ---- PatchEmbed on the matrix cores (fp16) --------------------------------------------------------------------------
+// Conv3d(k = s = 2) = a [tokens x 8 Cp] x [8 Cp -> 48] GEMM whose A row is gathered from the 2x2x2 voxels of the token (each
+// Cp channels = Cp * 2 contiguous bytes).  Same tile scheme as token_linear; the epilogue is stage_out's: + bias + t_proj row,
+// the fp32 stream, layer_norm without affine + the encoder's map into a channels-last slice (transformer.py:270-275).
+struct PatchArgs {
+  const f16* in; int B, D, H, W, Cs, Cp;
+  const float* wk; const float* bias; const float* tadd; int tadd_stride; float eps;
+  const f16* emb; float* x; f16* out; int out_stride, out_off;
+  int w_row, a_row, o_row, w_bytes;
+};
+
+__global__ __launch_bounds__(256) void patch_embed_mfma_kernel(PatchArgs a) {
+  constexpr int E = 48, NB = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;
+  char* At = smem + a.w_bytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int K = 8 * a.Cp, cpt = a.Cp >> 3;                          // 16-byte chunks per tap
+  for (int i = tid; i < NB * 32 * K; i += 256) {                  // W_l[n][k] = w_packed[k][n] as fp16 (rows >= 48: zero)
+    const int n = i / K, k = i - n * K;
+    *(f16*)(Wl + n * a.w_row + k * 2) = n < E ? (f16)a.wk[(long)k * E + n] : (f16)0.f;
+  }
+  const int D2 = a.D / 2, H2 = a.H / 2, W2 = a.W / 2;
+  const long per = (long)D2 * H2 * W2, total = a.B * per;
+  const long tiles = (total + 127) / 128;
+  for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long tok0 = tile * 128;
+    __syncthreads();
+    {                                                               // thread = (row, half of the taps)
+      const int row = tid >> 1, th = tid & 1;
+      const long tok = tok0 + row;
+      const bool ok = tok < total;
+      const long tc = ok ? tok : 0;
+      const int w2 = (int)(tc % W2), h2 = (int)((tc / W2) % H2), d2 = (int)((tc / ((long)W2 * H2)) % D2);
+      const int b = (int)(tc / per);
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp) {
+        const int tap = th * 4 + tp;
+        const int d = 2 * d2 + (tap >> 2), h = 2 * h2 + ((tap >> 1) & 1), w = 2 * w2 + (tap & 1);
+        const f16* p = a.in + ((((long)b * a.D + d) * a.H + h) * a.W + w) * a.Cs;
+        for (int c = 0; c < cpt; ++c) {
+          f16x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
+          if (ok) v = *(const f16x8*)(p + c * 8);
+          *(f16x8*)(At + row * a.a_row + (tap * cpt + c) * 16) = v;
+        }
+      }
+    }
+    __syncthreads();
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+    const char* arow = At + (wave * 32 + r) * a.a_row;
+    for (int ks = 0; ks * 16 < K; ++ks) {
+      const int kk = 16 * ks + 8 * hh;
+      f16x8 bf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bf[e] = (f16)0.f;
+      if (kk < K) bf = *(const f16x8*)(arow + kk * 2);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const f16x8 af = *(const f16x8*)(Wl + (nb * 32 + r) * a.w_row + kk * 2);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nb], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    char* orow = At + (wave * 32 + r) * a.o_row;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c0 = nb * 32 + 8 * j + 4 * hh;
+        if (c0 < E) *(f32x4*)(orow + c0 * 4) = f32x4{acc[nb][4 * j], acc[nb][4 * j + 1], acc[nb][4 * j + 2], acc[nb][4 * j + 3]};
+      }
+    __syncthreads();
+    const int jl = tid & 15;
+    for (int row = tid >> 4; row < 128; row += 16) {                // 16 lanes per token, channel = i*16 + jl
+      const long tok = tok0 + row;
+      const bool ok = tok < total;
+      const long tc = ok ? tok : 0;
+      const int b = (int)(tc / per);
+      float v[3];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c = i * 16 + jl;
+        v[i] = *(const float*)(At + row * a.o_row + c * 4) + a.bias[c] + (a.tadd ? a.tadd[(long)b * a.tadd_stride + c] : 0.f);
+        s += v[i];
+      }
+#pragma unroll
+      for (int o2 = 8; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2);
+      const float mean = s / (float)E;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
+#pragma unroll
+      for (int o2 = 8; o2 > 0; o2 >>= 1) q += __shfl_xor(q, o2);
+      const float rstd = rsqrtf(q / (float)E + a.eps);
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int c = i * 16 + jl;
+          if (a.x) a.x[tok * E + c] = v[i];
+          float o = (v[i] - mean) * rstd;
+          if (a.emb) o += (float)a.emb[tok * E + c];
+          a.out[tok * a.out_stride + a.out_off + c] = (f16)o;
+        }
+      }
+    }
+  }
+}
+
+int launch_patch_embed_mfma(int B, int D, int H, int W, int Cs, int Cp, const void* in, const float* wk, const float* bias,
+                            const float* tadd, int tadd_stride, float eps, const void* emb, float* x, void* out, int out_stride,
+                            int out_off, hipStream_t stream) {
+  PatchArgs a;
+  a.in = (const f16*)in; a.B = B; a.D = D; a.H = H; a.W = W; a.Cs = Cs; a.Cp = Cp; a.wk = wk; a.bias = bias; a.tadd = tadd;
+  a.tadd_stride = tadd_stride; a.eps = eps; a.emb = (const f16*)emb; a.x = x; a.out = (f16*)out; a.out_stride = out_stride;
+  a.out_off = out_off;
+  const int K = 8 * Cp;
+  a.w_row = padded_row(K * 2); a.a_row = padded_row(((K + 15) / 16) * 32); a.o_row = padded_row(48 * 4);
+  a.w_bytes = 64 * a.w_row + 16;
+  const int lds = a.w_bytes + 128 * (a.a_row > a.o_row ? a.a_row : a.o_row);
+  static bool raised = false;
+  if (lds > 64 * 1024 && !raised) {
+    if (hipFuncSetAttribute((const void*)patch_embed_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return DUA_ERR_ARG;
+    raised = true;
+  }
+  const long tiles = ((long)B * (D / 2) * (H / 2) * (W / 2) + 127) / 128;
+  dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
+  hipLaunchKernelGGL(patch_embed_mfma_kernel, grid, dim3(256), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
 }  // namespace dua
 
 extern "C" int dua_token_linear(const dua_token_linear_desc* d, void* stream) {

@@ -23,6 +23,11 @@
 
 namespace dua {
 
+// fp16 PatchEmbed on the matrix cores (swin_gemm.hip)
+int launch_patch_embed_mfma(int B, int D, int H, int W, int Cs, int Cp, const void* in, const float* wk, const float* bias,
+                            const float* tadd, int tadd_stride, float eps, const void* emb, float* x, void* out, int out_stride,
+                            int out_off, hipStream_t stream);
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -319,10 +324,9 @@ int dua_patch_embed(int dtype, int B, int D, int H, int W, int Cin_stride, int C
   const long total = (long)B * (D / 2) * (H / 2) * (W / 2);
   const size_t lds = (size_t)8 * Cin_packed * E * sizeof(float);
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == DUA_F16)
-    hipLaunchKernelGGL((patch_embed_kernel<f16, 48>), grid, dim3(256), lds, (hipStream_t)stream, B, D, H, W, Cin_stride,
-                       Cin_packed, (const f16*)in, w_packed, bias, tadd, tadd_stride, eps, (const f16*)emb, x, (f16*)out,
-                       out_stride, out_off);
+  if (dtype == DUA_F16)            // MFMA form; the fp32 parity mode keeps the VALU kernel (an fmaf chain per output)
+    return launch_patch_embed_mfma(B, D, H, W, Cin_stride, Cin_packed, in, w_packed, bias, tadd, tadd_stride, eps, emb, x, out,
+                                   out_stride, out_off, (hipStream_t)stream);
   else if (dtype == DUA_F32)
     hipLaunchKernelGGL((patch_embed_kernel<float, 48>), grid, dim3(256), lds, (hipStream_t)stream, B, D, H, W, Cin_stride,
                        Cin_packed, (const float*)in, w_packed, bias, tadd, tadd_stride, eps, (const float*)emb, x, (float*)out,

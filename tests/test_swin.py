@@ -239,7 +239,8 @@ def test_patch_embed_stage_out_gelu_kernels_match_oracle(dtype, tol):
     stream = torch.empty(B, D // 2, H // 2, W // 2, E, dtype=torch.float32, device="cuda")
     ops.patch_embed(xin, cp, wp, conv.bias.detach().cuda().contiguous(), out, E, tadd=tadd.cuda()[:, 8:8 + E],
                     emb=emb.permute(0, 2, 3, 4, 1).contiguous().cuda(), x=stream)
-    assert (stream.cpu().permute(0, 4, 1, 2, 3) - x0).abs().max() < 1e-4 * max(1.0, float(x0.abs().max()))
+    # fp16 mode contracts on MFMA with the weights rounded to fp16 (fp32 accumulation); fp32 mode is an fmaf chain
+    assert (stream.cpu().permute(0, 4, 1, 2, 3) - x0).abs().max() < (1e-4 if dtype == torch.float32 else 1e-3) * max(1.0, float(x0.abs().max()))
     got = out[..., E:].float().cpu().permute(0, 4, 1, 2, 3)
     assert float(out[..., :E].abs().max()) == 0.0
     assert (got - want).abs().max() < tol * max(1.0, float(want.abs().max()))

@@ -125,7 +125,7 @@ _SIGS = {
     "dua_pack_conv3_weights_dgrad": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_instnorm_finalize": (C.c_int, [C.c_int, C.c_int, C.POINTER(InNorm), _P, _P, _P]),
     "dua_instnorm_bwd_reduce": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P]),
-    "dua_instnorm_bwd_apply": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P, _P]),
+    "dua_instnorm_bwd_apply": (C.c_int, [C.POINTER(NormBwdDesc), _P, _P, C.POINTER(InNorm), _P, _P, _P, _P, _P, _P]),
     "dua_maxpool2_bwd_add": (C.c_int, [C.c_int] * 6 + [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "dua_pack_deconv_weights_dgrad": (C.c_long, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_deconv_k2s2_bwd_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),

@@ -86,7 +86,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ dA, int da_stride, int da_off,
                                                            const T* __restrict__ raw, int raw_stride, int raw_off,
                                                            InXform xf, const double* __restrict__ sums, int C, long vox,
-                                                           T* __restrict__ out, int out_stride, int out_off) {
+                                                           T* __restrict__ out, int out_stride, int out_off,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dadd) {
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
   extern __shared__ float sm[];
@@ -95,14 +97,21 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
   const int gpc = C / EPG, n = blockIdx.y;
   norm_preamble(xf, n, C, mu, rs, ga, be);
   for (int c = threadIdx.x; c < C; c += 256) {
-    double a1 = 0, a2 = 0;
+    double a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
     for (int r = 0; r < STAT_REPLICAS; ++r) {
       const double* p = sums + (((long)n * STAT_REPLICAS + r) * xf.c_pad + c) * 4;
-      a1 += p[1]; a2 += p[2];
+      a0 += p[0]; a1 += p[1]; a2 += p[2];
     }
     k1[c] = (float)(a1 * (double)xf.inv_count);
     k2[c] = (float)(a2 * (double)xf.inv_count);
+    // parameter gradients of this layer, by the first block of every sample (consecutive lanes, consecutive channels):
+    // d add[n][c] = sum dA, d beta[c] = sum_n sum dZ, d gamma[c] = sum_n sum dZ * zhat (buffers zeroed by the caller)
+    if (blockIdx.x == 0) {
+      if (dadd) dadd[(long)n * C + c] = (float)a0;
+      if (dbeta) unsafeAtomicAdd(dbeta + c, (float)a1);
+      if (dgamma) unsafeAtomicAdd(dgamma + c, (float)a2);
+    }
   }
   __syncthreads();
   const float slope = xf.slope;
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
 
 template <typename T>
 static int launch_bwd(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in, double* sums,
-                      void* out, hipStream_t s) {
+                      void* out, hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr, float* dadd = nullptr) {
   constexpr int EPG = Elem<T>::EPG;
   const InXform xf = make_xform(in, d->C);
   const int gpc = d->C / EPG;
@@ -174,7 +183,7 @@ static int launch_bwd(const dua_norm_bwd_desc* d, const void* dA, const void* ra
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(in_bwd_apply_kernel<T>, dim3((unsigned)blocks, d->N), dim3(256), sizeof(float) * 6 * d->C, s,
                        (const T*)dA, d->da_stride, d->da_off, (const T*)raw, d->raw_stride, d->raw_off, xf,
-                       (const double*)sums, d->C, d->voxels, (T*)out, d->out_stride, d->out_off);
+                       (const double*)sums, d->C, d->voxels, (T*)out, d->out_stride, d->out_off, dgamma, dbeta, dadd);
   }
   return (int)hipGetLastError();
 }
@@ -198,10 +207,11 @@ int dua_instnorm_bwd_reduce(const dua_norm_bwd_desc* d, const void* dA, const vo
 }
 
 int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
-                           const double* sums, void* dY, void* stream) {
+                           const double* sums, void* dY, float* dgamma, float* dbeta, float* dadd, void* stream) {
   if (!dua::bwd_args_ok(d, dA, raw, in, sums) || !dY || d->out_stride % 8 || d->out_off % 8) return DUA_ERR_ARG;
-  return d->dtype == DUA_F16 ? dua::launch_bwd<dua::f16>(d, dA, raw, in, (double*)sums, dY, (hipStream_t)stream)
-                             : dua::launch_bwd<float>(d, dA, raw, in, (double*)sums, dY, (hipStream_t)stream);
+  return d->dtype == DUA_F16
+             ? dua::launch_bwd<dua::f16>(d, dA, raw, in, (double*)sums, dY, (hipStream_t)stream, dgamma, dbeta, dadd)
+             : dua::launch_bwd<float>(d, dA, raw, in, (double*)sums, dY, (hipStream_t)stream, dgamma, dbeta, dadd);
 }
 
 }  // extern "C"

@@ -314,14 +314,17 @@ _WGRAD_WS_RETIRED = []
 
 
 def _wgrad_ws(nbytes, device):
-    """One grow-only scratch buffer per device for the weight-gradient partial sums (stream-ordered reuse).  A
-    captured training-step graph bakes the buffer's address in, so a buffer that is outgrown is RETIRED, never
-    freed: returning it to the caching allocator would let a replay scribble over whoever owns the memory next."""
+    """One grow-only scratch buffer per (device, stream) for the weight-gradient partial sums: reuse is ordered by the
+    stream, so launches on different streams (conv wgrad on the trainer's side stream, deconv / head backward on the main
+    one) must not share it.  A captured training-step graph bakes the buffer's address in, so a buffer that is outgrown is
+    RETIRED, never freed: returning it to the caching allocator would let a replay scribble over whoever owns the memory
+    next."""
+    device = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = _WGRAD_WS.get(device)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
             _WGRAD_WS_RETIRED.append(buf)
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device[0])
         _WGRAD_WS[device] = buf
     return buf
 
@@ -336,9 +339,9 @@ def instnorm_finalize(norm, N, Cc):
     return scale, shift
 
 
-def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0):
+def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0, want_add=True):
     """Backward of LeakyReLU(IN(raw)) [+ add] for channels [0, Cc) of ``raw``: writes d raw into ``dY`` and returns the
-    fp64 sums [N, Cc, 3] = (sum dA, sum dZ, sum dZ * zhat) -> d add, d beta (sum over n), d gamma (sum over n)."""
+    parameter gradients (dgamma [Cc], dbeta [Cc], dadd [N, Cc] or None), fp32, emitted by the apply launch itself."""
     _cl_check(dA, "dA"); _cl_check(raw, "raw"); _cl_check(dY, "dY")
     N = raw.shape[0]
     vox = raw.shape[1] * raw.shape[2] * raw.shape[3]
@@ -351,9 +354,11 @@ def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0):
     L = nv.lib()
     nv.check(L.dua_instnorm_bwd_reduce(C.byref(d), nv.ptr(dA), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(sums), nv.stream_ptr()),
              "dua_instnorm_bwd_reduce")
+    pg = zeros((2, Cc), torch.float32, raw.device)              # dgamma, dbeta (accumulated over the samples)
+    dadd = torch.empty((N, Cc), dtype=torch.float32, device=raw.device) if want_add else None
     nv.check(L.dua_instnorm_bwd_apply(C.byref(d), nv.ptr(dA), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(sums), nv.ptr(dY),
-                                      nv.stream_ptr()), "dua_instnorm_bwd_apply")
-    return sums.sum(1)[:, :Cc, :3]
+                                      nv.ptr(pg[0]), nv.ptr(pg[1]), nv.ptr(dadd), nv.stream_ptr()), "dua_instnorm_bwd_apply")
+    return pg[0], pg[1], dadd
 
 
 def maxpool2_bwd_add(act, act_off, Cc, dA, da_off, dP):

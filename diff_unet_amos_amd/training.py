@@ -60,6 +60,44 @@ def allreduce_mean_(tensors, group=None):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# ---- weight gradients on a side stream -------------------------------------------------------------------------------
+# A layer's weight gradient needs its input and its output gradient and nothing downstream needs it before the
+# optimizer: the MFMA-bound wgrad kernels (4.5 ms of a step) run on a second stream next to the rest of the backward
+# chain, whose InstanceNorm / pooling / concat passes are HBM-bound and whose coarse levels leave the chip idle.  The
+# operands are kept referenced until the join (the caching allocator must not hand their memory to the main stream while
+# the side stream still reads it); the accumulator itself is what autograd takes over as ``param.grad`` without touching it.
+_WGRAD = {"stream": None, "keep": []}
+
+
+def _wgrad(x, dy, cout, dw):
+    from . import ops
+    st = _WGRAD["stream"]
+    if st is None:
+        ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dy, cout, 0, dw)
+        return
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dy, cout, 0, dw)
+    _WGRAD["keep"].append((x, dy))
+
+
+class _wgrad_side:
+    """with _wgrad_side(stream): backward()  -- joins the side stream and drops the kept operands on exit."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        _WGRAD["stream"] = self.stream
+
+    def __exit__(self, *exc):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        _WGRAD["stream"] = None
+        _WGRAD["keep"].clear()
+        return False
+
+
 class _Conv3dK3(torch.autograd.Function):
     """y = conv3d(x, w, b), 3x3x3 / pad 1, channels-last.  forward: dua_conv3d_k3_fwd; backward: the same kernel on
     dy with the weights flipped and transposed (data gradient) + dua_conv3d_k3_wgrad (weight gradient)."""
@@ -101,7 +139,7 @@ class _Conv3dK3(torch.autograd.Function):
             dx = _Conv3dK3._dgrad(dy, weight.detach().float().contiguous(), x.shape[-1])
         if ctx.needs_input_grad[1]:
             dw = ops.zeros((cout, cin, 3, 3, 3), torch.float32, x.device)
-            ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dy, cout, 0, dw)
+            _wgrad(x, dy, cout, dw)
             dw = dw.to(weight.dtype)
         if ctx.needs_input_grad[2]:
             db = torch.sum(dy, dim=(0, 1, 2, 3), dtype=torch.float32)
@@ -201,16 +239,14 @@ class _ConvNormAct(torch.autograd.Function):
             off = 0
         norm = ops.Norm(stats, g32, b32, D * H * W)
         dY = torch.empty_like(raw)
-        sums = ops.instnorm_bwd(buf, off, raw, cout, norm, dY)
+        dgamma, dbeta, dadd = ops.instnorm_bwd(buf, off, raw, cout, norm, dY, want_add=ctx.has_add)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1])
         if ctx.needs_input_grad[1]:
             dw = ops.zeros(tuple(weight.shape), torch.float32, x.device)
-            ops.conv3d_k3_wgrad(x, x.shape[-1], 0, dY, cout, 0, dw)
+            _wgrad(x, dY, cout, dw)
         db = ops.zeros((cout,), torch.float32, x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
-        dgamma, dbeta = sums[:, :, 2].sum(0).float(), sums[:, :, 1].sum(0).float()
-        dadd = sums[:, :, 0].float() if ctx.has_add else None
         return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None
 
 
@@ -327,7 +363,8 @@ class NativeConvTrainer:
     collective stays an ordinary call, so any backend works (RCCL on a node, gloo in the tests)."""
 
     def __init__(self, net, lr=2e-4, weight_decay=1e-4, losses="mse,bce,dice", loss_combine="sum",
-                 dtype=torch.float16, init_scale=2.0 ** 12, overlap=True, graph=False, fused_optimizer=False):
+                 dtype=torch.float16, init_scale=2.0 ** 12, overlap=True, graph=False, fused_optimizer=False,
+                 wgrad_overlap=True):
         import torch.distributed as dist
         self.net, self.dtype = net, dtype
         self.lr, self.weight_decay, self.init_scale = lr, weight_decay, init_scale
@@ -350,6 +387,8 @@ class NativeConvTrainer:
         from . import ops
         dev = self.params[0].device
         self.arena = ops.ZeroArena(sum(p.numel() for p in self.params) * 4 + (96 << 20), dev) if dev.type == "cuda" else None
+        # weight gradients on a side stream (see _wgrad); not under the DDP reducer, whose hooks read them on the main stream
+        self.wgrad_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and not self.overlap and wgrad_overlap) else None
 
     def _allreduce(self):
         if not self.distributed or self.overlap:          # the DDP reducer already averaged them during backward
@@ -370,7 +409,8 @@ class NativeConvTrainer:
             self.optimizer.zero_grad(set_to_none=True)
             with torch.enable_grad():
                 loss = _SegLoss.apply(self.module(g["images"], x_t, g["t"]), g["labels"], self.loss_names, self.loss_combine)
-                (loss * g["scale"]).backward()
+                with _wgrad_side(self.wgrad_stream):
+                    (loss * g["scale"]).backward()
         return loss.detach()
 
     def _graph_update(self):
@@ -465,7 +505,8 @@ class NativeConvTrainer:
         with (self.arena if self.arena is not None else contextlib.nullcontext()), torch.enable_grad():
             loss = _SegLoss.apply(self.module(images, x_t, t), labels.float().contiguous(), self.loss_names,
                                   self.loss_combine)
-            (loss * self.scale).backward()
+            with _wgrad_side(self.wgrad_stream):
+                (loss * self.scale).backward()
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)

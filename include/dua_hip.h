@@ -100,8 +100,11 @@ typedef struct {
 } dua_norm_bwd_desc;
 int dua_instnorm_bwd_reduce(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
                             double* sums, void* stream);
+/* dgamma, dbeta (fp32 [C], ZEROED by the caller, accumulated over the samples) and dadd (fp32 [N][C], written) are the
+ * parameter gradients of the layer -- d gamma, d beta of InstanceNorm3d(affine) and the gradient of the timestep-embedding
+ * add -- emitted by the same launch; each may be NULL. */
 int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
-                           const double* sums, void* dY, void* stream);
+                           const double* sums, void* dY, float* dgamma, float* dbeta, float* dadd, void* stream);
 
 /* Backward of nn.MaxPool3d(2) (denoiser.py:100,106) fused with the sum of x_l's two gradient paths:
  *   out[v] = dA[v] (or 0 when dA is NULL) + (v is the arg-max of its 2x2x2 window ? dP[window] : 0),

@@ -464,3 +464,44 @@ def test_token_linear_kernel_epilogues_match_torch():
         ops.token_linear(A, W, b, "scatter", x=xb, geom=geom, gamma=gm, beta=bt, ln_out=lb)
         assert (xa - xb).abs().max() < 4e-3 * max(1.0, float(xa.abs().max()))
         assert (la.float() - lb.float()).abs().max() < 8e-3 * max(1.0, float(la.float().abs().max()))
+
+
+@pytest.mark.gpu
+def test_diff_swin_unetr_under_the_sliding_window_caller():
+    """Engine.infer's call (engine.py:167-182: sliding_window_inference(..., pred_type="ddim_sample")) with the swin variant
+    as the model: two overlapping 64^3 windows of a 64x64x96 volume, 3 classes, 2 DDIM steps, against
+    oracle.sliding_window_ref o the oracle's ddim_sample with the same per-window x_T (eta 0: no step noise)."""
+    from diff_unet_amos_amd import inference
+    from diff_unet_amos_amd.gaussian_diffusion import make_spaced
+    from oracle.diffusion_ref import RefDiffusion
+    from oracle.sliding_window_ref import sliding_window_ref
+    net, ref = _swin_pair(3, torch.float32, seed=9)
+    net.sample_diffusion = make_spaced(1000, [2])
+    ref.sample_diffusion = RefDiffusion(1000, [2])
+    g = torch.Generator().manual_seed(12)
+    vol = torch.rand(1, 1, 64, 64, 96, generator=g)
+    shape = (1, 3, 64, 64, 64)
+    count = [0]
+
+    def seed_of(win):
+        return int(win.double().abs().sum().item() * 1e3) % (2 ** 31)
+
+    def ref_fn(win):
+        w = torch.from_numpy(win).float()
+        torch.manual_seed(seed_of(w.cuda()))
+        xT = torch.randn(*shape, device="cuda").cpu()
+        count[0] += 1
+        with torch.no_grad():
+            return ref.ddim_sample(w, x_T=[xT], step_noise=[[torch.zeros(shape)] * 2]).numpy()
+
+    def predictor(x, **kw):
+        torch.manual_seed(seed_of(x))
+        return net(image=x, **kw)
+
+    want = torch.from_numpy(sliding_window_ref(vol.numpy(), (64, 64, 64), 0.5, ref_fn)).float()
+    with torch.no_grad():
+        got = inference.sliding_window_inference(vol.cuda(), (64, 64, 64), 1, predictor, 0.5, pred_type="ddim_sample").cpu()
+    d = (got - want).abs()
+    print(f"swin under the sliding window: {count[0]} windows, blended sum-x0 max |d| {d.max():.2e} mean {d.mean():.2e}")
+    assert count[0] == 2 and got.shape == (1, 3, 64, 64, 96)
+    assert d.max() < 5e-4 and d.mean() < 2e-5

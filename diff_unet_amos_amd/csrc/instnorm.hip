@@ -37,12 +37,23 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
   xform_preamble(xf, n, C, sm, sm + C, sm + 2 * C);
   __syncthreads();
   const long vox_n = (long)D * H * W;
+  // The grid stride is a multiple of 256: when the channel-group count divides 256 a thread keeps ONE channel group for all
+  // its iterations and its per-channel constants stay in registers.  (Capping the grid at 1024 workgroups to pay the
+  // preamble less often was measured: 61.9 -> 65.1 us on the 96^3 x 64 level -- the pass already streams at 5.5 TB/s.)
+  const bool fixed = 256 % gpc == 0;
+  float sc[EPG], sh[EPG], ad[EPG];
+  if (fixed) {
+    const int cg = threadIdx.x % gpc;
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) { sc[e] = sm[cg * EPG + e]; sh[e] = sm[C + cg * EPG + e]; ad[e] = sm[2 * C + cg * EPG + e]; }
+  }
   for (long it = blockIdx.x * 256L + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
     const int cg = (int)(it % gpc);
     long v = it / gpc;
-    float sc[EPG], sh[EPG], ad[EPG];
+    if (!fixed) {
 #pragma unroll
-    for (int e = 0; e < EPG; ++e) { sc[e] = sm[cg * EPG + e]; sh[e] = sm[C + cg * EPG + e]; ad[e] = sm[2 * C + cg * EPG + e]; }
+      for (int e = 0; e < EPG; ++e) { sc[e] = sm[cg * EPG + e]; sh[e] = sm[C + cg * EPG + e]; ad[e] = sm[2 * C + cg * EPG + e]; }
+    }
     if constexpr (!POOL) {
       const long gv = n * vox_n + v;
       Frag x = *(const Frag*)(raw + gv * raw_stride + cg * EPG);

@@ -202,11 +202,13 @@ __global__ __launch_bounds__(256) void final_conv_sampler_kernel(TailArgs a) {
 }
 
 // ---- fused tail on the matrix cores (fp16, C <= 16, K a multiple of 32) ----------------------------------
-// The 1x1x1 final_conv is a [voxels x K] x [K x C] GEMM: per wave 64 voxels = 4 blocks of 16, MFMA 16x16x32.
-// A fragments are loaded straight from the raw tensor (one 16-byte k-group per lane) and normalised in
-// registers; the accumulator layout (lane = class, 4 voxels per lane) is exactly what the sampler update
-// wants: one Philox4x32 call yields the lane's 4 normals of a block.  ~2.3x fewer instructions per voxel than
-// the VALU form below, which stays for fp32 parity mode and odd shapes.
+// The 1x1x1 final_conv is a [C x K] x [K x voxels] GEMM: per wave 64 voxels = 4 blocks of 16, MFMA 16x16x32 with the
+// CLASSES as rows (A operand = the weights, in registers) and the voxels as columns (B operand = raw fragments loaded
+// straight from the tensor, one 16-byte k-group per lane, normalised in registers).  The accumulator then holds, per lane,
+// four consecutive classes of ONE voxel: the sampler state moves as 16-byte loads / stores (64 contiguous bytes per voxel,
+// 1 KB per instruction -- the voxels-as-rows form moved it as 4-byte accesses and ran at 3.5 TB/s), the next input as 8-byte
+// stores, and one Philox4x32 call yields the lane's 4 normals with the same (voxel, class quad) counter as the VALU form
+// below, which stays for fp32 parity mode and odd shapes: both forms draw the same noise field.
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 template <int KS>
 __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a) {
@@ -216,19 +218,20 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
   xform_preamble(a.xf, n, K, sc_l, sh_l, sh_l + K);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = lane & 15, kq = lane >> 4;
-  const bool cok = c < a.C;
+  const int vl = lane & 15, kq = lane >> 4;            // B column (voxel) / A row (class) index; k-group and class quad
   float sc[KS][8], sh[KS][8];
-  f16x8 bw[KS];
+  f16x8 aw[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = 32 * ks + 8 * kq + e;
       sc[ks][e] = sc_l[k]; sh[ks][e] = sh_l[k];
-      bw[ks][e] = (f16)(cok ? a.wf[c * K + k] : 0.f);
+      aw[ks][e] = (f16)(vl < a.C ? a.wf[vl * K + k] : 0.f);          // A: row = class vl
     }
-  const float bias = cok ? a.bf[c] : 0.f;
+  float bias[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias[j] = 4 * kq + j < a.C ? a.bf[4 * kq + j] : 0.f;
   float k8[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) k8[i] = a.coef ? a.coef[8 * n + i] : 0.f;
@@ -236,29 +239,32 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
   uint32_t key0, key1;
   philox_key(a, key0, key1);
   const f16* raw = (const f16*)a.raw + (long)n * a.vox * a.raw_stride;
-  const long wbase = (blockIdx.x * 4L + wave) * 64;
   const bool sampling = a.mode != DUA_MODE_LOGITS;
+  // A workgroup walks several 256-voxel tiles: the preamble above (per-channel statistics -> scale / shift in double
+  // precision, weights to registers) is a few microseconds of dependent loads, too much to pay per 77 KB of traffic.
+  const long ntiles = (a.vox + 255) / 256;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const long wbase = (tile * 4L + wave) * 64;
   // Everything this wave needs from memory is requested up front (raw fragments of all four voxel blocks, the
-  // sampler state, injected noise): one memory round trip per wave instead of one per block and voxel.
+  // sampler state, injected noise): one memory round trip per wave instead of one per block.
   f16x8 fr[4][KS];
-  float xt[4][4], ez[4][4];
+  f32x4 xt[4];
+  float ez[4][4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
-    const long va = wbase + 16 * mb + c;                 // voxel whose row this lane feeds as A
-    const long vc = va < a.vox ? va : 0;
+    const long v = wbase + 16 * mb + vl;
+    const long vc = v < a.vox ? v : 0;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) fr[mb][ks] = *(const f16x8*)(raw + vc * a.raw_stride + 32 * ks + 8 * kq);
+    xt[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (sampling) xt[mb] = *(const f32x4*)(a.x_state + ((long)n * a.vox + vc) * 16 + 4 * kq);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long v = wbase + 16 * mb + 4 * kq + j;
-      const long vj = v < a.vox ? v : 0;
-      xt[mb][j] = sampling ? a.x_state[((long)n * a.vox + vj) * 16 + c] : 0.f;
-      ez[mb][j] = (sampling && a.noise && cok) ? a.noise[((long)n * a.C + c) * a.vox + vj] : 0.f;
-    }
+    for (int j = 0; j < 4; ++j)
+      ez[mb][j] = (sampling && a.noise && 4 * kq + j < a.C) ? a.noise[((long)n * a.C + 4 * kq + j) * a.vox + vc] : 0.f;
   }
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
-    f32x4a acc = {bias, bias, bias, bias};
+    f32x4a acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       f16x8 y;
@@ -268,32 +274,54 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
         t = t > 0.f ? t : t * a.xf.slope;
         y[e] = (f16)t;
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(y, bw[ks], acc, 0, 0, 0);     // rows of voxels >= vox are never stored
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks], y, acc, 0, 0, 0);     // columns of voxels >= vox are never stored
     }
-    // lane now holds logits of class c for voxels wbase + 16*mb + 4*kq + j
-    const long v0 = wbase + 16 * mb + 4 * kq;
-    if (sampling && !a.noise) {
-      const long gid = ((long)n * a.vox + v0) * 16 + c;    // unique per (lane, block): 4 normals per call
-      uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0x5eedu};
+    // lane now holds the logits of classes 4 kq + j of voxel wbase + 16 mb + vl
+    const long v = wbase + 16 * mb + vl;
+    if (v >= a.vox) continue;
+    const long gv = (long)n * a.vox + v;
+    if (a.logits) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * kq + j < a.C) a.logits[((long)n * a.C + 4 * kq + j) * a.vox + v] = acc[j];
+    }
+    if (!sampling) continue;
+    if (!a.noise) {                                          // same counter as the VALU form: (voxel, step, class quad)
+      uint32_t ctr[4] = {(uint32_t)gv, (uint32_t)(gv >> 32), step, (uint32_t)kq};
       philox4x32_10(ctr, key0, key1);
       box_muller(ctr[0], ctr[1], ez[mb][0], ez[mb][1]);
       box_muller(ctr[2], ctr[3], ez[mb][2], ez[mb][3]);
     }
+    f32x4 xn, x0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const long v = v0 + j;
-      if (v >= a.vox || !cok) continue;
-      const float lg = acc[j];
-      if (a.logits) a.logits[((long)n * a.C + c) * a.vox + v] = lg;
-      if (!sampling) continue;
-      const long gv = (long)n * a.vox + v;
-      float x0;
-      const float xn = sampler_update(a.mode, k8, lg, xt[mb][j], ez[mb][j], x0);
-      a.x_state[gv * 16 + c] = xn;
-      if (a.xsum) a.xsum[gv * 16 + c] += x0;
-      if (a.xstart) a.xstart[((long)n * a.C + c) * a.vox + v] = x0;
-      if (a.xin) ((f16*)a.xin)[gv * a.xin_stride + c] = (f16)xn;
+      float x0j;
+      xn[j] = sampler_update(a.mode, k8, acc[j], xt[mb][j], ez[mb][j], x0j);
+      x0[j] = x0j;
     }
+    *(f32x4*)(a.x_state + gv * 16 + 4 * kq) = xn;
+    if (a.xsum) {
+      f32x4 s4 = *(const f32x4*)(a.xsum + gv * 16 + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s4[j] += x0[j];
+      *(f32x4*)(a.xsum + gv * 16 + 4 * kq) = s4;
+    }
+    if (a.xstart) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * kq + j < a.C) a.xstart[((long)n * a.C + 4 * kq + j) * a.vox + v] = x0[j];
+    }
+    if (a.xin) {
+      f16* xp = (f16*)a.xin + gv * a.xin_stride + 4 * kq;
+      if (4 * kq + 4 <= a.C) {
+        *(f16x4*)xp = f16x4{(f16)xn[0], (f16)xn[1], (f16)xn[2], (f16)xn[3]};
+      } else {                       // channels >= C of the slice hold the conditioning image / zero padding: leave them alone
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * kq + j < a.C) xp[j] = (f16)xn[j];
+      }
+    }
+  }
   }
 }
 
@@ -366,7 +394,8 @@ int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in
   a.seed_lo = (unsigned)(d->seed & 0xffffffffull); a.seed_hi = (unsigned)(d->seed >> 32);
   a.seed_dev = d->seed_dev;
   if (d->dtype == DUA_F16 && d->CX == 16 && d->K % 32 == 0 && (d->K == 32 || d->K == 64 || d->K == 128)) {
-    dim3 grid((unsigned)((d->voxels + 255) / 256), d->N);
+    const long ntiles = (d->voxels + 255) / 256;
+    dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024), d->N);
     const size_t lds = (size_t)3 * d->K * sizeof(float);
     if (d->K == 32) hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else if (d->K == 64) hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -135,6 +135,124 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
   }
 }
 
+// fp16, C = 64: the backward on the matrix cores.  Per wave and 32 voxels:
+//   du^T[c][v] = W^T[c][k] . dlog^T[k][v]      MFMA 32x32x16 (k = the 16 classes), dlog rows straight from global as B
+//   dW[k][c]  += dlog^T[k][v] . u[v][c]        MFMA 16x16x32 (k = 32 voxels): both operands want 8 consecutive VOXELS of one
+//                                              class / channel per lane, i.e. the transposes of the channels-last tiles --
+//                                              built once per tile in LDS (2-byte scatter writes, 16-byte operand reads)
+//   db[k]     += dlog^T[k][v] . 1
+// The VALU form above spends 32 FMAs and 16 LDS reads per (voxel, channel) and ran at 7x its HBM time.
+__global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const f16* __restrict__ dlog, int dl_stride, int K,
+                                                            const f16* __restrict__ u, int u_stride,
+                                                            const float* __restrict__ W, f16* __restrict__ du, int du_stride,
+                                                            float* __restrict__ part, long total) {
+  constexpr int C = HEAD_C;
+  constexpr int UT = 32 * 2 + 16;                 // bytes per row of the transposed tiles (32 voxels + pad)
+  constexpr int OS = C * 2 + 16;                  // bytes per row of the du staging tile
+  __shared__ __attribute__((aligned(16))) char smem[4 * (C * UT + HEAD_K * UT + 32 * OS)];
+  __shared__ float red[4][(HEAD_K + 1) * HEAD_C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;         // 32x32x16 roles
+  const int l16 = lane & 15, kq = lane >> 4;       // 16x16x32 roles
+  char* uT = smem + wave * (C * UT + HEAD_K * UT + 32 * OS);       // [64 channels][32 voxels]
+  char* dT = uT + C * UT;                                           // [16 classes][32 voxels]
+  char* ot = dT + HEAD_K * UT;                                      // [32 voxels][64 channels] du staging
+  f16x8 aw[2];                                     // W^T fragments: row = channel nb*32 + r, k = classes 8hh..8hh+7
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aw[nb][e] = (f16)((8 * hh + e) < K ? W[(8 * hh + e) * C + nb * 32 + r] : 0.f);
+  f16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (f16)1.f;
+  typedef float f32x4a __attribute__((ext_vector_type(4)));
+  f32x4a dw[4], dbv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < 4; ++b) dw[b] = f32x4a{0.f, 0.f, 0.f, 0.f};
+  const long ntile = (total + 127) / 128;          // 128 voxels per workgroup tile, 32 per wave
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long v0 = tile * 128 + wave * 32;
+    const long v = v0 + r;
+    const bool ok = v < total;
+    const long vc = ok ? v : (total - 1);
+    // dlog row half of this lane's voxel (B operand of the du product) and the wave's u tile (4 x 16 B per lane)
+    f16x8 dl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl[e] = (f16)0.f;
+    if (ok) {
+      if (K == HEAD_K) dl = *(const f16x8*)(dlog + vc * dl_stride + 8 * hh);
+      else
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (8 * hh + e < K) dl[e] = dlog[vc * dl_stride + 8 * hh + e];
+    }
+    f16x8 uf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                   // chunk j*64 + lane of the 32 x 8 chunks: voxel = chunk / 8, group = chunk % 8
+      const int ch = j * 64 + lane, vl = ch >> 3, g = ch & 7;
+      const long vv = v0 + vl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) uf[j][e] = (f16)0.f;
+      if (vv < total) uf[j] = *(const f16x8*)(u + vv * u_stride + g * 8);
+    }
+    // transposes into LDS
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *(f16*)(dT + (8 * hh + e) * UT + r * 2) = dl[e];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = j * 64 + lane, vl = ch >> 3, g = ch & 7;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *(f16*)(uT + (g * 8 + e) * UT + vl * 2) = uf[j][e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // du^T = W^T . dlog^T
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[nb], dl, acc[nb], 0, 0, 0);
+    }
+    // dW += dlog^T . u, db += dlog^T . 1   (k = the wave's 32 voxels)
+    const f16x8 ad = *(const f16x8*)(dT + l16 * UT + kq * 16);             // A: row = class l16, voxels 8kq..8kq+7
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const f16x8 bu = *(const f16x8*)(uT + (b * 16 + l16) * UT + kq * 16);   // B: col = channel b*16 + l16
+      dw[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ad, bu, dw[b], 0, 0, 0);
+    }
+    dbv = __builtin_amdgcn_mfma_f32_16x16x32_f16(ad, ones, dbv, 0, 0, 0);
+    // du: accumulator (lane = voxel r, quads of 4 channels) -> staging rows -> 128-byte rows to global
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c0 = nb * 32 + 8 * j + 4 * hh;
+        *(f16x4*)(ot + r * OS + c0 * 2) = f16x4{(f16)acc[nb][4 * j], (f16)acc[nb][4 * j + 1], (f16)acc[nb][4 * j + 2], (f16)acc[nb][4 * j + 3]};
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = j * 64 + lane, vl = ch >> 3, g = ch & 7;
+      if (v0 + vl < total) *(f16x8*)(du + (v0 + vl) * du_stride + g * 8) = *(const f16x8*)(ot + vl * OS + g * 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // accumulators -> per-wave partials -> per-workgroup partials (summed by head_reduce_kernel)
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][(4 * kq + j) * HEAD_C + b * 16 + l16] = dw[b][j];
+  if (l16 == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][HEAD_K * HEAD_C + 4 * kq + j] = dbv[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < (HEAD_K + 1) * HEAD_C; i += 256) {
+    const bool live = i < HEAD_K * HEAD_C || i < HEAD_K * HEAD_C + HEAD_K;
+    const float sm_ = live ? (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]) : 0.f;
+    part[(long)blockIdx.x * (HEAD_K + 1) * HEAD_C + i] = sm_;
+  }
+}
+
 // dW[k][c] += sum over blocks of part[block][k][c]; db[k] += sum of part[block][HEAD_K][k]
 __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ part, int nblocks, int K, int C,
                                                           float* __restrict__ dW, float* __restrict__ db) {
@@ -194,6 +312,16 @@ int dua_head_bwd(int dtype, long voxels, int C, int K, const void* dlogits, int 
   const long tiles = (voxels + dua::HEAD_TV - 1) / dua::HEAD_TV;
   dim3 grid((unsigned)(tiles > 1024 ? 1024 : tiles));
   float* part = (workspace && workspace_bytes >= dua_head_bwd_workspace(voxels)) ? (float*)workspace : nullptr;
+  if (dtype == DUA_F16 && C == dua::HEAD_C && part && u_stride % 8 == 0 && du_stride % 8 == 0 && (K < dua::HEAD_K || dlogits_stride % 8 == 0)) {
+    // matrix-core form; its grid must not exceed what the workspace was sized for
+    const long t128 = (voxels + 127) / 128;
+    dim3 g2((unsigned)(t128 < (long)grid.x ? t128 : (long)grid.x));
+    hipLaunchKernelGGL(dua::head_bwd_mfma_kernel, g2, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)dlogits, dlogits_stride, K,
+                       (const dua::f16*)u, u_stride, W, (dua::f16*)du, du_stride, part, voxels);
+    hipLaunchKernelGGL(dua::head_reduce_kernel, dim3(((dua::HEAD_K + 1) * dua::HEAD_C + 255) / 256, 16), dim3(256), 0,
+                       (hipStream_t)stream, part, (int)g2.x, K, C, dW, db);
+    return (int)hipGetLastError();
+  }
   if (dtype == DUA_F16)
     hipLaunchKernelGGL(dua::head_bwd_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)dlogits,
                        dlogits_stride, K, (const dua::f16*)u, u_stride, C, W, (dua::f16*)du, du_stride, dW, db, part, voxels);

@@ -555,7 +555,8 @@ def test_maxpool_backward_add_matches_torch(dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 64, 16), (1, 3, 5, 7, 8, 2), (2, 6, 4, 10, 32, 13)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 64, 16), (1, 3, 5, 7, 8, 2), (2, 6, 4, 10, 32, 13), (1, 5, 7, 9, 64, 16),
+                                   (2, 4, 4, 5, 64, 11), (1, 16, 24, 20, 64, 16)])
 def test_head_forward_backward_match_torch(dtype, shape):
     ops = _ops()
     N, D, H, W, Cc, K = shape

@@ -135,6 +135,51 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ dlo
   }
 }
 
+// fp16 forward on the matrix cores (C a multiple of 32, K <= 16): classes as MFMA rows, voxels as columns -- the operand scheme
+// of the sampler's fused tail (sampler.hip): raw rows are the B operand straight from global memory, a lane ends up with four
+// consecutive classes of one voxel and stores them as 8 bytes (16 voxels x 32 B contiguous per instruction).
+template <int KS>
+__global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const f16* __restrict__ u, int u_stride, int C,
+                                                            const float* __restrict__ W, const float* __restrict__ b, int K,
+                                                            f16* __restrict__ out, int out_stride, long total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vl = lane & 15, kq = lane >> 4;
+  f16x8 aw[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aw[ks][e] = (f16)(vl < K ? W[vl * C + 32 * ks + 8 * kq + e] : 0.f);
+  typedef float f32x4a __attribute__((ext_vector_type(4)));
+  f32x4a bias;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias[j] = 4 * kq + j < K ? b[4 * kq + j] : 0.f;
+  const long ntile = (total + 255) / 256;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long wbase = (tile * 4 + wave) * 64;
+    f16x8 fr[4][KS];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const long v = wbase + 16 * mb + vl;
+      const long vc = v < total ? v : total - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fr[mb][ks] = *(const f16x8*)(u + vc * u_stride + 32 * ks + 8 * kq);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      f32x4a acc = bias;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks], fr[mb][ks], acc, 0, 0, 0);
+      const long v = wbase + 16 * mb + vl;
+      if (v >= total) continue;
+      f16* o = out + v * out_stride + 4 * kq;
+      if (4 * kq + 4 <= K && out_stride % 4 == 0) *(f16x4*)o = f16x4{(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
+      else
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * kq + j < K) o[j] = (f16)acc[j];
+    }
+  }
+}
+
 // fp16, C = 64: the backward on the matrix cores.  Per wave and 32 voxels:
 //   du^T[c][v] = W^T[c][k] . dlog^T[k][v]      MFMA 32x32x16 (k = the 16 classes), dlog rows straight from global as B
 //   dW[k][c]  += dlog^T[k][v] . u[v][c]        MFMA 16x16x32 (k = 32 voxels): both operands want 8 consecutive VOXELS of one
@@ -288,6 +333,13 @@ int dua_head_fwd(int dtype, long voxels, int C, int K, const void* u, int u_stri
   if (!u || !W || !b || !logits || voxels <= 0 || C <= 0 || C > dua::HEAD_C || C % 8 || K <= 0 || K > dua::HEAD_K ||
       u_stride % 8 || u_stride < C || logits_stride < K) return DUA_ERR_ARG;
   dim3 grid(dua::head_blocks(voxels));
+  if (dtype == DUA_F16 && (C == 32 || C == 64) && u_stride % 8 == 0) {
+    const long t256 = (voxels + 255) / 256;
+    dim3 g2((unsigned)(t256 < 1024 ? t256 : 1024));
+    if (C == 32) hipLaunchKernelGGL(dua::head_fwd_mfma_kernel<1>, g2, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)u, u_stride, C, W, b, K, (dua::f16*)logits, logits_stride, voxels);
+    else hipLaunchKernelGGL(dua::head_fwd_mfma_kernel<2>, g2, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)u, u_stride, C, W, b, K, (dua::f16*)logits, logits_stride, voxels);
+    return (int)hipGetLastError();
+  }
   if (dtype == DUA_F16)
     hipLaunchKernelGGL(dua::head_fwd_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, (const dua::f16*)u, u_stride,
                        C, W, b, K, (dua::f16*)logits, logits_stride, voxels);

@@ -2,7 +2,7 @@
 """Print the kernel timeline of one replayed step from a rocprofv3 --kernel-trace CSV directory."""
 import csv, glob, sys, collections
 d = sys.argv[1]
-f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
+f = (glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'step_begin' in r['Kernel_Name']]

@@ -26,53 +26,80 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // one wave per output token; lanes stride over the 8C gathered elements (two passes: moments, then normalise + store)
 // x is the fp32 token stream of the stage; y (optional, T) is the last block's MLP output still to be added to it
 // (transformer.py:477-480) -- the sum is formed on the fly, the stream itself is dead after the merge.
-// One wave per output token: lane l owns elements l, l + 64, ... of the 8C gathered vector (8C is a multiple of 64), held in
-// registers between the moments and the normalisation; corner and channel of an element advance incrementally (no division).
-template <typename T>
+// WPT waves per output token (1: a workgroup holds 4 tokens; 4: the whole workgroup works on one token -- the coarse stages
+// have 216 and 27 output tokens of 1536 / 3072 elements, where one wave per token leaves 27 waves walking 48 dependent loads
+// each: 59-88 us for a few hundred KB).  A lane owns elements l, l + 64 WPT, ... of the 8C gathered vector, held in registers
+// between the moments and the normalisation; corner and channel of an element advance incrementally (no division), and
+// every load is issued unconditionally on a clamped address (a load under a lane-dependent branch sits in its own basic
+// block and is waited for there).
+template <typename T, int WPT>
 __global__ __launch_bounds__(256) void patch_merge_norm_kernel(const float* __restrict__ x, const T* __restrict__ y, int B, int D,
                                                                int H, int W, int C, int legacy, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, T* __restrict__ out) {
-  constexpr int MAXV = 48;                               // 8C / 64 values per lane, C <= 384
+  constexpr int MAXV = 48 / WPT;                         // 8C / (64 WPT) values per lane, C <= 384
+  constexpr int STRIDE = 64 * WPT;
+  __shared__ float part[4][2];
   const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   const long ntok = (long)B * D2 * H2 * W2;
-  const int lane = threadIdx.x & 63;
-  const long tok = blockIdx.x * 4L + (threadIdx.x >> 6);
-  if (tok >= ntok) return;
-  const int w2 = (int)(tok % W2), h2 = (int)((tok / W2) % H2), d2 = (int)((tok / ((long)W2 * H2)) % D2), b = (int)(tok / ((long)W2 * H2 * D2));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long tok = WPT == 1 ? blockIdx.x * 4L + wave : (long)blockIdx.x;
+  const bool live = tok < ntok;
+  const long tk = live ? tok : 0;
+  const int w2 = (int)(tk % W2), h2 = (int)((tk / W2) % H2), d2 = (int)((tk / ((long)W2 * H2)) % D2), b = (int)(tk / ((long)W2 * H2 * D2));
   // corner k of the gathered vector -> (di, dj, dk); V2: itertools.product order; legacy: patch.py:82-89
   const int leg[8] = {0, 4, 2, 1, 5, 2, 1, 7};          // bit 2 = d offset, bit 1 = h offset, bit 0 = w offset
-  const int E = 8 * C, nper = E >> 6;
+  const int E = 8 * C, nper = E / STRIDE;
+  const int e0 = WPT == 1 ? lane : threadIdx.x;
   float v[MAXV];
-  float s = 0.f;
-  int k = 0, c = lane;
+  long idx[MAXV];
+  bool in[MAXV];
+  int k = 0, c = e0;
   while (c >= C) { c -= C; ++k; }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    v[i] = 0.f;
+    in[i] = false; idx[i] = 0;
     if (i < nper) {
-      const int code = legacy ? leg[k] : k;
+      const int code = legacy ? leg[k & 7] : (k & 7);
       const int d = 2 * d2 + (code >> 2), h = 2 * h2 + ((code >> 1) & 1), w = 2 * w2 + (code & 1);
-      if (d < D && h < H && w < W) {                     // F.pad(..., value 0) of odd extents
-        const long idx = ((((long)b * D + d) * H + h) * W + w) * C + c;
-        v[i] = y ? x[idx] + (float)y[idx] : x[idx];
-      }
-      s += v[i];
-      c += 64;
+      in[i] = d < D && h < H && w < W;                   // F.pad(..., value 0) of odd extents
+      idx[i] = in[i] ? ((((long)b * D + d) * H + h) * W + w) * C + c : 0;
+      c += STRIDE;
       while (c >= C) { c -= C; ++k; }
     }
   }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) v[i] = i < nper ? x[idx[i]] : 0.f;
+  if (y) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nper) v[i] += (float)y[idx[i]];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) { v[i] = in[i] ? v[i] : 0.f; s += v[i]; }
   s = wave_sum64(s);
+  if (WPT > 1) {
+    if (lane == 0) part[wave][0] = s;
+    __syncthreads();
+    s = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+  }
   const float mean = s / (float)E;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
     if (i < nper) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
   q = wave_sum64(q);
+  if (WPT > 1) {
+    if (lane == 0) part[wave][1] = q;
+    __syncthreads();
+    q = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+  }
   const float rstd = rsqrtf(q / (float)E + eps);
+  if (!live) return;
   T* o = out + tok * E;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
-    if (i < nper) { const int e = lane + 64 * i; o[e] = (T)((v[i] - mean) * rstd * gamma[e] + beta[e]); }
+    if (i < nper) { const int e = e0 + STRIDE * i; o[e] = (T)((v[i] - mean) * rstd * gamma[e] + beta[e]); }
 }
 
 template <typename T>
@@ -122,14 +149,15 @@ int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legac
                          const float* gamma, const float* beta, float eps, void* out, void* stream) {
   if (!x || !gamma || !beta || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C > 384) return DUA_ERR_ARG;
   const long ntok = (long)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
-  dim3 grid((unsigned)((ntok + 3) / 4));
-  if (dtype == DUA_F16)
-    hipLaunchKernelGGL(dua::patch_merge_norm_kernel<dua::f16>, grid, dim3(256), 0, (hipStream_t)stream, x, (const dua::f16*)y, B, D,
-                       H, W, C, legacy, gamma, beta, eps, (dua::f16*)out);
-  else if (dtype == DUA_F32)
-    hipLaunchKernelGGL(dua::patch_merge_norm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (const float*)y, B, D, H, W,
-                       C, legacy, gamma, beta, eps, (float*)out);
+  const bool wide = ntok < 2048 && (8 * C) % 256 == 0;        // few tokens: a whole workgroup per token
+  dim3 grid((unsigned)(wide ? ntok : (ntok + 3) / 4));
+#define DUA_PM(T_, WPT_)                                                                                                  \
+  hipLaunchKernelGGL((dua::patch_merge_norm_kernel<T_, WPT_>), grid, dim3(256), 0, (hipStream_t)stream, x, (const T_*)y, B, D, H, \
+                     W, C, legacy, gamma, beta, eps, (T_*)out)
+  if (dtype == DUA_F16) { if (wide) DUA_PM(dua::f16, 4); else DUA_PM(dua::f16, 1); }
+  else if (dtype == DUA_F32) { if (wide) DUA_PM(float, 4); else DUA_PM(float, 1); }
   else return DUA_ERR_ARG;
+#undef DUA_PM
   return (int)hipGetLastError();
 }
 

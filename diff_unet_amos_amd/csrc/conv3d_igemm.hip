@@ -66,7 +66,10 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // 27 MFMA k-steps on one channel; here its 27 taps are gathered from the halo into a [voxel][32] tile (im2col of one
 // channel) and contracted in TWO k-steps against a [32 taps][64 couts] weight block that dua_pack_conv3_weights_tap
 // appends to the packed weights: 27 + 2 k-steps per tile instead of 54 for DiffUNet's 17-channel first layer.
-template <typename T, int TDP = 4, int NKS = 2>
+// HALF: the last Cin chunk holds at most one k-step (16 channels) of real input (Cin = 48 = 32 + 16, the Swin-UNETR widths):
+// its second k-step per tap would multiply zero padding and is skipped.  A separate instantiation, so that the common
+// kernel keeps its schedule.
+template <typename T, int TDP = 4, int NKS = 2, bool HALF = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   using namespace c3v2;
   constexpr int TD = TDP, HD = TDP + 2, MB = TDP / 2;
@@ -208,16 +211,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
           fb1[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16 + 32 * 16);
           if (MB == 2) fa1[b] = *(const Frag*)(ap + 4 * RS + kw * VS + ks * 32);
         };
+        const bool short_chunk = HALF && u / 3 == a.nchunks - 1;     // uniform: skip the ks = 1 steps of this unit
         ld(0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (t + 1 < NT) ld(t + 1, (t + 1) & 1);
+          if (t + 1 < NT && !(HALF && short_chunk && ((t + 1) % NKS) == 1)) ld(t + 1, (t + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
-          mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
-          mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
-          if constexpr (MB == 2) {
-            mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
-            mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
+          if (!(HALF && short_chunk && (t % NKS) == 1)) {
+            mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
+            mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
+            if constexpr (MB == 2) {
+              mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
+              mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -439,6 +445,9 @@ static int ensure_lds_attr() {
       e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 4096);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 4096);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              c3v2::LDS_MAIN + 3 * 4 * 1024);
   }
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -511,7 +520,10 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
+  if (sizeof(T) == 2 && d->Cin - (a.nchunks - 1) * CK <= CK / 2)       // e.g. Cin = 48: the last chunk is half padding
+    hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 2, true>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
+  else
+    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
   return (int)hipGetLastError();
 }
 

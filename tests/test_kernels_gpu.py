@@ -84,7 +84,9 @@ def conv_variant(request):
     (1, 8, 8, 4, 8, 8),
     (1, 64, 128, 12, 12, 12),
     (1, 8, 16, 2, 2, 2),         # bottom level of the 32^3 config
-    (1, 72, 64, 16, 16, 24),     # several full tiles, three Cin chunks
+    (1, 72, 64, 16, 16, 24),     # several full tiles, three Cin chunks (the last one 8 channels: its second k-step is skipped)
+    (2, 48, 48, 16, 16, 32),     # the Swin-UNETR width: 32 + 16 channels, 48 outputs on a 64-wide tile
+    (1, 112, 48, 8, 16, 16),     # three full chunks + 16
 ])
 def test_conv3_raw_and_stats(dtype, shape, conv_variant):
     ops = _ops()

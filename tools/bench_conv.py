@@ -17,6 +17,8 @@ SHAPES = [  # (S, Cin, Cout, fused prologue)
     (24, 64, 128, False), (24, 128, 128, True), (24, 256, 128, False),
     (12, 128, 256, False), (12, 256, 256, True), (12, 512, 256, False),
     (6, 256, 512, False), (6, 512, 512, True),
+    # Swin-UNETR widths (BASELINE config 5): encoder1 / decoder1 at 96^3, encoder2 / decoder2 at 48^3
+    (96, 24, 48, False), (96, 48, 48, True), (96, 96, 48, False), (48, 48, 48, True), (48, 96, 48, False),
 ]
 
 

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f16* Kl = (f16*)smem;                           // [nb*32][16]
   f16* Ql = Kl + MAXB * 32 * HD;                  // [4*32][16]   the four query blocks of this workgroup
-  f16* Vp = Ql + 4 * 32 * HD;                     // [nb][2 s][2 hh][32 rows (dims, 16 real)][8 keys]  (permuted V^T)
-  float* tab = (float*)(Vp + MAXB * 2 * 2 * 32 * 8);                // [MAXTAB] bias table column of this head
+  f16* Vp = Ql + 4 * 32 * HD;                     // [nb][2 s][2 hh][16 rows (dims)][8 keys]  (permuted V^T; MFMA rows 16..31 are zeros)
+  float* tab = (float*)(Vp + MAXB * 2 * 2 * 16 * 8);                // [MAXTAB] bias table column of this head (x log2 e)
   short* koff = (short*)(tab + MAXTAB);                              // [nb*32] coordinate offset of every token
   unsigned char* regl = (unsigned char*)(koff + MAXB * 32);          // [nb*32] region id of every token of the window
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,24 +86,27 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     }
     *(f16x8*)(Ql + (tid >> 1) * HD + half * 8) = q;
   }
-  // Vp[kb][s][h2][row][j] = V[key = kb*32 + 16 s + 8 (j >> 2) + 4 h2 + (j & 3)][dim = row]  (row >= 16: 0)
-  for (int i = tid; i < nb * 2 * 2 * 32; i += 256) {
-    const int row = i & 31, h2 = (i >> 5) & 1, s = (i >> 6) & 1, kb = i >> 7;
+  // Vp[kb][s][h2][row][j] = V[key = kb*32 + 16 s + 8 (j >> 2) + 4 h2 + (j & 3)][dim = row], row < 16
+  for (int i = tid; i < nb * 2 * 2 * 16; i += 256) {
+    const int row = i & 15, h2 = (i >> 4) & 1, s = (i >> 5) & 1, kb = i >> 6;
     f16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int key = kb * 32 + 16 * s + 8 * (j >> 2) + 4 * h2 + (j & 3);
-      v[j] = (row < HD && key < n) ? (f16)(float)base[(long)key * 3 * C + 2 * C + row] : (f16)0.f;
+      v[j] = key < n ? (f16)(float)base[(long)key * 3 * C + 2 * C + row] : (f16)0.f;
     }
     *(f16x8*)(Vp + (long)i * 8) = v;
   }
   const bool has_table = a.table != nullptr;
   const int sh_ = 2 * a.gw - 1, sd_ = (2 * a.gh - 1) * sh_;         // strides of the (dd, dh, dw) difference grid
+  // scores are kept in units of log2 e (scale, bias and mask pre-multiplied): the softmax is exp2 without a multiply per
+  // element; koff holds BYTE offsets into the table so that a lookup address is one subtraction
+  constexpr float LOG2E = 1.4426950408889634f;
   if (has_table) {
-    for (int i = tid; i < a.tab_len; i += 256) tab[i] = a.table[(long)head * a.tab_len + i];
+    for (int i = tid; i < a.tab_len; i += 256) tab[i] = a.table[(long)head * a.tab_len + i] * LOG2E;
     for (int i = tid; i < nb * 32; i += 256) {
       const int t = i < n ? i : 0;
-      koff[i] = (short)((t / (a.gh * a.gw)) * sd_ + ((t / a.gw) % a.gh) * sh_ + t % a.gw);
+      koff[i] = (short)(4 * ((t / (a.gh * a.gw)) * sd_ + ((t / a.gw) % a.gh) * sh_ + t % a.gw));
     }
   }
   const bool has_region = a.region != nullptr;
@@ -121,7 +124,11 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   const int qc = qok ? q : 0;
   const f16x8 qf = *(const f16x8*)(Ql + (wave * 32 + r) * HD + hh * 8);      // B operand: Q^T[dims 8hh..][query r]
   const unsigned char rq = has_region ? regl[qb * 32 + r] : (unsigned char)0;
-  const int qoff = has_table ? (int)koff[qc] + (a.gd - 1) * sd_ + (a.gh - 1) * sh_ + (a.gw - 1) : 0;
+  const int qoff = has_table ? (int)koff[qc] + 4 * ((a.gd - 1) * sd_ + (a.gh - 1) * sh_ + (a.gw - 1)) : 0;   // bytes
+  const float scale2 = a.scale * LOG2E;
+  f16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (f16)0.f;
   // score tile of key block kb for this lane's query: scale * <q, k> + bias + mask (padding keys: -3e38)
   auto scores = [&](int kb) {
     const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
@@ -135,20 +142,20 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
         typedef short short4v __attribute__((ext_vector_type(4)));
         const short4v ko = *(const short4v*)(koff + kb * 32 + 8 * j + 4 * hh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) z[4 * j + e] = fmaf(z[4 * j + e], a.scale, tab[qoff - (int)ko[e]]);
+        for (int e = 0; e < 4; ++e) z[4 * j + e] = fmaf(z[4 * j + e], scale2, *(const float*)((const char*)tab + (qoff - (int)ko[e])));
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = kb * 32 + acc_row(i, hh);
-        z[i] = fmaf(z[i], a.scale, bias[(long)(key < n ? key : 0) * n + qc]);
+        z[i] = fmaf(z[i], scale2, bias[(long)(key < n ? key : 0) * n + qc] * LOG2E);
       }
     }
     if (mask) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = kb * 32 + acc_row(i, hh);
-        z[i] += mask[(long)(key < n ? key : 0) * n + qc];
+        z[i] += mask[(long)(key < n ? key : 0) * n + qc] * LOG2E;
       }
     }
     if (has_region) {                             // compute_mask's 0 / -100 from the region ids
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
       for (int j = 0; j < 4; ++j) {
         const unsigned rk = *(const unsigned*)(regl + kb * 32 + 8 * j + 4 * hh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) z[4 * j + e] += ((rk >> (8 * e)) & 255u) != (unsigned)rq ? -100.f : 0.f;
+        for (int e = 0; e < 4; ++e) z[4 * j + e] += ((rk >> (8 * e)) & 255u) != (unsigned)rq ? -100.f * LOG2E : 0.f;
       }
     }
     if (kb == nb - 1) {                           // only the last block holds padding keys: they never win the max
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     for (int i = 1; i < 16; ++i) bm = fmaxf(bm, z[i]);
     bm = fmaxf(bm, __shfl_xor(bm, 32));
     const float mnew = fmaxf(mx, bm);
-    const float alpha = __expf(mx - mnew);
+    const float alpha = __builtin_amdgcn_exp2f(mx - mnew);
     mx = mnew;
     sum *= alpha;
 #pragma unroll
@@ -188,13 +195,14 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     f16x8 p[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float e = __expf(z[i] - mnew);
+      const float e = __builtin_amdgcn_exp2f(z[i] - mnew);
       sum += e;
       p[i >> 3][i & 7] = (f16)e;
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const f16x8 vf = *(const f16x8*)(Vp + ((long)((kb * 2 + s) * 2 + hh) * 32 + r) * 8);
+      f16x8 vf = zero8;                            // rows 16..31 of the A operand are padding
+      if (r < HD) vf = *(const f16x8*)(Vp + ((long)((kb * 2 + s) * 2 + hh) * 16 + r) * 8);
       O = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, p[s], O, 0, 0, 0);
     }
   }
@@ -234,7 +242,7 @@ extern "C" int dua_window_attention_fwd(int dtype, int windows, int tokens, int 
   }
   a.n = tokens; a.heads = heads; a.nw = (mask_t || region_ids) ? windows_per_image : 1; a.scale = scale;
   const int nb = (tokens + 31) / 32;
-  const int lds = wa::MAXB * 32 * wa::HD * 2 + 4 * 32 * wa::HD * 2 + wa::MAXB * 2 * 2 * 32 * 8 * 2 +      // K, Q, V^T
+  const int lds = wa::MAXB * 32 * wa::HD * 2 + 4 * 32 * wa::HD * 2 + wa::MAXB * 2 * 2 * 16 * 8 * 2 +      // K, Q, V^T
                   wa::MAXTAB * 4 + wa::MAXB * 32 * 2 + wa::MAXB * 32;                                        // table, offsets, regions
   dim3 grid(windows, heads, (nb + 3) / 4);
   if (dtype == DUA_F16) hipLaunchKernelGGL(window_attention_kernel<f16>, grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -33,7 +33,8 @@ constexpr int HALO_BYTES = HD * PS;        // 39360
 constexpr int BN = 64;                     // output channels per workgroup
 }  // namespace c3
 
-// 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones); 2 forces 4x8x8 tiles without split-K, 3 forces 2x8x8
+// 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones); 2 forces 4x8x8 tiles without split-K, 3 forces 2x8x8,
+// 4 forces 8x8x8 tiles (512-thread workgroups)
 int g_conv_variant = 0;
 int g_skip_splitk_finish = 0;   // diagnostics (dua_set_option(2, 1)): time the split-K main kernel alone; outputs are not finished
 extern int g_wgrad_abl;
@@ -69,12 +70,18 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // HALF: the last Cin chunk holds at most one k-step (16 channels) of real input (Cin = 48 = 32 + 16, the Swin-UNETR widths):
 // its second k-step per tap would multiply zero padding and is skipped.  A separate instantiation, so that the common
 // kernel keeps its schedule.
+// TDP = 8: an 8x8x8 tile by EIGHT waves (512 threads, one workgroup per CU -- the same 8 waves per CU as two 4x8x8 workgroups):
+// every weight slab and every halo voxel staged serves twice the output (the packed weights are re-read from L2 by every
+// workgroup: 3 GB per 96^3 layer at 256 voxels per workgroup), and the halo overhead drops from 2.34 to 1.95 input voxels
+// per output voxel.
 template <typename T, int TDP = 4, int NKS = 2, bool HALF = false>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
+__global__ __launch_bounds__(TDP == 8 ? 512 : 256, TDP == 8 ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   using namespace c3v2;
-  constexpr int TD = TDP, HD = TDP + 2, MB = TDP / 2;
+  constexpr int TD = TDP, HD = TDP + 2, MB = TDP == 2 ? 1 : 2;
+  constexpr int NW = TDP == 8 ? 8 : 4, NTHR = 64 * NW;
   constexpr int HALO_BYTES = HD * PS, LDS_MAIN = HALO_BYTES + 2 * SLAB;
-  constexpr int NITEMS = HD * HH * HW * KG, NIT = (NITEMS + 255) / 256;
+  constexpr int NITEMS = HD * HH * HW * KG, NIT = (NITEMS + NTHR - 1) / NTHR;
+  constexpr int NPIECE = SLAB / 16, NSL = (NPIECE + NTHR - 1) / NTHR;      // 16-byte pieces of a weight slab per thread
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
   constexpr int CK = KG * EPG;
@@ -87,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int dwave = TDP == 4 ? wave : wave >> 1;          // depth slice of this wave
-  const int hbase = TDP == 4 ? 0 : (wave & 1) * 4;        // first h row of this wave's block(s)
+  const int dwave = TDP == 2 ? wave >> 1 : wave;          // depth slice of this wave
+  const int hbase = TDP == 2 ? (wave & 1) * 4 : 0;        // first h row of this wave's block(s)
   const int tile = xcd_remap(blockIdx.x, a.ntiles);
   const int ct = blockIdx.y, n = blockIdx.z % a.N;
   const int tw_ = tile % a.tiles_w, th_ = (tile / a.tiles_w) % a.tiles_h, td_ = tile / (a.tiles_w * a.tiles_h);
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off;
 #pragma unroll
   for (int j = 0; j < NIT; ++j) {
-    int it = tid + 256 * j;
+    int it = tid + NTHR * j;
     int hv = it >> 2;
     int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
     int gd = d0 + hd - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
@@ -114,16 +121,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   // counted lgkmcnt wait of the fragment pipeline below into lgkmcnt(0).
   // Two register sets: slab g is loaded during phase g-2 and written to LDS at the end of phase g-1, so
   // an L2 round trip has two MFMA phases to complete.
-  f32x4 wreg[3][3];   // set = (slab index within chunk) % 3, compile-time (9 slabs per chunk keeps the cycle)
+  f32x4 wreg[3][NSL];   // set = (slab index within chunk) % 3, compile-time (9 slabs per chunk keeps the cycle)
   auto load_slab = [&](int g, int set) {       // g = global slab index (chunk * 9 + kd * 3 + kh)
     const char* src = wsrc + (long)g * SLAB + tid * 16;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) wreg[set][j] = *(const f32x4*)(src + j * 4096);
+    for (int j = 0; j < NSL; ++j)
+      if (NPIECE % NTHR == 0 || tid + NTHR * j < NPIECE) wreg[set][j] = *(const f32x4*)(src + j * NTHR * 16);
   };
   auto store_slab = [&](int g, int set) {
     char* dst = wbuf + (g & 1) * SLAB + tid * 16;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) *(f32x4*)(dst + j * 4096) = wreg[set][j];
+    for (int j = 0; j < NSL; ++j)
+      if (NPIECE % NTHR == 0 || tid + NTHR * j < NPIECE) *(f32x4*)(dst + j * NTHR * 16) = wreg[set][j];
   };
   Frag hv_[NIT];
   auto load_halo = [&](int ch) {
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   // tiles that lie fully inside the volume -- all of them at 96/48/24^3 -- skip the per-voxel masks.
   constexpr int OS = 32 * (int)sizeof(T) + 16;
   char* ot = smem + wave * (32 * MB) * OS;
-  float* ex = (float*)(smem + 4 * (32 * MB) * OS);   // [4 waves][64 couts][2]
+  float* ex = (float*)(smem + NW * (32 * MB) * OS);   // [NW waves][64 couts][2]
   const int gd = d0 + dwave;
   const bool dok = gd < a.D;
   const bool full = d0 + TD <= a.D && h0 + TH <= a.H && w0 + TW <= a.W;
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   if (wave == 0) {
     double S = 0, Q = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
+    for (int w = 0; w < NW; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
     if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
   }
 }
@@ -452,6 +461,9 @@ static int ensure_lds_attr() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             c3v2::LDS_MAIN + 3 * 4 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            10 * c3::PS + 2 * c3v2::SLAB + 3 * 4 * 1024);
   if (e != hipSuccess) return (int)e;
   done[dev] = true;
   return 0;
@@ -506,6 +518,12 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2>), grid2, dim3(256), LDS2 + xf_bytes, s, a);
     return (int)hipGetLastError();
   }
+  if (a.ksplit == 1 && g_conv_variant == 4) {        // 8x8x8 tiles, eight waves per workgroup
+    a.ntiles = ((d->D + 7) / 8) * a.tiles_h * a.tiles_w;
+    dim3 grid8(a.ntiles, nct, d->N);
+    hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 8>), grid8, dim3(512), 10 * c3::PS + 2 * c3v2::SLAB + xf_bytes, s, a);
+    return (int)hipGetLastError();
+  }
   dim3 grid(a.ntiles, nct, d->N * a.ksplit);
   if (a.ksplit > 1) {
     hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
@@ -532,7 +550,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
 extern "C" {
 
 int dua_set_option(int key, int value) {
-  if (key == 1 && (value == 0 || value == 2 || value == 3)) { dua::g_conv_variant = value; return 0; }
+  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 4)) { dua::g_conv_variant = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
 #ifdef DUA_ABLATE
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only

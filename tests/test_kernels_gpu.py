@@ -73,7 +73,7 @@ def conv_variant(request):
     nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
 
 
-@pytest.mark.parametrize("conv_variant", [0, 2, 3], indirect=True)
+@pytest.mark.parametrize("conv_variant", [0, 2, 3, 4], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [
     (1, 64, 128, 24, 24, 24),    # auto picks 2x8x8 tiles (108 workgroups of 4x8x8 would half-fill the chip)
@@ -156,7 +156,7 @@ def test_conv3_split_k(dtype, shape):
     assert torch.allclose(ops.from_channels_last(y2, Cout, 8).cpu(), got, **TOL[dtype])
 
 
-@pytest.mark.parametrize("conv_variant", [2, 3], indirect=True)
+@pytest.mark.parametrize("conv_variant", [2, 3, 4], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_conv3_fused_input_transform_and_channel_slices(dtype, conv_variant):
     """Producer IN+LeakyReLU+temb add fused into the consumer's halo staging; input read from and

@@ -113,6 +113,7 @@ _SIGS = {
     "dua_instnorm_stats": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
     "dua_gelu": (C.c_int, [C.c_int, C.c_long, _P, _P]),
     "dua_token_linear": (C.c_int, [C.POINTER(TokenLinearDesc), _P]),
+    "dua_swin_mlp": (C.c_int, [C.c_long, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dua_denoiser_step": (C.c_int, [C.POINTER(DenoiserPlan), _P]),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),

@@ -236,6 +236,127 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
   }
 }
 
+// ---- the whole MLP of a Swin block in one kernel (fp16 operands) -----------------------------------------------------------
+//   x += linear2(GELU(linear1(ln2)))          (MONAI MLPBlock; transformer.py:376,433-434,477-480), hidden = 4 C
+// linear1's accumulator (lane = token, registers = hidden units) IS linear2's B operand after GELU and a conversion to fp16:
+// the 16 hidden units a lane pair holds in registers [8s, 8s+8) of block nb are one k-step of the second product, provided
+// the rows of W2 are stored in the same permuted order (k = nb*32 + 16 s + (e & 3) + 8 (e >> 2) + 4 hh) -- the hidden
+// activation (42 MB per block at 48^3 tokens) never exists in memory.  Hidden units are walked 192 at a time (6 accumulator
+// blocks); with hidden = 192 (C = 48) both weight matrices stay resident in LDS for the whole launch, with hidden = 384
+// (C = 96) each pass reloads its halves.
+struct MlpArgs {
+  const f16* ln; long M; int C, hidden;
+  const f16* W1; const float* b1; const f16* W2; const float* b2;
+  float* x;
+  int w1_row, w2_row, a_row, o_row;       // LDS row strides in bytes
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void swin_mlp_kernel(MlpArgs a) {
+  constexpr int HB = 6, HP = 32 * HB;             // hidden units per pass
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NB2 = (C + 31) >> 5, npass = 4 * C / HP;
+  char* W1l = smem;                               // [HP][w1_row]            rows = hidden units of the pass, k = C
+  char* W2l = W1l + HP * a.w1_row;                // [NB2*32][w2_row]        rows = output channels, k = permuted hidden units of the pass
+  char* At = W2l + NB2 * 32 * a.w2_row;           // [128][a_row] ln2 tile, later [128][o_row] fp32 output tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  constexpr int kg = C >> 3;
+  auto load_weights = [&](int p) {
+    for (int i = tid; i < HP * kg; i += 256) {                    // W1 rows [p*HP, (p+1)*HP)
+      const int n = i / kg, g8 = i - n * kg;
+      *(f16x8*)(W1l + n * a.w1_row + g8 * 16) = *(const f16x8*)(a.W1 + (long)(p * HP + n) * C + g8 * 8);
+    }
+    for (int i = tid; i < NB2 * 32 * HB * 2 * 2; i += 256) {      // W2p[c][nb][s][hh][8] <- W2[c][p*HP + nb*32 + 16 s + perm(hh, e)]
+      const int h2 = i & 1, s2 = (i >> 1) & 1, nb = (i >> 2) % HB, c = i / (4 * HB);
+      f16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = c < C ? a.W2[(long)c * a.hidden + p * HP + nb * 32 + 16 * s2 + (e & 3) + 8 * (e >> 2) + 4 * h2] : (f16)0.f;
+      *(f16x8*)(W2l + c * a.w2_row + ((nb * 2 + s2) * 2 + h2) * 16) = v;
+    }
+  };
+  if constexpr (npass == 1) load_weights(0);
+  const long tiles = (a.M + 127) / 128;
+  for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long tok0 = tile * 128;
+    __syncthreads();
+    for (int c8 = tid; c8 < 128 * kg; c8 += 256) {                // ln2 tile, coalesced
+      const int row = c8 / kg, col = c8 - row * kg;
+      f16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
+      if (tok0 + row < a.M) v = *(const f16x8*)(a.ln + (tok0 + row) * C + col * 8);
+      *(f16x8*)(At + row * a.a_row + col * 16) = v;
+    }
+    f32x16 acc2[NB2];
+#pragma unroll
+    for (int nb = 0; nb < NB2; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc2[nb][i] = 0.f;
+    for (int p = 0; p < npass; ++p) {
+      if constexpr (npass > 1) { __syncthreads(); load_weights(p); }
+      __syncthreads();
+      // ---- linear1: 192 hidden units x 32 tokens per wave ----
+      f32x16 acc1[HB];
+#pragma unroll
+      for (int nb = 0; nb < HB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[nb][i] = 0.f;
+      const char* arow = At + (wave * 32 + r) * a.a_row;
+      for (int ks = 0; ks * 16 < C; ++ks) {
+        const f16x8 bf = *(const f16x8*)(arow + (16 * ks + 8 * hh) * 2);
+#pragma unroll
+        for (int nb = 0; nb < HB; ++nb) {
+          const f16x8 af = *(const f16x8*)(W1l + (nb * 32 + r) * a.w1_row + (16 * ks + 8 * hh) * 2);
+          acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc1[nb], 0, 0, 0);
+        }
+      }
+      // ---- + bias, GELU, to fp16: the B operand of linear2; linear2 accumulates over the passes ----
+#pragma unroll
+      for (int nb = 0; nb < HB; ++nb) {
+        f16x8 g[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int hu = p * HP + nb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          g[i >> 3][i & 7] = (f16)gelu_erf(acc1[nb][i] + a.b1[hu]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int cb = 0; cb < NB2; ++cb) {
+            const f16x8 af = *(const f16x8*)(W2l + (cb * 32 + r) * a.w2_row + ((nb * 2 + s2) * 2 + hh) * 16);
+            acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, g[s2], acc2[cb], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();                                              // the ln2 tile is dead: reuse it for the output
+    char* orow = At + (wave * 32 + r) * a.o_row;
+#pragma unroll
+    for (int cb = 0; cb < NB2; ++cb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c0 = cb * 32 + 8 * j + 4 * hh;
+        if (c0 < C)
+          *(f32x4*)(orow + c0 * 4) = f32x4{acc2[cb][4 * j] + a.b2[c0], acc2[cb][4 * j + 1] + a.b2[c0 + 1],
+                                           acc2[cb][4 * j + 2] + a.b2[c0 + 2], acc2[cb][4 * j + 3] + a.b2[c0 + 3]};
+      }
+    }
+    __syncthreads();
+    constexpr int cpr = C >> 2;
+    for (int c4 = tid; c4 < 128 * cpr; c4 += 256) {               // x += out, coalesced 16-byte read-modify-write
+      const int row = c4 / cpr, col = c4 - row * cpr;
+      if (tok0 + row < a.M) {
+        float* xp = a.x + (tok0 + row) * C + col * 4;
+        f32x4 xv = *(const f32x4*)xp;
+        const f32x4 dv = *(const f32x4*)(At + row * a.o_row + col * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] += dv[e];
+        *(f32x4*)xp = xv;
+      }
+    }
+  }
+}
+
 // ---- PatchEmbed on the matrix cores (fp16) --------------------------------------------------------------------------
 // Conv3d(k = s = 2) = a [tokens x 8 Cp] x [8 Cp -> 48] GEMM whose A row is gathered from the 2x2x2 voxels of the token (each
 // Cp channels = Cp * 2 contiguous bytes).  Same tile scheme as token_linear; the epilogue is stage_out's: + bias + t_proj row,
@@ -375,6 +496,30 @@ int launch_patch_embed_mfma(int B, int D, int H, int W, int Cs, int Cp, const vo
 }
 
 }  // namespace dua
+
+extern "C" int dua_swin_mlp(long tokens, int C, const void* ln2, const void* W1, const float* b1, const void* W2, const float* b2,
+                            float* x, void* stream) {
+  using namespace dua;
+  if (tokens <= 0 || (C != 48 && C != 96) || !ln2 || !W1 || !b1 || !W2 || !b2 || !x) return DUA_ERR_ARG;
+  MlpArgs a;
+  a.ln = (const f16*)ln2; a.M = tokens; a.C = C; a.hidden = 4 * C; a.W1 = (const f16*)W1; a.b1 = b1; a.W2 = (const f16*)W2; a.b2 = b2;
+  a.x = x;
+  a.w1_row = padded_row(C * 2); a.w2_row = padded_row(192 * 2); a.a_row = padded_row(C * 2); a.o_row = padded_row(C * 4);
+  const int nb2 = (C + 31) / 32;
+  const int lds = 192 * a.w1_row + nb2 * 32 * a.w2_row + 128 * (a.a_row > a.o_row ? a.a_row : a.o_row);
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute((const void*)swin_mlp_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)swin_mlp_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return DUA_ERR_ARG;
+    raised = true;
+  }
+  const long tiles = (tokens + 127) / 128;
+  dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
+  if (C == 48) hipLaunchKernelGGL(swin_mlp_kernel<48>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(swin_mlp_kernel<96>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
 
 extern "C" int dua_token_linear(const dua_token_linear_desc* d, void* stream) {
   using namespace dua;

@@ -856,3 +856,18 @@ def token_linear(A, W, bias=None, mode="plain", out=None, out_off=0, x=None, sta
         d.geom, d.gamma, d.beta, d.eps, d.ln_out = geom, gamma.data_ptr(), beta.data_ptr(), eps, ln_out.data_ptr()
     nv.check(nv.lib().dua_token_linear(C.byref(d), nv.stream_ptr()), "dua_token_linear")
     return out if mode in ("plain", "gelu", "stats") else x
+
+
+def swin_mlp(ln2, w1, b1, w2, b2, x):
+    """x += linear2(GELU(linear1(ln2))) in one launch (dua_swin_mlp): ln2 fp16 [tokens, C], w1 fp16 [4C, C], w2 fp16 [C, 4C],
+    biases fp32, x the fp32 stream [tokens, C] (updated in place).  C = 48 or 96."""
+    assert ln2.is_cuda and ln2.dtype == torch.float16 and ln2.is_contiguous() and ln2.dim() == 2
+    M, Cc = ln2.shape
+    assert Cc in (48, 96) and tuple(w1.shape) == (4 * Cc, Cc) and tuple(w2.shape) == (Cc, 4 * Cc)
+    assert w1.dtype == w2.dtype == torch.float16 and w1.is_contiguous() and w2.is_contiguous()
+    _f32c(b1, "b1"); _f32c(b2, "b2")
+    assert b1.numel() == 4 * Cc and b2.numel() == Cc
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == M * Cc
+    nv.check(nv.lib().dua_swin_mlp(M, Cc, nv.ptr(ln2), nv.ptr(w1), nv.ptr(b1), nv.ptr(w2), nv.ptr(b2), nv.ptr(x), nv.stream_ptr()),
+             "dua_swin_mlp")
+    return x

@@ -146,6 +146,7 @@ class SwinPlan:
         self.ln2 = torch.zeros(tok_max, dtype=dtype, device=device)
         self.merged = torch.zeros(tok_max, dtype=dtype, device=device)        # gathered + normalised 8C tokens (= tokens * C)
         self.fused_linear = dtype == torch.float16                            # swin_gemm.hip is an fp16-operand kernel
+        self.fused_mlp = True
         if self.fused_linear:
             self.qkv_buf = torch.zeros(3 * tok_max, dtype=dtype, device=device)
             self.hid_buf = torch.zeros(4 * tok_max, dtype=dtype, device=device)
@@ -357,8 +358,11 @@ class SwinPlan:
                 if fused:
                     ops.token_linear(att.view(-1, C_), b["wproj"], b["fproj"], "scatter", x=x, geom=geom, gamma=b["g2"],
                                      beta=b["b2"], ln_out=ln2)
-                    ops.token_linear(ln2, b["w1"], b["f1"], "gelu", out=hid)
-                    ops.token_linear(hid, b["w2"], b["f2"], "residual", x=x)       # x + mlp(norm2(x)) lands in the stream
+                    if self.fused_mlp:                                             # linear1 + GELU + linear2 + residual, one launch
+                        ops.swin_mlp(ln2, b["w1"], b["f1"], b["w2"], b["f2"], x)
+                    else:
+                        ops.token_linear(ln2, b["w1"], b["f1"], "gelu", out=hid)
+                        ops.token_linear(hid, b["w2"], b["f2"], "residual", x=x)   # x + mlp(norm2(x)) lands in the stream
                 else:
                     po = F.linear(att, b["wproj"], b["bproj"])
                     ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)

@@ -410,6 +410,13 @@ typedef struct dua_token_linear_desc {
 } dua_token_linear_desc;
 int dua_token_linear(const dua_token_linear_desc* d, void* stream);
 
+/* The MLP of a Swin block in one launch (fp16 operands, C = 48 or 96, hidden = 4 C): x[token] += linear2(GELU(linear1(ln2[token])))
+ * on the fp32 stream (MONAI MLPBlock; transformer.py:376,433-434,477-480).  ln2: fp16 [tokens][C] (norm2 of the stream, from
+ * dua_token_linear SCATTER / dua_window_scatter_add_norm); W1 [4C][C], W2 [C][4C]: the nn.Linear weights as they are (fp16);
+ * b1 [4C], b2 [C]: fp32.  The hidden activation stays in registers (linear1's accumulator is linear2's operand). */
+int dua_swin_mlp(long tokens, int C, const void* ln2, const void* W1, const float* b1, const void* W2, const float* b2, float* x,
+                 void* stream);
+
 /* Exact (erf) GELU in place between the two MLP GEMMs (MONAI MLPBlock act "GELU"). */
 int dua_gelu(int dtype, long elems, void* x, void* stream);
 

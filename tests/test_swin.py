@@ -505,3 +505,29 @@ def test_diff_swin_unetr_under_the_sliding_window_caller():
     print(f"swin under the sliding window: {count[0]} windows, blended sum-x0 max |d| {d.max():.2e} mean {d.mean():.2e}")
     assert count[0] == 2 and got.shape == (1, 3, 64, 64, 96)
     assert d.max() < 5e-4 and d.mean() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C_,M", [(48, 1000), (96, 777), (48, 128), (96, 13824)])
+def test_fused_swin_mlp_kernel_matches_torch(C_, M):
+    """dua_swin_mlp (linear1 + GELU + linear2 + residual on the fp32 stream, hidden activation in registers) against
+    torch.nn.functional on the same fp16 operands, and against the two-launch token_linear form."""
+    import torch.nn.functional as F
+    from diff_unet_amos_amd import ops
+    g = torch.Generator().manual_seed(C_ + M)
+    dev = "cuda"
+    ln2 = torch.randn(M, C_, generator=g).half().to(dev)
+    w1 = (torch.randn(4 * C_, C_, generator=g) / C_ ** 0.5).half().to(dev)
+    w2 = (torch.randn(C_, 4 * C_, generator=g) / (4 * C_) ** 0.5).half().to(dev)
+    b1, b2 = torch.randn(4 * C_, generator=g).to(dev), torch.randn(C_, generator=g).to(dev)
+    x0 = torch.randn(M, C_, generator=g).to(dev)
+    h = F.gelu(F.linear(ln2.float(), w1.float(), b1))
+    want = x0 + F.linear(h.half().float(), w2.float(), b2)           # the hidden activation feeds linear2 as fp16 in both forms
+    xa = x0.clone()
+    ops.swin_mlp(ln2, w1, b1, w2, b2, xa)
+    assert (xa - want).abs().max() < 3e-3 * max(1.0, float(want.abs().max()))
+    xb = x0.clone()
+    hid = torch.empty(M, 4 * C_, dtype=torch.float16, device=dev)
+    ops.token_linear(ln2, w1, b1, "gelu", out=hid)
+    ops.token_linear(hid, w2, b2, "residual", x=xb)
+    assert (xa - xb).abs().max() < 2e-3 * max(1.0, float(want.abs().max()))

@@ -147,6 +147,10 @@ class SwinPlan:
         self.merged = torch.zeros(tok_max, dtype=dtype, device=device)        # gathered + normalised 8C tokens (= tokens * C)
         self.fused_linear = dtype == torch.float16                            # swin_gemm.hip is an fp16-operand kernel
         self.fused_mlp = True
+        self.fused_reduction = False
+        # stage 0 only (110 592 tokens x 48): at stage 1 (13 824 x 96) a launch has ~100 tiles and the library's 10 us GEMMs
+        # beat the per-workgroup weight staging of the fused kernels (same-process A/B, tools/bench_swin_ab.py)
+        self.fused_max_c = 48
         if self.fused_linear:
             self.qkv_buf = torch.zeros(3 * tok_max, dtype=dtype, device=device)
             self.hid_buf = torch.zeros(4 * tok_max, dtype=dtype, device=device)
@@ -341,7 +345,7 @@ class SwinPlan:
             att = self.att[:ntok_w * C_].view(N * g["nw"], g["n"], C_)
             ln2 = self.ln2[:ntok * C_].view(ntok, C_)
             y = None
-            fused = self.fused_linear and C_ <= 96          # tall token GEMMs with fused epilogues (swin_gemm.hip)
+            fused = self.fused_linear and C_ <= self.fused_max_c     # tall token GEMMs with fused epilogues (swin_gemm.hip)
             if fused:
                 qkv_buf = self.qkv_buf[:ntok_w * 3 * C_].view(N * g["nw"], g["n"], 3 * C_)
                 hid = self.hid_buf[:ntok * 4 * C_].view(ntok, 4 * C_)
@@ -373,7 +377,7 @@ class SwinPlan:
             mshape = (N, (dims[0] + 1) // 2, (dims[1] + 1) // 2, (dims[2] + 1) // 2, 8 * C_)
             merged = self.merged[:mshape[0] * mshape[1] * mshape[2] * mshape[3] * mshape[4]].view(mshape)
             ops.patch_merge_norm(x, st["gm"], st["bm"], legacy=True, y=y, dtype=dt, out=merged)
-            if fused and 8 * C_ <= 384:
+            if fused and 8 * C_ <= 384 and self.fused_reduction:
                 red = ops.token_linear(merged.view(-1, 8 * C_), st["wred"], None, "plain",
                                        out=self.red_buf[:merged.numel() // 4].view(-1, 2 * C_))
             else:

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Same-process A/B of SwinPlan switches on the config-5 step (96^3, 16 classes, one patch): each setting is captured into its
+own HIP graph, rounds are interleaved.  usage: bench_swin_ab.py [rounds] [steps per round]
+Settings: two_streams, fused_mlp, fused_linear, fused_max_c, fused_reduction (swin_engine.SwinPlan attributes)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diff_unet_amos_amd import _native as nv, ops                     # noqa: E402
+from diff_unet_amos_amd.diff_swin_unetr import DiffSwinUNETR          # noqa: E402
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = DiffSwinUNETR(in_channels=1, out_channels=16, feature_size=48).to(dev).eval()
+    image = torch.rand(1, 1, 96, 96, 96, device=dev)
+    plan = net._rt.plan(1, (96, 96, 96), dev)
+    settings = {"default": {}, "fused kernels at stage 1 too": {"fused_max_c": 96}, "fused reduction": {"fused_reduction": True},
+                "one-kernel MLP off": {"fused_mlp": False}, "one stream": {"two_streams": False}, "library GEMMs": {"fused_linear": False}}
+    base = {k: getattr(plan, k) for k in ("two_streams", "fused_mlp", "fused_linear", "fused_max_c", "fused_reduction")}
+    graphs = {}
+    with torch.no_grad():
+        net.embed_model(image)
+        T = net.diffusion.num_timesteps
+        order = list(range(T))[::-1]
+        coef_table = net.diffusion.ddpm_coef(torch.tensor(order)).to(dev).contiguous()
+        row_of_step = torch.tensor(order, dtype=torch.int32, device=dev)
+        plan.new_seed(3)
+
+        def one_step():
+            ops.step_begin(1, plan.temb_table, plan.cur_add, row_of_step=row_of_step, counter=plan.counter, coef_table=coef_table,
+                           cur_coef=plan.cur_coef, step_word=plan.step_word, err_word=plan.err_word)
+            plan.denoiser_body()
+            plan.tail(nv.MODE_DDPM)
+
+        for name, kv in settings.items():
+            for k, v in {**base, **kv}.items():
+                setattr(plan, k, v)
+            plan.counter.zero_()
+            one_step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step()
+            graphs[name] = g
+        res = {n: [] for n in graphs}
+        for _ in range(rounds):
+            for name, g in graphs.items():
+                plan.counter.zero_()
+                g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    g.replay()
+                torch.cuda.synchronize()
+                res[name].append((time.perf_counter() - t0) / steps * 1e3)
+    for name, v in res.items():
+        v = sorted(v)
+        print(f"{name:22s} median {v[len(v) // 2]:.3f} ms  best {v[0]:.3f}  ({' '.join(f'{x:.3f}' for x in v)})")
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,7 @@ class SwinPlan:
         self.fused_linear = dtype == torch.float16                            # swin_gemm.hip is an fp16-operand kernel
         self.fused_mlp = True
         self.fused_reduction = False
+        self.tl_qkv = self.tl_proj = self.tl_conv3 = True
         # stage 0 only (110 592 tokens x 48): at stage 1 (13 824 x 96) a launch has ~100 tiles and the library's 10 us GEMMs
         # beat the per-workgroup weight staging of the fused kernels (same-process A/B, tools/bench_swin_ab.py)
         self.fused_max_c = 48
@@ -315,7 +316,7 @@ class SwinPlan:
         if r.has3:
             res = self._view(b3, l, r.cout)
             x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
-            if self.fused_linear and r.cout <= 64 and cin <= 384:
+            if self.fused_linear and self.tl_conv3 and r.cout <= 64 and cin <= 384:
                 ops.token_linear(x2, r.w3, None, "stats", out=res.view(-1, r.cout), stats=r.st[2], samples=N)   # conv3 + norm3 sums
             else:
                 torch.matmul(x2, r.w3.t(), out=res.view(-1, r.cout))                 # 1x1x1 conv3 = library GEMM
@@ -353,15 +354,18 @@ class SwinPlan:
                 shifted = k % 2 == 1 and any(g["ss"])
                 geom = g["g1"] if shifted else g["g0"]
                 ops.window_gather_norm(x, geom, b["g1"], b["b1"], win, y=y)
-                if fused:
+                if fused and self.tl_qkv:
                     qkv = ops.token_linear(win.view(-1, C_), b["wqkv"], b["fqkv"], "plain", out=qkv_buf)
                 else:
                     qkv = F.linear(win, b["wqkv"], b["bqkv"])
                 ops.window_attention(qkv, HEADS[i], None, region_ids=g["region"] if shifted else None,
                                      windows_per_image=g["nw"], out=att, bias_table=b["table"], table_grid=WINDOW)
                 if fused:
-                    ops.token_linear(att.view(-1, C_), b["wproj"], b["fproj"], "scatter", x=x, geom=geom, gamma=b["g2"],
-                                     beta=b["b2"], ln_out=ln2)
+                    if self.tl_proj:
+                        ops.token_linear(att.view(-1, C_), b["wproj"], b["fproj"], "scatter", x=x, geom=geom, gamma=b["g2"],
+                                         beta=b["b2"], ln_out=ln2)
+                    else:
+                        ops.window_scatter_add_norm(x, geom, F.linear(att, b["wproj"], b["bproj"]), b["g2"], b["b2"], ln2)
                     if self.fused_mlp:                                             # linear1 + GELU + linear2 + residual, one launch
                         ops.swin_mlp(ln2, b["w1"], b["f1"], b["w2"], b["f2"], x)
                     else:

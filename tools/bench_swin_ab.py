@@ -22,8 +22,11 @@ def main():
     image = torch.rand(1, 1, 96, 96, 96, device=dev)
     plan = net._rt.plan(1, (96, 96, 96), dev)
     settings = {"default": {}, "fused kernels at stage 1 too": {"fused_max_c": 96}, "fused reduction": {"fused_reduction": True},
-                "one-kernel MLP off": {"fused_mlp": False}, "one stream": {"two_streams": False}, "library GEMMs": {"fused_linear": False}}
-    base = {k: getattr(plan, k) for k in ("two_streams", "fused_mlp", "fused_linear", "fused_max_c", "fused_reduction")}
+                "one-kernel MLP off": {"fused_mlp": False}, "one stream": {"two_streams": False}, "library GEMMs": {"fused_linear": False},
+                "library qkv": {"tl_qkv": False}, "library proj + scatter kernel": {"tl_proj": False},
+                "library conv3 + stats kernel": {"tl_conv3": False}}
+    base = {k: getattr(plan, k) for k in ("two_streams", "fused_mlp", "fused_linear", "fused_max_c", "fused_reduction", "tl_qkv",
+                                          "tl_proj", "tl_conv3")}
     graphs = {}
     with torch.no_grad():
         net.embed_model(image)

@@ -13,7 +13,8 @@ struct Conv3Args {
   int Cout, Cout_stride, Cout_off;
   int nchunks, ntiles, tiles_h, tiles_w, cout_pad;
   int ksplit, units_per_split;      // split-K over (chunk, kd) units; partial tiles go to `part` in fp32
-  float* part;
+  float* part;                      // fp32 partial tiles [ks][n][voxel][cout_pad]: split-K, or the partial-sum form (ksplit 1)
+  const float* init;                // fp32 [n][voxel][cout_pad] added to the accumulators at the start, or null
   int tap_ch;                       // single-channel tap form: packed index of that channel, else -1
 };
 

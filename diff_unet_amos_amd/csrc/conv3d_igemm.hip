@@ -164,11 +164,27 @@ __global__ __launch_bounds__(TDP == 8 ? 512 : 256, TDP == 8 ? 1 : 2) void conv3d
   f32x16 acc[MB][2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const float b0 = a.ksplit > 1 ? 0.f : a.bias[ct * BN + q * 32 + r];
+    const float b0 = a.part ? 0.f : a.bias[ct * BN + q * 32 + r];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][q][i] = b0;
+  }
+  // conv(cat[a | b]) = conv_a(a) + conv_b(b): the other part's fp32 tile sums (dua_conv3d_k3_partial) join the accumulators
+  // here.  They are stored in the accumulators' own layout ([n][tile][cout tile][wave][m][q][lane][16 floats]: the two launches
+  // share shape, tiling and grid), so this is 4 x 16-byte loads per accumulator, consecutive lanes on consecutive 64 bytes,
+  // all requested before the first slab is waited for.  (Per-element loads from a [voxel][channel] buffer cost 80 us of
+  // a 230 us launch.)
+  if (a.init) {
+    const float* ip = a.init + ((((long)n * a.ntiles + tile) * gridDim.y + ct) * NW + wave) * (MB * 2 * 64 * 16) + lane * 16;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x16 pv = *(const f32x16*)(ip + (m * 2 + q) * 64 * 16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][q][i] += pv[i];
+      }
   }
 
   // ---- work range: units u = chunk * 3 + kd, three (kd, kh) slabs each ----
@@ -280,7 +296,16 @@ __global__ __launch_bounds__(TDP == 8 ? 512 : 256, TDP == 8 ? 1 : 2) void conv3d
     }
     __syncthreads();     // the epilogue's staging tile reuses the halo; nobody may still be gathering from it
   }
-  if (a.ksplit > 1) {
+  if (a.part != nullptr && a.ksplit == 1) {
+    // ---- partial-sum form (dua_conv3d_k3_partial): the accumulators as they are, see a.init above ----
+    float* pw = a.part + ((((long)n * a.ntiles + tile) * gridDim.y + ct) * NW + wave) * (MB * 2 * 64 * 16) + lane * 16;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) *(f32x16*)(pw + (m * 2 + q) * 64 * 16) = acc[m][q];
+    return;
+  }
+  if (a.part != nullptr) {
     // ---- split-K: this workgroup's fp32 partial tile goes to part[ks][n][voxel][cout_pad] ----
     constexpr int OSF = 32 * 4 + 16;
     char* otf = smem + wave * (32 * MB) * OSF;
@@ -440,6 +465,11 @@ static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups) 
   *ksplit = (units + *ups - 1) / *ups;
 }
 
+// The partial-sum launch (dua_conv3d_k3_partial) is meant to run on a second stream UNDER other launches: it asks for enough
+// extra LDS that only ONE of its workgroups fits a CU, so that every CU keeps 64 KB and half its wave slots free for the
+// main stream's workgroups (two of them per CU leave no room: the co-running launches then wait for retiring workgroups).
+constexpr int PARTIAL_LDS_PAD = 36 * 1024;
+
 // hipFuncSetAttribute is per device: remember which devices have the dynamic-LDS limit raised
 template <typename T>
 static int ensure_lds_attr() {
@@ -448,7 +478,7 @@ static int ensure_lds_attr() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DUA_ERR_ARG;
   if (done[dev]) return 0;
   hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     c3v2::LDS_MAIN + 3 * 4 * 1024);
+                                     c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD);
   if constexpr (sizeof(T) == 2) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 4096);
@@ -471,7 +501,8 @@ static int ensure_lds_attr() {
 
 template <typename T>
 static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
-                        const dua_in_norm* in, void* y, double* stats, float* ws, long ws_bytes, hipStream_t s) {
+                        const dua_in_norm* in, void* y, double* stats, float* ws, long ws_bytes, hipStream_t s,
+                        float* part_out = nullptr, const float* init = nullptr) {
   using namespace c3;
   constexpr int CK = KG * Elem<T>::EPG;
   Conv3Args a;
@@ -486,7 +517,8 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   a.ntiles = td * a.tiles_h * a.tiles_w;
   const int nct = (d->Cout + BN - 1) / BN;
   a.cout_pad = nct * BN;
-  a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = nullptr; a.tap_ch = -1;
+  a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = part_out; a.init = init; a.tap_ch = -1;
+  if (part_out || init) { ws = nullptr; if (d->tap_channel_plus1 > 0) return DUA_ERR_ARG; }     // the two-part form is never split-K
   if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
   const int xf_bytes = in && in->stats ? 3 * 4 * a.nchunks * CK : 0;
   if (int e = ensure_lds_attr<T>()) return e;
@@ -538,7 +570,9 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
     return (int)hipGetLastError();
   }
-  if (sizeof(T) == 2 && d->Cin - (a.nchunks - 1) * CK <= CK / 2)       // e.g. Cin = 48: the last chunk is half padding
+  if (part_out)                                                        // one workgroup per CU, see PARTIAL_LDS_PAD
+    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes + PARTIAL_LDS_PAD, s, a);
+  else if (sizeof(T) == 2 && d->Cin - (a.nchunks - 1) * CK <= CK / 2)       // e.g. Cin = 48: the last chunk is half padding
     hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 2, true>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
   else
     hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
@@ -556,6 +590,39 @@ int dua_set_option(int key, int value) {
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only
 #endif
   if (key == 4 && value >= 0 && value < 128) { dua::g_wgrad_variant = value; return 0; }
+  return DUA_ERR_ARG;
+}
+
+long dua_conv3d_k3_partial_bytes(const dua_conv3_desc* d) {
+  using namespace dua::c3;
+  if (!d || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return DUA_ERR_ARG;
+  // whole tiles of the smallest tile shape the launcher may pick (2x8x8), 64-wide output tiles, fp32
+  const long tiles = (long)((d->D + 1) / 2) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
+  return tiles * 2 * TH * TW * ((d->Cout + BN - 1) / BN) * BN * 4 * d->N;
+}
+
+int dua_conv3d_k3_partial(const dua_conv3_desc* d, const void* x, const void* w_packed, const dua_in_norm* in, float* partial,
+                          void* stream) {
+  if (!d || !x || !w_packed || !partial || d->tap_channel_plus1) return DUA_ERR_ARG;
+  if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cin_off % 8) return DUA_ERR_ARG;
+  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin)) return DUA_ERR_ARG;
+  if (d->dtype == DUA_F16)
+    return dua::launch_conv3<dua::f16>(d, x, w_packed, nullptr, in, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, partial, nullptr);
+  if (d->dtype == DUA_F32)
+    return dua::launch_conv3<float>(d, x, w_packed, nullptr, in, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, partial, nullptr);
+  return DUA_ERR_ARG;
+}
+
+int dua_conv3d_k3_fwd_acc(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
+                          const dua_in_norm* in, const float* partial, void* y, double* out_stats, void* stream) {
+  if (!d || !x || !w_packed || !bias_padded || !partial || !y || !out_stats || d->tap_channel_plus1) return DUA_ERR_ARG;
+  if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)
+    return DUA_ERR_ARG;
+  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin)) return DUA_ERR_ARG;
+  if (d->dtype == DUA_F16)
+    return dua::launch_conv3<dua::f16>(d, x, w_packed, bias_padded, in, y, out_stats, nullptr, 0, (hipStream_t)stream, nullptr, partial);
+  if (d->dtype == DUA_F32)
+    return dua::launch_conv3<float>(d, x, w_packed, bias_padded, in, y, out_stats, nullptr, 0, (hipStream_t)stream, nullptr, partial);
   return DUA_ERR_ARG;
 }
 

@@ -36,6 +36,44 @@ class recording:
         return False
 
 
+# ---- second stream -------------------------------------------------------------------------------------------------
+# ``with side_stream(stream): ...`` runs the enclosed launches on ``stream`` after it has waited for everything enqueued on
+# the current stream (fork); ``join_stream(stream)`` makes the current stream wait for it.  Under ``recording`` the same
+# calls append FORK / JOIN ops and mark the enclosed ops side = 1 for dua_denoiser_step.
+_SIDE = 0
+
+
+class side_stream:
+    def __init__(self, stream):
+        self.stream = stream
+        self.ctx = None
+
+    def __enter__(self):
+        global _SIDE
+        assert _SIDE == 0
+        if _RECORD is not None:
+            _RECORD.append(nv.StepOp(nv.OP_FORK))
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+        _SIDE = 1
+
+    def __exit__(self, *exc):
+        global _SIDE
+        _SIDE = 0
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_stream(stream):
+    if _RECORD is not None:
+        _RECORD.append(nv.StepOp(nv.OP_JOIN))
+    else:
+        torch.cuda.current_stream().wait_stream(stream)
+
+
 def _norm_value(norm, N, Cc):
     """(has_norm, nv.InNorm by value) for a StepOp."""
     if norm is None:
@@ -246,12 +284,15 @@ def conv3_workspace_bytes(dtype, N, D, H, W, cin, cout):
     return int(nv.lib().dua_conv3d_k3_workspace(C.byref(d)))
 
 
-def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None, workspace=None, tap_channel=None):
+def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None, workspace=None, tap_channel=None,
+              init=None):
     """Raw 3x3x3 convolution (+bias); ``norm`` = producer descriptor of x (fused IN+LeakyReLU+add);
     accumulates this layer's InstanceNorm sums into ``out_stats`` (must be zero on entry).
     ``tap_channel`` (0 or 16, fp16, cin == tap_channel + 8): the single-channel tap form for first layers -- that packed
     channel is the last real input channel and is contracted as two k-steps over its 27 taps (weights packed with the
-    same ``tap_channel``)."""
+    same ``tap_channel``).
+    ``init`` (fp32 [N, D, H, W, ceil(cout/64)*64] from conv3d_k3_partial): the other part of a convolution over a channel
+    concatenation; the accumulators start from bias + init (dua_conv3d_k3_fwd_acc)."""
     _cl_check(x, "x"); _cl_check(y, "y")
     assert x.dtype == y.dtype and x.device == y.device
     N, D, H, W, cs_in = x.shape
@@ -270,10 +311,17 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
     assert out_stats.dtype == torch.float64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, nct * 64, 2)
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off,
                      0 if tap_channel is None else tap_channel + 1)
+    if init is not None:
+        assert tap_channel is None and init.is_cuda and init.dtype == torch.float32 and init.is_contiguous()
+        assert init.numel() * 4 >= conv3_partial_bytes(x.dtype, N, D, H, W, cout)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, cin)
-        _RECORD.append(nv.StepOp(nv.OP_CONV3, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),
-                                 _addr(y), _addr(out_stats), None, None))
+        _RECORD.append(nv.StepOp(nv.OP_CONV3 if init is None else nv.OP_CONV3_ACC, _SIDE, _addr(init), has, d, nv.MaterializeDesc(),
+                                 nval, _addr(x), _addr(w_packed), _addr(bias_pad), _addr(y), _addr(out_stats), None, None))
+        return
+    if init is not None:
+        nv.check(nv.lib().dua_conv3d_k3_fwd_acc(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),
+                                                nv.ptr(init), nv.ptr(y), nv.ptr(out_stats), nv.stream_ptr()), "dua_conv3d_k3_fwd_acc")
         return
     ws_bytes = 0
     if workspace is not None:
@@ -282,6 +330,33 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
     nv.check(nv.lib().dua_conv3d_k3_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),
                                         nv.ptr(y), nv.ptr(out_stats), nv.ptr(workspace), ws_bytes, nv.stream_ptr()),
              "dua_conv3d_k3_fwd")
+
+
+def conv3_partial_bytes(dtype, N, D, H, W, cout):
+    d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, 8, 8, 0, cout, cout, 0, 0)
+    return int(nv.lib().dua_conv3d_k3_partial_bytes(C.byref(d)))
+
+
+def conv3d_k3_partial(x, cin, cin_off, w_packed, cout, partial, norm=None):
+    """fp32 tile sums of the convolution of channels [cin_off, cin_off + cin) of ``x`` with ``w_packed`` (no bias, no
+    statistics) into ``partial`` (fp32, conv3_partial_bytes(...) bytes, the kernel's accumulator layout): one part of a
+    convolution over a channel concatenation (dua_conv3d_k3_partial); the other part takes it as ``init``."""
+    _cl_check(x, "x")
+    N, D, H, W, cs_in = x.shape
+    assert cin % 8 == 0 and cin_off % 8 == 0 and cin_off + cin <= cs_in and cout % 8 == 0
+    ck = chunk_elems(x.dtype)
+    nch, nct = -(-cin // ck), -(-cout // 64)
+    assert w_packed.numel() == nct * nch * 27 * 4 * 64 * 16, "packed weights do not match (Cin, Cout, dtype)"
+    assert partial.is_cuda and partial.dtype == torch.float32 and partial.is_contiguous()
+    assert partial.numel() * 4 >= conv3_partial_bytes(x.dtype, N, D, H, W, cout)
+    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, nct * 64, 0, 0)
+    if _RECORD is not None:
+        has, nval = _norm_value(norm, N, cin)
+        _RECORD.append(nv.StepOp(nv.OP_CONV3_PARTIAL, _SIDE, None, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), None,
+                                 _addr(partial), None, None, None))
+        return
+    nv.check(nv.lib().dua_conv3d_k3_partial(C.byref(d), nv.ptr(x), nv.ptr(w_packed), _norm_ref(norm, N, cin), nv.ptr(partial),
+                                            nv.stream_ptr()), "dua_conv3d_k3_partial")
 
 
 def conv3d_k3_wgrad(x, cin, cin_off, dy, cout, cout_off, dw, perm=None, workspace=None):
@@ -506,7 +581,7 @@ def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None):
     d = nv.MaterializeDesc(nv.dt_code(raw.dtype), N, D, H, W, Cc, rs, es, out.shape[-1], out_off, ps)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, Cc)
-        _RECORD.append(nv.StepOp(nv.OP_MATERIALIZE, has, nv.Conv3Desc(), d, nval, _addr(raw), None, None, _addr(out), None,
+        _RECORD.append(nv.StepOp(nv.OP_MATERIALIZE, _SIDE, None, has, nv.Conv3Desc(), d, nval, _addr(raw), None, None, _addr(out), None,
                                  _addr(emb), _addr(pooled)))
         return
     nv.check(nv.lib().dua_materialize(C.byref(d), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(emb), nv.ptr(out),
@@ -527,7 +602,7 @@ def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=Non
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, cin)
-        _RECORD.append(nv.StepOp(nv.OP_DECONV, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),
+        _RECORD.append(nv.StepOp(nv.OP_DECONV, _SIDE, None, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),
                                  _addr(y), None, None, None))
         return
     nv.check(nv.lib().dua_deconv_k2s2_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),

@@ -67,6 +67,21 @@ int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_pack
                       const dua_in_norm* in, void* y, double* out_stats, void* workspace, long workspace_bytes,
                       void* stream);
 
+/* Two-part form of a convolution whose input is a channel concatenation (torch.cat([x_e, x_0], dim=1) in front of
+ * UpCat.convs, models/basic_unet/denoiser.py:190; torch.cat((out, skip), dim=1) in UnetrUpBlock, swin_unetr/blocks.py:90):
+ *   conv(cat[a | b]) = conv_a(a) + conv_b(b),
+ * so the part that reads the SKIP connection can run as soon as the skip exists -- on a second stream, under the launches of
+ * the coarser levels that leave the chip idle -- and the layer on the critical path contracts only the other half.
+ * dua_conv3d_k3_partial: fp32 tile sums of one part (w_packed: the packed weights of that part's input channels), no bias,
+ *   no statistics, into `partial` (dua_conv3d_k3_partial_bytes(d) bytes; the layout is the kernel's accumulator layout and
+ *   is only meaningful to dua_conv3d_k3_fwd_acc called with the same N, D, H, W, Cout and dtype).
+ * dua_conv3d_k3_fwd_acc: dua_conv3d_k3_fwd for the other part, its accumulators starting from bias + partial. */
+long dua_conv3d_k3_partial_bytes(const dua_conv3_desc* d);
+int dua_conv3d_k3_partial(const dua_conv3_desc* d, const void* x, const void* w_packed, const dua_in_norm* in, float* partial,
+                          void* stream);
+int dua_conv3d_k3_fwd_acc(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
+                          const dua_in_norm* in, const float* partial, void* y, double* out_stats, void* stream);
+
 /* Weight gradient of the same convolution (backward of train.py:258-268 through denoiser.py:56-59):
  *   dw[co][ci][kd][kh][kw] += sum over (n, voxel) of dy[n, v, co] * x[n, v + tap - 1, ci]
  * d describes the FORWARD convolution (x: Cin channels at Cin_off of a Cin_stride buffer; dy: Cout channels at
@@ -280,8 +295,14 @@ int dua_step_begin(int N, int P, const float* table, int table_rows, const int* 
 #define DUA_OP_CONV3 1        /* dua_conv3d_k3_fwd(conv, x, w, bias, norm?, y, stats, workspace) */
 #define DUA_OP_MATERIALIZE 2  /* dua_materialize(mat, raw = x, norm, emb, out = y, pooled) */
 #define DUA_OP_DECONV 3       /* dua_deconv_k2s2_fwd(conv, x, w, bias, norm?, y) */
+#define DUA_OP_CONV3_PARTIAL 4  /* dua_conv3d_k3_partial(conv, x, w, norm?, partial = y) */
+#define DUA_OP_CONV3_ACC 5    /* dua_conv3d_k3_fwd_acc(conv, x, w, bias, norm?, partial = init, y, stats) */
+#define DUA_OP_FORK 6         /* the side stream waits for everything enqueued on the main stream so far */
+#define DUA_OP_JOIN 7         /* the main stream waits for everything enqueued on the side stream so far */
 typedef struct {
   int kind;                /* DUA_OP_* */
+  int side;                /* 0: launch on the step's stream; 1: on plan->side_stream (between a FORK and a JOIN) */
+  const float* init;       /* CONV3_ACC: the other part's partial sums */
   int has_norm;            /* norm below describes the producer of x (fused InstanceNorm + LeakyReLU + add) */
   dua_conv3_desc conv;
   dua_materialize_desc mat;
@@ -307,12 +328,17 @@ typedef struct {
   /* the launch sequence */
   const dua_step_op* ops; int n_ops;
   void* workspace; long workspace_bytes;     /* split-K scratch shared by the CONV3 ops */
+  /* second stream for ops with side = 1 and two events (dua_event_create) for FORK / JOIN; all NULL when no op uses them */
+  void* side_stream; void* ev_fork; void* ev_join;
   /* tail (dua_final_conv_sampler) */
   dua_tail_desc tail; const void* tail_raw; dua_in_norm tail_norm; const float* wf; const float* bf;
   float* x_state; const float* noise; void* xin; float* xstart_sum; float* logits; float* xstart;
 } dua_denoiser_plan;
 
 int dua_denoiser_step(const dua_denoiser_plan* plan, void* stream);
+/* An event without timing for the FORK / JOIN ops above (hipEventCreateWithFlags(hipEventDisableTiming)); 0 on failure. */
+void* dua_event_create(void);
+void dua_event_destroy(void* event);
 
 /* ---- windowed multi-head self-attention (DiffSwinUNETR, BASELINE config 5) -------------------------------------------
  * The core of WindowAttention.forward (models/swin_unetr/attention.py:97-120) between its two Linear layers:

@@ -124,6 +124,38 @@ def test_conv3_raw_and_stats(dtype, shape, conv_variant):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(1, 64, 64, 64, 16, 16, 32), (2, 40, 24, 72, 6, 10, 12), (1, 48, 48, 48, 8, 24, 24)])
+def test_conv3_two_part_form_equals_the_convolution_over_the_concatenation(dtype, shape):
+    """conv(cat[a | b]) = conv_a(a) + conv_b(b): dua_conv3d_k3_partial on the first half of a concat buffer, then
+    dua_conv3d_k3_fwd_acc on the second half starting from bias + partial, against the one-launch convolution over the
+    whole buffer (same kernel, same operands) and against torch; statistics included."""
+    ops = _ops()
+    N, Ca, Cb, Cout, D, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, Ca + Cb, D, H, W, generator=g)
+    w = torch.randn(Cout, Ca + Cb, 3, 3, 3, generator=g) / (27 * (Ca + Cb)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv3d(x.to(dtype).float(), w.to(dtype).float(), b, padding=1)
+    xcl = _cl(x, dtype)
+    wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), dtype)
+    y0 = torch.zeros((N, D, H, W, Cout), dtype=dtype, device="cuda")
+    st0 = ops.stats_buffer(N, Cout, "cuda")
+    ops.conv3d_k3(xcl, Ca + Cb, 0, wp, bp, Cout, y0, 0, st0)
+    wa, _ = ops.pack_conv3_weights(w[:, :Ca].contiguous().cuda(), None, dtype)
+    wb, _ = ops.pack_conv3_weights(w[:, Ca:].contiguous().cuda(), None, dtype)
+    part = torch.full((ops.conv3_partial_bytes(dtype, N, D, H, W, Cout) // 4,), float("nan"), dtype=torch.float32, device="cuda")
+    ops.conv3d_k3_partial(xcl, Ca, 0, wa, Cout, part)
+    y1 = torch.zeros_like(y0)
+    st1 = ops.stats_buffer(N, Cout, "cuda")
+    ops.conv3d_k3(xcl, Cb, Ca, wb, bp, Cout, y1, 0, st1, init=part)
+    got = ops.from_channels_last(y1, Cout).cpu()
+    assert torch.allclose(got, ref, **TOL[dtype]), float((got - ref).abs().max())
+    tol = 1e-5 if dtype == torch.float32 else 4e-3           # summation order differs between the two forms
+    assert (y1.float() - y0.float()).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    assert torch.allclose(st1.sum(1)[:, :Cout], st0.sum(1)[:, :Cout], rtol=2e-3, atol=2e-2 * (D * H * W) ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [(1, 128, 256, 12, 12, 12), (2, 72, 136, 6, 6, 6), (1, 136, 64, 8, 16, 16)])
 def test_conv3_split_k(dtype, shape):
     """Layers too small to fill 256 CUs split K = (Cin chunk, kd) over workgroups; fp32 partial tiles are

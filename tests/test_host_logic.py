@@ -106,3 +106,38 @@ def test_forward_dispatch_errors_and_no_cpu_fallback():
     # the sub-networks on their own run the inference launch plan, which keeps no tape: gradients are refused there
     with pytest.raises(NotImplementedError, match="pred_type"):
         net.model(x, torch.zeros(1).long(), image=torch.zeros(1, 1, 32, 32, 32), embeddings=[None] * 5)
+
+
+def test_patch_embed_weight_packing_is_the_strided_convolution():
+    """ops.pack_patch_embed_weights: [E, Cin, 2, 2, 2] -> [8 taps (kd, kh, kw), cin_packed, E] with a channel permutation; a
+    plain einsum over the packed form on gathered 2x2x2 patches equals Conv3d(k = s = 2) (MONAI PatchEmbed)."""
+    import torch.nn.functional as F
+    from diff_unet_amos_amd import ops
+    g = torch.Generator().manual_seed(0)
+    E, cin, cp = 48, 17, 24
+    w = torch.randn(E, cin, 2, 2, 2, generator=g)
+    x = torch.randn(1, cin, 4, 6, 8, generator=g)
+    perm = list(range(1, cin)) + [0]                          # packed channel p holds source channel perm[p]
+    wp = ops.pack_patch_embed_weights(w, cp, perm)
+    assert tuple(wp.shape) == (8, cp, E) and float(wp[:, cin:].abs().max()) == 0.0
+    xp = torch.zeros(1, cp, 4, 6, 8)
+    xp[:, :cin] = x[:, perm]
+    patches = xp.unfold(2, 2, 2).unfold(3, 2, 2).unfold(4, 2, 2)          # [1, cp, 2, 3, 4, kd, kh, kw]
+    got = torch.einsum("ncdhwijk,ijkce->nedhw", patches, wp.view(2, 2, 2, cp, E))
+    want = F.conv3d(x, w, stride=2)
+    assert torch.allclose(got, want, atol=1e-4)
+
+
+def test_side_stream_recording_marks_ops_for_the_step_executor():
+    """Under ops.recording the side-stream context appends a FORK op, join_stream a JOIN op (what dua_denoiser_step turns
+    into an event record / wait pair), and nothing touches a device."""
+    from diff_unet_amos_amd import _native as nv
+    from diff_unet_amos_amd import ops
+    rec = []
+    with ops.recording(rec):
+        with ops.side_stream(None):
+            assert ops._SIDE == 1
+        assert ops._SIDE == 0
+        ops.join_stream(None)
+    assert [op.kind for op in rec] == [nv.OP_FORK, nv.OP_JOIN] and all(op.side == 0 and not op.init for op in rec)
+    assert ops._RECORD is None

@@ -60,6 +60,13 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.f + copysignf(e, x));
 }
 
+// The value the lane 32 away holds (lane ^ 32): one v_permlane32_swap on gfx950 -- __shfl_xor(v, 32) goes through
+// ds_bpermute, an LDS round trip in the middle of a dependent chain.
+__device__ __forceinline__ float other_half(float v) {
+  const auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float((threadIdx.x & 32) ? pr[0] : pr[1]);
+}
+
 // Row of a 32x32 MFMA accumulator held in register i (0..15) of lane-half h.
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     float bm = z[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) bm = fmaxf(bm, z[i]);
-    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    bm = fmaxf(bm, other_half(bm));
     const float mnew = fmaxf(mx, bm);
     const float alpha = __builtin_amdgcn_exp2f(mx - mnew);
     mx = mnew;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
       O = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, p[s], O, 0, 0, 0);
     }
   }
-  sum += __shfl_xor(sum, 32);
+  sum += other_half(sum);
   const float inv = 1.f / sum;
   // O^T rows = dims: register i of half hh holds dim (i & 3) + 8 (i >> 2) + 4 hh; dims < 16 are i = 0..7
   if (qok) {

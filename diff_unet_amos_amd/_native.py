@@ -103,7 +103,7 @@ _SIGS = {
     "dua_sampler_step": (C.c_int, [C.c_int, C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dua_final_conv_sampler": (C.c_int, [C.POINTER(TailDesc), _P, C.POINTER(InNorm)] + [_P] * 11),
     "dua_window_attention_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
-                                           C.c_float, _P, _P]),
+                                           _P, C.c_float, _P, _P]),
     "dua_patch_merge_norm": (C.c_int, [C.c_int] * 7 + [_P, _P, _P, _P, C.c_float, _P, _P]),
     "dua_residual_norm_act": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.POINTER(InNorm), _P, C.c_int,
                                         C.POINTER(InNorm), _P, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_int,

@@ -23,6 +23,10 @@
 // keeps the 2197-entry column of its head in LDS (8.8 KB instead of 343 x 343 floats from L2) and looks up
 // table[off(q) - off(k) + centre].  Token -> coordinate uses the TABLE's grid (7, 7, 7) even for clipped windows: the
 // reference slices relative_position_index[:n, :n] of the 7^3 index (attention.py:104).
+// Fastest form (bias_tiles): the same bias, gathered once per weight version on the host side into the ACCUMULATOR's order --
+// [head][query block][key block][lane][16] fp32, pre-multiplied by log2 e -- so that a key block costs four 16-byte loads per
+// lane (4 KB contiguous per wave, shared by all windows of the image: 1.45 MB at 3 heads x 343 tokens, L2 resident) instead of
+// 16 per-lane LDS gathers and their address arithmetic (LDS instructions per launch 1.08 M -> 0.22 M, VALU 14.1 M -> 11.9 M).
 // Bias and mask otherwise arrive TRANSPOSED ([head][key][query], [window][key][query], fp32) so that the 32 lanes of a half read
 // 128 contiguous bytes per key.  The shifted-window mask can instead be given as what compute_mask builds it from: one
 // region id per token of every window ([windows per image][tokens], uint8; attention.py:135-157) -- 343 bytes per window
@@ -41,6 +45,7 @@ constexpr int MAXTAB = 2208;    // (2*7-1)^3 = 2197 table entries per head, padd
 struct WinAttnArgs {
   const void* qkv; const float* bias_t; const float* mask_t; const unsigned char* region; void* out;
   const float* table;           // [heads][tab_len] or null (then bias_t)
+  const float* btile;           // [heads][nb][nb][64 lanes][16] bias in accumulator order, x log2 e; takes precedence
   int gd, gh, gw, tab_len;      // grid the relative-position index was built for
   int n, heads, nw;             // tokens per window, heads, windows per image (mask index = window % nw)
   float scale;
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     }
     *(f16x8*)(Vp + (long)i * 8) = v;
   }
-  const bool has_table = a.table != nullptr;
+  const bool has_tiles = a.btile != nullptr;
+  const bool has_table = a.table != nullptr && !has_tiles;
   const int sh_ = 2 * a.gw - 1, sd_ = (2 * a.gh - 1) * sh_;         // strides of the (dd, dh, dw) difference grid
   // scores are kept in units of log2 e (scale, bias and mask pre-multiplied): the softmax is exp2 without a multiply per
   // element; koff holds BYTE offsets into the table so that a lookup address is one subtraction
@@ -126,17 +132,22 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   const unsigned char rq = has_region ? regl[qb * 32 + r] : (unsigned char)0;
   const int qoff = has_table ? (int)koff[qc] + 4 * ((a.gd - 1) * sd_ + (a.gh - 1) * sh_ + (a.gw - 1)) : 0;   // bytes
   const float scale2 = a.scale * LOG2E;
-  f16x8 zero8;
+  f16x8 zero8, ones8;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) zero8[e] = (f16)0.f;
+  for (int e = 0; e < 8; ++e) { zero8[e] = (f16)0.f; ones8[e] = (f16)1.f; }
   // score tile of key block kb for this lane's query: scale * <q, k> + bias + mask (padding keys: -3e38)
   auto scores = [&](int kb) {
+    f32x16 bt;
+    if (has_tiles) bt = *(const f32x16*)(a.btile + ((((long)head * nb + qb) * nb + kb) * 64 + lane) * 16);   // 4 x 16 B, L2 resident
     const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
     f32x16 z;
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, z, 0, 0, 0);
-    if (has_table) {
+    if (has_tiles) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) z[i] = fmaf(z[i], scale2, bt[i]);
+    } else if (has_table) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {               // register quad j = keys kb*32 + 8j + 4hh + (0..3): one 8-byte read of offsets
         typedef short short4v __attribute__((ext_vector_type(4)));
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   // tile, and recomputing them costs as much as the softmax itself): when a block raises the maximum, the sum and the
   // eight live registers of O^T are rescaled by exp(old - new).  Both halves of a query's keys feed the same MFMA
   // contraction, so they share one maximum per block (one exchange with lane ^ 32).
-  float mx = -3.0e38f, sum = 0.f;
+  float mx = -3.0e38f;
   f32x16 O;
 #pragma unroll
   for (int i = 0; i < 16; ++i) O[i] = 0.f;
@@ -189,25 +200,19 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     const float mnew = fmaxf(mx, bm);
     const float alpha = __builtin_amdgcn_exp2f(mx - mnew);
     mx = mnew;
-    sum *= alpha;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) O[i] *= alpha;    // rows 16..31 of O^T are padding (zero V rows): registers 8..15 stay 0
+    for (int i = 0; i < 9; ++i) O[i] *= alpha;    // dims 0..15 (registers 0..7) and the denominator row 16 (register 8, lanes hh = 0)
     f16x8 p[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float e = __builtin_amdgcn_exp2f(z[i] - mnew);
-      sum += e;
-      p[i >> 3][i & 7] = (f16)e;
-    }
+    for (int i = 0; i < 16; ++i) p[i >> 3][i & 7] = (f16)__builtin_amdgcn_exp2f(z[i] - mnew);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      f16x8 vf = zero8;                            // rows 16..31 of the A operand are padding
-      if (r < HD) vf = *(const f16x8*)(Vp + ((long)((kb * 2 + s) * 2 + hh) * 16 + r) * 8);
+      f16x8 vf = r == HD ? ones8 : zero8;          // rows 17..31 of the A operand are padding; row 16 is all ones: its output
+      if (r < HD) vf = *(const f16x8*)(Vp + ((long)((kb * 2 + s) * 2 + hh) * 16 + r) * 8);   // row is the softmax denominator
       O = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, p[s], O, 0, 0, 0);
     }
   }
-  sum += other_half(sum);
-  const float inv = 1.f / sum;
+  const float inv = 1.f / (O[8] + other_half(O[8]));     // row 16 lives in the hh = 0 lanes (row 20, hh = 1, is zero)
   // O^T rows = dims: register i of half hh holds dim (i & 3) + 8 (i >> 2) + 4 hh; dims < 16 are i = 0..7
   if (qok) {
     T* o = outp + (long)q * C;
@@ -227,15 +232,16 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 extern "C" int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image,
                                         const void* qkv, const float* bias_t, const float* mask_t,
                                         const unsigned char* region_ids, const float* bias_table, int grid_d, int grid_h,
-                                        int grid_w, float scale, void* out, void* stream) {
+                                        int grid_w, const float* bias_tiles, float scale, void* out, void* stream) {
   using namespace dua;
-  if (!qkv || (!bias_t && !bias_table) || !out || windows <= 0 || heads <= 0 || tokens <= 0 || tokens > wa::MAXB * 32)
+  if (!qkv || (!bias_t && !bias_table && !bias_tiles) || !out || windows <= 0 || heads <= 0 || tokens <= 0 || tokens > wa::MAXB * 32)
     return DUA_ERR_ARG;
   if ((mask_t || region_ids) && (windows_per_image <= 0 || windows % windows_per_image)) return DUA_ERR_ARG;
   WinAttnArgs a;
-  a.qkv = qkv; a.bias_t = bias_table ? nullptr : bias_t; a.mask_t = mask_t; a.region = region_ids; a.out = out;
-  a.table = bias_table; a.gd = grid_d; a.gh = grid_h; a.gw = grid_w; a.tab_len = 0;
-  if (bias_table) {
+  a.btile = bias_tiles;
+  a.qkv = qkv; a.bias_t = (bias_table || bias_tiles) ? nullptr : bias_t; a.mask_t = mask_t; a.region = region_ids; a.out = out;
+  a.table = bias_tiles ? nullptr : bias_table; a.gd = grid_d; a.gh = grid_h; a.gw = grid_w; a.tab_len = 0;
+  if (bias_table && !bias_tiles) {
     if (grid_d <= 0 || grid_h <= 0 || grid_w <= 0 || tokens > grid_d * grid_h * grid_w) return DUA_ERR_ARG;
     a.tab_len = (2 * grid_d - 1) * (2 * grid_h - 1) * (2 * grid_w - 1);
     if (a.tab_len > wa::MAXTAB) return DUA_ERR_ARG;

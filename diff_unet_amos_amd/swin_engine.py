@@ -232,8 +232,7 @@ class SwinPlan:
             for blk in layer.blocks:
                 a = blk.attn
                 blocks.append(dict(g1=f32(blk.norm1.weight), b1=f32(blk.norm1.bias), g2=f32(blk.norm2.weight), b2=f32(blk.norm2.bias),
-                                   tiles=ops.attention_bias_tiles(a.relative_position_bias_table.detach().float()[
-                                       a.relative_position_index[:n, :n].reshape(-1)].reshape(n, n, -1).permute(2, 0, 1)),
+                                   table=a.relative_position_bias_table.detach().float().t().contiguous(),     # [head, 13^3]
                                    wqkv=a.qkv.weight.detach().to(dt).contiguous(), bqkv=a.qkv.bias.detach().to(dt).contiguous(),
                                    wproj=a.proj.weight.detach().to(dt).contiguous(), bproj=a.proj.bias.detach().to(dt).contiguous(),
                                    w1=blk.mlp.linear1.weight.detach().to(dt).contiguous(), bb1=blk.mlp.linear1.bias.detach().to(dt).contiguous(),
@@ -360,7 +359,7 @@ class SwinPlan:
                 else:
                     qkv = F.linear(win, b["wqkv"], b["bqkv"])
                 ops.window_attention(qkv, HEADS[i], None, region_ids=g["region"] if shifted else None,
-                                     windows_per_image=g["nw"], out=att, bias_tiles=b["tiles"])
+                                     windows_per_image=g["nw"], out=att, bias_table=b["table"], table_grid=WINDOW)
                 if fused:
                     if self.tl_proj:
                         ops.token_linear(att.view(-1, C_), b["wproj"], b["fproj"], "scatter", x=x, geom=geom, gamma=b["g2"],

@@ -66,41 +66,45 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   const int win = blockIdx.x, head = blockIdx.y, qb0 = blockIdx.z * 4;
   const int n = a.n, nb = (n + 31) >> 5, C = a.heads * HD;
   const T* base = (const T*)a.qkv + (long)win * n * 3 * C + head * HD;
-  // ---- stage K (row major), this workgroup's Q blocks and V (permuted, zero padded) ----
+  // ---- stage K (row major), V (permuted, zero padded) and this workgroup's Q blocks: one 16-byte load per (token, half
+  // of the head dimension) and operand; V^T is built by scattering the 8 dims of a key into its permuted column (2-byte LDS
+  // writes) -- gathering it with 2-byte GLOBAL loads made the staging the longest phase of the workgroup ----
+  auto load8 = [](const T* p) {
+    f16x8 o;
+    if constexpr (sizeof(T) == 2) {
+      o = *(const f16x8*)p;
+    } else {
+      const f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = (f16)lo[e]; o[4 + e] = (f16)hi[e]; }
+    }
+    return o;
+  };
   for (int i = tid; i < nb * 32 * 2; i += 256) {          // (token, half of the 16 dims)
     const int tok = i >> 1, half = i & 1;
-    f16x8 k;
+    f16x8 k, v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) k[e] = (f16)0.f;
+    for (int e = 0; e < 8; ++e) { k[e] = (f16)0.f; v[e] = (f16)0.f; }
     if (tok < n) {
-      const T* p = base + (long)tok * 3 * C + C + half * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) k[e] = (f16)(float)p[e];
+      const T* p = base + (long)tok * 3 * C + half * 8;
+      k = load8(p + C);
+      v = load8(p + 2 * C);
     }
     *(f16x8*)(Kl + tok * HD + half * 8) = k;
+    // Vp[kb][s][h2][row][j] = V[key = kb*32 + 16 s + 8 (j >> 2) + 4 h2 + (j & 3)][dim = row], row < 16
+    const int kb = tok >> 5, u = tok & 15, s2 = (tok >> 4) & 1;
+    const int h2 = (u >> 2) & 1, jj = ((u >> 3) << 2) | (u & 3);
+    f16* vp = Vp + (((kb * 2 + s2) * 2 + h2) * 16 + half * 8) * 8 + jj;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vp[e * 8] = v[e];
   }
   {
     const int tok = qb0 * 32 + (tid >> 1), half = tid & 1;  // 128 tokens x 2 halves = 256 threads
     f16x8 q;
 #pragma unroll
     for (int e = 0; e < 8; ++e) q[e] = (f16)0.f;
-    if (tok < n) {
-      const T* p = base + (long)tok * 3 * C + half * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) q[e] = (f16)(float)p[e];
-    }
+    if (tok < n) q = load8(base + (long)tok * 3 * C + half * 8);
     *(f16x8*)(Ql + (tid >> 1) * HD + half * 8) = q;
-  }
-  // Vp[kb][s][h2][row][j] = V[key = kb*32 + 16 s + 8 (j >> 2) + 4 h2 + (j & 3)][dim = row], row < 16
-  for (int i = tid; i < nb * 2 * 2 * 16; i += 256) {
-    const int row = i & 15, h2 = (i >> 4) & 1, s = (i >> 5) & 1, kb = i >> 6;
-    f16x8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int key = kb * 32 + 16 * s + 8 * (j >> 2) + 4 * h2 + (j & 3);
-      v[j] = key < n ? (f16)(float)base[(long)key * 3 * C + 2 * C + row] : (f16)0.f;
-    }
-    *(f16x8*)(Vp + (long)i * 8) = v;
   }
   const bool has_tiles = a.btile != nullptr;
   const bool has_table = a.table != nullptr && !has_tiles;

@@ -56,14 +56,13 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   using namespace wa;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f16* Kl = (f16*)smem;                           // [nb*32][16]
-  f16* Ql = Kl + MAXB * 32 * HD;                  // [4*32][16]   the four query blocks of this workgroup
-  f16* Vp = Ql + 4 * 32 * HD;                     // [nb][2 s][2 hh][16 rows (dims)][8 keys]  (permuted V^T; MFMA rows 16..31 are zeros)
+  f16* Vp = Kl + MAXB * 32 * HD;                     // [nb][2 s][2 hh][16 rows (dims)][8 keys]  (permuted V^T; MFMA rows 16..31 are zeros)
   float* tab = (float*)(Vp + MAXB * 2 * 2 * 16 * 8);                // [MAXTAB] bias table column of this head (x log2 e)
   short* koff = (short*)(tab + MAXTAB);                              // [nb*32] coordinate offset of every token
   unsigned char* regl = (unsigned char*)(koff + MAXB * 32);          // [nb*32] region id of every token of the window
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int win = blockIdx.x, head = blockIdx.y, qb0 = blockIdx.z * 4;
+  const int win = blockIdx.x, head = blockIdx.y;
   const int n = a.n, nb = (n + 31) >> 5, C = a.heads * HD;
   const T* base = (const T*)a.qkv + (long)win * n * 3 * C + head * HD;
   // ---- stage K (row major), V (permuted, zero padded) and this workgroup's Q blocks: one 16-byte load per (token, half
@@ -98,14 +97,6 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) vp[e * 8] = v[e];
   }
-  {
-    const int tok = qb0 * 32 + (tid >> 1), half = tid & 1;  // 128 tokens x 2 halves = 256 threads
-    f16x8 q;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) q[e] = (f16)0.f;
-    if (tok < n) q = load8(base + (long)tok * 3 * C + half * 8);
-    *(f16x8*)(Ql + (tid >> 1) * HD + half * 8) = q;
-  }
   const bool has_tiles = a.btile != nullptr;
   const bool has_table = a.table != nullptr && !has_tiles;
   const int sh_ = 2 * a.gw - 1, sd_ = (2 * a.gh - 1) * sh_;         // strides of the (dd, dh, dw) difference grid
@@ -124,15 +115,20 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     for (int i = tid; i < nb * 32; i += 256) regl[i] = i < n ? a.region[(long)(win % a.nw) * n + i] : (unsigned char)255;
   __syncthreads();
 
-  const int qb = qb0 + wave;
-  if (qb >= nb) return;
   const float* bias = has_table ? nullptr : a.bias_t + (long)head * n * n;
   const float* mask = a.mask_t ? a.mask_t + (long)(win % a.nw) * n * n : nullptr;
   T* outp = (T*)a.out + (long)win * n * C + head * HD;
+  // A wave owns query blocks blockIdx.z * 4 + wave, + 4 * gridDim.z, ...: with one workgroup per (window, head) (gridDim.z = 1,
+  // the 48^3-token stage: 1029 workgroups, all resident at five per CU) K and V are staged once for the whole window; the
+  // coarse stages split the query blocks over gridDim.z workgroups to have enough of them.
+  for (int qb = blockIdx.z * 4 + wave; qb < nb; qb += 4 * gridDim.z) {
   const int q = qb * 32 + r;                     // this lane's query
   const bool qok = q < n;
   const int qc = qok ? q : 0;
-  const f16x8 qf = *(const f16x8*)(Ql + (wave * 32 + r) * HD + hh * 8);      // B operand: Q^T[dims 8hh..][query r]
+  f16x8 qf;                                      // B operand: Q^T[dims 8hh..][query r], straight from global memory
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qf[e] = (f16)0.f;
+  if (qok) qf = load8(base + (long)q * 3 * C + hh * 8);
   const unsigned char rq = has_region ? regl[qb * 32 + r] : (unsigned char)0;
   const int qoff = has_table ? (int)koff[qc] + 4 * ((a.gd - 1) * sd_ + (a.gh - 1) * sh_ + (a.gw - 1)) : 0;   // bytes
   const float scale2 = a.scale * LOG2E;
@@ -229,6 +225,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
       *(TV4*)(o + 8 * g + 4 * hh) = w;
     }
   }
+  }
 }
 
 }  // namespace dua
@@ -252,9 +249,9 @@ extern "C" int dua_window_attention_fwd(int dtype, int windows, int tokens, int 
   }
   a.n = tokens; a.heads = heads; a.nw = (mask_t || region_ids) ? windows_per_image : 1; a.scale = scale;
   const int nb = (tokens + 31) / 32;
-  const int lds = wa::MAXB * 32 * wa::HD * 2 + 4 * 32 * wa::HD * 2 + wa::MAXB * 2 * 2 * 16 * 8 * 2 +      // K, Q, V^T
+  const int lds = wa::MAXB * 32 * wa::HD * 2 + wa::MAXB * 2 * 2 * 16 * 8 * 2 +                            // K, V^T
                   wa::MAXTAB * 4 + wa::MAXB * 32 * 2 + wa::MAXB * 32;                                        // table, offsets, regions
-  dim3 grid(windows, heads, (nb + 3) / 4);
+  dim3 grid(windows, heads, (long)windows * heads >= 1024 ? 1 : (nb + 3) / 4);
   if (dtype == DUA_F16) hipLaunchKernelGGL(window_attention_kernel<f16>, grid, dim3(256), lds, (hipStream_t)stream, a);
   else if (dtype == DUA_F32) hipLaunchKernelGGL(window_attention_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
   else return DUA_ERR_ARG;

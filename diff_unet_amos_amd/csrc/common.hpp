@@ -14,6 +14,18 @@
 #include <stdint.h>
 
 namespace dua {
+// hipFuncSetAttribute acts on the current device only: a launcher keeps one of these per kernel (a function-local static)
+// and raises the dynamic-LDS limit the first time it runs on each device of the process.
+struct PerDeviceOnce {
+  bool done[64] = {};
+  // nullptr: no current device; otherwise the flag of the current device (the caller sets it after the attribute calls)
+  bool* flag() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    return &done[dev];
+  }
+};
+
 
 using f16 = _Float16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));

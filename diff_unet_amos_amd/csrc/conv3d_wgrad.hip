@@ -368,24 +368,28 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
   a.plain_order = (g_wgrad_variant & 1) || P < 8;
   a.part = (ws && (long)P * combos * 9 * 4096 * 4 <= ws_bytes && P > 1) ? ws : nullptr;
   const int lds = 2 * (XV + TV) * 32 * (int)sizeof(T) + 4 * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  bool* attr_set = once.flag();
+  if (!attr_set) return DUA_ERR_ARG;
+  if (!*attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    *attr_set = true;
   }
   const int groups = (P * a.ncombo + 7) / 8;        // groups of 8 (partition, combo) pairs, one per XCD
   const dim3 grid(a.plain_order ? P * a.ncombo * 3 : groups * 24);
   // f16 default: the 12-wave form (-5...-14 % against the 6-wave one on every layer shape, same-process A/B);
   // dua_set_option(4, 64) selects the 6-wave pipelined form, (4, 32) its compiler-scheduled k loop.  f32: 6 waves.
   if (sizeof(T) == 2 && !(g_wgrad_variant & (64 | 32))) {
-    static bool attr12 = false;
-    if (!attr12) {
+    static PerDeviceOnce once12;
+    bool* attr12 = once12.flag();
+    if (!attr12) return DUA_ERR_ARG;
+    if (!*attr12) {
       hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad12_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return (int)e;
-      attr12 = true;
+      *attr12 = true;
     }
     hipLaunchKernelGGL(conv3d_k3_wgrad12_kernel<T>, grid, dim3(768), lds, s, a);
   } else

@@ -280,11 +280,13 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   if (vox >= 256L * 128 && a.nchunks <= 4) {          // enough tiles to fill the chip with one workgroup per 8 taps
     const int lds = dc::TM * (a.nchunks * 64 + 16) + 2 * a.nchunks * dc::W_BYTES + dc::TM * (32 * (int)sizeof(T) + 16) +
                     (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0);
-    static bool attr2 = false;
-    if (!attr2) {
+    static PerDeviceOnce once2;
+    bool* attr2 = once2.flag();
+    if (!attr2) return DUA_ERR_ARG;
+    if (!*attr2) {
       hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_alltaps_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
-      attr2 = true;
+      *attr2 = true;
     }
     dim3 grid2((unsigned)((vox + dc::TM - 1) / dc::TM), a.nct, d->N);
     hipLaunchKernelGGL(deconv_k2s2_alltaps_kernel<T>, grid2, dim3(256), lds, s, a);
@@ -295,11 +297,13 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   constexpr int LDS = (dc::TM * OS > dc::A_BYTES + dc::W_BYTES) ? dc::TM * OS : dc::A_BYTES + dc::W_BYTES;
   a.lds_base = LDS;
   if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  bool* attr_set = once.flag();
+  if (!attr_set) return DUA_ERR_ARG;
+  if (!*attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 3 * 4 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    *attr_set = true;
   }
   hipLaunchKernelGGL(deconv_k2s2_kernel<T>, grid, dim3(256), LDS + (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0), s, a);
   return (int)hipGetLastError();

@@ -296,11 +296,13 @@ static int launch_deconv_bwd(const dua_conv3_desc* d, const void* x, const void*
     a.nct = (d->Cin + db::BN - 1) / db::BN;          // output tiles over Cin
     constexpr int OS = db::BN * (int)sizeof(T) + 16;
     constexpr int LDS = (db::TM * OS > db::A_BYTES + db::W_BYTES) ? db::TM * OS : db::A_BYTES + db::W_BYTES;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce once;
+    bool* attr = once.flag();
+    if (!attr) return DUA_ERR_ARG;
+    if (!*attr) {
       hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_dgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       if (e != hipSuccess) return (int)e;
-      attr = true;
+      *attr = true;
     }
     dim3 grid((unsigned)((vox + db::TM - 1) / db::TM), a.nct, d->N);
     hipLaunchKernelGGL(deconv_k2s2_dgrad_kernel<T>, grid, dim3(256), LDS, s, a);
@@ -313,11 +315,13 @@ static int launch_deconv_bwd(const dua_conv3_desc* d, const void* x, const void*
     constexpr int TV = dwg::tile_voxels<T>();
     a.total_tiles = (int)(d->N * ((vox + TV - 1) / TV));
     const int lds = 18 * (TV * 32 * (int)sizeof(T) + 64);
-    static bool attr2 = false;
-    if (!attr2) {
+    static PerDeviceOnce once2;
+    bool* attr2 = once2.flag();
+    if (!attr2) return DUA_ERR_ARG;
+    if (!*attr2) {
       hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return (int)e;
-      attr2 = true;
+      *attr2 = true;
     }
     hipLaunchKernelGGL(deconv_k2s2_wgrad_kernel<T>, dim3(P, ncombo), dim3(dwg::NT), lds, s, a);
     const long per_p = (long)ncombo * 8 * 4096;

@@ -483,11 +483,13 @@ int launch_patch_embed_mfma(int B, int D, int H, int W, int Cs, int Cp, const vo
   a.w_row = padded_row(K * 2); a.a_row = padded_row(((K + 15) / 16) * 32); a.o_row = padded_row(48 * 4);
   a.w_bytes = 64 * a.w_row + 16;
   const int lds = a.w_bytes + 128 * (a.a_row > a.o_row ? a.a_row : a.o_row);
-  static bool raised = false;
-  if (lds > 64 * 1024 && !raised) {
+  static PerDeviceOnce once;
+  bool* raised = once.flag();
+  if (!raised) return DUA_ERR_ARG;
+  if (lds > 64 * 1024 && !*raised) {
     if (hipFuncSetAttribute((const void*)patch_embed_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return DUA_ERR_ARG;
-    raised = true;
+    *raised = true;
   }
   const long tiles = ((long)B * (D / 2) * (H / 2) * (W / 2) + 127) / 128;
   dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
@@ -507,12 +509,14 @@ extern "C" int dua_swin_mlp(long tokens, int C, const void* ln2, const void* W1,
   a.w1_row = padded_row(C * 2); a.w2_row = padded_row(192 * 2); a.a_row = padded_row(C * 2); a.o_row = padded_row(C * 4);
   const int nb2 = (C + 31) / 32;
   const int lds = 192 * a.w1_row + nb2 * 32 * a.w2_row + 128 * (a.a_row > a.o_row ? a.a_row : a.o_row);
-  static bool raised = false;
-  if (!raised) {
+  static PerDeviceOnce once;
+  bool* raised = once.flag();
+  if (!raised) return DUA_ERR_ARG;
+  if (!*raised) {
     if (hipFuncSetAttribute((const void*)swin_mlp_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)swin_mlp_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return DUA_ERR_ARG;
-    raised = true;
+    *raised = true;
   }
   const long tiles = (tokens + 127) / 128;
   dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
@@ -567,15 +571,13 @@ extern "C" int dua_token_linear(const dua_token_linear_desc* d, void* stream) {
 #undef ROW
   const Kern kern = table[d->mode][NB - 1];
   if (lds > 64 * 1024) {
-    static bool raised[5][6] = {};
-    static int attr_dev = -1;
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (attr_dev != dev) { for (auto& row : raised) for (bool& b : row) b = false; attr_dev = dev; }
-    if (!raised[d->mode][NB - 1]) {
+    static PerDeviceOnce once[5][6];
+    bool* raised = once[d->mode][NB - 1].flag();
+    if (!raised) return DUA_ERR_ARG;
+    if (!*raised) {
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return DUA_ERR_ARG;
-      raised[d->mode][NB - 1] = true;
+      *raised = true;
     }
   }
   // Enough workgroups to fill every CU to its occupancy limit: a wave works through load -> MFMA -> epilogue of one tile

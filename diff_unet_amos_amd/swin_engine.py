@@ -94,7 +94,7 @@ class SwinPlan:
     def __init__(self, net, N, D, H, W, dtype, device):
         assert D % 32 == 0 and H % 32 == 0 and W % 32 == 0, \
             "input image size (image_size) should be divisible by stage-wise image resolution."      # denoiser.py:110-113
-        assert min(D, H, W) >= 64, "InstanceNorm3d needs more than one voxel at the 1/32 level"
+        assert (D // 32) * (H // 32) * (W // 32) > 1, "InstanceNorm3d needs more than one voxel at the 1/32 level"
         self.net, self.N, self.dims, self.dtype, self.dev = net, N, (D, H, W), dtype, device
         self.C = net.num_classes
         f = net.feature_size

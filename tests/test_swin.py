@@ -408,6 +408,43 @@ def test_diff_swin_unetr_graph_replay_equals_eager_and_full_size_runs():
 
 
 @pytest.mark.gpu
+def test_full_size_config5_evaluation_matches_oracle():
+    """BASELINE config 5 at its real geometry: one 96^3 patch, 16 classes, feature size 48, fp16 operands -- the shape bench.py
+    --config 5 times -- against the oracle in fp32 on the host (stage grids 48/24/12/6/3: padded 7^3 windows on the first three
+    stages, clipped 6^3 and 3^3 windows on the last two, which the 64^3 cases do not have)."""
+    net, ref = _swin_pair(16, torch.float16, seed=11)
+    g = torch.Generator().manual_seed(12)
+    image = torch.rand(1, 1, 96, 96, 96, generator=g)
+    x = torch.randn(1, 16, 96, 96, 96, generator=g)
+    t = torch.tensor([433])
+    with torch.no_grad():
+        want = ref(image=image, x=x, step=t, pred_type="denoise")
+        got = net(image=image.cuda(), x=x.cuda(), step=t.cuda(), pred_type="denoise").float().cpu()
+    d = (got - want).abs()
+    print(f"config 5 full size fp16: max |d| {d.max():.2e} mean {d.mean():.2e} (|ref| max {want.abs().max():.2f} mean {want.abs().mean():.2f})")
+    assert d.max() < 1e-2 * max(1.0, float(want.abs().max())) and d.mean() < 1e-3
+    agree = ((got > 0) == (want > 0)).float().mean()              # the binarisation the caller applies to sigmoid(logits)
+    print(f"sign agreement {agree:.6f}")
+    assert agree > 1 - 1e-3
+
+
+@pytest.mark.gpu
+def test_diff_swin_unetr_on_a_non_cubic_patch_matches_oracle():
+    """A 64 x 96 x 32 patch: every stage has a different window clipping per axis (grids 32x48x16 ... 2x3x1), fp32."""
+    net, ref = _swin_pair(2, torch.float32, seed=13)
+    g = torch.Generator().manual_seed(14)
+    image = torch.randn(1, 1, 64, 96, 32, generator=g)
+    x = torch.randn(1, 2, 64, 96, 32, generator=g)
+    t = torch.tensor([77])
+    with torch.no_grad():
+        want = ref(image=image, x=x, step=t, pred_type="denoise")
+        got = net(image=image.cuda(), x=x.cuda(), step=t.cuda(), pred_type="denoise").cpu()
+    d = (got - want).abs()
+    print(f"64x96x32 fp32: max |d| {d.max():.2e} mean {d.mean():.2e}")
+    assert d.max() < 1e-4 * max(1.0, float(want.abs().max())) and d.mean() < 1e-5
+
+
+@pytest.mark.gpu
 def test_token_linear_kernel_epilogues_match_torch():
     """dua_token_linear against torch.nn.functional on the same fp16 operands: plain / GELU (also split over 288 and 384
     outputs), conv3 + statistics, residual add on the fp32 stream, window scatter + shortcut + LayerNorm."""

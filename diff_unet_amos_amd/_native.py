@@ -26,7 +26,8 @@ class NativeLibraryMissing(RuntimeError):
 class Conv3Desc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("Cin", C.c_int), ("Cin_stride", C.c_int), ("Cin_off", C.c_int),
-                ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int), ("tap_channel_plus1", C.c_int)]
+                ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int), ("tap_channel_plus1", C.c_int),
+                ("background", C.c_int)]
 
 
 class InNorm(C.Structure):

@@ -481,12 +481,14 @@ static int ensure_lds_attr() {
                                      c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD);
   if constexpr (sizeof(T) == 2) {
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 4096);
+      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              c3v2::LDS_MAIN + 4096 + PARTIAL_LDS_PAD);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c3v2::LDS_MAIN + 4096);
+      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              c3v2::LDS_MAIN + 4096 + PARTIAL_LDS_PAD);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              c3v2::LDS_MAIN + 3 * 4 * 1024);
+                              c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD);
   }
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -523,6 +525,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   const int xf_bytes = in && in->stats ? 3 * 4 * a.nchunks * CK : 0;
   if (int e = ensure_lds_attr<T>()) return e;
   const long vox = (long)d->D * d->H * d->W;
+  const int bg_pad = (part_out || d->background) ? PARTIAL_LDS_PAD : 0;     // one workgroup per CU, see PARTIAL_LDS_PAD
   if (d->tap_channel_plus1 > 0) {
     // single-channel tap form (see the kernel): fp16, one Cin chunk, no fused input transform, 16 * NKS ordinary
     // channels in front of the tap channel, zero padding behind it; weights from dua_pack_conv3_weights_tap
@@ -531,8 +534,8 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     else {
       if (a.nchunks != 1 || (in && in->stats) || (a.tap_ch != 0 && a.tap_ch != 16) || d->Cin != a.tap_ch + 8) return DUA_ERR_ARG;
       dim3 grid(a.ntiles, nct, d->N);
-      if (a.tap_ch == 16) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 1>), grid, dim3(256), c3v2::LDS_MAIN + 4096, s, a);
-      else hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 0>), grid, dim3(256), c3v2::LDS_MAIN + 4096, s, a);
+      if (a.tap_ch == 16) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 1>), grid, dim3(256), c3v2::LDS_MAIN + 4096 + bg_pad, s, a);
+      else hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 0>), grid, dim3(256), c3v2::LDS_MAIN + 4096 + bg_pad, s, a);
       return (int)hipGetLastError();
     }
   }
@@ -570,12 +573,12 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
     return (int)hipGetLastError();
   }
-  if (part_out)                                                        // one workgroup per CU, see PARTIAL_LDS_PAD
-    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes + PARTIAL_LDS_PAD, s, a);
+  if (part_out)
+    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes + bg_pad, s, a);
   else if (sizeof(T) == 2 && d->Cin - (a.nchunks - 1) * CK <= CK / 2)       // e.g. Cin = 48: the last chunk is half padding
-    hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 2, true>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
+    hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 2, true>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes + bg_pad, s, a);
   else
-    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
+    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes + bg_pad, s, a);
   return (int)hipGetLastError();
 }
 

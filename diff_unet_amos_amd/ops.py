@@ -285,14 +285,16 @@ def conv3_workspace_bytes(dtype, N, D, H, W, cin, cout):
 
 
 def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None, workspace=None, tap_channel=None,
-              init=None):
+              init=None, background=False):
     """Raw 3x3x3 convolution (+bias); ``norm`` = producer descriptor of x (fused IN+LeakyReLU+add);
     accumulates this layer's InstanceNorm sums into ``out_stats`` (must be zero on entry).
     ``tap_channel`` (0 or 16, fp16, cin == tap_channel + 8): the single-channel tap form for first layers -- that packed
     channel is the last real input channel and is contracted as two k-steps over its 27 taps (weights packed with the
     same ``tap_channel``).
     ``init`` (fp32 [N, D, H, W, ceil(cout/64)*64] from conv3d_k3_partial): the other part of a convolution over a channel
-    concatenation; the accumulators start from bias + init (dua_conv3d_k3_fwd_acc)."""
+    concatenation; the accumulators start from bias + init (dua_conv3d_k3_fwd_acc).
+    ``background``: the launch runs on a second stream under a chain of small launches (one workgroup per CU, see
+    dua_conv3_desc.background)."""
     _cl_check(x, "x"); _cl_check(y, "y")
     assert x.dtype == y.dtype and x.device == y.device
     N, D, H, W, cs_in = x.shape
@@ -310,7 +312,7 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
     assert bias_pad.numel() == nct * 64 and bias_pad.dtype == torch.float32
     assert out_stats.dtype == torch.float64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, nct * 64, 2)
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off,
-                     0 if tap_channel is None else tap_channel + 1)
+                     0 if tap_channel is None else tap_channel + 1, 1 if background else 0)
     if init is not None:
         assert tap_channel is None and init.is_cuda and init.dtype == torch.float32 and init.is_contiguous()
         assert init.numel() * 4 >= conv3_partial_bytes(x.dtype, N, D, H, W, cout)

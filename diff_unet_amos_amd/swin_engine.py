@@ -88,6 +88,20 @@ class SwinEmbeddings(list):
         return (self[i] for i in range(5))
 
 
+class _OneGraph:
+    """The whole step as one HIP graph; the two-stream schedule is a fork / join captured inside it.  (Replaying the step as
+    single-branch graphs per stream with host-side fork / join events was built and measured: tools/ubench_two_graphs.py shows a
+    chain of 400 small launches losing 0.3 ms to a fork inside its graph and nothing to a second graph on another stream, but on
+    the real step the segment boundaries cost more than that returns -- 2.61 against 2.55 ms, profiles/r2_swin_step_program_ab.txt.)"""
+
+    def __init__(self, g):
+        self.g = g
+
+    def replay(self, times=1):
+        for _ in range(times):
+            self.g.replay()
+
+
 class SwinPlan:
     """Buffers + launch sequences for one (N, D, H, W, dtype)."""
 
@@ -126,6 +140,7 @@ class SwinPlan:
         self.raw1b, self.raw2b, self.res3b = (torch.zeros(big, dtype=dtype, device=device) for _ in range(3))   # side stream
         self.side_stream = torch.cuda.Stream(device=device)
         self.two_streams = True
+        self.background_convs = True        # side-stream 3x3x3 convolutions leave half of every CU to the main stream's chain
         self.enc_done = [torch.cuda.Event() for _ in range(4)]
         self.stream = [torch.zeros((N, *S[i + 1], self.tok_c[i]), dtype=torch.float32, device=device) for i in range(5)]
         self.geo = []
@@ -311,8 +326,9 @@ class SwinPlan:
                        ops.Norm(r.st[1], r.ones, r.zeros, count, slope=SLOPE, eps=EPS),
                        ops.Norm(r.st[2], r.ones, r.zeros, count, slope=SLOPE, eps=EPS))
         n1, n2, n3 = r.norms
-        ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws)
-        ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=ws)
+        bg = side and self.two_streams and self.background_convs
+        ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws, background=bg)
+        ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=ws, background=bg)
         if r.has3:
             res = self._view(b3, l, r.cout)
             x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
@@ -468,6 +484,16 @@ class SwinPlan:
             self._res_block(self.u_res[k], cat[k], 2 * cout, dec[k], 0, ra=ra, ra_off=cout)
             src = dec[k]
 
+    def capture_step(self, step_fn):
+        """Record ``step_fn`` (one sampler step: step_begin + denoiser_body + tail on the current stream) into a HIP graph;
+        the result has ``replay(times=1)``."""
+        step_fn()                                   # warm-up outside capture (kernel attributes, GEMM workspaces)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step_fn()
+        return _OneGraph(g)
+
     def tail(self, mode, noise=None, logits=None, use_sum=False):
         """UnetOutBlock (1x1x1, denoiser.py:399-400) fused with the sampler update (engine.Plan.tail's kernel, fed the
         materialised decoder1 output)."""
@@ -556,14 +582,9 @@ class SwinPlan:
         else:
             g = self.graphs.get(tkey)
             if g is None:
-                one_step(None)                    # warm-up outside capture (kernel attributes, GEMM workspaces)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    one_step(None)
+                g = self.capture_step(lambda: one_step(None))
                 self.graphs[tkey] = g
                 reset()
-            for _ in range(T):
-                g.replay()
+            g.replay(T)
         return {"sample": ops.from_channels_last(self.x_state, self.C),
                 "sum_pred_xstart": ops.from_channels_last(self.x_sum, self.C)}

@@ -55,6 +55,10 @@ typedef struct {
                                       producer): packed input channel k-1 (0 or 16) is the LAST real channel (Cin = k-1 + 8,
                                       channels behind it are zero padding); its 27 taps are contracted as two 16-wide k-steps
                                       instead of 27 padded ones.  Needs weights from dua_pack_conv3_weights_tap. */
+  int background;                  /* dua_conv3d_k3_fwd only.  1 = this launch runs on a second stream UNDER a chain of small
+                                      launches that the caller is waiting for: it asks for LDS it does not use, so that one of
+                                      its workgroups fits a CU instead of two and the chain's workgroups always find free
+                                      registers and LDS.  Same result, longer launch.  0 = ordinary launch. */
 } dua_conv3_desc;
 
 /* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32[ceil(Cout/64)*64].  in: NULL or the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-process A/B of SwinPlan switches on the config-5 step (96^3, 16 classes, one patch): each setting is captured into its
 own HIP graph, rounds are interleaved.  usage: bench_swin_ab.py [rounds] [steps per round]
-Settings: two_streams, fused_mlp, fused_linear, fused_max_c, fused_reduction (swin_engine.SwinPlan attributes)."""
+Settings: two_streams, background_convs, fused_mlp, fused_linear, fused_max_c, fused_reduction (swin_engine.SwinPlan attributes)."""
 import os
 import sys
 import time
@@ -22,11 +22,11 @@ def main():
     image = torch.rand(1, 1, 96, 96, 96, device=dev)
     plan = net._rt.plan(1, (96, 96, 96), dev)
     settings = {"default": {}, "fused kernels at stage 1 too": {"fused_max_c": 96}, "fused reduction": {"fused_reduction": True},
-                "one-kernel MLP off": {"fused_mlp": False}, "one stream": {"two_streams": False}, "library GEMMs": {"fused_linear": False},
+                "one-kernel MLP off": {"fused_mlp": False}, "one stream": {"two_streams": False}, "side-stream convolutions at two workgroups per CU": {"background_convs": False}, "library GEMMs": {"fused_linear": False},
                 "library qkv": {"tl_qkv": False}, "library proj + scatter kernel": {"tl_proj": False},
                 "library conv3 + stats kernel": {"tl_conv3": False}}
     base = {k: getattr(plan, k) for k in ("two_streams", "fused_mlp", "fused_linear", "fused_max_c", "fused_reduction", "tl_qkv",
-                                          "tl_proj", "tl_conv3")}
+                                          "tl_proj", "tl_conv3", "background_convs")}
     graphs = {}
     with torch.no_grad():
         net.embed_model(image)
@@ -46,12 +46,7 @@ def main():
             for k, v in {**base, **kv}.items():
                 setattr(plan, k, v)
             plan.counter.zero_()
-            one_step()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                one_step()
-            graphs[name] = g
+            graphs[name] = plan.capture_step(one_step)
         res = {n: [] for n in graphs}
         for _ in range(rounds):
             for name, g in graphs.items():
@@ -59,8 +54,7 @@ def main():
                 g.replay()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(steps):
-                    g.replay()
+                g.replay(steps)
                 torch.cuda.synchronize()
                 res[name].append((time.perf_counter() - t0) / steps * 1e3)
     for name, v in res.items():

@@ -54,6 +54,11 @@ class TailDesc(C.Structure):
                 ("seed", C.c_ulonglong), ("seed_dev", C.c_void_p)]
 
 
+class TailResidual(C.Structure):
+    _fields_ = [("res", C.c_void_p), ("res_stride", C.c_int), ("res_norm", InNorm), ("ra_src", C.c_void_p),
+                ("ra_stride", C.c_int), ("ra_off", C.c_int), ("channels", C.c_int)]
+
+
 MODE_LOGITS, MODE_DDPM, MODE_DDIM = 0, 1, 2
 OP_CONV3, OP_MATERIALIZE, OP_DECONV, OP_CONV3_PARTIAL, OP_CONV3_ACC, OP_FORK, OP_JOIN = 1, 2, 3, 4, 5, 6, 7
 
@@ -103,6 +108,7 @@ _SIGS = {
     "dua_q_sample": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P]),
     "dua_sampler_step": (C.c_int, [C.c_int, C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dua_final_conv_sampler": (C.c_int, [C.POINTER(TailDesc), _P, C.POINTER(InNorm)] + [_P] * 11),
+    "dua_final_conv_sampler_res": (C.c_int, [C.POINTER(TailDesc), _P, C.POINTER(InNorm), C.POINTER(TailResidual)] + [_P] * 11),
     "dua_window_attention_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                            _P, C.c_float, _P, _P]),
     "dua_patch_merge_norm": (C.c_int, [C.c_int] * 7 + [_P, _P, _P, _P, C.c_float, _P, _P]),

@@ -82,6 +82,8 @@ struct TailArgs {
   float* xsum; float* logits; float* xstart;
   long vox; int K, raw_stride, C, xin_stride, mode; unsigned seed_lo, seed_hi;
   const unsigned long long* seed_dev;
+  // residual form (MFMA kernel only): act = LeakyReLU(xf(raw) + rf(res)) + reverse_attention(ra), real channels [0, kvalid)
+  const void* res; InXform rf; int res_stride; const void* ra; int ra_stride, ra_off, kvalid;
 };
 
 __device__ __forceinline__ void philox_key(const TailArgs& a, uint32_t& k0, uint32_t& k1) {
@@ -210,25 +212,37 @@ __global__ __launch_bounds__(256) void final_conv_sampler_kernel(TailArgs a) {
 // stores, and one Philox4x32 call yields the lane's 4 normals with the same (voxel, class quad) counter as the VALU form
 // below, which stays for fp32 parity mode and odd shapes: both forms draw the same noise field.
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-template <int KS>
+// RES: the residual form -- the activation is assembled from the last UnetResBlock's two branches and the reverse-attention
+// term instead of being read back from a materialised tensor (three 16-byte loads per fragment, two voxel blocks in flight).
+template <int KS, bool RES = false>
 __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];   // scale[K], shift[K], add[K]
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // scale[K], shift[K], add[K] (+ the same of the residual branch)
   const int n = blockIdx.y, K = a.K;
   float* sc_l = wl; float* sh_l = wl + K;
-  xform_preamble(a.xf, n, K, sc_l, sh_l, sh_l + K);
+  float* rsc_l = wl + 3 * K; float* rsh_l = wl + 4 * K;
+  xform_preamble(a.xf, n, a.kvalid, sc_l, sh_l, sh_l + K);
+  if (RES) xform_preamble(a.rf, n, a.kvalid, rsc_l, rsh_l, rsh_l + K);
+  for (int k = a.kvalid + threadIdx.x; k < K; k += 256) {      // padding channels contribute nothing
+    sc_l[k] = 0.f; sh_l[k] = 0.f;
+    if (RES) { rsc_l[k] = 0.f; rsh_l[k] = 0.f; }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int vl = lane & 15, kq = lane >> 4;            // B column (voxel) / A row (class) index; k-group and class quad
-  float sc[KS][8], sh[KS][8];
+  float sc[KS][8], sh[KS][8], rsc[RES ? KS : 1][8], rsh[RES ? KS : 1][8];
   f16x8 aw[KS];
+  bool kok[KS];                                        // this lane's 8 channels of k-step ks are real channels
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
+  for (int ks = 0; ks < KS; ++ks) {
+    kok[ks] = 32 * ks + 8 * kq < a.kvalid;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = 32 * ks + 8 * kq + e;
       sc[ks][e] = sc_l[k]; sh[ks][e] = sh_l[k];
+      if (RES) { rsc[ks][e] = rsc_l[k]; rsh[ks][e] = rsh_l[k]; }
       aw[ks][e] = (f16)(vl < a.C ? a.wf[vl * K + k] : 0.f);          // A: row = class vl
     }
+  }
   float bias[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bias[j] = 4 * kq + j < a.C ? a.bf[4 * kq + j] : 0.f;
@@ -239,6 +253,12 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
   uint32_t key0, key1;
   philox_key(a, key0, key1);
   const f16* raw = (const f16*)a.raw + (long)n * a.vox * a.raw_stride;
+  const f16* res = RES ? (const f16*)a.res + (long)n * a.vox * a.res_stride : nullptr;
+  const f16* rav = RES && a.ra ? (const f16*)a.ra + (long)n * a.vox * a.ra_stride + a.ra_off : nullptr;
+  constexpr int MBS = RES ? 2 : 4;                     // voxel blocks whose loads are in flight together
+  f16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (f16)0.f;
   const bool sampling = a.mode != DUA_MODE_LOGITS;
   // A workgroup walks several 256-voxel tiles: the preamble above (per-channel statistics -> scale / shift in double
   // precision, weights to registers) is a few microseconds of dependent loads, too much to pay per 77 KB of traffic.
@@ -247,15 +267,23 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
   const long wbase = (tile * 4L + wave) * 64;
   // Everything this wave needs from memory is requested up front (raw fragments of all four voxel blocks, the
   // sampler state, injected noise): one memory round trip per wave instead of one per block.
-  f16x8 fr[4][KS];
-  f32x4 xt[4];
-  float ez[4][4];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    const long v = wbase + 16 * mb + vl;
+  for (int mb0 = 0; mb0 < 4; mb0 += MBS) {
+  f16x8 fr[MBS][KS], fr2[RES ? MBS : 1][KS], fr3[RES ? MBS : 1][KS];
+  f32x4 xt[MBS];
+  float ez[MBS][4];
+#pragma unroll
+  for (int mb = 0; mb < MBS; ++mb) {
+    const long v = wbase + 16 * (mb0 + mb) + vl;
     const long vc = v < a.vox ? v : 0;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) fr[mb][ks] = *(const f16x8*)(raw + vc * a.raw_stride + 32 * ks + 8 * kq);
+    for (int ks = 0; ks < KS; ++ks) {
+      fr[mb][ks] = kok[ks] ? *(const f16x8*)(raw + vc * a.raw_stride + 32 * ks + 8 * kq) : zero8;
+      if (RES) {
+        fr2[mb][ks] = kok[ks] ? *(const f16x8*)(res + vc * a.res_stride + 32 * ks + 8 * kq) : zero8;
+        fr3[mb][ks] = kok[ks] && rav ? *(const f16x8*)(rav + vc * a.ra_stride + 32 * ks + 8 * kq) : zero8;
+      }
+    }
     xt[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (sampling) xt[mb] = *(const f32x4*)(a.x_state + ((long)n * a.vox + vc) * 16 + 4 * kq);
 #pragma unroll
@@ -263,7 +291,7 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
       ez[mb][j] = (sampling && a.noise && 4 * kq + j < a.C) ? a.noise[((long)n * a.C + 4 * kq + j) * a.vox + vc] : 0.f;
   }
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
+  for (int mb = 0; mb < MBS; ++mb) {
     f32x4a acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -271,13 +299,15 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = fmaf((float)fr[mb][ks][e], sc[ks][e], sh[ks][e]);
+        if (RES) t += fmaf((float)fr2[mb][ks][e], rsc[ks][e], rsh[ks][e]);      // same order as residual_norm_act_kernel
         t = t > 0.f ? t : t * a.xf.slope;
+        if (RES) { const float s = (float)fr3[mb][ks][e]; if (rav) t += s * (1.f - 1.f / (1.f + __expf(-s))); }
         y[e] = (f16)t;
       }
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks], y, acc, 0, 0, 0);     // columns of voxels >= vox are never stored
     }
-    // lane now holds the logits of classes 4 kq + j of voxel wbase + 16 mb + vl
-    const long v = wbase + 16 * mb + vl;
+    // lane now holds the logits of classes 4 kq + j of voxel wbase + 16 (mb0 + mb) + vl
+    const long v = wbase + 16 * (mb0 + mb) + vl;
     if (v >= a.vox) continue;
     const long gv = (long)n * a.vox + v;
     if (a.logits) {
@@ -321,6 +351,7 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
           if (4 * kq + j < a.C) xp[j] = (f16)xn[j];
       }
     }
+  }
   }
   }
 }
@@ -372,14 +403,21 @@ int dua_sampler_step(int mode, int N, long per_sample, const float* model_out, c
   return (int)hipGetLastError();
 }
 
-int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in_norm* in,
-                           const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
-                           const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
-                           void* stream) {
+static int tail_entry(const dua_tail_desc* d, const void* raw, const dua_in_norm* in, const dua_tail_residual* r,
+                      const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
+                      const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart, void* stream) {
   if (!d || !raw || !wf || !bf) return DUA_ERR_ARG;
   const bool identity = !in || !in->stats;        // raw is an already materialised activation (Swin-UNETR's decoder1 output)
-  if (!identity && (!in->gamma || !in->beta || in->c_pad < d->K)) return DUA_ERR_ARG;
-  if (d->K % 8 || d->raw_stride % 8 || d->K > d->raw_stride || d->C <= 0 || d->C > d->CX || d->K > 512) return DUA_ERR_ARG;
+  const int real = r ? r->channels : d->K;        // channels actually present in raw
+  if (!identity && (!in->gamma || !in->beta || in->c_pad < real)) return DUA_ERR_ARG;
+  if (d->K % 8 || d->raw_stride % 8 || real > d->raw_stride || d->C <= 0 || d->C > d->CX || d->K > 512) return DUA_ERR_ARG;
+  if (r) {
+    if (identity || d->dtype != DUA_F16 || d->CX != 16 || (d->K != 32 && d->K != 64) || real <= 0 || real % 8 || real > d->K ||
+        !r->res || r->res_stride % 8 || real > r->res_stride || !r->res_norm.stats || !r->res_norm.gamma || !r->res_norm.beta ||
+        r->res_norm.c_pad < real)
+      return DUA_ERR_ARG;
+    if (r->ra_src && (r->ra_stride % 8 || r->ra_off % 8 || r->ra_off + real > r->ra_stride)) return DUA_ERR_ARG;
+  }
   if (d->mode == DUA_MODE_LOGITS) { if (!logits) return DUA_ERR_ARG; }
   else if (d->mode == DUA_MODE_DDPM || d->mode == DUA_MODE_DDIM) { if (!coef || !x_state) return DUA_ERR_ARG; }
   else return DUA_ERR_ARG;
@@ -393,10 +431,21 @@ int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in
   a.mode = d->mode;
   a.seed_lo = (unsigned)(d->seed & 0xffffffffull); a.seed_hi = (unsigned)(d->seed >> 32);
   a.seed_dev = d->seed_dev;
+  a.res = nullptr; a.ra = nullptr; a.kvalid = d->K; a.res_stride = a.ra_stride = a.ra_off = 0; a.rf = dua::InXform{};
+  if (r) {
+    a.res = r->res; a.res_stride = r->res_stride; a.rf = dua::make_xform(&r->res_norm, real);
+    a.ra = r->ra_src; a.ra_stride = r->ra_stride; a.ra_off = r->ra_off; a.kvalid = real;
+    const long ntiles = (d->voxels + 255) / 256;
+    dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024), d->N);
+    const size_t lds = (size_t)6 * d->K * sizeof(float);
+    if (d->K == 32) hipLaunchKernelGGL((dua::final_conv_sampler_mfma_kernel<1, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((dua::final_conv_sampler_mfma_kernel<2, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   if (d->dtype == DUA_F16 && d->CX == 16 && d->K % 32 == 0 && (d->K == 32 || d->K == 64 || d->K == 128)) {
     const long ntiles = (d->voxels + 255) / 256;
     dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024), d->N);
-    const size_t lds = (size_t)3 * d->K * sizeof(float);
+    const size_t lds = (size_t)6 * d->K * sizeof(float);
     if (d->K == 32) hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else if (d->K == 64) hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
@@ -405,6 +454,21 @@ int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in
   if (d->dtype == DUA_F16) return dua::dispatch_tail<dua::f16>(d, a, (hipStream_t)stream);
   if (d->dtype == DUA_F32) return dua::dispatch_tail<float>(d, a, (hipStream_t)stream);
   return DUA_ERR_ARG;
+}
+
+int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in_norm* in,
+                           const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
+                           const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
+                           void* stream) {
+  return tail_entry(d, raw, in, nullptr, wf, bf, coef, x_state, noise, step_word, xin, xstart_sum, logits, xstart, stream);
+}
+
+int dua_final_conv_sampler_res(const dua_tail_desc* d, const void* raw, const dua_in_norm* in, const dua_tail_residual* r,
+                               const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
+                               const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
+                               void* stream) {
+  if (!r) return DUA_ERR_ARG;
+  return tail_entry(d, raw, in, r, wf, bf, coef, x_state, noise, step_word, xin, xstart_sum, logits, xstart, stream);
 }
 
 }  // extern "C"

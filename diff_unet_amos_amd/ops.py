@@ -647,14 +647,28 @@ def state_stride(num_classes):
 
 
 def final_conv_sampler(raw, K, norm, wf, bf, num_classes, mode, coef=None, x_state=None, noise=None,
-                       step_word=None, xin=None, xstart_sum=None, logits=None, xstart=None, seed=0, seed_dev=None):
+                       step_word=None, xin=None, xstart_sum=None, logits=None, xstart=None, seed=0, seed_dev=None,
+                       residual=None):
     """``seed_dev``: optional int64[1] device tensor holding the Philox key (read by the kernel at run time, so a
-    captured graph draws a fresh noise field whenever the host rewrites the word); otherwise ``seed`` is the key."""
+    captured graph draws a fresh noise field whenever the host rewrites the word); otherwise ``seed`` is the key.
+    ``residual`` = (res, res_norm, ra_src, ra_off, channels): the residual form (dua_final_conv_sampler_res) -- the 1x1x1
+    convolution reads LeakyReLU(norm(raw) + res_norm(res)) + reverse_attention(ra_src[..., ra_off:ra_off + channels])
+    assembled in registers; fp16, K = channels rounded up to 32, ``wf`` columns behind ``channels`` zero."""
     _cl_check(raw, "raw")
     N, D, H, W, rs = raw.shape
     vox = D * H * W
     cx = state_stride(num_classes)
-    assert K % 8 == 0 and K <= rs and K <= 512
+    if residual is not None:
+        res, res_norm, ra_src, ra_off, channels = residual
+        _cl_check(res, "res")
+        assert raw.dtype == torch.float16 and res.dtype == raw.dtype and tuple(res.shape[:4]) == (N, D, H, W)
+        assert norm is not None and res_norm is not None and cx == 16 and K in (32, 64)
+        assert channels % 8 == 0 and 0 < channels <= min(K, rs, res.shape[-1])
+        if ra_src is not None:
+            _cl_check(ra_src, "ra_src")
+            assert ra_src.dtype == raw.dtype and tuple(ra_src.shape[:4]) == (N, D, H, W)
+            assert ra_off % 8 == 0 and ra_off + channels <= ra_src.shape[-1]
+    assert K % 8 == 0 and (K <= rs or residual is not None) and K <= 512
     _f32c(wf, "wf"); _f32c(bf, "bf")
     assert wf.numel() == num_classes * K and bf.numel() == num_classes
     if mode != nv.MODE_LOGITS:
@@ -676,6 +690,15 @@ def final_conv_sampler(raw, K, norm, wf, bf, num_classes, mode, coef=None, x_sta
         assert seed_dev.is_cuda and seed_dev.dtype == torch.int64 and seed_dev.numel() >= 1
     d = nv.TailDesc(nv.dt_code(raw.dtype), N, vox, K, rs, num_classes, cx, mode, xs, seed,
                     seed_dev.data_ptr() if seed_dev is not None else None)
+    if residual is not None:
+        _, rn = _norm_value(res_norm, N, channels)
+        r = nv.TailResidual(res.data_ptr(), res.shape[-1], rn, _addr(ra_src), ra_src.shape[-1] if ra_src is not None else 0,
+                            ra_off, channels)
+        nv.check(nv.lib().dua_final_conv_sampler_res(C.byref(d), nv.ptr(raw), _norm_ref(norm, N, channels), C.byref(r), nv.ptr(wf),
+                                                     nv.ptr(bf), nv.ptr(coef), nv.ptr(x_state), nv.ptr(noise),
+                                                     nv.ptr(step_word), nv.ptr(xin), nv.ptr(xstart_sum), nv.ptr(logits),
+                                                     nv.ptr(xstart), nv.stream_ptr()), "dua_final_conv_sampler_res")
+        return
     nv.check(nv.lib().dua_final_conv_sampler(C.byref(d), nv.ptr(raw), _norm_ref(norm, N, K), nv.ptr(wf),
                                              nv.ptr(bf), nv.ptr(coef), nv.ptr(x_state), nv.ptr(noise),
                                              nv.ptr(step_word), nv.ptr(xin), nv.ptr(xstart_sum), nv.ptr(logits),

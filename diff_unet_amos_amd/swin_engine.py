@@ -140,6 +140,8 @@ class SwinPlan:
         self.raw1b, self.raw2b, self.res3b = (torch.zeros(big, dtype=dtype, device=device) for _ in range(3))   # side stream
         self.side_stream = torch.cuda.Stream(device=device)
         self.two_streams = True
+        self.fused_tail = dtype == torch.float16 and self.cx == 16     # the tail assembles decoder1's output itself (MFMA tail kernel: fp16, 9..16 classes)
+        self._tail_src = None
         self.background_convs = True        # side-stream 3x3x3 convolutions leave half of every CU to the main stream's chain
         self.enc_done = [torch.cuda.Event() for _ in range(4)]
         self.stream = [torch.zeros((N, *S[i + 1], self.tok_c[i]), dtype=torch.float32, device=device) for i in range(5)]
@@ -312,9 +314,10 @@ class SwinPlan:
     def _tadd(self, off, c):
         return None if off is None else self.cur_add[:, off:off + c]
 
-    def _res_block(self, r, x, cin, out, out_off=0, post_add=None, ra=None, ra_off=0, side=False):
+    def _res_block(self, r, x, cin, out, out_off=0, post_add=None, ra=None, ra_off=0, side=False, defer=False):
         """UnetResBlock.forward (blocks.py:298-316) on channels [0, cin) of ``x`` -> channels [out_off, ...) of ``out``.
-        ``side``: use the second set of scratch buffers (blocks running on the side stream, see denoiser_body)."""
+        ``side``: use the second set of scratch buffers (blocks running on the side stream, see denoiser_body).
+        ``defer``: do not materialise the output; return (raw2, norm2, res, norm3) for a consumer that assembles it (tail)."""
         l, N = r.level, self.N
         count = self.S[l][0] * self.S[l][1] * self.S[l][2]
         b1, b2, b3, ws = (self.raw1b, self.raw2b, self.res3b, self.splitk_ws_b) if side else (self.raw1, self.raw2, self.res3, self.splitk_ws)
@@ -329,6 +332,7 @@ class SwinPlan:
         bg = side and self.two_streams and self.background_convs
         ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws, background=bg)
         ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=ws, background=bg)
+        assert r.has3 or not defer
         if r.has3:
             res = self._view(b3, l, r.cout)
             x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
@@ -337,6 +341,8 @@ class SwinPlan:
             else:
                 torch.matmul(x2, r.w3.t(), out=res.view(-1, r.cout))                 # 1x1x1 conv3 = library GEMM
                 ops.instnorm_stats(res, r.cout, r.st[2])
+            if defer:
+                return raw2, n2, res, n3
             ops.residual_norm_act(raw2, n2, res, n3, slope=SLOPE, out=out, out_off=out_off, post_add=post_add, ra_src=ra,
                                   ra_off=ra_off)
         else:
@@ -481,6 +487,11 @@ class SwinPlan:
             if two and k < 4:
                 main.wait_event(self.enc_done[k])                                  # the skip half of cat[k]
             ra = cat[k] if k < 4 else None                                         # + r_k (not for decoder5: skip = hs[3])
+            if k == 0 and self.fused_tail:
+                # decoder1's output is consumed by the `out` convolution only: the tail assembles it from the block's two
+                # branches instead of reading it back (saves writing and re-reading 2 x 113 MB at 96^3)
+                self._tail_src = self._res_block(self.u_res[0], cat[0], 2 * cout, dec[0], 0, defer=True) + (cat[0], cout, cout)
+                break
             self._res_block(self.u_res[k], cat[k], 2 * cout, dec[k], 0, ra=ra, ra_off=cout)
             src = dec[k]
 
@@ -497,10 +508,15 @@ class SwinPlan:
     def tail(self, mode, noise=None, logits=None, use_sum=False):
         """UnetOutBlock (1x1x1, denoiser.py:399-400) fused with the sampler update (engine.Plan.tail's kernel, fed the
         materialised decoder1 output)."""
-        ops.final_conv_sampler(self.dec[0], self.tail_k, None, self.wf, self.bf, self.C, mode, coef=self.cur_coef,
+        raw, norm, residual = self.dec[0], None, None
+        if self.fused_tail:
+            raw, norm, res, n3, ra, ra_off, ch = self._tail_src
+            residual = (res, n3, ra, ra_off, ch)
+        ops.final_conv_sampler(raw, self.tail_k, norm, self.wf, self.bf, self.C, mode, coef=self.cur_coef,
                                x_state=self.x_state, noise=noise, step_word=self.step_word,
                                xin=self.xin if mode != nv.MODE_LOGITS else None,
-                               xstart_sum=self.x_sum if use_sum else None, logits=logits, seed_dev=self.seed_word)
+                               xstart_sum=self.x_sum if use_sum else None, logits=logits, seed_dev=self.seed_word,
+                               residual=residual)
 
     def new_seed(self, seed=None):
         """Philox key of this call's in-kernel noise (engine.Plan.new_seed)."""

@@ -268,6 +268,27 @@ int dua_final_conv_sampler(const dua_tail_desc* d, const void* raw, const dua_in
                            const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
                            void* stream);
 
+/* The same tail fed by the last UnetResBlock of SwinUNETRDenoiser (decoder1's conv_block) BEFORE its output is
+ * materialised: the 1x1x1 convolution's input is assembled in registers as
+ *   LeakyReLU(norm(raw) + norm_res(res)) + ra * (1 - sigmoid(ra))
+ * -- norm2(conv2) + norm3(conv3) and the activation of UnetResBlock.forward (models/swin_unetr/blocks.py:306-316), plus the
+ * reverse-attention term of the skip (models/swin_unetr/denoiser.py:397,405-408) -- with the arithmetic order of
+ * dua_residual_norm_act, so both routes give the same bits.  DUA_F16, CX == 16, d->K in {32, 64} = channels rounded up to 32
+ * (wf is [C][K] with zero columns behind `channels`; raw / res / ra_src may have channel strides below K). */
+typedef struct {
+  const void* res;         /* the shortcut branch (conv3 output), channels [0, channels) */
+  int res_stride;
+  dua_in_norm res_norm;    /* its InstanceNorm (norm3); stats must be set */
+  const void* ra_src;      /* NULL or the tensor whose channels [ra_off, ra_off + channels) enter x * (1 - sigmoid(x)) */
+  int ra_stride, ra_off;
+  int channels;            /* real channels of raw / res / ra_src (multiple of 8, <= d->K) */
+} dua_tail_residual;
+
+int dua_final_conv_sampler_res(const dua_tail_desc* d, const void* raw, const dua_in_norm* in, const dua_tail_residual* r,
+                               const float* wf, const float* bf, const float* coef, float* x_state, const float* noise,
+                               const int* step_word, void* xin, float* xstart_sum, float* logits, float* xstart,
+                               void* stream);
+
 /* ---- timestep embedding ---------------------------------------------------------------------
  * table[i][:] = concat over TwoConv blocks of temb_proj(swish(TimeStepEmbedder(timesteps[i])))
  * (models/diffusion/utils.py:6-54; models/basic_unet/denoiser.py:51-52,65).  freqs = the

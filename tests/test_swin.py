@@ -571,3 +571,48 @@ def test_fused_swin_mlp_kernel_matches_torch(C_, M):
     ops.token_linear(ln2, w1, b1, "gelu", out=hid)
     ops.token_linear(hid, w2, b2, "residual", x=xb)
     assert (xa - xb).abs().max() < 2e-3 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["logits", "ddpm"])
+def test_tail_residual_form_equals_the_materialised_route(mode):
+    """dua_final_conv_sampler_res (decoder1's output assembled inside the tail) against residual_norm_act + the ordinary tail on
+    the same operands: the same bits (same arithmetic order, same fp16 rounding point), 48 real channels in a K = 64 tail, a
+    voxel count that is not a multiple of the 256-voxel tile, two samples."""
+    from diff_unet_amos_amd import ops, _native as nv
+    dev = "cuda"
+    g = torch.Generator().manual_seed(31)
+    N, D, H, W, Cc, K, classes = 2, 9, 10, 11, 48, 64, 16
+    vox = D * H * W
+    raw = torch.randn(N, D, H, W, Cc, generator=g).half().to(dev)
+    res = (torch.randn(N, D, H, W, Cc, generator=g) * 2 + 0.5).half().to(dev)
+    cat = torch.randn(N, D, H, W, 2 * Cc, generator=g).half().to(dev)
+    ones, zeros = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    st_a, st_b = ops.stats_buffer(N, Cc, dev), ops.stats_buffer(N, Cc, dev)
+    ops.instnorm_stats(raw, Cc, st_a)
+    ops.instnorm_stats(res, Cc, st_b)
+    na = ops.Norm(st_a, ones, zeros, vox, slope=0.01, eps=1e-5)
+    nb = ops.Norm(st_b, ones, zeros, vox, slope=0.01, eps=1e-5)
+    wf = torch.zeros(classes, K, device=dev)
+    wf[:, :Cc] = torch.randn(classes, Cc, generator=g).to(dev) / Cc ** 0.5
+    bf = torch.randn(classes, generator=g).to(dev)
+    coef = torch.rand(N, 8, generator=g).to(dev)
+    x0 = torch.randn(N * vox * 16, generator=g).to(dev)
+    seed = torch.tensor([1234], dtype=torch.int64, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(fused):
+        state, logits = x0.clone(), torch.zeros(N, classes, D, H, W, device=dev)
+        kw = dict(coef=coef, x_state=state, step_word=step, seed_dev=seed) if mode == "ddpm" else dict(logits=logits)
+        m = nv.MODE_DDPM if mode == "ddpm" else nv.MODE_LOGITS
+        if fused:
+            ops.final_conv_sampler(raw, K, na, wf, bf, classes, m, residual=(res, nb, cat, Cc, Cc), **kw)
+        else:
+            dec = torch.zeros(N, D, H, W, K, dtype=torch.float16, device=dev)
+            ops.residual_norm_act(raw, na, res, nb, slope=0.01, out=dec, out_off=0, ra_src=cat, ra_off=Cc)
+            ops.final_conv_sampler(dec, K, None, wf, bf, classes, m, **kw)
+        return state if mode == "ddpm" else logits
+
+    a, b = run(True), run(False)
+    assert bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0.1
+    assert torch.equal(a, b), float((a - b).abs().max())

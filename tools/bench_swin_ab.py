@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-process A/B of SwinPlan switches on the config-5 step (96^3, 16 classes, one patch): each setting is captured into its
 own HIP graph, rounds are interleaved.  usage: bench_swin_ab.py [rounds] [steps per round]
-Settings: two_streams, background_convs, fused_mlp, fused_linear, fused_max_c, fused_reduction (swin_engine.SwinPlan attributes)."""
+Settings: two_streams, fused_tail, background_convs, fused_mlp, fused_linear, fused_max_c, fused_reduction (swin_engine.SwinPlan attributes)."""
 import os
 import sys
 import time
@@ -22,11 +22,11 @@ def main():
     image = torch.rand(1, 1, 96, 96, 96, device=dev)
     plan = net._rt.plan(1, (96, 96, 96), dev)
     settings = {"default": {}, "fused kernels at stage 1 too": {"fused_max_c": 96}, "fused reduction": {"fused_reduction": True},
-                "one-kernel MLP off": {"fused_mlp": False}, "one stream": {"two_streams": False}, "side-stream convolutions at two workgroups per CU": {"background_convs": False}, "library GEMMs": {"fused_linear": False},
+                "one-kernel MLP off": {"fused_mlp": False}, "one stream": {"two_streams": False}, "decoder1 output materialised for the tail": {"fused_tail": False}, "side-stream convolutions at two workgroups per CU": {"background_convs": False}, "library GEMMs": {"fused_linear": False},
                 "library qkv": {"tl_qkv": False}, "library proj + scatter kernel": {"tl_proj": False},
                 "library conv3 + stats kernel": {"tl_conv3": False}}
     base = {k: getattr(plan, k) for k in ("two_streams", "fused_mlp", "fused_linear", "fused_max_c", "fused_reduction", "tl_qkv",
-                                          "tl_proj", "tl_conv3", "background_convs")}
+                                          "tl_proj", "tl_conv3", "background_convs", "fused_tail")}
     graphs = {}
     with torch.no_grad():
         net.embed_model(image)

@@ -31,12 +31,14 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // each: 59-88 us for a few hundred KB).  A lane owns elements l, l + 64 WPT, ... of the 8C gathered vector, held in registers
 // between the moments and the normalisation; corner and channel of an element advance incrementally (no division), and
 // every load is issued unconditionally on a clamped address (a load under a lane-dependent branch sits in its own basic
-// block and is waited for there).
-template <typename T, int WPT>
+// block and is waited for there).  NPER > 0 fixes the values per lane at compile time (the Swin-UNETR widths: 6 or 12): with
+// the run-time count every one of the 48 / WPT slots keeps its value, address and flag in registers (~200 VGPRs, two waves
+// per SIMD -- 59 us for the 32 MB of the 48^3-token merge).
+template <typename T, int WPT, int NPER = 0>
 __global__ __launch_bounds__(256) void patch_merge_norm_kernel(const float* __restrict__ x, const T* __restrict__ y, int B, int D,
                                                                int H, int W, int C, int legacy, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, T* __restrict__ out) {
-  constexpr int MAXV = 48 / WPT;                         // 8C / (64 WPT) values per lane, C <= 384
+  constexpr int MAXV = NPER > 0 ? NPER : 48 / WPT;       // 8C / (64 WPT) values per lane, C <= 384
   constexpr int STRIDE = 64 * WPT;
   __shared__ float part[4][2];
   const int D2 = (D + 1) / 2, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void patch_merge_norm_kernel(const float* __re
   const int w2 = (int)(tk % W2), h2 = (int)((tk / W2) % H2), d2 = (int)((tk / ((long)W2 * H2)) % D2), b = (int)(tk / ((long)W2 * H2 * D2));
   // corner k of the gathered vector -> (di, dj, dk); V2: itertools.product order; legacy: patch.py:82-89
   const int leg[8] = {0, 4, 2, 1, 5, 2, 1, 7};          // bit 2 = d offset, bit 1 = h offset, bit 0 = w offset
-  const int E = 8 * C, nper = E / STRIDE;
+  const int E = 8 * C, nper = NPER > 0 ? NPER : E / STRIDE;
   const int e0 = WPT == 1 ? lane : threadIdx.x;
   float v[MAXV];
   long idx[MAXV];
@@ -151,12 +153,18 @@ int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legac
   const long ntok = (long)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
   const bool wide = ntok < 2048 && (8 * C) % 256 == 0;        // few tokens: a whole workgroup per token
   dim3 grid((unsigned)(wide ? ntok : (ntok + 3) / 4));
-#define DUA_PM(T_, WPT_)                                                                                                  \
-  hipLaunchKernelGGL((dua::patch_merge_norm_kernel<T_, WPT_>), grid, dim3(256), 0, (hipStream_t)stream, x, (const T_*)y, B, D, H, \
-                     W, C, legacy, gamma, beta, eps, (T_*)out)
-  if (dtype == DUA_F16) { if (wide) DUA_PM(dua::f16, 4); else DUA_PM(dua::f16, 1); }
-  else if (dtype == DUA_F32) { if (wide) DUA_PM(float, 4); else DUA_PM(float, 1); }
+  const int nper = 8 * C / (wide ? 256 : 64);            // values per lane
+#define DUA_PM(T_, WPT_, NPER_)                                                                                           \
+  hipLaunchKernelGGL((dua::patch_merge_norm_kernel<T_, WPT_, NPER_>), grid, dim3(256), 0, (hipStream_t)stream, x, (const T_*)y, B, \
+                     D, H, W, C, legacy, gamma, beta, eps, (T_*)out)
+#define DUA_PM_T(T_)                                                                                                      \
+  if (wide) { if (nper == 6) DUA_PM(T_, 4, 6); else if (nper == 12) DUA_PM(T_, 4, 12); else if (nper == 3) DUA_PM(T_, 4, 3);  \
+              else DUA_PM(T_, 4, 0); }                                                                                    \
+  else { if (nper == 6) DUA_PM(T_, 1, 6); else if (nper == 12) DUA_PM(T_, 1, 12); else DUA_PM(T_, 1, 0); }
+  if (dtype == DUA_F16) { DUA_PM_T(dua::f16) }
+  else if (dtype == DUA_F32) { DUA_PM_T(float) }
   else return DUA_ERR_ARG;
+#undef DUA_PM_T
 #undef DUA_PM
   return (int)hipGetLastError();
 }

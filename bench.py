@@ -271,19 +271,21 @@ def run_config2(args, D):
             plan.native_step(nv.MODE_DDPM, row_of_step=row_of_step, coef_table=coef_table, use_sum=False)
 
         assert args.warmup + args.steps + 2 <= T, "the 1000-step process bounds warmup+steps"
+        one_step()
+        torch.cuda.synchronize()
         if args.no_graph:
-            one_step()
-            torch.cuda.synchronize()
-
-            def run(times):
-                for _ in range(times):
-                    one_step()
+            run = one_step
         else:
-            run = plan.capture_step(one_step).replay
-        run(args.warmup)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step()
+            run = g.replay
+        for _ in range(args.warmup):
+            run()
         D.barrier()
         t0 = time.perf_counter()
-        run(args.steps)
+        for _ in range(args.steps):
+            run()
         torch.cuda.synchronize()
         dt = D.max_over_ranks(time.perf_counter() - t0)
         D.barrier()
@@ -452,21 +454,19 @@ def run_config5(args, D):
             plan.tail(nv.MODE_DDPM)
 
         assert args.warmup + args.steps + 2 <= T
-        one_step()
-        torch.cuda.synchronize()
         if args.no_graph:
-            run = one_step
+            one_step()
+            torch.cuda.synchronize()
+
+            def run(times):
+                for _ in range(times):
+                    one_step()
         else:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                one_step()
-            run = g.replay
-        for _ in range(args.warmup):
-            run()
+            run = plan.capture_step(one_step).replay
+        run(args.warmup)
         D.barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
+        run(args.steps)
         torch.cuda.synchronize()
         dt = D.max_over_ranks(time.perf_counter() - t0)
         D.barrier()

@@ -553,7 +553,8 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2>), grid2, dim3(256), LDS2 + xf_bytes, s, a);
     return (int)hipGetLastError();
   }
-  if (a.ksplit == 1 && g_conv_variant == 4) {        // 8x8x8 tiles, eight waves per workgroup
+  if (a.ksplit == 1 && g_conv_variant == 4 && !part_out && !init) {        // 8x8x8 tiles, eight waves per workgroup (never the two-part form:
+                                                                             // its partial-sum buffer is sized for 4-deep tiles)
     a.ntiles = ((d->D + 7) / 8) * a.tiles_h * a.tiles_w;
     dim3 grid8(a.ntiles, nct, d->N);
     hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 8>), grid8, dim3(512), 10 * c3::PS + 2 * c3v2::SLAB + xf_bytes, s, a);
@@ -599,9 +600,10 @@ int dua_set_option(int key, int value) {
 long dua_conv3d_k3_partial_bytes(const dua_conv3_desc* d) {
   using namespace dua::c3;
   if (!d || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return DUA_ERR_ARG;
-  // whole tiles of the smallest tile shape the launcher may pick (2x8x8), 64-wide output tiles, fp32
-  const long tiles = (long)((d->D + 1) / 2) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
-  return tiles * 2 * TH * TW * ((d->Cout + BN - 1) / BN) * BN * 4 * d->N;
+  // whole 4x8x8 tiles (the tile shape of both two-part launches), 64-wide output tiles, fp32.  (Depth counted in whole
+  // 4-deep tiles: ceil(D / 2) two-deep layers are one layer short whenever D mod 4 is 1 or 2.)
+  const long tiles = (long)((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
+  return tiles * TD * TH * TW * ((d->Cout + BN - 1) / BN) * BN * 4 * d->N;
 }
 
 int dua_conv3d_k3_partial(const dua_conv3_desc* d, const void* x, const void* w_packed, const dua_in_norm* in, float* partial,

@@ -143,8 +143,11 @@ def test_conv3_two_part_form_equals_the_convolution_over_the_concatenation(dtype
     ops.conv3d_k3(xcl, Ca + Cb, 0, wp, bp, Cout, y0, 0, st0)
     wa, _ = ops.pack_conv3_weights(w[:, :Ca].contiguous().cuda(), None, dtype)
     wb, _ = ops.pack_conv3_weights(w[:, Ca:].contiguous().cuda(), None, dtype)
-    part = torch.full((ops.conv3_partial_bytes(dtype, N, D, H, W, Cout) // 4,), float("nan"), dtype=torch.float32, device="cuda")
+    nfl = ops.conv3_partial_bytes(dtype, N, D, H, W, Cout) // 4
+    guard = torch.full((nfl + 65536,), float("nan"), dtype=torch.float32, device="cuda")       # the buffer + a canary behind it
+    part = guard[:nfl]
     ops.conv3d_k3_partial(xcl, Ca, 0, wa, Cout, part)
+    assert bool(torch.isnan(guard[nfl:]).all()), "the partial-sum launch wrote behind conv3_partial_bytes()"
     y1 = torch.zeros_like(y0)
     st1 = ops.stats_buffer(N, Cout, "cuda")
     ops.conv3d_k3(xcl, Cb, Ca, wb, bp, Cout, y1, 0, st1, init=part)

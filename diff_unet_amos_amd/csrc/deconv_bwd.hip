@@ -130,31 +130,43 @@ __global__ __launch_bounds__(256) void deconv_k2s2_dgrad_kernel(DeconvBwdArgs a)
 
 // ---------------------------------------------------------------------------------------------------------------
 namespace dwg {
-constexpr int NT = 512;                 // 8 waves = 8 taps
-template <typename T> constexpr int tile_voxels() { return sizeof(T) == 2 ? 128 : 64; }   // 18 half-images must fit 160 KB of LDS
+constexpr int NT = 256;                 // 4 waves: each contracts a quarter of a tile's voxels into its own 64 x 64 accumulators
+template <typename T> constexpr int tile_voxels() { return sizeof(T) == 2 ? 128 : 64; }   // 8 k-steps of 16 (f16) / 8 (f32) voxels
 typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 }
 
+// Weight gradient of the transposed convolution: eight independent GEMMs dW_tap[ci][co] = sum_v x[v][ci] * dy[2v + tap][co].
+// One workgroup = one tap, one (64 ci x 64 co) tile, one partition of the input voxels; it walks its partition in tiles of
+// TV voxels: the x tile and the tap's dy tile are staged in LDS exactly as they lie in HBM (rows of 32 channels) and read
+// with the transposing LDS read (conv3d_wgrad.hip); the NEXT tile's 16-byte pieces are already in registers while the current
+// one is multiplied.  Wave w contracts k-steps w, w + 4: the four 64 x 64 partial results are summed through LDS at the end and
+// written as one [ci][co] tile of the partial-sum buffer, which deconv_wgrad_reduce_kernel adds over the partitions.
+// (The first version gave a workgroup all eight taps of a tile -- 147 KB of LDS, one workgroup per CU, no prefetch, 768
+// partitions to fill the chip: 920 us + 190 us of reduction for the 48^3 -> 96^3 layer at batch 2, whose operands are 254 MB.)
 template <typename T>
 __global__ __launch_bounds__(dwg::NT) void deconv_k2s2_wgrad_kernel(DeconvBwdArgs a) {
   using namespace dwg;
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
   constexpr int TV = tile_voxels<T>();
-  constexpr int G = 64 / EPG;
+  constexpr int G = 64 / EPG;                      // 16-byte pieces per voxel
   constexpr int RSB = 32 * (int)sizeof(T);
   constexpr int IMG = TV * RSB + 64;               // one 32-channel half image of one tile; +64 B: the two halves of a voxel
                                                    // land in different halves of the 32 store banks (as conv3d_wgrad.hip)
   constexpr int KV = sizeof(T) == 2 ? 16 : 8;      // voxels per mma32 call
+  constexpr int NI = TV * G / NT;                  // pieces per thread and operand (4)
+  static_assert(TV * G % NT == 0 && (TV / KV) % 4 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xs = smem;                                 // [2][TV][32]
-  char* Ys = smem + 2 * IMG;                       // [8 taps][2][TV][32]
+  char* Ys = smem + 2 * IMG;                       // [2][TV][32]
 
-  const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6, hl = lane >> 5;
-  const int part_id = blockIdx.x, combo = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5;
+  const int part_id = blockIdx.x, tap = blockIdx.y & 7, combo = blockIdx.y >> 3;
   const int ci_t = combo / a.ncc, co_t = combo % a.ncc;          // ncc = co tiles
-  const long vox = (long)a.D * a.H * a.W;
+  const int vox = a.D * a.H * a.W;                 // the launcher checks that 8 * vox fits an int
   const int H2 = 2 * a.H, W2 = 2 * a.W;
+  const int toff = ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
+  const int tiles_per_n = (vox + TV - 1) / TV;
 
   f32x16 acc[2][2];                                // [ci half][co half]
 #pragma unroll
@@ -164,9 +176,6 @@ __global__ __launch_bounds__(dwg::NT) void deconv_k2s2_wgrad_kernel(DeconvBwdArg
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // staging items: x: TV x G 16-byte groups; dy: 8 taps x TV x G.  512 threads: x = 2 (f16) / 4 (f32) items per thread,
-  // dy = 16 / 32 per thread -- wave w stages the tile of tap w (its own operand), all waves share x.
-  constexpr int NXI = TV * G / NT, NYI = TV * G / 64;
   int a_off[2], b_col;
   if constexpr (sizeof(T) == 2) {
     const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3, g1 = (lane >> 4) & 1;
@@ -177,46 +186,52 @@ __global__ __launch_bounds__(dwg::NT) void deconv_k2s2_wgrad_kernel(DeconvBwdArg
     b_col = (lane & 31) * 4;
     a_off[0] = a_off[1] = 0;
   }
-  const long toff = ((long)(tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
+  // this thread's pieces: voxel vl[j] of the tile, 16-byte group g (the same for all j: NT is a multiple of G)
+  const int g = tid % G, vl0 = tid / G;
+  constexpr int VSTEP = NT / G;
+  const int lds_off = ((g * EPG) >> 5) * IMG + ((g * EPG) & 31) * (int)sizeof(T);
+  const bool xg_ok = ci_t * 64 + g * EPG < a.Cin, yg_ok = co_t * 64 + g * EPG < a.Cout;
 
-  for (int tile = part_id; tile < a.total_tiles; tile += a.P) {
-    const long tiles_per_n = (vox + TV - 1) / TV;
-    const int n = (int)(tile / tiles_per_n);
-    const long v0 = (tile % tiles_per_n) * TV;
-    const T* xb = (const T*)a.x + (long)n * vox * a.Cin_stride + a.Cin_off + ci_t * 64;
-    const T* yb = (const T*)a.dy + (long)n * vox * 8 * a.Cout_stride + a.Cout_off + co_t * 64;
-    __syncthreads();                               // previous tile's fragment reads are done
+  Frag xr[NI], yr[NI];
+  auto load_tile = [&](int tile) {
+    const int n = tile / tiles_per_n, v0 = (tile - n * tiles_per_n) * TV;
+    // channel groups behind Cin / Cout are zero-filled below: their loads go to the slice's first group (a real address)
+    const T* xb = (const T*)a.x + (long)n * vox * a.Cin_stride + a.Cin_off + (xg_ok ? ci_t * 64 + g * EPG : 0);
+    const T* yb = (const T*)a.dy + (long)n * vox * 8 * a.Cout_stride + a.Cout_off + (yg_ok ? co_t * 64 + g * EPG : 0);
 #pragma unroll
-    for (int j = 0; j < NXI; ++j) {
-      const int it = tid + NT * j, vl = it / G, g = it % G;
-      const long v = v0 + vl;
-      Frag f;
-      const bool ok = v < vox && ci_t * 64 + g * EPG < a.Cin;
-      f = *(const Frag*)(xb + (ok ? v * a.Cin_stride + g * EPG : 0));
+    for (int j = 0; j < NI; ++j) {
+      const int v = v0 + vl0 + VSTEP * j;
+      const bool in = v < vox;
+      const int vc = in ? v : 0;
+      const int w = vc % a.W, t = vc / a.W, h = t % a.H, d = t / a.H;
+      const long ov = (long)((2 * d) * H2 + 2 * h) * W2 + 2 * w + toff;
+      xr[j] = *(const Frag*)(xb + (long)vc * a.Cin_stride);             // unconditional loads on clamped addresses
+      yr[j] = *(const Frag*)(yb + ov * a.Cout_stride);
+      if (!(in && xg_ok)) {
 #pragma unroll
-      for (int e = 0; e < EPG; ++e) f[e] = ok ? f[e] : (T)0.f;
-      *(Frag*)(Xs + ((g * EPG) >> 5) * IMG + vl * RSB + ((g * EPG) & 31) * (int)sizeof(T)) = f;
-    }
-#pragma unroll 4
-    for (int j = 0; j < NYI; ++j) {
-      const int it = lane + 64 * j, vl = it / G, g = it % G;
-      const long v = v0 + vl;
-      const bool ok = v < vox && co_t * 64 + g * EPG < a.Cout;
-      long ov = 0;
-      if (ok) {
-        const int w = (int)(v % a.W); const long t = v / a.W;
-        const int h = (int)(t % a.H), d = (int)(t / a.H);
-        ov = ((long)(2 * d) * H2 + 2 * h) * W2 + 2 * w + toff;
+        for (int e = 0; e < EPG; ++e) xr[j][e] = (T)0.f;
       }
-      Frag f = *(const Frag*)(yb + (ok ? ov * a.Cout_stride + g * EPG : 0));
+      if (!(in && yg_ok)) {
 #pragma unroll
-      for (int e = 0; e < EPG; ++e) f[e] = ok ? f[e] : (T)0.f;
-      *(Frag*)(Ys + tap * 2 * IMG + ((g * EPG) >> 5) * IMG + vl * RSB + ((g * EPG) & 31) * (int)sizeof(T)) = f;
+        for (int e = 0; e < EPG; ++e) yr[j][e] = (T)0.f;
+      }
+    }
+  };
+
+  int tile = part_id;
+  if (tile < a.total_tiles) load_tile(tile);
+  for (; tile < a.total_tiles; tile += a.P) {
+    __syncthreads();                               // the previous tile's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      *(Frag*)(Xs + lds_off + (vl0 + VSTEP * j) * RSB) = xr[j];
+      *(Frag*)(Ys + lds_off + (vl0 + VSTEP * j) * RSB) = yr[j];
     }
     __syncthreads();
-    const char* yt = Ys + tap * 2 * IMG;
-#pragma unroll 2
-    for (int s = 0; s < TV / KV; ++s) {
+    if (tile + a.P < a.total_tiles) load_tile(tile + a.P);
+#pragma unroll
+    for (int ss = 0; ss < TV / KV / 4; ++ss) {
+      const int s = wave + 4 * ss;
       Frag fx[2], fy[2];
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -224,8 +239,8 @@ __global__ __launch_bounds__(dwg::NT) void deconv_k2s2_wgrad_kernel(DeconvBwdArg
           h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(Xs + hf * IMG + s * 16 * RSB + a_off[0]));
           h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(Xs + hf * IMG + s * 16 * RSB + a_off[1]));
           fx[hf] = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
-          h4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(yt + hf * IMG + s * 16 * RSB + a_off[0]));
-          h4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(yt + hf * IMG + s * 16 * RSB + a_off[1]));
+          h4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(Ys + hf * IMG + s * 16 * RSB + a_off[0]));
+          h4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(Ys + hf * IMG + s * 16 * RSB + a_off[1]));
           fy[hf] = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo2), __builtin_bit_cast(f16x4, hi2), 0, 1, 2, 3, 4, 5, 6, 7);
         }
       } else {
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(dwg::NT) void deconv_k2s2_wgrad_kernel(DeconvBwdArg
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             fx[hf][e] = *(const float*)(Xs + hf * IMG + (s * 8 + 2 * e + hl) * RSB + b_col);
-            fy[hf][e] = *(const float*)(yt + hf * IMG + (s * 8 + 2 * e + hl) * RSB + b_col);
+            fy[hf][e] = *(const float*)(Ys + hf * IMG + (s * 8 + 2 * e + hl) * RSB + b_col);
           }
       }
 #pragma unroll
@@ -243,8 +258,35 @@ __global__ __launch_bounds__(dwg::NT) void deconv_k2s2_wgrad_kernel(DeconvBwdArg
         for (int j = 0; j < 2; ++j) mma32(acc[i][j], fx[i], fy[j]);      // rows = ci, columns = co
     }
   }
-  // partial sums: part[P][combo][tap][ci 64][co 64]; lane column = co (lane & 31), register i -> ci row
-  float* pp = a.part + (((long)part_id * gridDim.y + combo) * 8 + tap) * 4096 + (lane & 31);
+  // sum the four waves' 64 x 64 results through LDS in two halving rounds (waves 2, 3 -> 0, 1; wave 1 -> 0: 32 KB, inside the
+  // tile buffers), then wave 0 writes its tile of part[P][combo][tap][ci 64][co 64]; lane column = co (lane & 31),
+  // register e -> ci row
+  float* red = (float*)smem + (wave & 1) * 4096 + (lane & 31);
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const bool writer = round == 0 ? wave >= 2 : wave == 1, reader = round == 0 ? wave < 2 : wave == 0;
+    __syncthreads();
+    if (writer) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red[(i * 32 + acc_row(e, hl)) * 64 + j * 32] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (reader) {
+      const float* rd = round == 0 ? red : (const float*)smem + 4096 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += rd[(i * 32 + acc_row(e, hl)) * 64 + j * 32];
+    }
+  }
+  if (wave != 0) return;
+  float* pp = a.part + (((long)part_id * (gridDim.y >> 3) + combo) * 8 + tap) * 4096 + (lane & 31);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -275,7 +317,7 @@ static inline int deconv_wgrad_partitions(const dua_conv3_desc* d, int* ncombo) 
   const long vox = (long)d->D * d->H * d->W;
   const int tv = d->dtype == DUA_F16 ? dwg::tile_voxels<f16>() : dwg::tile_voxels<float>();
   const long total = d->N * ((vox + tv - 1) / tv);
-  long P = (3 * 256 + combos - 1) / combos;
+  long P = (3 * 256 + 8 * combos - 1) / (8 * combos);      // ~three workgroups per CU over the launch: (partition, tap, combo)
   if (P > total) P = total;
   if (ncombo) *ncombo = combos;
   return (int)(P < 1 ? 1 : P);
@@ -314,7 +356,9 @@ static int launch_deconv_bwd(const dua_conv3_desc* d, const void* x, const void*
     a.P = P; a.ncc = (d->Cout + 63) / 64;
     constexpr int TV = dwg::tile_voxels<T>();
     a.total_tiles = (int)(d->N * ((vox + TV - 1) / TV));
-    const int lds = 18 * (TV * 32 * (int)sizeof(T) + 64);
+    if (vox * 8 > 0x7fffffffL) return DUA_ERR_ARG;                      // the kernel indexes voxels with ints
+    const int lds = 4 * (TV * 32 * (int)sizeof(T) + 64);                // x and dy tile, two half images each (>= 32 KB: the
+                                                                        // end-of-kernel reduction reuses it)
     static PerDeviceOnce once2;
     bool* attr2 = once2.flag();
     if (!attr2) return DUA_ERR_ARG;
@@ -323,7 +367,7 @@ static int launch_deconv_bwd(const dua_conv3_desc* d, const void* x, const void*
       if (e != hipSuccess) return (int)e;
       *attr2 = true;
     }
-    hipLaunchKernelGGL(deconv_k2s2_wgrad_kernel<T>, dim3(P, ncombo), dim3(dwg::NT), lds, s, a);
+    hipLaunchKernelGGL(deconv_k2s2_wgrad_kernel<T>, dim3(P, 8 * ncombo), dim3(dwg::NT), lds, s, a);
     const long per_p = (long)ncombo * 8 * 4096;
     long nb = (per_p + 255) / 256;
     hipLaunchKernelGGL(deconv_wgrad_reduce_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, s, ws, P, a.ncc, ncombo,

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Same-process A/B of NativeConvTrainer switches on the config-4 step (batch 2, 96^3, 16 classes, whole-step HIP graph): one
+trainer per setting on its own copy of the network, interleaved rounds.  usage: bench_train_ab.py [rounds] [steps per round]"""
+import copy
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diff_unet_amos_amd.diff_unet import DiffUNet          # noqa: E402
+from diff_unet_amos_amd.training import NativeConvTrainer         # noqa: E402
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    base = DiffUNet(in_channels=1, out_channels=16).to(dev)
+    image = torch.rand(2, 1, 96, 96, 96, device=dev)
+    labels = (torch.rand(2, 16, 96, 96, 96, device=dev) > 0.8).float()
+    settings = {"default": {}, "weight gradients in line with the backward chain": {"wgrad_overlap": False}}     # constructor arguments
+    trainers = {}
+    for name, kv in settings.items():
+        tr = NativeConvTrainer(copy.deepcopy(base), dtype=torch.float16, graph=True, **kv)
+        for _ in range(3):
+            tr.step(image, labels)
+        trainers[name] = tr
+    res = {n: [] for n in trainers}
+    for _ in range(rounds):
+        for name, tr in trainers.items():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.step(image, labels)
+            torch.cuda.synchronize()
+            res[name].append((time.perf_counter() - t0) / steps * 1e3)
+    for name, v in res.items():
+        v.sort()
+        print(f"{name:42s} median {v[len(v) // 2]:.3f} ms  best {v[0]:.3f}  ({' '.join(f'{x:.2f}' for x in v)})")
+
+
+if __name__ == "__main__":
+    main()

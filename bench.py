@@ -76,6 +76,9 @@ def conv3_flops(plan):
     return out
 
 
+_LAST_CONV_CALLS = []
+
+
 def time_conv_launches(plan, reps):
     """HIP events (torch.cuda.Event on the launch stream) around the conv3d_k3 kernel: one eager denoiser evaluation
     records the arguments of its 18 launches; each launch is then replayed `reps` times back to back between ONE event
@@ -86,6 +89,8 @@ def time_conv_launches(plan, reps):
     from diff_unet_amos_amd import ops
     real = ops.conv3d_k3
     calls = []
+    global _LAST_CONV_CALLS
+    _LAST_CONV_CALLS = calls
 
     def wrapped(*a, **k):
         calls.append((a, k))
@@ -471,6 +476,21 @@ def run_config5(args, D):
         dt = D.max_over_ranks(time.perf_counter() - t0)
         D.barrier()
         finite = bool(torch.isfinite(plan.x_state).all())
+        roof = None
+        if rank == 0 and not args.no_roofline:
+            # the 3x3x3 convolutions are the largest share of this step too (20 launches, ~45 %): the same HIP-event timing as
+            # config 2 (every launch replayed alone, back to back); useful FLOPs = 2 * 27 * Cin * Cout * voxels, so the 48-wide
+            # layers are charged for their padding to 32-channel chunks and 64-output tiles
+            avg_ms, per_step, by_launch = time_conv_launches(plan, 20)
+            fl = [2.0 * 27 * a[1] * a[5] * a[0].shape[0] * a[0].shape[1] * a[0].shape[2] * a[0].shape[3] for a, _ in _LAST_CONV_CALLS]
+            achieved = sum(fl) / (sum(by_launch) * 1e-3) / 1e12
+            peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_F32_TFLOPS
+            roof = {"bound": "mfma", "kernel": CONV_KERNEL, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": per_step,
+                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_gflop_per_launch": round(sum(fl) / len(fl) / 1e9, 2),
+                    "conv_ms_per_step": round(sum(by_launch), 3), "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
+                    "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
+                    "note": "side-stream launches are timed as they are launched in the step (one workgroup per CU)"}
     if rank == 0:
         ms = dt / args.steps * 1e3
         line = {
@@ -482,6 +502,8 @@ def run_config5(args, D):
                        "patch": [96, 96, 96], "classes": CLASSES, "batch_per_gpu": B, "graph_replay": not args.no_graph,
                        "noise": "in-kernel Philox4x32-10", "weights": "torch.manual_seed(0) default init"},
             "finite": finite}
+        if roof is not None:
+            line["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(state, host_threads(), swin=True)
         print(json.dumps(line), flush=True)

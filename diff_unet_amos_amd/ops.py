@@ -406,6 +406,28 @@ def _wgrad_ws(nbytes, device):
     return buf
 
 
+_SPLITK_WS = {}
+TRAIN_SPLITK = True          # tools/bench_train_ab.py switches it off for a same-process comparison
+
+
+def splitk_ws(dtype, N, D, H, W, cin, cout, device):
+    """Split-K scratch of conv3d_k3 for this layer shape (None when the launcher would not split): one grow-only buffer per
+    (device, stream), retired instead of freed when outgrown, like the weight-gradient scratch above.  The training step's
+    convolutions take it from here (the inference plans own theirs): without it the <= 12^3 levels run as a few dozen
+    workgroups walking the whole contraction -- 100 us for the 6^3 512 -> 512 layer at batch 2 instead of ~25."""
+    nbytes = conv3_workspace_bytes(dtype, N, D, H, W, cin, cout) if TRAIN_SPLITK else 0
+    if nbytes <= 0:
+        return None
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SPLITK_WS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        if buf is not None:
+            _WGRAD_WS_RETIRED.append(buf)
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _SPLITK_WS[key] = buf
+    return buf
+
+
 def instnorm_finalize(norm, N, Cc):
     """scale, shift = fp32 [N, C] exactly as consumers compute them in their preamble."""
     dev = norm.keep[0].device

@@ -109,7 +109,7 @@ class _Conv3dK3(torch.autograd.Function):
         wp, bp = ops.pack_conv3_weights(w, bias, x.dtype, cin_packed=cs)
         y = torch.empty((N, D, H, W, cout), dtype=x.dtype, device=x.device)
         stats = ops.stats_buffer(N, cout, x.device)
-        ops.conv3d_k3(x, cs, 0, wp, bp, cout, y, 0, stats)
+        ops.conv3d_k3(x, cs, 0, wp, bp, cout, y, 0, stats, workspace=ops.splitk_ws(x.dtype, N, D, H, W, cs, cout, x.device))
         return y
 
     @staticmethod
@@ -119,7 +119,8 @@ class _Conv3dK3(torch.autograd.Function):
         N, D, H, W, cs = dy.shape
         wp, bp = ops.pack_conv3_weights_dgrad(w, dy.dtype, cout_packed=cs)
         dx = torch.empty((N, D, H, W, cin_padded), dtype=dy.dtype, device=dy.device)
-        ops.conv3d_k3(dy, cs, 0, wp, bp, cin_padded, dx, 0, ops.stats_buffer(N, cin_padded, dy.device))
+        ops.conv3d_k3(dy, cs, 0, wp, bp, cin_padded, dx, 0, ops.stats_buffer(N, cin_padded, dy.device),
+                      workspace=ops.splitk_ws(dy.dtype, N, D, H, W, cs, cin_padded, dy.device))
         return dx
 
     @staticmethod
@@ -217,7 +218,7 @@ class _ConvNormAct(torch.autograd.Function):
         wp, bp = ops.pack_conv3_weights(weight.detach().float().contiguous(), bias.detach().float(), x.dtype, cin_packed=cs)
         raw = torch.empty((N, D, H, W, cout), dtype=x.dtype, device=x.device)
         stats = ops.stats_buffer(N, cout, x.device)
-        ops.conv3d_k3(x, cs, 0, wp, bp, cout, raw, 0, stats)
+        ops.conv3d_k3(x, cs, 0, wp, bp, cout, raw, 0, stats, workspace=ops.splitk_ws(x.dtype, N, D, H, W, cs, cout, x.device))
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         a32 = add.detach().float().contiguous() if add is not None else None
         norm = ops.Norm(stats, g32, b32, D * H * W, add=a32, add_stride=cout)

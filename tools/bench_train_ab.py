@@ -21,12 +21,27 @@ def main():
     base = DiffUNet(in_channels=1, out_channels=16).to(dev)
     image = torch.rand(2, 1, 96, 96, 96, device=dev)
     labels = (torch.rand(2, 16, 96, 96, 96, device=dev) > 0.8).float()
-    settings = {"default": {}, "weight gradients in line with the backward chain": {"wgrad_overlap": False}}     # constructor arguments
+    # constructor arguments; "_ops": attributes of diff_unet_amos_amd.ops set while this trainer warms up and captures its graph
+    settings = {"default": {}, "weight gradients in line with the backward chain": {"wgrad_overlap": False},
+                "no split-K scratch for the training convolutions": {"_ops": {"TRAIN_SPLITK": False}}}
+    from diff_unet_amos_amd import ops, _native as nv
     trainers = {}
     for name, kv in settings.items():
+        kv = dict(kv)
+        mod = kv.pop("_ops", {})
+        opt = kv.pop("_option", None)
+        if opt is not None:
+            nv.check(nv.lib().dua_set_option(*opt), "dua_set_option")
+        saved = {k: getattr(ops, k) for k in mod}
+        for k, v in mod.items():
+            setattr(ops, k, v)
         tr = NativeConvTrainer(copy.deepcopy(base), dtype=torch.float16, graph=True, **kv)
         for _ in range(3):
             tr.step(image, labels)
+        for k, v in saved.items():
+            setattr(ops, k, v)
+        if opt is not None:
+            nv.check(nv.lib().dua_set_option(opt[0], 0), "dua_set_option")
         trainers[name] = tr
     res = {n: [] for n in trainers}
     for _ in range(rounds):

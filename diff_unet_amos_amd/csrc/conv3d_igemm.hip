@@ -164,7 +164,8 @@ __global__ __launch_bounds__(TDP == 8 ? 512 : 256, TDP == 8 ? 1 : 2) void conv3d
   f32x16 acc[MB][2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const float b0 = a.part ? 0.f : a.bias[ct * BN + q * 32 + r];
+    const int bc = ct * BN + q * 32 + r;               // bias needs Cout entries only (padding channels start at zero)
+    const float b0 = (a.part || bc >= a.Cout) ? 0.f : a.bias[bc];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   const int cg = threadIdx.x % G, vl = threadIdx.x / G;
   const int c = cg * 4;
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  f32x4 b4 = *(const f32x4*)(bias + c);
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (c < Cout) b4 = *(const f32x4*)(bias + c);      // Cout is a multiple of 8, c of 4: bias needs Cout entries only
   if (vl < VL) {
     for (int i = 0; i < ITER; ++i) {
       const long v = ((long)blockIdx.x * ITER + i) * VL + vl;

@@ -122,9 +122,24 @@ def from_channels_last(src, C_, c_off=0, out=None):
     return out
 
 
-def pack_conv3_weights(w, bias, dtype, cin_packed=None, perm=None, tap_channel=None):
+_ZERO_BIAS = {}
+
+
+def zero_bias(n, device):
+    """A shared, never-written fp32 zero vector of at least n entries (the bias of data-gradient convolutions)."""
+    key = torch.device(device)
+    z = _ZERO_BIAS.get(key)
+    if z is None or z.numel() < n:
+        z = torch.zeros(max(n, 4096), dtype=torch.float32, device=device)     # channel counts are <= 1024 everywhere
+        _ZERO_BIAS[key] = z
+    return z
+
+
+def pack_conv3_weights(w, bias, dtype, cin_packed=None, perm=None, tap_channel=None, pad_bias=True):
     """nn.Conv3d parameters -> (packed weights as a byte tensor, bias padded to a multiple of 64).
-    ``tap_channel``: packed index of the channel handled by conv3d_k3(tap_channel=...) (single-channel tap form)."""
+    ``tap_channel``: packed index of the channel handled by conv3d_k3(tap_channel=...) (single-channel tap form).
+    ``pad_bias=False``: hand back the fp32 bias itself (conv3d_k3 reads Cout entries only) -- the training step, which repacks
+    every layer every step, saves a fill and a copy launch per layer that way."""
     assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
     w = w.contiguous()
     cout, cin = w.shape[:2]
@@ -152,6 +167,8 @@ def pack_conv3_weights(w, bias, dtype, cin_packed=None, perm=None, tap_channel=N
                                           nv.stream_ptr())
     if rc != nbytes:
         raise RuntimeError(f"dua_pack_conv3_weights failed ({rc})")
+    if not pad_bias:
+        return buf, (zero_bias(cout, w.device) if bias is None else bias.detach().float().contiguous())
     cpad = -(-cout // 64) * 64
     b = torch.zeros(cpad, dtype=torch.float32, device=w.device)
     if bias is not None:
@@ -171,7 +188,7 @@ def pack_conv3_weights_dgrad(w, dtype, cout_packed=None):
     rc = L.dua_pack_conv3_weights_dgrad(code, cout, cin, cout_packed, nv.ptr(w), nv.ptr(buf), nv.stream_ptr())
     if rc != nbytes:
         raise RuntimeError(f"dua_pack_conv3_weights_dgrad failed ({rc})")
-    return buf, torch.zeros(-(-cin // 64) * 64, dtype=torch.float32, device=w.device)
+    return buf, zero_bias(cin, w.device)          # shared, never written
 
 
 def pack_deconv_weights(w, bias, dtype):
@@ -309,7 +326,7 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
         assert x.dtype == torch.float16 and tap_channel in (0, 16) and cin == tap_channel + 8 and norm is None
         tap_bytes = nct * 4096
     assert w_packed.numel() == nct * nch * 27 * 4 * 64 * 16 + tap_bytes, "packed weights do not match (Cin, Cout, dtype)"
-    assert bias_pad.numel() == nct * 64 and bias_pad.dtype == torch.float32
+    assert bias_pad.numel() >= cout and bias_pad.dtype == torch.float32 and bias_pad.is_contiguous()     # the kernels read [0, cout)
     assert out_stats.dtype == torch.float64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, nct * 64, 2)
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off,
                      0 if tap_channel is None else tap_channel + 1, 1 if background else 0)

@@ -106,7 +106,7 @@ class _Conv3dK3(torch.autograd.Function):
     def _run(x, w, bias, cout):
         from . import ops
         N, D, H, W, cs = x.shape
-        wp, bp = ops.pack_conv3_weights(w, bias, x.dtype, cin_packed=cs)
+        wp, bp = ops.pack_conv3_weights(w, bias, x.dtype, cin_packed=cs, pad_bias=False)
         y = torch.empty((N, D, H, W, cout), dtype=x.dtype, device=x.device)
         stats = ops.stats_buffer(N, cout, x.device)
         ops.conv3d_k3(x, cs, 0, wp, bp, cout, y, 0, stats, workspace=ops.splitk_ws(x.dtype, N, D, H, W, cs, cout, x.device))
@@ -215,7 +215,8 @@ class _ConvNormAct(torch.autograd.Function):
         N, D, H, W, cs = x.shape
         cout = weight.shape[0]
         assert x.is_contiguous() and cs % 8 == 0 and cout % 8 == 0 and weight.shape[1] <= cs
-        wp, bp = ops.pack_conv3_weights(weight.detach().float().contiguous(), bias.detach().float(), x.dtype, cin_packed=cs)
+        wp, bp = ops.pack_conv3_weights(weight.detach().float().contiguous(), bias.detach().float(), x.dtype, cin_packed=cs,
+                                        pad_bias=False)
         raw = torch.empty((N, D, H, W, cout), dtype=x.dtype, device=x.device)
         stats = ops.stats_buffer(N, cout, x.device)
         ops.conv3d_k3(x, cs, 0, wp, bp, cout, raw, 0, stats, workspace=ops.splitk_ws(x.dtype, N, D, H, W, cs, cout, x.device))

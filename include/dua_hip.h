@@ -61,7 +61,8 @@ typedef struct {
                                       registers and LDS.  Same result, longer launch.  0 = ordinary launch. */
 } dua_conv3_desc;
 
-/* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32[ceil(Cout/64)*64].  in: NULL or the
+/* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32, at least Cout entries (a buffer padded to
+ * ceil(Cout/64)*64 works, entries behind Cout are never read).  in: NULL or the
  * producer descriptor of x.  y: raw output.  out_stats: fp64 [N][8][ceil(Cout/64)*64][2], pre-zeroed.
  * workspace (may be NULL): scratch for split-K on layers too small to fill 256 CUs (<= 24^3): the K range
  * (Cin chunk x kd) is divided over workgroups, fp32 partial tiles land in the workspace and a finish kernel

@@ -595,7 +595,7 @@ int dua_set_option(int key, int value) {
 #ifdef DUA_ABLATE
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only
 #endif
-  if (key == 4 && value >= 0 && value < 128) { dua::g_wgrad_variant = value; return 0; }
+  if (key == 4 && value >= 0 && value < 256) { dua::g_wgrad_variant = value; return 0; }
   return DUA_ERR_ARG;
 }
 

@@ -40,7 +40,19 @@ struct Args {
 
 }  // namespace wg
 
-template <typename T, bool PIPE, int NCOH>
+// 16 bytes per lane from global memory straight into LDS: lane i of the wave lands at lds_wave_base + 16 i
+// Written as inline assembly on purpose: behind the builtin hipcc (ROCm 7.2) cannot tell which LDS bytes a pending transfer
+// will write and puts an s_waitcnt vmcnt(0) in front of the next LDS read -- the k loop would wait for the transfer it is
+// meant to run under.  The loop below waits for its transfers itself (s_waitcnt vmcnt(0) + barrier before a buffer is read).
+__device__ __forceinline__ void wg_glds16(const void* g, void* lds_wave_base) {
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(__builtin_amdgcn_readfirstlane(base)) : "memory");
+}
+
+// DMA (f16, 12 waves): the tiles go from global memory straight into one of TWO LDS buffers (global_load_lds), issued one
+// tile ahead -- no staging registers, no store phase, one barrier per tile; pieces outside the volume are overwritten
+// with zeros once the transfer has landed.
+template <typename T, bool PIPE, int NCOH, bool DMA = false>
 __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
   constexpr int NT = NCOH == 2 ? 384 : 768;          // 6 waves (two co halves each) or 12 waves (one co half each)
   using namespace wg;
@@ -88,6 +100,70 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
     yl[j] = inl ? ((g * EPG) >> 5) * YIMG + v * RSB + ((g * EPG) & 31) * (int)sizeof(T) : -1;
   }
   const int xg_off = cc * 64, yg_off = ct * 64;
+  // DMA slots: one wave instruction moves 16 voxels x 32 channels (1 KB) of ONE half image: x = 2 halves x 13 voxel blocks
+  // (the last one 8 voxels), dy = 2 x 8; wave w takes instructions w, w + 12, (w + 24)
+  constexpr int XB = (XV + 15) / 16, NXD = (2 * XB + 11) / 12, NYD = (2 * (TV / 16) + 11) / 12;
+  int dxc[NXD], dxg[NXD], dxl[NXD], dyc[NYD], dyg[NYD], dyl[NYD];   // packed coords (-1: lane has no piece) / channel / LDS base
+  bool dxch[NXD], dych[NYD];                                        // the piece's channels exist
+  if constexpr (DMA) {
+    const int vloc = lane >> 2, g4 = lane & 3;
+#pragma unroll
+    for (int k = 0; k < NXD; ++k) {
+      const int q = wave + 12 * k, h = q / XB, b = q % XB, v = 16 * b + vloc;
+      const int pd = v / (XH * XW), rem = v % (XH * XW), hy = rem / XW, hx = rem % XW;
+      dxc[k] = (q < 2 * XB && v < XV) ? (pd << 16) | (hy << 8) | hx : -1;
+      dxg[k] = 32 * h + 8 * g4;
+      dxch[k] = cc * 64 + dxg[k] < a.Cin;
+      dxl[k] = h * XIMG + 16 * b * RSB;
+    }
+#pragma unroll
+    for (int k = 0; k < NYD; ++k) {
+      const int q = wave + 12 * k, h = q / (TV / 16), b = q % (TV / 16);
+      dyc[k] = q < 2 * (TV / 16) ? 16 * b + vloc : -1;
+      dyg[k] = 32 * h + 8 * g4;
+      dych[k] = ct * 64 + dyg[k] < a.Cout;
+      dyl[k] = h * YIMG + 16 * b * RSB;
+    }
+  }
+  // issue_tile returns one bit per slot: the piece lies inside the volume and its channels exist (fix_tile zeroes the others)
+  auto issue_tile = [&](int tile, char* buf) -> unsigned {
+    unsigned okbits = 0;
+    int t = tile;
+    const int tw_ = t % a.tiles_w; t /= a.tiles_w;
+    const int th_ = t % a.tiles_h; t /= a.tiles_h;
+    const int td_ = t % a.tiles_d; const int n = t / a.tiles_d;
+    const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
+    const T* xb = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off + xg_off;
+    const T* yb = (const T*)a.dy + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + yg_off;
+#pragma unroll
+    for (int k = 0; k < NXD; ++k) {
+      const int gd = d0 + kd - 1 + (dxc[k] >> 16), gh = h0 - 1 + ((dxc[k] >> 8) & 255), gw = w0 - 1 + (dxc[k] & 255);
+      const bool ok = dxch[k] && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+      okbits |= ok ? 1u << k : 0u;
+      const long off = ok ? (((long)gd * a.H + gh) * a.W + gw) * a.Cin_stride + dxg[k] : 0;
+      if (dxc[k] >= 0) wg_glds16(xb + off, buf + dxl[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NYD; ++k) {
+      const int v = dyc[k], gd = d0 + (v >> 6), gh = h0 + ((v >> 3) & 7), gw = w0 + (v & 7);
+      const bool ok = dych[k] && gd < a.D && gh < a.H && gw < a.W;
+      okbits |= ok ? 1u << (NXD + k) : 0u;
+      const long off = ok ? (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + dyg[k] : 0;
+      if (dyc[k] >= 0) wg_glds16(yb + off, buf + 2 * XIMG + dyl[k]);
+    }
+    return okbits;
+  };
+  auto fix_tile = [&](char* buf, unsigned okbits) {   // after the transfer has landed: zeros over the pieces that are not data
+    Frag z;
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) z[e] = (T)0.f;
+#pragma unroll
+    for (int k = 0; k < NXD; ++k)
+      if (dxc[k] >= 0 && !(okbits >> k & 1)) *(Frag*)(buf + dxl[k] + lane * 16) = z;
+#pragma unroll
+    for (int k = 0; k < NYD; ++k)
+      if (dyc[k] >= 0 && !(okbits >> (NXD + k) & 1)) *(Frag*)(buf + 2 * XIMG + dyl[k] + lane * 16) = z;
+  };
 
   Frag xr[NX], yr[NY];
   auto zero = [](Frag& f) {
@@ -161,13 +237,7 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
     a_off[0] = a_off[1] = 0; b_row[0] = b_row[1] = 0;
   }
 
-  int tile = part_id;
-  if (tile < a.total_tiles) load_tile(tile);
-  for (; tile < a.total_tiles; tile += a.P) {
-    __syncthreads();                       // previous tile's fragment reads are done
-    store_tile();
-    __syncthreads();
-    if (tile + a.P < a.total_tiles) load_tile(tile + a.P);
+  auto kloop = [&]() {
     if constexpr (PIPE && sizeof(T) == 2) {
       // explicit two-stage pipeline: the 10 transposed reads of k-step s+1 are issued before the 6 MFMAs of step s
       const char* ya = Ys + a_off[0];
@@ -264,6 +334,35 @@ __device__ __forceinline__ void wgrad_body(const wg::Args& a) {
           mma32(acc[kw][coh], fa[coh], fb[kw]);
         }
     }
+  };
+  int tile = part_id;
+  if constexpr (DMA) {
+    // Two buffers, ONE tile in flight.  (Three buffers with two tiles in flight -- the transfers cost no registers -- were
+    // measured: 5-8 % slower on every layer shape, like the two-register-set form of the other path: more of this kernel's
+    // traffic in flight makes the memory side slower, not faster.)
+    constexpr int BUFB = 2 * XIMG + 2 * YIMG;
+    int cur = 0;
+    unsigned okbits = 0;
+    if (tile < a.total_tiles) okbits = issue_tile(tile, smem);
+    for (; tile < a.total_tiles; tile += a.P) {
+      char* buf = smem + cur * BUFB;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile has landed ...
+      fix_tile(buf, okbits);
+      __syncthreads();                                     // ... for every wave, and the other buffer's readers are through
+      Xs = buf; Ys = buf + 2 * XIMG;
+      if (tile + a.P < a.total_tiles) okbits = issue_tile(tile + a.P, smem + (cur ^ 1) * BUFB);
+      kloop();
+      cur ^= 1;
+    }
+  } else {
+  if (tile < a.total_tiles) load_tile(tile);
+  for (; tile < a.total_tiles; tile += a.P) {
+    __syncthreads();                       // previous tile's fragment reads are done
+    store_tile();
+    __syncthreads();
+    if (tile + a.P < a.total_tiles) load_tile(tile + a.P);
+    kloop();
+  }
   }
 
   // acc[kw][coh]: lane column = ci (lane & 31), register i -> co row acc_row(i, hl)
@@ -304,9 +403,9 @@ __global__ __launch_bounds__(wg::NT) void conv3d_k3_wgrad_kernel(wg::Args a) {
 }
 // 12 waves, three per SIMD (<= 168 VGPRs): wave = (kh, ci half, co half) with 3 accumulators -- every SIMD carries the
 // same MFMA load; the 6-wave form leaves two SIMDs with one wave
-template <typename T>
+template <typename T, bool DMA = false>
 __global__ __launch_bounds__(768) void conv3d_k3_wgrad12_kernel(wg::Args a) {
-  wgrad_body<T, true, 1>(a);
+  wgrad_body<T, true, 1, DMA>(a);
 }
 
 // dw[co][ci_src][tap] += sum_p part[p][combo][tap][co][ci]; one thread per (combo, tap, co, ci)
@@ -387,11 +486,16 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
     bool* attr12 = once12.flag();
     if (!attr12) return DUA_ERR_ARG;
     if (!*attr12) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad12_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad12_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess && sizeof(T) == 2)
+        e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad12_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds);
       if (e != hipSuccess) return (int)e;
       *attr12 = true;
     }
-    hipLaunchKernelGGL(conv3d_k3_wgrad12_kernel<T>, grid, dim3(768), lds, s, a);
+    if constexpr (sizeof(T) == 2) {
+      if (g_wgrad_variant & 128) hipLaunchKernelGGL((conv3d_k3_wgrad12_kernel<T, false>), grid, dim3(768), lds, s, a);   // register prefetch + one LDS buffer
+      else hipLaunchKernelGGL((conv3d_k3_wgrad12_kernel<T, true>), grid, dim3(768), 2 * lds, s, a);
+    }
   } else
   // f16 default: explicit two-stage k loop (reads of step s+1 before the MFMAs of step s): 3-7 % over hipcc's own
   // schedule on every layer shape in a same-process A/B; dua_set_option(4, 32) selects the plain loop.  f32: plain.

@@ -21,9 +21,10 @@ def main():
     base = DiffUNet(in_channels=1, out_channels=16).to(dev)
     image = torch.rand(2, 1, 96, 96, 96, device=dev)
     labels = (torch.rand(2, 16, 96, 96, 96, device=dev) > 0.8).float()
-    # constructor arguments; "_ops": attributes of diff_unet_amos_amd.ops set while this trainer warms up and captures its graph
+    # constructor arguments; "_option": a dua_set_option(key, value) in force while the trainer captures; "_ops": attributes of diff_unet_amos_amd.ops set while this trainer warms up and captures its graph
     settings = {"default": {}, "weight gradients in line with the backward chain": {"wgrad_overlap": False},
-                "no split-K scratch for the training convolutions": {"_ops": {"TRAIN_SPLITK": False}}}
+                "no split-K scratch for the training convolutions": {"_ops": {"TRAIN_SPLITK": False}},
+                "weight-gradient tiles through registers (dua_set_option(4, 128))": {"_option": (4, 128)}}
     from diff_unet_amos_amd import ops, _native as nv
     trainers = {}
     for name, kv in settings.items():

@@ -153,7 +153,11 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
         typedef short short4v __attribute__((ext_vector_type(4)));
         const short4v ko = *(const short4v*)(koff + kb * 32 + 8 * j + 4 * hh);
 #pragma unroll
+#if defined(WA_ABL) && (WA_ABL & 1)
+        for (int e = 0; e < 4; ++e) z[4 * j + e] = z[4 * j + e] * scale2 + (float)ko[e] * 1e-9f;      // ablation: no table lookup
+#else
         for (int e = 0; e < 4; ++e) z[4 * j + e] = fmaf(z[4 * j + e], scale2, *(const float*)((const char*)tab + (qoff - (int)ko[e])));
+#endif
       }
     } else {
 #pragma unroll
@@ -169,7 +173,11 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
         z[i] += mask[(long)(key < n ? key : 0) * n + qc] * LOG2E;
       }
     }
+#if defined(WA_ABL) && (WA_ABL & 4)
+    if (false) {
+#else
     if (has_region) {                             // compute_mask's 0 / -100 from the region ids
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const unsigned rk = *(const unsigned*)(regl + kb * 32 + 8 * j + 4 * hh);
@@ -197,14 +205,22 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 #pragma unroll
     for (int i = 1; i < 16; ++i) bm = fmaxf(bm, z[i]);
     bm = fmaxf(bm, other_half(bm));
+#if defined(WA_ABL) && (WA_ABL & 8)
+    const float mnew = 0.f * bm;                  // ablation: no running maximum, no rescale
+#else
     const float mnew = fmaxf(mx, bm);
     const float alpha = __builtin_amdgcn_exp2f(mx - mnew);
     mx = mnew;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) O[i] *= alpha;    // dims 0..15 (registers 0..7) and the denominator row 16 (register 8, lanes hh = 0)
+    for (int i = 0; i < 9; ++i) O[i] *= alpha;
+#endif    // dims 0..15 (registers 0..7) and the denominator row 16 (register 8, lanes hh = 0)
     f16x8 p[2];
 #pragma unroll
+#if defined(WA_ABL) && (WA_ABL & 2)
+    for (int i = 0; i < 16; ++i) p[i >> 3][i & 7] = (f16)fminf(z[i] - mnew, 1.f);      // ablation: no exp2
+#else
     for (int i = 0; i < 16; ++i) p[i >> 3][i & 7] = (f16)__builtin_amdgcn_exp2f(z[i] - mnew);
+#endif
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       f16x8 vf = r == HD ? ones8 : zero8;          // rows 17..31 of the A operand are padding; row 16 is all ones: its output

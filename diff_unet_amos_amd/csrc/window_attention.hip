@@ -110,10 +110,19 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
       koff[i] = (short)(4 * ((t / (a.gh * a.gw)) * sd_ + ((t / a.gw) % a.gh) * sh_ + t % a.gw));
     }
   }
-  const bool has_region = a.region != nullptr;
-  if (has_region)
-    for (int i = tid; i < nb * 32; i += 256) regl[i] = i < n ? a.region[(long)(win % a.nw) * n + i] : (unsigned char)255;
-  __syncthreads();
+  // Shift mask: most windows of a shifted grid lie inside ONE region (only the last window along an axis is assembled from
+  // wrapped pieces: 127 of 343 at the 48^3-token stage) -- their mask is all zeros and the compare per score is skipped.
+  int mixed = 0;
+  if (a.region != nullptr) {
+    const unsigned char* rg = a.region + (long)(win % a.nw) * n;
+    const unsigned char r0 = rg[0];
+    for (int i = tid; i < nb * 32; i += 256) {
+      const unsigned char v = i < n ? rg[i] : (unsigned char)255;
+      regl[i] = v;
+      mixed |= (i < n && v != r0) ? 1 : 0;
+    }
+  }
+  const bool has_region = __syncthreads_or(mixed) != 0;
 
   const float* bias = has_table ? nullptr : a.bias_t + (long)head * n * n;
   const float* mask = a.mask_t ? a.mask_t + (long)(win % a.nw) * n * n : nullptr;

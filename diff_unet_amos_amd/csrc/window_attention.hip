@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   // A wave owns query blocks blockIdx.z * 4 + wave, + 4 * gridDim.z, ...: with one workgroup per (window, head) (gridDim.z = 1,
   // the 48^3-token stage: 1029 workgroups, all resident at five per CU) K and V are staged once for the whole window; the
   // coarse stages split the query blocks over gridDim.z workgroups to have enough of them.
+#if defined(WA_ABL) && (WA_ABL & 16)
+  if (a.scale != -1.f) return;                   // ablation: staging only
+#endif
   for (int qb = blockIdx.z * 4 + wave; qb < nb; qb += 4 * gridDim.z) {
   const int q = qb * 32 + r;                     // this lane's query
   const bool qok = q < n;

@@ -60,12 +60,11 @@ class TailResidual(C.Structure):
 
 
 MODE_LOGITS, MODE_DDPM, MODE_DDIM = 0, 1, 2
-OP_CONV3, OP_MATERIALIZE, OP_DECONV, OP_CONV3_PARTIAL, OP_CONV3_ACC, OP_FORK, OP_JOIN = 1, 2, 3, 4, 5, 6, 7
+OP_CONV3, OP_MATERIALIZE, OP_DECONV = 1, 2, 3
 
 
 class StepOp(C.Structure):
-    _fields_ = [("kind", C.c_int), ("side", C.c_int), ("init", C.c_void_p),
-                ("has_norm", C.c_int), ("conv", Conv3Desc), ("mat", MaterializeDesc), ("norm", InNorm),
+    _fields_ = [("kind", C.c_int), ("has_norm", C.c_int), ("conv", Conv3Desc), ("mat", MaterializeDesc), ("norm", InNorm),
                 ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("stats", C.c_void_p),
                 ("emb", C.c_void_p), ("pooled", C.c_void_p)]
 
@@ -79,7 +78,6 @@ class DenoiserPlan(C.Structure):
                 ("stat_arena", C.c_void_p), ("stat_bytes", C.c_long),
                 ("ops", C.POINTER(StepOp)), ("n_ops", C.c_int),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
-                ("side_stream", C.c_void_p), ("ev_fork", C.c_void_p), ("ev_join", C.c_void_p),
                 ("tail", TailDesc), ("tail_raw", C.c_void_p), ("tail_norm", InNorm), ("wf", C.c_void_p), ("bf", C.c_void_p),
                 ("x_state", C.c_void_p), ("noise", C.c_void_p), ("xin", C.c_void_p), ("xstart_sum", C.c_void_p),
                 ("logits", C.c_void_p), ("xstart", C.c_void_p)]
@@ -122,11 +120,6 @@ _SIGS = {
     "dua_instnorm_stats": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
     "dua_gelu": (C.c_int, [C.c_int, C.c_long, _P, _P]),
     "dua_token_linear": (C.c_int, [C.POINTER(TokenLinearDesc), _P]),
-    "dua_conv3d_k3_partial_bytes": (C.c_long, [C.POINTER(Conv3Desc)]),
-    "dua_conv3d_k3_partial": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, C.POINTER(InNorm), _P, _P]),
-    "dua_conv3d_k3_fwd_acc": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P, _P, _P]),
-    "dua_event_create": (C.c_void_p, []),
-    "dua_event_destroy": (None, [_P]),
     "dua_swin_mlp": (C.c_int, [C.c_long, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dua_denoiser_step": (C.c_int, [C.POINTER(DenoiserPlan), _P]),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),

@@ -97,14 +97,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // embedding bias of TwoConv.forward (models/basic_unet/denoiser.py:63-67).
 constexpr int STAT_REPLICAS = 8;   // producers spread their atomics over 8 replica rows
 
+// InstanceNorm sums are accumulated ORDER-INDEPENDENTLY: a workgroup's (sum x, sum x^2) contribution (a double, combined
+// inside the workgroup in a fixed order) is split into its integer part and its fraction scaled by 2^44, and both are added
+// with 64-bit INTEGER atomics -- integer addition is associative, so any arrival order of the workgroups gives the same
+// words, and every consumer derives bit-identical scale / shift from them (two replays of a step agree bit for bit; fp64
+// atomics differed in the last place from run to run).  Row layout: [N][8 replicas][4 words][c_pad] =
+// (sum int, sum frac, sumsq int, sumsq frac).  Range: |total| < 2^62; resolution 2^-44 per contribution; up to 2^18
+// contributions per replica row.
+using stat_t = long long;
+constexpr int STAT_WORDS = 4;
+constexpr double STAT_FRAC = 17592186044416.0;        // 2^44
+
 struct InXform {
-  const double* stats;  // [N][8][c_pad][2] = (sum x, sum x^2) replicas, or null (input already materialised)
+  const stat_t* stats;  // [N][8][4][c_pad] fixed-point (sum x, sum x^2) replicas, or null (input already materialised)
   const float* gamma;   // [C]
   const float* beta;    // [C]
   const float* add;     // [N][add_stride] or null
   int add_stride, c_pad;
   float inv_count, eps, slope;
 };
+
+// (sum x, sum x^2) of channel c of sample n: the replica rows are summed as integers (exact), then converted.
+__device__ __forceinline__ void stats_read(const stat_t* stats, int n, int c_pad, int c, double& S, double& Q) {
+  stat_t w[STAT_WORDS] = {0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < STAT_REPLICAS; ++r) {
+    const stat_t* p = stats + ((long)n * STAT_REPLICAS + r) * STAT_WORDS * c_pad + c;
+#pragma unroll
+    for (int k = 0; k < STAT_WORDS; ++k) w[k] += p[(long)k * c_pad];
+  }
+  S = (double)w[0] + (double)w[1] * (1.0 / STAT_FRAC);
+  Q = (double)w[2] + (double)w[3] * (1.0 / STAT_FRAC);
+}
 
 // Preamble: threads cooperatively compute scale/shift/add for channels [0, C) into LDS arrays.
 __device__ __forceinline__ void xform_preamble(const InXform& xf, int n, int C, float* sc, float* sh, float* ad,
@@ -115,12 +139,8 @@ __device__ __forceinline__ void xform_preamble(const InXform& xf, int n, int C, 
       ad[c] = xf.add ? xf.add[(long)n * xf.add_stride + c] : 0.f;
       continue;
     }
-    double S = 0, Q = 0;
-#pragma unroll
-    for (int r = 0; r < STAT_REPLICAS; ++r) {
-      const double* p = xf.stats + (((long)n * STAT_REPLICAS + r) * xf.c_pad + c) * 2;
-      S += p[0]; Q += p[1];
-    }
+    double S, Q;
+    stats_read(xf.stats, n, xf.c_pad, c, S, Q);
     const double mean = S * (double)xf.inv_count;
     double var = Q * (double)xf.inv_count - mean * mean;
     var = var > 0 ? var : 0;
@@ -146,10 +166,14 @@ static inline InXform make_xform(const dua_in_norm* in, int C) {
 }
 
 // Epilogue side: one (sum, sum of squares) contribution per (n, c) from a workgroup.
-__device__ __forceinline__ void stats_add(double* stats, int n, int c_pad, int replica, int c, double S, double Q) {
-  double* p = stats + (((long)n * STAT_REPLICAS + replica) * c_pad + c) * 2;
-  unsafeAtomicAdd(p, S);
-  unsafeAtomicAdd(p + 1, Q);
+__device__ __forceinline__ void stats_add(stat_t* stats, int n, int c_pad, int replica, int c, double S, double Q) {
+  unsigned long long* p = (unsigned long long*)stats + ((long)n * STAT_REPLICAS + replica) * STAT_WORDS * c_pad + c;
+  const double Si = rint(S), Qi = rint(Q);
+  // two's-complement adds: negative parts wrap, the integer sum is exact either way
+  __hip_atomic_fetch_add(p, (unsigned long long)(long long)Si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(p + c_pad, (unsigned long long)(long long)rint((S - Si) * STAT_FRAC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(p + 2L * c_pad, (unsigned long long)(long long)Qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(p + 3L * c_pad, (unsigned long long)(long long)rint((Q - Qi) * STAT_FRAC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename T>

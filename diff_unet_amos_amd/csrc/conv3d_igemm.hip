@@ -33,8 +33,7 @@ constexpr int HALO_BYTES = HD * PS;        // 39360
 constexpr int BN = 64;                     // output channels per workgroup
 }  // namespace c3
 
-// 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones); 2 forces 4x8x8 tiles without split-K, 3 forces 2x8x8,
-// 4 forces 8x8x8 tiles (512-thread workgroups)
+// 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones); 2 forces 4x8x8 tiles without split-K, 3 forces 2x8x8
 int g_conv_variant = 0;
 int g_skip_splitk_finish = 0;   // diagnostics (dua_set_option(2, 1)): time the split-K main kernel alone; outputs are not finished
 extern int g_wgrad_abl;
@@ -70,15 +69,11 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // HALF: the last Cin chunk holds at most one k-step (16 channels) of real input (Cin = 48 = 32 + 16, the Swin-UNETR widths):
 // its second k-step per tap would multiply zero padding and is skipped.  A separate instantiation, so that the common
 // kernel keeps its schedule.
-// TDP = 8: an 8x8x8 tile by EIGHT waves (512 threads, one workgroup per CU -- the same 8 waves per CU as two 4x8x8 workgroups):
-// every weight slab and every halo voxel staged serves twice the output (the packed weights are re-read from L2 by every
-// workgroup: 3 GB per 96^3 layer at 256 voxels per workgroup), and the halo overhead drops from 2.34 to 1.95 input voxels
-// per output voxel.
 template <typename T, int TDP = 4, int NKS = 2, bool HALF = false>
-__global__ __launch_bounds__(TDP == 8 ? 512 : 256, TDP == 8 ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Args a) {
+__global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   using namespace c3v2;
   constexpr int TD = TDP, HD = TDP + 2, MB = TDP == 2 ? 1 : 2;
-  constexpr int NW = TDP == 8 ? 8 : 4, NTHR = 64 * NW;
+  constexpr int NW = 4, NTHR = 64 * NW;
   constexpr int HALO_BYTES = HD * PS, LDS_MAIN = HALO_BYTES + 2 * SLAB;
   constexpr int NITEMS = HD * HH * HW * KG, NIT = (NITEMS + NTHR - 1) / NTHR;
   constexpr int NPIECE = SLAB / 16, NSL = (NPIECE + NTHR - 1) / NTHR;      // 16-byte pieces of a weight slab per thread
@@ -171,23 +166,6 @@ __global__ __launch_bounds__(TDP == 8 ? 512 : 256, TDP == 8 ? 1 : 2) void conv3d
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][q][i] = b0;
   }
-  // conv(cat[a | b]) = conv_a(a) + conv_b(b): the other part's fp32 tile sums (dua_conv3d_k3_partial) join the accumulators
-  // here.  They are stored in the accumulators' own layout ([n][tile][cout tile][wave][m][q][lane][16 floats]: the two launches
-  // share shape, tiling and grid), so this is 4 x 16-byte loads per accumulator, consecutive lanes on consecutive 64 bytes,
-  // all requested before the first slab is waited for.  (Per-element loads from a [voxel][channel] buffer cost 80 us of
-  // a 230 us launch.)
-  if (a.init) {
-    const float* ip = a.init + ((((long)n * a.ntiles + tile) * gridDim.y + ct) * NW + wave) * (MB * 2 * 64 * 16) + lane * 16;
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f32x16 pv = *(const f32x16*)(ip + (m * 2 + q) * 64 * 16);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][q][i] += pv[i];
-      }
-  }
-
   // ---- work range: units u = chunk * 3 + kd, three (kd, kh) slabs each ----
   const int ks_id = blockIdx.z / a.N;
   const int u0 = ks_id * a.units_per_split;
@@ -297,15 +275,6 @@ __global__ __launch_bounds__(TDP == 8 ? 512 : 256, TDP == 8 ? 1 : 2) void conv3d
     }
     __syncthreads();     // the epilogue's staging tile reuses the halo; nobody may still be gathering from it
   }
-  if (a.part != nullptr && a.ksplit == 1) {
-    // ---- partial-sum form (dua_conv3d_k3_partial): the accumulators as they are, see a.init above ----
-    float* pw = a.part + ((((long)n * a.ntiles + tile) * gridDim.y + ct) * NW + wave) * (MB * 2 * 64 * 16) + lane * 16;
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) *(f32x16*)(pw + (m * 2 + q) * 64 * 16) = acc[m][q];
-    return;
-  }
   if (a.part != nullptr) {
     // ---- split-K: this workgroup's fp32 partial tile goes to part[ks][n][voxel][cout_pad] ----
     constexpr int OSF = 32 * 4 + 16;
@@ -402,7 +371,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, int N, long vox,
                                                             int cout_pad, int Cout, const float* __restrict__ bias,
                                                             T* __restrict__ y, int Cout_stride, int Cout_off,
-                                                            double* stats, int G, int VL, int ITER) {
+                                                            stat_t* stats, int G, int VL, int ITER) {
   __shared__ float red[256][8];
   const int n = blockIdx.y;
   const int cg = threadIdx.x % G, vl = threadIdx.x / G;
@@ -467,7 +436,7 @@ static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups) 
   *ksplit = (units + *ups - 1) / *ups;
 }
 
-// The partial-sum launch (dua_conv3d_k3_partial) is meant to run on a second stream UNDER other launches: it asks for enough
+// A background launch (dua_conv3_desc.background) runs on a second stream UNDER other launches: it asks for enough
 // extra LDS that only ONE of its workgroups fits a CU, so that every CU keeps 64 KB and half its wave slots free for the
 // main stream's workgroups (two of them per CU leave no room: the co-running launches then wait for retiring workgroups).
 constexpr int PARTIAL_LDS_PAD = 36 * 1024;
@@ -495,9 +464,6 @@ static int ensure_lds_attr() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             c3v2::LDS_MAIN + 3 * 4 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            10 * c3::PS + 2 * c3v2::SLAB + 3 * 4 * 1024);
   if (e != hipSuccess) return (int)e;
   done[dev] = true;
   return 0;
@@ -505,8 +471,7 @@ static int ensure_lds_attr() {
 
 template <typename T>
 static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
-                        const dua_in_norm* in, void* y, double* stats, float* ws, long ws_bytes, hipStream_t s,
-                        float* part_out = nullptr, const float* init = nullptr) {
+                        const dua_in_norm* in, void* y, stat_t* stats, float* ws, long ws_bytes, hipStream_t s) {
   using namespace c3;
   constexpr int CK = KG * Elem<T>::EPG;
   Conv3Args a;
@@ -521,13 +486,12 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   a.ntiles = td * a.tiles_h * a.tiles_w;
   const int nct = (d->Cout + BN - 1) / BN;
   a.cout_pad = nct * BN;
-  a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = part_out; a.init = init; a.tap_ch = -1;
-  if (part_out || init) { ws = nullptr; if (d->tap_channel_plus1 > 0) return DUA_ERR_ARG; }     // the two-part form is never split-K
+  a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = nullptr; a.tap_ch = -1;
   if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
   const int xf_bytes = in && in->stats ? 3 * 4 * a.nchunks * CK : 0;
   if (int e = ensure_lds_attr<T>()) return e;
   const long vox = (long)d->D * d->H * d->W;
-  const int bg_pad = (part_out || d->background) ? PARTIAL_LDS_PAD : 0;     // one workgroup per CU, see PARTIAL_LDS_PAD
+  const int bg_pad = d->background ? PARTIAL_LDS_PAD : 0;     // one workgroup per CU, see PARTIAL_LDS_PAD
   if (d->tap_channel_plus1 > 0) {
     // single-channel tap form (see the kernel): fp16, one Cin chunk, no fused input transform, 16 * NKS ordinary
     // channels in front of the tap channel, zero padding behind it; weights from dua_pack_conv3_weights_tap
@@ -555,13 +519,6 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2>), grid2, dim3(256), LDS2 + xf_bytes, s, a);
     return (int)hipGetLastError();
   }
-  if (a.ksplit == 1 && g_conv_variant == 4 && !part_out && !init) {        // 8x8x8 tiles, eight waves per workgroup (never the two-part form:
-                                                                             // its partial-sum buffer is sized for 4-deep tiles)
-    a.ntiles = ((d->D + 7) / 8) * a.tiles_h * a.tiles_w;
-    dim3 grid8(a.ntiles, nct, d->N);
-    hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 8>), grid8, dim3(512), 10 * c3::PS + 2 * c3v2::SLAB + xf_bytes, s, a);
-    return (int)hipGetLastError();
-  }
   dim3 grid(a.ntiles, nct, d->N * a.ksplit);
   if (a.ksplit > 1) {
     hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
@@ -576,9 +533,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
     return (int)hipGetLastError();
   }
-  if (part_out)
-    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes + bg_pad, s, a);
-  else if (sizeof(T) == 2 && d->Cin - (a.nchunks - 1) * CK <= CK / 2)       // e.g. Cin = 48: the last chunk is half padding
+  if (sizeof(T) == 2 && d->Cin - (a.nchunks - 1) * CK <= CK / 2)       // e.g. Cin = 48: the last chunk is half padding
     hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 2, true>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes + bg_pad, s, a);
   else
     hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes + bg_pad, s, a);
@@ -590,46 +545,12 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
 extern "C" {
 
 int dua_set_option(int key, int value) {
-  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 4)) { dua::g_conv_variant = value; return 0; }
+  if (key == 1 && (value == 0 || value == 2 || value == 3)) { dua::g_conv_variant = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
 #ifdef DUA_ABLATE
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only
 #endif
   if (key == 4 && value >= 0 && value < 256) { dua::g_wgrad_variant = value; return 0; }
-  return DUA_ERR_ARG;
-}
-
-long dua_conv3d_k3_partial_bytes(const dua_conv3_desc* d) {
-  using namespace dua::c3;
-  if (!d || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return DUA_ERR_ARG;
-  // whole 4x8x8 tiles (the tile shape of both two-part launches), 64-wide output tiles, fp32.  (Depth counted in whole
-  // 4-deep tiles: ceil(D / 2) two-deep layers are one layer short whenever D mod 4 is 1 or 2.)
-  const long tiles = (long)((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
-  return tiles * TD * TH * TW * ((d->Cout + BN - 1) / BN) * BN * 4 * d->N;
-}
-
-int dua_conv3d_k3_partial(const dua_conv3_desc* d, const void* x, const void* w_packed, const dua_in_norm* in, float* partial,
-                          void* stream) {
-  if (!d || !x || !w_packed || !partial || d->tap_channel_plus1) return DUA_ERR_ARG;
-  if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cin_off % 8) return DUA_ERR_ARG;
-  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin)) return DUA_ERR_ARG;
-  if (d->dtype == DUA_F16)
-    return dua::launch_conv3<dua::f16>(d, x, w_packed, nullptr, in, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, partial, nullptr);
-  if (d->dtype == DUA_F32)
-    return dua::launch_conv3<float>(d, x, w_packed, nullptr, in, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, partial, nullptr);
-  return DUA_ERR_ARG;
-}
-
-int dua_conv3d_k3_fwd_acc(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
-                          const dua_in_norm* in, const float* partial, void* y, double* out_stats, void* stream) {
-  if (!d || !x || !w_packed || !bias_padded || !partial || !y || !out_stats || d->tap_channel_plus1) return DUA_ERR_ARG;
-  if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)
-    return DUA_ERR_ARG;
-  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin)) return DUA_ERR_ARG;
-  if (d->dtype == DUA_F16)
-    return dua::launch_conv3<dua::f16>(d, x, w_packed, bias_padded, in, y, out_stats, nullptr, 0, (hipStream_t)stream, nullptr, partial);
-  if (d->dtype == DUA_F32)
-    return dua::launch_conv3<float>(d, x, w_packed, bias_padded, in, y, out_stats, nullptr, 0, (hipStream_t)stream, nullptr, partial);
   return DUA_ERR_ARG;
 }
 
@@ -645,7 +566,7 @@ long dua_conv3d_k3_workspace(const dua_conv3_desc* d) {
 }
 
 int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
-                      const dua_in_norm* in, void* y, double* out_stats, void* workspace, long workspace_bytes,
+                      const dua_in_norm* in, void* y, dua_stat_word* out_stats, void* workspace, long workspace_bytes,
                       void* stream) {
   if (!d || !x || !w_packed || !bias_padded || !y || !out_stats) return DUA_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)

@@ -15,21 +15,12 @@ extern "C" int dua_denoiser_step(const dua_denoiser_plan* p, void* stream) {
   if (rc) return rc;
   hipError_t e = hipMemsetAsync(p->stat_arena, 0, (size_t)p->stat_bytes, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  void* const main_stream = stream;
   for (int i = 0; i < p->n_ops; ++i) {
     const dua_step_op& o = p->ops[i];
     const dua_in_norm* in = o.has_norm ? &o.norm : nullptr;
-    if (o.side && !p->side_stream) return DUA_ERR_ARG;
-    stream = o.side ? p->side_stream : main_stream;
     switch (o.kind) {
       case DUA_OP_CONV3:
         rc = dua_conv3d_k3_fwd(&o.conv, o.x, o.w, o.bias, in, o.y, o.stats, p->workspace, p->workspace_bytes, stream);
-        break;
-      case DUA_OP_CONV3_PARTIAL:
-        rc = dua_conv3d_k3_partial(&o.conv, o.x, o.w, in, (float*)o.y, stream);
-        break;
-      case DUA_OP_CONV3_ACC:
-        rc = dua_conv3d_k3_fwd_acc(&o.conv, o.x, o.w, o.bias, in, o.init, o.y, o.stats, stream);
         break;
       case DUA_OP_MATERIALIZE:
         if (!in) return DUA_ERR_ARG;
@@ -38,32 +29,11 @@ extern "C" int dua_denoiser_step(const dua_denoiser_plan* p, void* stream) {
       case DUA_OP_DECONV:
         rc = dua_deconv_k2s2_fwd(&o.conv, o.x, o.w, o.bias, in, o.y, stream);
         break;
-      case DUA_OP_FORK:
-      case DUA_OP_JOIN: {
-        if (!p->side_stream || !p->ev_fork || !p->ev_join) return DUA_ERR_ARG;
-        const bool fork = o.kind == DUA_OP_FORK;
-        hipEvent_t ev = (hipEvent_t)(fork ? p->ev_fork : p->ev_join);
-        hipError_t he = hipEventRecord(ev, (hipStream_t)(fork ? main_stream : p->side_stream));
-        if (he == hipSuccess) he = hipStreamWaitEvent((hipStream_t)(fork ? p->side_stream : main_stream), ev, 0);
-        rc = (int)he;
-        break;
-      }
       default:
         return DUA_ERR_ARG;
     }
     if (rc) return rc;
   }
-  stream = main_stream;
   return dua_final_conv_sampler(&p->tail, p->tail_raw, &p->tail_norm, p->wf, p->bf, p->cur_coef, p->x_state, p->noise,
                                 p->step_word, p->xin, p->xstart_sum, p->logits, p->xstart, stream);
-}
-
-extern "C" void* dua_event_create(void) {
-  hipEvent_t ev = nullptr;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-  return (void*)ev;
-}
-
-extern "C" void dua_event_destroy(void* event) {
-  if (event) (void)hipEventDestroy((hipEvent_t)event);
 }

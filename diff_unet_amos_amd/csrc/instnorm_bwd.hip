@@ -16,12 +16,8 @@ namespace dua {
 // mean / rstd / gamma / beta of channels [0, C) into LDS
 __device__ __forceinline__ void norm_preamble(const InXform& xf, int n, int C, float* mu, float* rs, float* ga, float* be) {
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double S = 0, Q = 0;
-#pragma unroll
-    for (int r = 0; r < STAT_REPLICAS; ++r) {
-      const double* p = xf.stats + (((long)n * STAT_REPLICAS + r) * xf.c_pad + c) * 2;
-      S += p[0]; Q += p[1];
-    }
+    double S, Q;
+    stats_read(xf.stats, n, xf.c_pad, c, S, Q);
     const double mean = S * (double)xf.inv_count;
     double var = Q * (double)xf.inv_count - mean * mean;
     var = var > 0 ? var : 0;

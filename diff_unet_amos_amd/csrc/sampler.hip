@@ -230,7 +230,11 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int vl = lane & 15, kq = lane >> 4;            // B column (voxel) / A row (class) index; k-group and class quad
   float sc[KS][8], sh[KS][8], rsc[RES ? KS : 1][8], rsh[RES ? KS : 1][8];
-  f16x8 aw[KS];
+  // The head runs at (almost) fp32 precision on fp16 MFMAs: weights and activations are split into an fp16 value and the
+  // fp16 image of its rounding error, and hi*hi + lo*hi + hi*lo are accumulated (lo*lo is below fp32 round-off).  The logits
+  // are the one output that nothing averages afterwards, and the head's rounding was a seventh of the whole network's logit
+  // error (tools/precision_sites.py); three MFMAs per k-step instead of one are free in an HBM-bound kernel.
+  f16x8 aw[KS], awl[KS];
   bool kok[KS];                                        // this lane's 8 channels of k-step ks are real channels
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -240,7 +244,9 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
       const int k = 32 * ks + 8 * kq + e;
       sc[ks][e] = sc_l[k]; sh[ks][e] = sh_l[k];
       if (RES) { rsc[ks][e] = rsc_l[k]; rsh[ks][e] = rsh_l[k]; }
-      aw[ks][e] = (f16)(vl < a.C ? a.wf[vl * K + k] : 0.f);          // A: row = class vl
+      const float wv = vl < a.C ? a.wf[vl * K + k] : 0.f;            // A: row = class vl
+      aw[ks][e] = (f16)wv;
+      awl[ks][e] = (f16)(wv - (float)aw[ks][e]);
     }
   }
   float bias[4];
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
     f32x4a acc = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      f16x8 y;
+      f16x8 y, yl;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = fmaf((float)fr[mb][ks][e], sc[ks][e], sh[ks][e]);
@@ -303,7 +309,10 @@ __global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a
         t = t > 0.f ? t : t * a.xf.slope;
         if (RES) { const float s = (float)fr3[mb][ks][e]; if (rav) t += s * (1.f - 1.f / (1.f + __expf(-s))); }
         y[e] = (f16)t;
+        yl[e] = (f16)(t - (float)y[e]);
       }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(awl[ks], y, acc, 0, 0, 0);    // small terms first
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks], yl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks], y, acc, 0, 0, 0);     // columns of voxels >= vox are never stored
     }
     // lane now holds the logits of classes 4 kq + j of voxel wbase + 16 (mb0 + mb) + vl

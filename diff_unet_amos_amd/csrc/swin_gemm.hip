@@ -36,7 +36,7 @@ struct TokLinArgs {
   int mode;
   f16* out; int ldc, out_off;
   float* x;
-  double* stats; int c_pad;
+  stat_t* stats; int c_pad;
   WinGeom g; const float* gamma; const float* beta; float eps; f16* ln_out;
   int w_row, a_row, o_row, w_bytes;   // LDS row strides (bytes) of W, the A tile, the output tile; size of the W region
 };

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(int B, int D, int H, i
 // in LDS and land with one pair of atomics per (block, channel) in replica blockIdx.x % 8 of the statistics buffer.
 template <typename T>
 __global__ __launch_bounds__(256) void instnorm_stats_kernel(const T* __restrict__ x, int x_stride, int x_off, long vox, int C,
-                                                             double* __restrict__ stats, int c_pad) {
+                                                             stat_t* __restrict__ stats, int c_pad) {
   constexpr int EPG = Elem<T>::EPG;
   using Frag = typename Elem<T>::Frag;
   extern __shared__ float red[];                    // [vl][C][2]
@@ -335,7 +335,7 @@ int dua_patch_embed(int dtype, int B, int D, int H, int W, int Cin_stride, int C
   return (int)hipGetLastError();
 }
 
-int dua_instnorm_stats(int dtype, int N, long voxels, int C, const void* x, int x_stride, int x_off, double* stats,
+int dua_instnorm_stats(int dtype, int N, long voxels, int C, const void* x, int x_stride, int x_off, dua_stat_word* stats,
                        int c_pad, void* stream) {
   using namespace dua;
   if (N <= 0 || voxels <= 0 || C <= 0 || C % 8 || C > 2048 || !x || !stats || c_pad < C || x_stride % 8 || x_off % 8 ||

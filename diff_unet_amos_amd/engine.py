@@ -82,7 +82,7 @@ class Plan:
         self.uA = [z(l, dec_out[l]) for l in range(4)]
         self.uB = [z(l, dec_out[l]) for l in range(4)]
         self.dec_out = dec_out
-        # InstanceNorm sums of every conv layer live in ONE fp64 arena, zeroed by a single memset per pass
+        # InstanceNorm sums of every conv layer live in ONE arena of fixed-point words, zeroed by a single memset per pass
         self._stat_slices = []
         # sampler state
         self.x_state = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
@@ -99,18 +99,6 @@ class Plan:
         self.weights_version = None
         self.graphs = {}
         self.tables = {}
-        # Two-part decoder convolutions (dua_conv3d_k3_partial / _fwd_acc): UpCat's first convolution reads
-        # torch.cat([x_e, x_0]) (denoiser.py:190); its x_e (skip) half exists as soon as the encoder level is done, so that
-        # half can be contracted on a side stream under the coarser levels and the layer on the critical path contracts the
-        # upsampled half only (level 0: 128 -> 64 at 96^3, the largest launch of a step, 384 -> 226 us).  MEASURED, same
-        # process (tools/bench_split_ab.py): the launches of the coarse levels that share the chip with the 258 us partial
-        # convolution stretch by as much as the decoder layer shrinks (1.706 -> 1.715 ms per step, also with the partial
-        # launch held to one workgroup per CU, also with a high-priority main stream), so the default is OFF; set
-        # ``split_levels = (0,)`` before the first step to use it.
-        self.split_levels = ()
-        self.partial = {}
-        self.side_stream = None
-        self._events = None
 
     # ---- parameter binding -------------------------------------------------------------------
     def _mk(self, name, block, cin_packed=None, perm=None, tap=None):
@@ -128,11 +116,11 @@ class Plan:
 
     def _alloc_stats(self):
         convs = [c for pair in self.enc + self.den + self.dec for c in pair]
-        sizes = [self.N * ops.STAT_REPLICAS * (-(-c.cout // 64) * 64) * 2 for c in convs]
-        self.stat_arena = torch.zeros(sum(sizes), dtype=torch.float64, device=self.dev)
+        sizes = [self.N * ops.STAT_REPLICAS * ops.STAT_WORDS * (-(-c.cout // 64) * 64) for c in convs]
+        self.stat_arena = torch.zeros(sum(sizes), dtype=torch.int64, device=self.dev)
         o = 0
         for c, n in zip(convs, sizes):
-            c.stats = self.stat_arena[o:o + n].view(self.N, ops.STAT_REPLICAS, -1, 2)
+            c.stats = self.stat_arena[o:o + n].view(self.N, ops.STAT_REPLICAS, ops.STAT_WORDS, -1)
             o += n
         n_enc = sum(sizes[:10])
         self.enc_stats, self.den_stats = self.stat_arena[:n_enc], self.stat_arena[n_enc:]
@@ -180,7 +168,7 @@ class Plan:
 
     def refresh_weights(self):
         """Re-pack when any parameter changed (optimizer step, load_state_dict)."""
-        ver = (tuple((p.data_ptr(), p._version) for p in self._params()), tuple(self.split_levels))
+        ver = tuple((p.data_ptr(), p._version) for p in self._params())
         if ver == self.weights_version:
             return
         dt = self.dtype
@@ -192,16 +180,6 @@ class Plan:
                     c.gamma_c = c.gamma.detach().float().contiguous()
                     c.beta_c = c.beta.detach().float().contiguous()
                     c.norm = c.norm_add = None       # rebuilt lazily against the new gamma/beta
-            for l in self.split_levels:             # the two input-channel halves of UpCat's first convolution, packed apart
-                if l not in self.partial:
-                    self.partial[l] = torch.zeros(ops.conv3_partial_bytes(dt, self.N, *self.S[l], self.dec_out[l]) // 4,
-                                                  dtype=torch.float32, device=self.dev)
-                if self.side_stream is None:
-                    self.side_stream = torch.cuda.Stream(device=self.dev)
-                c = self.dec[l][0]
-                w = c.w.detach().float()
-                c.wp_skip, _ = ops.pack_conv3_weights(w[:, :self.f[l]].contiguous(), None, dt)
-                c.wp_up, _ = ops.pack_conv3_weights(w[:, self.f[l]:].contiguous(), None, dt)
             for l in range(4):
                 d = self.deconv[l]
                 self.deconv_packed[l] = ops.pack_deconv_weights(d.weight.detach().float().contiguous(), d.bias.detach(), dt)
@@ -297,10 +275,6 @@ class Plan:
                 ops.materialize(self.rawB[l], b.cout, self._norm(b, l), self.cat[l], 0, emb=self.emb[l],
                                 pooled=self.pool[l])
                 x, cin = self.pool[l], b.cout
-                if l - 1 in self.split_levels:      # the skip half of upcat's first convolution at the level above, off the
-                    ua = self.dec[l - 1][0]         # critical path: started once the NEXT level is through (its own convolutions
-                    with ops.side_stream(self.side_stream):     # fill the chip; the levels below it do not)
-                        ops.conv3d_k3_partial(self.cat[l - 1], f[l - 1], 0, ua.wp_skip, ua.cout, self.partial[l - 1])
             else:
                 ops.materialize(self.rawB[4], b.cout, self._norm(b, 4), self.x4, 0, emb=self.emb[4])
         src, src_c, src_conv = self.x4, f[4], None
@@ -309,11 +283,7 @@ class Plan:
             norm = self._norm(src_conv, l + 1) if src_conv is not None else None
             ops.deconv_k2s2(src, src_c, 0, wp, bp, self.up[l], self.cat[l], f[l], norm=norm)
             a, b = self.dec[l]
-            if l in self.split_levels:
-                ops.join_stream(self.side_stream)
-                ops.conv3d_k3(self.cat[l], self.up[l], f[l], a.wp_up, a.bp, a.cout, self.uA[l], 0, a.stats, init=self.partial[l])
-            else:
-                self._conv(a, self.cat[l], f[l] + self.up[l], self.uA[l], l)
+            self._conv(a, self.cat[l], f[l] + self.up[l], self.uA[l], l)
             self._conv(b, self.uA[l], a.cout, self.uB[l], l, xform_from=a, add_key=f"u{l}")
             src, src_c, src_conv = self.uB[l], b.cout, b
         return self.dec[0][1]
@@ -343,16 +313,6 @@ class Plan:
         self.calls += 1
         self.seed_word.fill_(int(seed) & (2 ** 63 - 1))
         return seed
-
-    def _event(self, i):
-        """The two hipEvents dua_denoiser_step uses for its FORK / JOIN ops (created on first use, owned by the plan)."""
-        if not self.split_levels:
-            return None
-        if self._events is None:
-            L = nv.lib()
-            self._events = [L.dua_event_create(), L.dua_event_create()]
-            assert all(self._events), "hipEventCreate failed"
-        return self._events[i]
 
     # ---- the evaluation as one C-ABI call -------------------------------------------------------------------
     def native_step(self, mode, rows_per_sample=None, row_of_step=None, coef_table=None, noise=None, logits=None,
@@ -392,7 +352,6 @@ class Plan:
             self.cur_add.data_ptr(), self.cur_coef.data_ptr(), self.step_word.data_ptr(), self.err_word.data_ptr(),
             self.den_stats.data_ptr(), self.den_stats.numel() * 8,
             self._step_ops, len(self._step_ops), self.splitk_ws.data_ptr(), self.splitk_ws.numel() * 4,
-            self.side_stream.cuda_stream if self.side_stream is not None else None, self._event(0), self._event(1),
             tail, self.uB[0].data_ptr(), nv.InNorm(tn.stats, tn.gamma, tn.beta, tn.add, tn.add_stride, tn.c_pad, tn.inv_count, tn.eps, tn.slope),
             self.wf.data_ptr(), self.bf.data_ptr(), self.x_state.data_ptr(), ptr(noise),
             self.xin.data_ptr() if sampling else None, self.x_sum.data_ptr() if (use_sum and sampling) else None,

@@ -36,44 +36,6 @@ class recording:
         return False
 
 
-# ---- second stream -------------------------------------------------------------------------------------------------
-# ``with side_stream(stream): ...`` runs the enclosed launches on ``stream`` after it has waited for everything enqueued on
-# the current stream (fork); ``join_stream(stream)`` makes the current stream wait for it.  Under ``recording`` the same
-# calls append FORK / JOIN ops and mark the enclosed ops side = 1 for dua_denoiser_step.
-_SIDE = 0
-
-
-class side_stream:
-    def __init__(self, stream):
-        self.stream = stream
-        self.ctx = None
-
-    def __enter__(self):
-        global _SIDE
-        assert _SIDE == 0
-        if _RECORD is not None:
-            _RECORD.append(nv.StepOp(nv.OP_FORK))
-        else:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            self.ctx = torch.cuda.stream(self.stream)
-            self.ctx.__enter__()
-        _SIDE = 1
-
-    def __exit__(self, *exc):
-        global _SIDE
-        _SIDE = 0
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-
-def join_stream(stream):
-    if _RECORD is not None:
-        _RECORD.append(nv.StepOp(nv.OP_JOIN))
-    else:
-        torch.cuda.current_stream().wait_stream(stream)
-
-
 def _norm_value(norm, N, Cc):
     """(has_norm, nv.InNorm by value) for a StepOp."""
     if norm is None:
@@ -265,27 +227,55 @@ def zeros(shape, dtype, device):
     return torch.zeros(shape, dtype=dtype, device=device)
 
 
+STAT_WORDS = 4
+STAT_FRAC = float(2 ** 44)
+
+
 def stats_buffer(N, cout, device):
-    """Zeroed fp64 [N][8][ceil(cout/64)*64][2] accumulator a convolution adds (sum x, sum x^2) into."""
-    return zeros((N, STAT_REPLICAS, -(-cout // 64) * 64, 2), torch.float64, device)
+    """Zeroed int64 [N][8 replicas][4 words][ceil(cout/64)*64] accumulator a convolution adds (sum x, sum x^2) into:
+    fixed-point words (integer part, fraction * 2^44) added with integer atomics, so the totals do not depend on the
+    order in which workgroups arrive (include/dua_hip.h, dua_in_norm)."""
+    return zeros((N, STAT_REPLICAS, STAT_WORDS, -(-cout // 64) * 64), torch.int64, device)
+
+
+def stats_decode(stats):
+    """int64 [N, 8, 4, c_pad] statistics words -> float64 [N, c_pad, 2] = (sum x, sum x^2), as the kernels read them."""
+    w = stats.sum(1)
+    S = w[:, 0].double() + w[:, 1].double() / STAT_FRAC
+    Q = w[:, 2].double() + w[:, 3].double() / STAT_FRAC
+    return torch.stack([S, Q], -1)
+
+
+def stats_encode(sums, out=None):
+    """float64 [N, C, 2] (sum x, sum x^2) -> statistics words in replica row 0 of an int64 [N, 8, 4, c_pad] buffer."""
+    N, Cc = sums.shape[:2]
+    if out is None:
+        out = torch.zeros((N, STAT_REPLICAS, STAT_WORDS, -(-Cc // 64) * 64), dtype=torch.int64, device=sums.device)
+    out.zero_()
+    s = sums.double()
+    hi = torch.round(s)
+    lo = torch.round((s - hi) * STAT_FRAC)
+    out[:, 0, 0, :Cc] = hi[..., 0].long(); out[:, 0, 1, :Cc] = lo[..., 0].long()
+    out[:, 0, 2, :Cc] = hi[..., 1].long(); out[:, 0, 3, :Cc] = lo[..., 1].long()
+    return out
 
 
 class Norm:
     """Producer-side normalisation descriptor (dua_in_norm) a consumer fuses into its input staging."""
 
     def __init__(self, stats, gamma, beta, count, add=None, add_stride=0, slope=0.1, eps=1e-5):
-        assert stats.is_cuda and stats.dtype == torch.float64 and stats.is_contiguous() and stats.dim() == 4
-        assert stats.shape[1] == STAT_REPLICAS and stats.shape[3] == 2
+        assert stats.is_cuda and stats.dtype == torch.int64 and stats.is_contiguous() and stats.dim() == 4
+        assert stats.shape[1] == STAT_REPLICAS and stats.shape[2] == STAT_WORDS
         for v in (gamma, beta):
             assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()
-        assert gamma.numel() == beta.numel() <= stats.shape[2]
+        assert gamma.numel() == beta.numel() <= stats.shape[3]
         if add is not None:
             assert add.is_cuda and add.dtype == torch.float32
             assert add.numel() >= (stats.shape[0] - 1) * (add_stride or gamma.numel()) + gamma.numel()
         self.keep = (stats, gamma, beta, add)
         self.N, self.C = stats.shape[0], gamma.numel()
         self.c = nv.InNorm(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), add.data_ptr() if add is not None else None,
-                           add_stride, stats.shape[2], 1.0 / count, eps, slope)
+                           add_stride, stats.shape[3], 1.0 / count, eps, slope)
 
     def ref(self, N, Cc):
         assert self.N == N and self.C >= Cc, "normalisation descriptor does not match the consumer's input"
@@ -302,14 +292,12 @@ def conv3_workspace_bytes(dtype, N, D, H, W, cin, cout):
 
 
 def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None, workspace=None, tap_channel=None,
-              init=None, background=False):
+              background=False):
     """Raw 3x3x3 convolution (+bias); ``norm`` = producer descriptor of x (fused IN+LeakyReLU+add);
     accumulates this layer's InstanceNorm sums into ``out_stats`` (must be zero on entry).
     ``tap_channel`` (0 or 16, fp16, cin == tap_channel + 8): the single-channel tap form for first layers -- that packed
     channel is the last real input channel and is contracted as two k-steps over its 27 taps (weights packed with the
     same ``tap_channel``).
-    ``init`` (fp32 [N, D, H, W, ceil(cout/64)*64] from conv3d_k3_partial): the other part of a convolution over a channel
-    concatenation; the accumulators start from bias + init (dua_conv3d_k3_fwd_acc).
     ``background``: the launch runs on a second stream under a chain of small launches (one workgroup per CU, see
     dua_conv3_desc.background)."""
     _cl_check(x, "x"); _cl_check(y, "y")
@@ -327,20 +315,13 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
         tap_bytes = nct * 4096
     assert w_packed.numel() == nct * nch * 27 * 4 * 64 * 16 + tap_bytes, "packed weights do not match (Cin, Cout, dtype)"
     assert bias_pad.numel() >= cout and bias_pad.dtype == torch.float32 and bias_pad.is_contiguous()     # the kernels read [0, cout)
-    assert out_stats.dtype == torch.float64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, nct * 64, 2)
+    assert out_stats.dtype == torch.int64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, STAT_WORDS, nct * 64)
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off,
                      0 if tap_channel is None else tap_channel + 1, 1 if background else 0)
-    if init is not None:
-        assert tap_channel is None and init.is_cuda and init.dtype == torch.float32 and init.is_contiguous()
-        assert init.numel() * 4 >= conv3_partial_bytes(x.dtype, N, D, H, W, cout)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, cin)
-        _RECORD.append(nv.StepOp(nv.OP_CONV3 if init is None else nv.OP_CONV3_ACC, _SIDE, _addr(init), has, d, nv.MaterializeDesc(),
+        _RECORD.append(nv.StepOp(nv.OP_CONV3, has, d, nv.MaterializeDesc(),
                                  nval, _addr(x), _addr(w_packed), _addr(bias_pad), _addr(y), _addr(out_stats), None, None))
-        return
-    if init is not None:
-        nv.check(nv.lib().dua_conv3d_k3_fwd_acc(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),
-                                                nv.ptr(init), nv.ptr(y), nv.ptr(out_stats), nv.stream_ptr()), "dua_conv3d_k3_fwd_acc")
         return
     ws_bytes = 0
     if workspace is not None:
@@ -349,33 +330,6 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
     nv.check(nv.lib().dua_conv3d_k3_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),
                                         nv.ptr(y), nv.ptr(out_stats), nv.ptr(workspace), ws_bytes, nv.stream_ptr()),
              "dua_conv3d_k3_fwd")
-
-
-def conv3_partial_bytes(dtype, N, D, H, W, cout):
-    d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, 8, 8, 0, cout, cout, 0, 0)
-    return int(nv.lib().dua_conv3d_k3_partial_bytes(C.byref(d)))
-
-
-def conv3d_k3_partial(x, cin, cin_off, w_packed, cout, partial, norm=None):
-    """fp32 tile sums of the convolution of channels [cin_off, cin_off + cin) of ``x`` with ``w_packed`` (no bias, no
-    statistics) into ``partial`` (fp32, conv3_partial_bytes(...) bytes, the kernel's accumulator layout): one part of a
-    convolution over a channel concatenation (dua_conv3d_k3_partial); the other part takes it as ``init``."""
-    _cl_check(x, "x")
-    N, D, H, W, cs_in = x.shape
-    assert cin % 8 == 0 and cin_off % 8 == 0 and cin_off + cin <= cs_in and cout % 8 == 0
-    ck = chunk_elems(x.dtype)
-    nch, nct = -(-cin // ck), -(-cout // 64)
-    assert w_packed.numel() == nct * nch * 27 * 4 * 64 * 16, "packed weights do not match (Cin, Cout, dtype)"
-    assert partial.is_cuda and partial.dtype == torch.float32 and partial.is_contiguous()
-    assert partial.numel() * 4 >= conv3_partial_bytes(x.dtype, N, D, H, W, cout)
-    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, nct * 64, 0, 0)
-    if _RECORD is not None:
-        has, nval = _norm_value(norm, N, cin)
-        _RECORD.append(nv.StepOp(nv.OP_CONV3_PARTIAL, _SIDE, None, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), None,
-                                 _addr(partial), None, None, None))
-        return
-    nv.check(nv.lib().dua_conv3d_k3_partial(C.byref(d), nv.ptr(x), nv.ptr(w_packed), _norm_ref(norm, N, cin), nv.ptr(partial),
-                                            nv.stream_ptr()), "dua_conv3d_k3_partial")
 
 
 def conv3d_k3_wgrad(x, cin, cin_off, dy, cout, cout_off, dw, perm=None, workspace=None):
@@ -464,7 +418,7 @@ def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0, want_add=True):
     assert dA.dtype == raw.dtype == dY.dtype and tuple(dA.shape[:4]) == tuple(raw.shape[:4]) == tuple(dY.shape[:4])
     assert Cc % 8 == 0 and Cc <= raw.shape[-1] and da_off % 8 == 0 and da_off + Cc <= dA.shape[-1]
     assert dy_off % 8 == 0 and dy_off + Cc <= dY.shape[-1]
-    cpad = norm.keep[0].shape[2]
+    cpad = norm.keep[0].shape[3]
     sums = zeros((N, STAT_REPLICAS, cpad, 4), torch.float64, raw.device)
     d = nv.NormBwdDesc(nv.dt_code(raw.dtype), N, vox, Cc, dA.shape[-1], da_off, raw.shape[-1], 0, dY.shape[-1], dy_off)
     L = nv.lib()
@@ -622,7 +576,7 @@ def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None):
     d = nv.MaterializeDesc(nv.dt_code(raw.dtype), N, D, H, W, Cc, rs, es, out.shape[-1], out_off, ps)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, Cc)
-        _RECORD.append(nv.StepOp(nv.OP_MATERIALIZE, _SIDE, None, has, nv.Conv3Desc(), d, nval, _addr(raw), None, None, _addr(out), None,
+        _RECORD.append(nv.StepOp(nv.OP_MATERIALIZE, has, nv.Conv3Desc(), d, nval, _addr(raw), None, None, _addr(out), None,
                                  _addr(emb), _addr(pooled)))
         return
     nv.check(nv.lib().dua_materialize(C.byref(d), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(emb), nv.ptr(out),
@@ -643,7 +597,7 @@ def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=Non
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, cin)
-        _RECORD.append(nv.StepOp(nv.OP_DECONV, _SIDE, None, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),
+        _RECORD.append(nv.StepOp(nv.OP_DECONV, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),
                                  _addr(y), None, None, None))
         return
     nv.check(nv.lib().dua_deconv_k2s2_fwd(C.byref(d), nv.ptr(x), nv.ptr(w_packed), nv.ptr(bias_pad), _norm_ref(norm, N, cin),
@@ -961,7 +915,7 @@ def instnorm_stats(x, Cc, stats, c_off=0):
     _cl_check(x, "x")
     N, D, H, W, Cs = x.shape
     nv.check(nv.lib().dua_instnorm_stats(nv.dt_code(x.dtype), N, D * H * W, Cc, nv.ptr(x), Cs, c_off, nv.ptr(stats),
-                                         stats.shape[2], nv.stream_ptr()), "dua_instnorm_stats")
+                                         stats.shape[3], nv.stream_ptr()), "dua_instnorm_stats")
     return stats
 
 
@@ -1002,8 +956,8 @@ def token_linear(A, W, bias=None, mode="plain", out=None, out_off=0, x=None, sta
         assert out.numel() == M * ldc and out_off + N <= ldc
         d.out, d.ldc, d.out_off = out.data_ptr(), ldc, out_off
     if mode == "stats":
-        assert stats is not None and stats.dtype == torch.float64 and stats.is_contiguous() and stats.shape[0] == samples and M % samples == 0
-        d.stats, d.c_pad = stats.data_ptr(), stats.shape[2]
+        assert stats is not None and stats.dtype == torch.int64 and stats.is_contiguous() and stats.shape[0] == samples and M % samples == 0
+        d.stats, d.c_pad = stats.data_ptr(), stats.shape[3]
     if mode in ("residual", "scatter"):
         assert x is not None and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         d.x = x.data_ptr()

@@ -208,14 +208,14 @@ class SwinPlan:
         ups = [den.decoder1, den.decoder2, den.decoder3, den.decoder4, den.decoder5]
         self.u_res = [self._res(f"u{k + 1}", ups[k].conv_block, k) for k in range(5)]
         self.ups = ups
-        # one fp64 arena for the InstanceNorm sums, zeroed by one memset per pass
+        # one arena for the InstanceNorm sums (fixed-point words, ops.stats_buffer), zeroed by one memset per pass
         sizes, blocks = [], self.e_res + self.d_res + self.u_res
         for r in blocks:
-            sizes.append(self.N * ops.STAT_REPLICAS * (-(-r.cout // 64) * 64) * 2)
-        self.stat_arena = torch.zeros(3 * sum(sizes), dtype=torch.float64, device=self.dev)
+            sizes.append(self.N * ops.STAT_REPLICAS * ops.STAT_WORDS * (-(-r.cout // 64) * 64))
+        self.stat_arena = torch.zeros(3 * sum(sizes), dtype=torch.int64, device=self.dev)
         o = 0
         for r, n in zip(blocks, sizes):
-            r.st = [self.stat_arena[o + k * n:o + (k + 1) * n].view(self.N, ops.STAT_REPLICAS, -1, 2) for k in range(3)]
+            r.st = [self.stat_arena[o + k * n:o + (k + 1) * n].view(self.N, ops.STAT_REPLICAS, ops.STAT_WORDS, -1) for k in range(3)]
             o += 3 * n
         n_enc = 3 * sum(sizes[:len(self.e_res)])
         self.enc_stats, self.den_stats = self.stat_arena[:n_enc], self.stat_arena[n_enc:]

@@ -105,7 +105,7 @@ def _channel_sums(t, c, c_off):
     from . import ops
     st = ops.stats_buffer(t.shape[0], c, t.device)
     ops.instnorm_stats(t, c, st, c_off=c_off)
-    return st[:, :, :c, 0].sum(dim=(0, 1)).float()
+    return ops.stats_decode(st)[:, :c, 0].sum(0).float()
 
 
 class _Conv3dK3(torch.autograd.Function):

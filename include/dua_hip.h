@@ -25,14 +25,18 @@ extern "C" {
 
 /* ---- fused producer normalisation --------------------------------------------------------------
  * A convolution stores its RAW output (conv + bias) and accumulates per-(n, c) sums of it into
- * out_stats = fp64 [N][8][c_pad][2] (8 replica rows; (sum x, sum x^2); the caller zeroes it before the
- * producing launch).  Whoever consumes the raw tensor passes this descriptor and applies
+ * out_stats = dua_stat_word [N][8][4][c_pad] (8 replica rows x 4 words x channels; the caller zeroes it before the
+ * producing launch).  The words of a channel are (sum x: integer part, sum x: fraction * 2^44, sum x^2: integer part,
+ * sum x^2: fraction * 2^44), added with 64-bit INTEGER atomics: integer addition is associative, so the sums -- and every
+ * scale / shift derived from them -- do not depend on the order in which workgroups arrive (two launches on the same
+ * inputs agree bit for bit).  Whoever consumes the raw tensor passes this descriptor and applies
  *   y = LeakyReLU(x * scale + shift) + add,  scale = gamma / sqrt(var + eps), shift = beta - mean * scale
  * (biased variance) while staging its input: InstanceNorm3d(affine) -> Dropout(0) -> LeakyReLU of MONAI's
  * ADN (models/basic_unet/denoiser.py:206-207, models/diff_unet.py:34-35) and the temb add of
  * TwoConv.forward (denoiser.py:65).  stats == NULL means "input is already materialised". */
+typedef long long dua_stat_word;
 typedef struct {
-  const double* stats;       /* producer's sums, [N][8][c_pad][2] */
+  const dua_stat_word* stats; /* producer's sums, [N][8][4][c_pad] */
   const float* gamma;        /* producer's InstanceNorm weight [C] */
   const float* beta;         /* producer's InstanceNorm bias [C] */
   const float* add;          /* optional fp32 [N][add_stride] bias added after the activation, or NULL */
@@ -51,11 +55,11 @@ typedef struct {
   int N, D, H, W;
   int Cin, Cin_stride, Cin_off;    /* all multiples of 8 */
   int Cout, Cout_stride, Cout_off; /* all multiples of 8 */
-  int tap_channel_plus1;           /* 0 = ordinary convolution.  k > 0 (dua_conv3d_k3_fwd only, DUA_F16, Cin <= 32, no fused
+  int tap_channel_plus1;           /* 0 = ordinary convolution.  k > 0 (DUA_F16, Cin <= 32, no fused
                                       producer): packed input channel k-1 (0 or 16) is the LAST real channel (Cin = k-1 + 8,
                                       channels behind it are zero padding); its 27 taps are contracted as two 16-wide k-steps
                                       instead of 27 padded ones.  Needs weights from dua_pack_conv3_weights_tap. */
-  int background;                  /* dua_conv3d_k3_fwd only.  1 = this launch runs on a second stream UNDER a chain of small
+  int background;                  /* 1 = this launch runs on a second stream UNDER a chain of small
                                       launches that the caller is waiting for: it asks for LDS it does not use, so that one of
                                       its workgroups fits a CU instead of two and the chain's workgroups always find free
                                       registers and LDS.  Same result, longer launch.  0 = ordinary launch. */
@@ -63,29 +67,14 @@ typedef struct {
 
 /* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32, at least Cout entries (a buffer padded to
  * ceil(Cout/64)*64 works, entries behind Cout are never read).  in: NULL or the
- * producer descriptor of x.  y: raw output.  out_stats: fp64 [N][8][ceil(Cout/64)*64][2], pre-zeroed.
+ * producer descriptor of x.  y: raw output.  out_stats: dua_stat_word [N][8][4][ceil(Cout/64)*64], pre-zeroed.
  * workspace (may be NULL): scratch for split-K on layers too small to fill 256 CUs (<= 24^3): the K range
  * (Cin chunk x kd) is divided over workgroups, fp32 partial tiles land in the workspace and a finish kernel
  * sums them, adds the bias and takes the statistics.  dua_conv3d_k3_workspace gives the bytes that enables it. */
 long dua_conv3d_k3_workspace(const dua_conv3_desc* d);
 int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
-                      const dua_in_norm* in, void* y, double* out_stats, void* workspace, long workspace_bytes,
+                      const dua_in_norm* in, void* y, dua_stat_word* out_stats, void* workspace, long workspace_bytes,
                       void* stream);
-
-/* Two-part form of a convolution whose input is a channel concatenation (torch.cat([x_e, x_0], dim=1) in front of
- * UpCat.convs, models/basic_unet/denoiser.py:190; torch.cat((out, skip), dim=1) in UnetrUpBlock, swin_unetr/blocks.py:90):
- *   conv(cat[a | b]) = conv_a(a) + conv_b(b),
- * so the part that reads the SKIP connection can run as soon as the skip exists -- on a second stream, under the launches of
- * the coarser levels that leave the chip idle -- and the layer on the critical path contracts only the other half.
- * dua_conv3d_k3_partial: fp32 tile sums of one part (w_packed: the packed weights of that part's input channels), no bias,
- *   no statistics, into `partial` (dua_conv3d_k3_partial_bytes(d) bytes; the layout is the kernel's accumulator layout and
- *   is only meaningful to dua_conv3d_k3_fwd_acc called with the same N, D, H, W, Cout and dtype).
- * dua_conv3d_k3_fwd_acc: dua_conv3d_k3_fwd for the other part, its accumulators starting from bias + partial. */
-long dua_conv3d_k3_partial_bytes(const dua_conv3_desc* d);
-int dua_conv3d_k3_partial(const dua_conv3_desc* d, const void* x, const void* w_packed, const dua_in_norm* in, float* partial,
-                          void* stream);
-int dua_conv3d_k3_fwd_acc(const dua_conv3_desc* d, const void* x, const void* w_packed, const float* bias_padded,
-                          const dua_in_norm* in, const float* partial, void* y, double* out_stats, void* stream);
 
 /* Weight gradient of the same convolution (backward of train.py:258-268 through denoiser.py:56-59):
  *   dw[co][ci][kd][kh][kw] += sum over (n, voxel) of dy[n, v, co] * x[n, v + tap - 1, ci]
@@ -321,14 +310,8 @@ int dua_step_begin(int N, int P, const float* table, int table_rows, const int* 
 #define DUA_OP_CONV3 1        /* dua_conv3d_k3_fwd(conv, x, w, bias, norm?, y, stats, workspace) */
 #define DUA_OP_MATERIALIZE 2  /* dua_materialize(mat, raw = x, norm, emb, out = y, pooled) */
 #define DUA_OP_DECONV 3       /* dua_deconv_k2s2_fwd(conv, x, w, bias, norm?, y) */
-#define DUA_OP_CONV3_PARTIAL 4  /* dua_conv3d_k3_partial(conv, x, w, norm?, partial = y) */
-#define DUA_OP_CONV3_ACC 5    /* dua_conv3d_k3_fwd_acc(conv, x, w, bias, norm?, partial = init, y, stats) */
-#define DUA_OP_FORK 6         /* the side stream waits for everything enqueued on the main stream so far */
-#define DUA_OP_JOIN 7         /* the main stream waits for everything enqueued on the side stream so far */
 typedef struct {
   int kind;                /* DUA_OP_* */
-  int side;                /* 0: launch on the step's stream; 1: on plan->side_stream (between a FORK and a JOIN) */
-  const float* init;       /* CONV3_ACC: the other part's partial sums */
   int has_norm;            /* norm below describes the producer of x (fused InstanceNorm + LeakyReLU + add) */
   dua_conv3_desc conv;
   dua_materialize_desc mat;
@@ -337,7 +320,7 @@ typedef struct {
   const void* w;           /* packed weights (CONV3 / DECONV) */
   const float* bias;       /* padded bias (CONV3 / DECONV) */
   void* y;                 /* output */
-  double* stats;           /* CONV3: this layer's statistics rows inside the arena */
+  dua_stat_word* stats;    /* CONV3: this layer's statistics rows inside the arena */
   const void* emb;         /* MATERIALIZE: encoder feature map added after the activation, or NULL */
   void* pooled;            /* MATERIALIZE: MaxPool3d(2) output, or NULL */
 } dua_step_op;
@@ -350,21 +333,16 @@ typedef struct {
   const int* row_of_step; int nsteps; const float* coef_table; int* counter;   /* ... or the sampling loop's tables */
   float* cur_add; float* cur_coef; int* step_word; int* err_word;
   /* statistics arena of all CONV3 ops, zeroed at the start of the evaluation */
-  double* stat_arena; long stat_bytes;
+  dua_stat_word* stat_arena; long stat_bytes;
   /* the launch sequence */
   const dua_step_op* ops; int n_ops;
   void* workspace; long workspace_bytes;     /* split-K scratch shared by the CONV3 ops */
-  /* second stream for ops with side = 1 and two events (dua_event_create) for FORK / JOIN; all NULL when no op uses them */
-  void* side_stream; void* ev_fork; void* ev_join;
   /* tail (dua_final_conv_sampler) */
   dua_tail_desc tail; const void* tail_raw; dua_in_norm tail_norm; const float* wf; const float* bf;
   float* x_state; const float* noise; void* xin; float* xstart_sum; float* logits; float* xstart;
 } dua_denoiser_plan;
 
 int dua_denoiser_step(const dua_denoiser_plan* plan, void* stream);
-/* An event without timing for the FORK / JOIN ops above (hipEventCreateWithFlags(hipEventDisableTiming)); 0 on failure. */
-void* dua_event_create(void);
-void dua_event_destroy(void* event);
 
 /* ---- windowed multi-head self-attention (DiffSwinUNETR, BASELINE config 5) -------------------------------------------
  * The core of WindowAttention.forward (models/swin_unetr/attention.py:97-120) between its two Linear layers:
@@ -436,7 +414,7 @@ int dua_patch_embed(int dtype, int B, int D, int H, int W, int Cin_stride, int C
                     float* x, void* out, int out_stride, int out_off, void* stream);
 /* Sum / sum of squares per (n, c) of a channels-last slice, accumulated into a dua_in_norm statistics buffer (zeroed by
  * the caller): the statistics of UnetResBlock's 1x1x1 conv3 (blocks.py:286-296), whose GEMM is a library call. */
-int dua_instnorm_stats(int dtype, int N, long voxels, int C, const void* x, int x_stride, int x_off, double* stats,
+int dua_instnorm_stats(int dtype, int N, long voxels, int C, const void* x, int x_stride, int x_off, dua_stat_word* stats,
                        int c_pad, void* stream);
 /* Token GEMM with a fused epilogue for the tall / skinny Linear layers of the fine Swin stages and the 1x1x1 conv3 of
  * UnetResBlock: out[token][n] = sum_k A[token][k] W[n][k] (+ bias[n]), fp16 operands (A: [samples * M][lda], W: the
@@ -444,7 +422,7 @@ int dua_instnorm_stats(int dtype, int N, long voxels, int C, const void* x, int 
  * W).  Modes:
  *   PLAIN    out[token][out_off + n] (fp16, row stride ldc)                              qkv, proj, reduction
  *   GELU     the same after exact GELU                                                   MLPBlock linear1 + act
- *   STATS    PLAIN without bias, and stats[sample][replica][c][2] += (sum, sum^2) of the ROUNDED outputs (N <= 64; M = voxels
+ *   STATS    PLAIN without bias, and stats[sample][replica][4][c] += (sum, sum^2) of the ROUNDED outputs (N <= 64; M = voxels
  *            per sample, `samples` grid rows)                                            conv3 + norm3 statistics
  *   RESIDUAL x[token][n] += out + bias on the fp32 stream                                x + mlp(norm2(x)), transformer.py:477-480
  *   SCATTER  token = window order: x[voxel(token)] += out + bias, ln_out[voxel] = LayerNorm(x)*gamma+beta; padding tokens
@@ -460,7 +438,7 @@ typedef struct dua_token_linear_desc {
   int mode, samples;
   void* out; int ldc, out_off;
   float* x;
-  double* stats; int c_pad;
+  dua_stat_word* stats; int c_pad;
   dua_window_geom geom; const float* gamma; const float* beta; float eps; void* ln_out;
 } dua_token_linear_desc;
 int dua_token_linear(const dua_token_linear_desc* d, void* stream);

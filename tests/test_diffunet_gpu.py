@@ -502,34 +502,3 @@ def test_config3_full_size_properties():
     assert float(d.mean()) < 1e-2, float(d.mean())         # same window, same x_T: equal up to the order of fp64 atomics
     seg = inference.binarise(out)
     assert seg.shape == out.shape and set(seg.unique().tolist()) <= {0.0, 1.0}
-
-
-def test_two_part_decoder_convolution_is_the_same_network():
-    """Plan.split_levels = (0,): upcat_1's first convolution as conv_skip(x_e) on a side stream + conv_up(x_0) started from
-    its partial sums (dua_conv3d_k3_partial / _fwd_acc, FORK / JOIN ops of dua_denoiser_step) gives the logits of the
-    one-launch form, eagerly and from a replayed graph."""
-    from diff_unet_amos_amd.diff_unet import DiffUNet
-    torch.manual_seed(3)
-    net = DiffUNet(in_channels=1, out_channels=2, features=(8, 8, 16, 32, 64, 8), compute_dtype=torch.float32).cuda().eval()
-    g = torch.Generator().manual_seed(4)
-    image = torch.rand(2, 1, 32, 32, 32, generator=g).cuda()
-    x = torch.randn(2, 2, 32, 32, 32, generator=g).cuda()
-    t = torch.tensor([11, 700]).cuda()
-    with torch.no_grad():
-        want = net(image=image, x=x, step=t, pred_type="denoise").clone()
-        plan = net._rt.plan(2, (32, 32, 32), image.device)
-        plan.split_levels = (0,)                        # re-packs on the next call: the two halves, the partial buffer, the side stream
-        got = net(image=image, x=x, step=t, pred_type="denoise").clone()
-        assert any(op.kind == 6 for op in plan._step_ops) and any(op.kind == 7 for op in plan._step_ops)   # FORK, JOIN
-        gr = torch.cuda.CUDAGraph()
-        out = torch.empty_like(got)
-        rows = t.to(torch.int32)
-        plan.native_step(0, rows_per_sample=rows, logits=out)
-        torch.cuda.synchronize()
-        with torch.cuda.graph(gr):
-            plan.native_step(0, rows_per_sample=rows, logits=out)
-        out.zero_()
-        gr.replay()
-        torch.cuda.synchronize()
-    assert (got - want).abs().max() < 1e-4 * max(1.0, float(want.abs().max()))
-    assert (out - got).abs().max() < 1e-5

@@ -126,18 +126,3 @@ def test_patch_embed_weight_packing_is_the_strided_convolution():
     got = torch.einsum("ncdhwijk,ijkce->nedhw", patches, wp.view(2, 2, 2, cp, E))
     want = F.conv3d(x, w, stride=2)
     assert torch.allclose(got, want, atol=1e-4)
-
-
-def test_side_stream_recording_marks_ops_for_the_step_executor():
-    """Under ops.recording the side-stream context appends a FORK op, join_stream a JOIN op (what dua_denoiser_step turns
-    into an event record / wait pair), and nothing touches a device."""
-    from diff_unet_amos_amd import _native as nv
-    from diff_unet_amos_amd import ops
-    rec = []
-    with ops.recording(rec):
-        with ops.side_stream(None):
-            assert ops._SIDE == 1
-        assert ops._SIDE == 0
-        ops.join_stream(None)
-    assert [op.kind for op in rec] == [nv.OP_FORK, nv.OP_JOIN] and all(op.side == 0 and not op.init for op in rec)
-    assert ops._RECORD is None

@@ -129,8 +129,9 @@ def test_unet_res_block_on_hip_kernels_matches_oracle(dtype, tol, cin, cout):
         r = (xcl.float() @ blk.conv3.conv.weight.detach().reshape(cout, cin).t().to(dev)).to(dtype).contiguous()     # 1x1x1 conv = GEMM
         st3 = ops.instnorm_stats(r.view(N, D, H, W, cout), cout, ops.stats_buffer(N, cout, dev))
         rf = r.float().view(N, V, cout)
-        assert torch.allclose(st3[:, :, :cout, 0].sum(1), rf.sum(1).double(), rtol=1e-5, atol=1e-3)
-        assert torch.allclose(st3[:, :, :cout, 1].sum(1), (rf * rf).sum(1).double(), rtol=1e-5, atol=1e-3)
+        sd = ops.stats_decode(st3)
+        assert torch.allclose(sd[:, :cout, 0], rf.sum(1).double(), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(sd[:, :cout, 1], (rf * rf).sum(1).double(), rtol=1e-5, atol=1e-3)
         n3 = ops.Norm(st3, blk.norm3.weight.detach().to(dev), blk.norm3.bias.detach().to(dev), V, slope=0.01)
         out = ops.residual_norm_act(raw2, n2, r, n3, slope=0.01)
     else:
@@ -473,8 +474,9 @@ def test_token_linear_kernel_epilogues_match_torch():
     want = F.linear(buf[:, :K].float(), W.float())
     assert (out.float() - want).abs().max() < 4e-3 * max(1.0, float(want.abs().max()))
     o = out.float().view(B, V, N)
-    assert torch.allclose(st[:, :, :N, 0].sum(1), o.sum(1).double(), rtol=1e-4, atol=1e-2)
-    assert torch.allclose(st[:, :, :N, 1].sum(1), (o * o).sum(1).double(), rtol=1e-4, atol=1e-2)
+    sd = ops.stats_decode(st)
+    assert torch.allclose(sd[:, :N, 0], o.sum(1).double(), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sd[:, :N, 1], (o * o).sum(1).double(), rtol=1e-4, atol=1e-2)
     # residual
     for M, K, N in ((900, 192, 48), (450, 384, 96)):
         A = torch.randn(M, K, generator=g).half().to(dev)
@@ -577,8 +579,9 @@ def test_fused_swin_mlp_kernel_matches_torch(C_, M):
 @pytest.mark.parametrize("mode", ["logits", "ddpm"])
 def test_tail_residual_form_equals_the_materialised_route(mode):
     """dua_final_conv_sampler_res (decoder1's output assembled inside the tail) against residual_norm_act + the ordinary tail on
-    the same operands: the same bits (same arithmetic order, same fp16 rounding point), 48 real channels in a K = 64 tail, a
-    voxel count that is not a multiple of the 256-voxel tile, two samples."""
+    the same operands, 48 real channels in a K = 64 tail, a voxel count that is not a multiple of the 256-voxel tile, two
+    samples.  The fused form feeds the head the fp32 activation (split into an fp16 value + its rounding error); the
+    materialised route rounds it to fp16 once on the way: equal up to that rounding."""
     from diff_unet_amos_amd import ops, _native as nv
     dev = "cuda"
     g = torch.Generator().manual_seed(31)
@@ -615,7 +618,7 @@ def test_tail_residual_form_equals_the_materialised_route(mode):
 
     a, b = run(True), run(False)
     assert bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0.1
-    assert torch.equal(a, b), float((a - b).abs().max())
+    assert float((a - b).abs().max()) < 3e-3, float((a - b).abs().max())
 
 
 @pytest.mark.gpu

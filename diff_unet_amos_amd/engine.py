@@ -68,6 +68,15 @@ class Plan:
         self.S = S
         z = lambda l, c, dt=dtype: torch.zeros((N, *S[l], c), dtype=dt, device=device)  # noqa: E731
         # encoder
+        # The encoder's first TwoConv (two 96^3 convolutions, ONCE per patch) runs on the exact-fp32 MFMA path also in an
+        # fp16 plan: embeddings[0] is added to x_0 in every one of the T steps, so its rounding error is the same in every
+        # step and does not average out of the sum of predictions -- emulated on the oracle (tools/precision_sites.py) it was
+        # 45 % of the 50-step Dice deviation of an all-fp16 pass, for ~2 ms per patch.
+        self.enc_hi = dtype == torch.float16 and bool(getattr(net, "encoder_level0_fp32", True))
+        if self.enc_hi:
+            f32 = torch.float32
+            self.img_in32 = z(0, 8, f32)
+            self.rawA32, self.rawB32, self.emb32, self.pool32 = z(0, f[0], f32), z(0, f[0], f32), z(0, f[0], f32), z(1, f[0], f32)
         self.img_in = z(0, 8)
         self.rawA = [z(l, f[l]) for l in range(5)]
         self.rawB = [z(l, f[l]) for l in range(5)]
@@ -112,6 +121,7 @@ class Plan:
         c.cin_packed, c.perm = cin_packed, perm
         c.wp = c.bp = None
         c.stats = c.norm = c.norm_add = None
+        c.dt = self.dtype                 # operand type of this layer (enc_hi: fp32 for the encoder's first block)
         return c
 
     def _alloc_stats(self):
@@ -130,13 +140,16 @@ class Plan:
             for l, pair in zip(levels, pairs):
                 for c in pair:
                     cin = c.cin_packed or c.cin
-                    need = max(need, ops.conv3_workspace_bytes(self.dtype, self.N, *self.S[l], -(-cin // 8) * 8, c.cout))
+                    need = max(need, ops.conv3_workspace_bytes(c.dt, self.N, *self.S[l], -(-cin // 8) * 8, c.cout))
         self.splitk_ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=self.dev)
 
     def _bind(self):
         net = self.net
         enc, den = net.embed_model, net.model
         self.enc = [(self._mk("e0a", enc.conv_0.conv_0, cin_packed=8, perm=[0] + [-1] * 7, tap=0), self._mk("e0b", enc.conv_0.conv_1))]
+        if self.enc_hi:
+            for c in self.enc[0]:
+                c.dt, c.tap = torch.float32, None
         for i in range(4):
             tc = enc.down[i].convs
             self.enc.append((self._mk(f"e{i+1}a", tc.conv_0), self._mk(f"e{i+1}b", tc.conv_1)))
@@ -175,7 +188,7 @@ class Plan:
         with torch.no_grad():
             for pair in self.enc + self.den + self.dec:
                 for c in pair:
-                    c.wp, c.bp = ops.pack_conv3_weights(c.w.detach().float().contiguous(), c.b.detach(), dt,
+                    c.wp, c.bp = ops.pack_conv3_weights(c.w.detach().float().contiguous(), c.b.detach(), c.dt,
                                                         cin_packed=c.cin_packed, perm=c.perm, tap_channel=c.tap)
                     c.gamma_c = c.gamma.detach().float().contiguous()
                     c.beta_c = c.beta.detach().float().contiguous()
@@ -230,6 +243,15 @@ class Plan:
         x, cin = self.img_in, 8
         for l in range(5):
             a, b = self.enc[l]
+            if l == 0 and self.enc_hi:          # exact-fp32 operands for the first block, fp16 copies for its consumers
+                ops.to_channels_last(img, self.img_in32, 0, 8)
+                self._conv(a, self.img_in32, 8, self.rawA32, 0)
+                self._conv(b, self.rawA32, a.cout, self.rawB32, 0, xform_from=a)
+                ops.materialize(self.rawB32, b.cout, self._norm(b, 0), self.emb32, 0, pooled=self.pool32)
+                self.emb[0].copy_(self.emb32)
+                self.pool[0].copy_(self.pool32)
+                x, cin = self.pool[0], b.cout
+                continue
             self._conv(a, x, cin, self.rawA[l], l)
             self._conv(b, self.rawA[l], a.cout, self.rawB[l], l, xform_from=a)
             ops.materialize(self.rawB[l], b.cout, self._norm(b, l), self.emb[l], 0,

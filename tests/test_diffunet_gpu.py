@@ -170,10 +170,9 @@ def test_graph_replay_equals_eager_and_forward_ddim_sample():
         g1 = plan.sample_loop(d50, "ddpm", noise=xT, use_graph=True, seed=7)["sample"].clone()
         g2 = plan.sample_loop(d50, "ddpm", noise=xT, use_graph=True, seed=7)["sample"].clone()
         eg = plan.sample_loop(d50, "ddpm", noise=xT, use_graph=False, seed=7)["sample"].clone()
-    # fp64 atomics make the InstanceNorm sums order-dependent in their last bits: equal up to fp16 noise
+    # InstanceNorm sums are integer (fixed-point) atomics: no launch order can change a bit of the result
     for other in (g2, eg):
-        d = (g1 - other).abs()
-        assert float(d.mean()) < 1e-3 and float(d.max()) < 0.1, (float(d.mean()), float(d.max()))
+        assert torch.equal(g1, other), float((g1 - other).abs().max())
     del a, b
 
 
@@ -206,8 +205,7 @@ def test_full_size_config2_evaluation_matches_oracle():
         b = plan.sample_loop(net.sample_diffusion, "ddpm", noise=xT, seed=11)
         c = plan.sample_loop(net.sample_diffusion, "ddpm", noise=xT)            # key drawn from torch's generator
     assert torch.isfinite(s1).all() and float(x1.abs().max()) <= 10.0 + 1e-4
-    dd = (s1 - b["sample"]).abs()
-    assert float(dd.mean()) < 2e-3      # same seed, same inputs: equal up to the order of fp64 atomics
+    assert torch.equal(s1, b["sample"])      # same seed, same inputs: the same bits (order-independent statistics)
     assert float((s1 - c["sample"]).abs().mean()) > 1e-2      # another key: another noise field
 
 
@@ -303,8 +301,8 @@ def test_sharded_sliding_window_with_the_hip_sampler_two_ranks():
                                                   pred_type="ddim_sample").cpu().numpy()
     assert want.shape == (1, 2, 40, 48, 32) and np.isfinite(want).all()
     assert np.array_equal(outs[0], outs[1])
-    # same windows, same seeds; the only freedom is the order of the fp64 statistics atomics
-    assert np.abs(outs[0] - want).max() < 1e-3, np.abs(outs[0] - want).max()
+    # same windows, same seeds; sharded and single-process runs blend the same window outputs
+    assert np.abs(outs[0] - want).max() < 1e-5, np.abs(outs[0] - want).max()
     seg_a = inference.binarise(torch.from_numpy(outs[0]))
     seg_b = inference.binarise(torch.from_numpy(want))
     assert (seg_a != seg_b).float().mean().item() < 1e-4
@@ -402,7 +400,7 @@ def test_in_kernel_noise_follows_torch_seed_and_differs_between_calls():
         torch.manual_seed(1234)
         c = net.sample_diffusion.p_sample_loop(net.model, shape, noise=xT, model_kwargs=kw).clone()
     assert float((a - b).abs().mean()) > 1e-2            # consecutive calls: different noise
-    assert float((a - c).abs().max()) < 1e-3             # same torch seed: same noise (up to the order of fp64 atomics)
+    assert torch.equal(a, c)                             # same torch seed: same noise, same bits
 
 
 def test_out_of_range_timestep_is_a_clean_error():
@@ -472,11 +470,10 @@ def test_config3_composition_matches_oracle(dtype):
         assert d.max() < 5e-2 and d.mean() < 1e-3
         assert min(dice) > 1 - 1e-3
     else:
-        # fp16 over 50 DDIM steps with random weights sits AT the 1e-3 line for the worst of 16 classes, and moves across
-        # it from run to run (0.9988 .. 0.9992 measured: InstanceNorm sums are fp64 atomics, their order is not fixed):
-        # the mean over classes carries the north-star bound, the worst class gets the slack of the 1000-step test
+        # the north-star bound (Dice within 1e-3) for EVERY class in the production dtype: the encoder's first block runs on
+        # exact-fp32 operands (its error is the same in all 50 steps) and the 1x1x1 head on split-precision operands
         assert d.mean() < 2e-2
-        assert sum(dice) / len(dice) > 1 - 1e-3 and min(dice) > 1 - 3e-3
+        assert min(dice) > 1 - 1e-3, dice
     assert torch.equal(seg, binarise(got))
 
 
@@ -499,6 +496,6 @@ def test_config3_full_size_properties():
         alone = net(image=vol[:, :, :96, :96, :96], pred_type="ddim_sample")
     only0 = out[:, :, :72, :72, :72]            # the next windows start at 72 along every axis
     d = (only0 - alone[:, :, :72, :72, :72]).abs()
-    assert float(d.mean()) < 1e-2, float(d.mean())         # same window, same x_T: equal up to the order of fp64 atomics
+    assert float(d.max()) == 0.0, float(d.max())           # same window, same x_T, order-independent statistics: the same bits
     seg = inference.binarise(out)
     assert seg.shape == out.shape and set(seg.unique().tolist()) <= {0.0, 1.0}

@@ -642,6 +642,6 @@ def test_diff_swin_unetr_long_ddpm_run_is_finite_and_follows_the_torch_seed():
         c = d200.p_sample_loop(net.model, shape, noise=xT, model_kwargs=kw).clone()
         assert bool(torch.isfinite(a).all()) and float(a.abs().max()) < 20.0
         assert float((a - b).abs().mean()) > 1e-2
-        assert float((a - c).abs().max()) < 2e-2           # same noise field; fp16 + the order of the fp64 statistics atomics
+        assert torch.equal(a, c)                           # same noise field, order-independent statistics: the same bits
         with pytest.raises((RuntimeError, AssertionError, ValueError)):
             net(image=image, x=xT, step=torch.tensor([1000]), pred_type="denoise")

@@ -120,6 +120,94 @@ def time_conv_launches(plan, reps):
     return sum(by_launch) / len(by_launch), len(calls), by_launch
 
 
+def conv_roofline(plan, dtype_flag, reps=20):
+    """roofline object for the 3x3x3 convolution kernel over one denoiser evaluation of `plan` (HIP events, see
+    time_conv_launches); FLOPs are algorithmic (2 * Cin * Cout * 27 * voxels * batch)."""
+    fl = conv3_flops(plan)
+    avg_ms, per_step, by_launch = time_conv_launches(plan, reps)
+    assert per_step == len(fl)
+    flops_per_launch = sum(fl) / len(fl)
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    peak = PEAK_F16_TFLOPS if dtype_flag == "f16" else PEAK_F32_TFLOPS
+    return {"bound": "mfma", "kernel": CONV_KERNEL, "achieved": round(achieved, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4),
+            "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 2),
+            "conv_ms_per_step": round(avg_ms * per_step, 3),
+            "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
+            "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
+            "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3",
+                               "tflops": round(max(fl) / (by_launch[fl.index(max(fl))] * 1e-3) / 1e12, 2)}}
+
+
+def wgrad_roofline(step_fn, reps=10):
+    """roofline object for the weight-gradient kernel of the training step (the kernel with the largest share of config 4):
+    one eager step records the arguments of its conv3d_k3_wgrad launches, each is then replayed `reps` times between one HIP
+    event pair on the launch stream.  FLOPs are algorithmic: 2 * Cin * Cout * 27 * voxels * batch per launch."""
+    from diff_unet_amos_amd import ops
+    real = ops.conv3d_k3_wgrad
+    calls = []
+
+    def wrapped(*a, **k):
+        calls.append((a, k))
+        return real(*a, **k)
+
+    ops.conv3d_k3_wgrad = wrapped
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv3d_k3_wgrad = real
+    if not calls:
+        return None
+    fl, by_launch = [], []
+    for a, k in calls:
+        x, cin, dy, cout, dw = a[0], a[1], a[3], a[4], a[6]
+        scratch = torch.zeros_like(dw)               # the launch accumulates: never into the live gradient
+        a2 = a[:6] + (scratch,) + a[7:]
+        real(*a2, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            real(*a2, **k)
+        e1.record()
+        torch.cuda.synchronize()
+        by_launch.append(e0.elapsed_time(e1) / reps)
+        fl.append(2.0 * dw.shape[1] * cout * 27 * x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3])
+    achieved = sum(fl) / (sum(by_launch) * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv3d_k3_wgrad12_kernel (+ wgrad_reduce_kernel)", "achieved": round(achieved, 2),
+            "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+            "launches_per_step": len(calls), "avg_launch_ms": round(sum(by_launch) / len(by_launch), 4),
+            "algorithmic_gflop_per_launch": round(sum(fl) / len(fl) / 1e9, 2), "wgrad_ms_per_step": round(sum(by_launch), 3),
+            "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
+            "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)]}
+
+
+def cpu_training_baseline(net_state, threads):
+    """Oracle training step (oracle/train_ref.ref_training_step: q_sample + denoise + mse/bce/dice, backward through torch
+    autograd) on the host cores: bounded sample, ONE 96^3 x 16-class sample, one warm-up + one timed step."""
+    from oracle.train_ref import RefLoss, ref_training_step
+    from oracle.unet_ref import RefDiffUNet
+    torch.set_num_threads(threads)
+    ref = RefDiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES)
+    ref.load_state_dict(net_state)
+    g = torch.Generator().manual_seed(1)
+    image = torch.rand(1, 1, 96, 96, 96, generator=g)
+    labels = (torch.rand(1, CLASSES, 96, 96, 96, generator=g) > 0.8).float()
+    noise = torch.randn(1, CLASSES, 96, 96, 96, generator=g)
+    crit = RefLoss("mse,bce,dice", "sum")
+    dt = None
+    for i in range(2):
+        t0 = time.perf_counter()
+        loss = ref_training_step(ref, image, labels, crit, noise, torch.tensor([500]))
+        loss.backward()
+        dt = time.perf_counter() - t0
+        ref.zero_grad(set_to_none=True)
+    return {"value": 1.0 / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"1 warm-up + 1 timed training step (forward + loss + backward, no optimizer) of the torch CPU fp32 oracle on "
+                      f"ONE 96^3 x 16-class sample, {dt:.2f} s/sample"}
+
+
 def measure_traffic(dtype_flag):
     """HBM bytes per conv launch from the PMC counters, as MI355X_MICROARCH.md (HBM / rocprofv3 sections) prescribes:
     FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes over a short eager run of this script (a child
@@ -298,21 +386,7 @@ def run_config2(args, D):
 
         roof = None
         if rank == 0 and not args.no_roofline:
-            fl = conv3_flops(plan)
-            avg_ms, per_step, by_launch = time_conv_launches(plan, 20)
-            assert per_step == len(fl)
-            flops_per_launch = sum(fl) / len(fl)
-            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_F32_TFLOPS
-            roof = {"bound": "mfma", "kernel": CONV_KERNEL, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                    "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 2),
-                    "conv_ms_per_step": round(avg_ms * per_step, 3),
-                    "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
-                    "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
-                    "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3",
-                                       "tflops": round(max(fl) / (by_launch[fl.index(max(fl))] * 1e-3) / 1e12, 2)}}
+            roof = conv_roofline(plan, args.dtype)
     if rank == 0 and roof is not None:
         roof["traffic"] = getattr(args, "traffic", None)   # measured by main() before this process touched the GPU
     if rank == 0:
@@ -342,6 +416,7 @@ def run_config3(args, D):
     dev, rank, world = D.dev, D.rank, D.world
     torch.manual_seed(0)
     net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES, sample_steps=50).to(dev).eval()
+    state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     vol = torch.rand(1, 1, 256, 256, 192, generator=torch.Generator().manual_seed(1)).to(dev)      # same volume on every rank
     nwin = len(inference._plan(vol, (96, 96, 96), 0.25)[4])
     swb = args.sw_batch
@@ -368,10 +443,14 @@ def run_config3(args, D):
         torch.cuda.synchronize()
         dt = D.max_over_ranks(time.perf_counter() - t0)
         D.barrier()
+        roof = None
+        if rank == 0 and not args.no_roofline:      # the conv kernel over one denoiser evaluation of the sampler's own plan
+            roof = conv_roofline(net._rt.plan(swb, (96, 96, 96), dev), "f16")
+            roof["note"] = f"one denoiser evaluation at batch {swb} (the windows of one sampler pass)"
     if rank == 0:
         per = dt / args.steps
         gather_s = timings.get("all_gather_s", 0.0) / max(1, args.steps)
-        print(json.dumps({
+        line = {
             "metric": "sliding-window DDIM inference: denoised voxel-steps/sec over a full volume", "value": nwin * VOX * 50 / per,
             "unit": "voxel-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
@@ -379,7 +458,13 @@ def run_config3(args, D):
                                    "sharded over the ranks, one all_gather_into_tensor of the per-window sums (BASELINE.json configs[2])",
                        "windows": nwin, "sw_batch_size": swb, "gather_dtype": "f16" if args.gather_fp16 else "f32"},
             "seconds_per_volume": per, "all_gather_seconds": gather_s, "all_gather_share": gather_s / per if per > 0 else None,
-            "gathered_bytes": timings.get("gathered_bytes"), "foreground_fraction": float(seg.mean())}), flush=True)
+            "gathered_bytes": timings.get("gathered_bytes"), "foreground_fraction": float(seg.mean())}
+        if roof is not None:
+            line["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(state, host_threads())
+            line["cpu_baseline"]["sample"] += "; a volume is 48 windows x (50 such evaluations + one encoder pass)"
+        print(json.dumps(line), flush=True)
 
 
 def run_config4(args, D):
@@ -389,6 +474,7 @@ def run_config4(args, D):
     dev, rank, world = D.dev, D.rank, D.world
     torch.manual_seed(0)
     net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES).to(dev)
+    state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     B = 2                                          # cfg/amos/train.yaml: batch 10 over 5 GPUs
     tr = NativeConvTrainer(net, dtype=torch.float16, overlap=not args.flat_allreduce, graph=args.train_graph)
     g = torch.Generator(device=dev).manual_seed(10 + rank)
@@ -412,9 +498,13 @@ def run_config4(args, D):
         allreduce_mean_(grads)
     torch.cuda.synchronize()
     ar = D.max_over_ranks((time.perf_counter() - t1) / 5) if world > 1 else 0.0
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        probe = tr if not args.train_graph else NativeConvTrainer(net, dtype=torch.float16, overlap=False, graph=False)
+        roof = wgrad_roofline(lambda: probe.step(image, labels))
     if rank == 0:
         per = dt / args.steps
-        print(json.dumps({
+        line = {
             "metric": "DDP training samples/sec on synthetic 96^3 16-class batches", "value": world * B / per, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
@@ -423,7 +513,13 @@ def run_config4(args, D):
                        "gradient_sync": "flat all-reduce after backward" if args.flat_allreduce else "DDP reducer, 32 MB buckets overlapped with backward",
                        "graph": bool(args.train_graph)},
             "flat_allreduce_seconds": ar, "flat_allreduce_share": ar / per if per > 0 else None,
-            "gradient_bytes": sum(p.numel() for p in net.parameters()) * 4, "loss": float(loss)}), flush=True)
+            "gradient_bytes": sum(p.numel() for p in net.parameters()) * 4, "loss": float(loss),
+            "step_tflops": B * 3 * (1.0564e12 + 0.2798e12) / per / 1e12}
+        if roof is not None:
+            line["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_training_baseline(state, host_threads())
+        print(json.dumps(line), flush=True)
 
 
 def run_config5(args, D):
@@ -521,7 +617,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--batch", type=int, default=1, help="config 2: patches per GPU (BASELINE config 2 is 1)")
-    ap.add_argument("--sw-batch", type=int, default=1, help="config 3: windows per sampler pass")
+    ap.add_argument("--sw-batch", type=int, default=4, help="config 3: windows per sampler pass (cfg/btcv/test.yaml:4 of the reference: 4)")
     ap.add_argument("--gather-fp16", action="store_true", help="config 3: all-gather the window sums in fp16")
     ap.add_argument("--flat-allreduce", action="store_true", help="config 4: one flat all-reduce instead of DDP buckets")
     ap.add_argument("--train-graph", action="store_true", help="config 4: whole step as one HIP graph")

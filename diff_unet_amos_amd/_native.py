@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (must precede CDLL: maps libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdua_hip.so")
+# DUA_HIP_LIB: a diagnostic build of the same library (tools/build_diag.sh: stamps, ablations) instead of the shipped one
+LIB_PATH = os.environ.get("DUA_HIP_LIB") or os.path.join(_HERE, "libdua_hip.so")
 
 F32, F16 = 0, 1
 ERR_ARG = -22

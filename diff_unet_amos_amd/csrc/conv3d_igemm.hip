@@ -35,6 +35,25 @@ constexpr int BN = 64;                     // output channels per workgroup
 
 // 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones); 2 forces 4x8x8 tiles without split-K, 3 forces 2x8x8
 int g_conv_variant = 0;
+
+// ---- diagnostic build only (-DDUA_STAMP, tools/build_diag.sh -> a separate library selected with DUA_HIP_LIB): lane 0 of
+// every workgroup stamps the shader-clock counter at the phase boundaries of the convolution kernel and the 100 MHz
+// real-time counter at its start and end.  The stamps go to a buffer of their own that no kernel reads
+// (dua_debug_stamps copies it out); the shipped library contains none of this.
+#ifdef DUA_STAMP
+constexpr int STAMP_WGS = 8192, STAMP_SLOTS = 64;
+__device__ unsigned long long g_stamp[STAMP_WGS][STAMP_SLOTS];
+#define DUA_STAMP_AT(slot, rt)                                                                          \
+  do {                                                                                                   \
+    if (threadIdx.x == 0) {                                                                              \
+      const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                    \
+      if (wg_ < STAMP_WGS && (slot) < STAMP_SLOTS)                                                      \
+        g_stamp[wg_][slot] = (rt) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();    \
+    }                                                                                                    \
+  } while (0)
+#else
+#define DUA_STAMP_AT(slot, rt) do { } while (0)
+#endif
 int g_skip_splitk_finish = 0;   // diagnostics (dua_set_option(2, 1)): time the split-K main kernel alone; outputs are not finished
 extern int g_wgrad_abl;
 extern int g_wgrad_variant;
@@ -172,6 +191,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   const int u1 = NKS == 0 ? u0 : min(a.nchunks * 3, u0 + a.units_per_split);   // NKS 0: the tap channel is the whole input
   const int g0 = u0 * 3, g1 = u1 * 3;
 
+  DUA_STAMP_AT(0, true);
+  DUA_STAMP_AT(2, false);
   // ---- prologue ----
   load_slab(g0, 0);
   load_slab(g0 + 1, 1);
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   }
   __syncthreads();
 
+  DUA_STAMP_AT(3, false);
   const int a_base = dwave * PS + (hbase + (r >> 3)) * RS + (r & 7) * VS + hh * 16;
   const int b_base = (hh * BN + r) * 16;
   for (int u = u0; u < u1; ++u) {
@@ -233,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
         }
       }
       __syncthreads();   // next slab visible and everyone is done with this one
+      DUA_STAMP_AT(4 + (g - g0), false);
     }
     if (next_chunk) {
       store_halo(u / 3 + 1);
@@ -275,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
     }
     __syncthreads();     // the epilogue's staging tile reuses the halo; nobody may still be gathering from it
   }
+  DUA_STAMP_AT(62, false);
   if (a.part != nullptr) {
     // ---- split-K: this workgroup's fp32 partial tile goes to part[ks][n][voxel][cout_pad] ----
     constexpr int OSF = 32 * 4 + 16;
@@ -300,6 +324,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
       }
       if (q == 0) __syncthreads();
     }
+    DUA_STAMP_AT(63, false);
+    DUA_STAMP_AT(1, true);
     return;
   }
   // ---- epilogue, one 32-channel half at a time (fits fp32 too) ----
@@ -363,6 +389,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
     for (int w = 0; w < NW; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
     if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
   }
+  DUA_STAMP_AT(63, false);
+  DUA_STAMP_AT(1, true);
 }
 
 // ---- split-K finish: y = sum_k part[k] + bias (stored as T), and this layer's InstanceNorm sums ----
@@ -543,6 +571,19 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
 }  // namespace dua
 
 extern "C" {
+
+#ifdef DUA_STAMP
+// diagnostic build: copy the stamp buffer out ([8192 workgroups][64 slots] of 64-bit counters) and clear it
+long dua_debug_stamps(void* host, long bytes) {
+  const long all = (long)sizeof(unsigned long long) * dua::STAMP_WGS * dua::STAMP_SLOTS;
+  if (!host || bytes < all) return all;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(dua::g_stamp), all) != hipSuccess) return -1;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(dua::g_stamp)) == hipSuccess) (void)hipMemset(p, 0, all);
+  return all;
+}
+#endif
 
 int dua_set_option(int key, int value) {
   if (key == 1 && (value == 0 || value == 2 || value == 3)) { dua::g_conv_variant = value; return 0; }

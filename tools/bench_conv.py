@@ -50,8 +50,9 @@ def main():
         ws = torch.empty(max(nb, 16) // 4, device=dev)
         norm = None
         if fused:
-            st = ops.stats_buffer(1, cin, dev)
-            st[:, 0, :, 0] = 0.0; st[:, 0, :, 1] = float(S ** 3)
+            sums = torch.zeros(1, cin, 2, dtype=torch.float64, device=dev)
+            sums[..., 1] = float(S ** 3)                   # mean 0, variance 1
+            st = ops.stats_encode(sums)
             norm = ops.Norm(st, torch.ones(cin, device=dev), torch.zeros(cin, device=dev), S ** 3,
                             add=torch.zeros(cin, device=dev))
         res = {v: [] for v in variants}

@@ -47,10 +47,17 @@ def save_checkpoint(save_path, model, optimizer=None, scheduler=None, epoch=0, *
     return state
 
 
-def load_checkpoint(model_path, model, optimizer=None, scheduler=None, map_location=None) -> dict:
+def load_checkpoint(model_path, model, optimizer=None, scheduler=None, map_location=None, trusted=False) -> dict:
     """train.py:152-164: restores whichever of model / optimizer / scheduler the file holds and returns the bookkeeping
-    (start_epoch, noise_ratio, project_name, global_step, best_mean_dice, wandb_id) the trainer keeps as attributes."""
-    state = torch.load(model_path, map_location=map_location, weights_only=False)
+    (start_epoch, noise_ratio, project_name, global_step, best_mean_dice, wandb_id) the trainer keeps as attributes.
+    The dictionary holds state_dicts and plain values only, so it is read with ``weights_only=True`` (no code runs while
+    unpickling); ``trusted=True`` falls back to the reference's permissive ``torch.load`` for files that need it."""
+    try:
+        state = torch.load(model_path, map_location=map_location, weights_only=True)
+    except Exception:
+        if not trusted:
+            raise
+        state = torch.load(model_path, map_location=map_location, weights_only=False)
     if isinstance(model, (nn.DataParallel, nn.parallel.DistributedDataParallel)):
         model = model.module
     for key, obj in (("model", model), ("optimizer", optimizer), ("scheduler", scheduler)):

@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
         if (kk < kc) bf = *(const f16x8*)(arow + kk * 2);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const f16x8 af = *(const f16x8*)(Wl + (nb * 32 + r) * a.w_row + (k0 + kk) * 2);
+          // K % 16 == 8: the upper lane half of the last k-step lies behind the row (next row's weights, or the slack
+          // behind the last row: 0 x NaN would poison the output) -- it contributes zero weights
+          f16x8 af = bf;                                           // zeros when kk >= kc
+          if (kk < kc) af = *(const f16x8*)(Wl + (nb * 32 + r) * a.w_row + (k0 + kk) * 2);
           acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[nb], 0, 0, 0);
         }
       }

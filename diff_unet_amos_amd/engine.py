@@ -419,7 +419,7 @@ class Plan:
         ops.to_channels_last(x_T, self.xin, 0, self.C)
         self.x_sum.zero_()
         mode = nv.MODE_DDPM if kind == "ddpm" else nv.MODE_DDIM
-        tkey = (id(diffusion), kind, float(eta))
+        tkey = (diffusion, kind, float(eta))          # the object itself: the table keeps it alive, no id() reuse after GC
         if tkey not in self.tables:
             order = list(range(T))[::-1]
             tt = torch.tensor(order)

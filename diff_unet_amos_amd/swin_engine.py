@@ -572,7 +572,7 @@ class SwinPlan:
 
         reset()
         mode = nv.MODE_DDPM if kind == "ddpm" else nv.MODE_DDIM
-        tkey = (id(diffusion), kind, float(eta))
+        tkey = (diffusion, kind, float(eta))          # the object itself: the table keeps it alive, no id() reuse after GC
         if tkey not in self.tables:
             order = list(range(T))[::-1]
             tt = torch.tensor(order)

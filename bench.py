@@ -550,8 +550,9 @@ def run_config5(args, D):
 
         def one_step():
             ops.step_begin(B, plan.temb_table, plan.cur_add, row_of_step=row_of_step, counter=plan.counter,
-                           coef_table=coef_table, cur_coef=plan.cur_coef, step_word=plan.step_word, err_word=plan.err_word)
-            plan.denoiser_body()
+                           coef_table=coef_table, cur_coef=plan.cur_coef, step_word=plan.step_word, err_word=plan.err_word,
+                           clear=plan.den_stats)
+            plan.denoiser_body(zero_stats=False)
             plan.tail(nv.MODE_DDPM)
 
         assert args.warmup + args.steps + 2 <= T
@@ -621,6 +622,7 @@ def main():
     ap.add_argument("--gather-fp16", action="store_true", help="config 3: all-gather the window sums in fp16")
     ap.add_argument("--flat-allreduce", action="store_true", help="config 4: one flat all-reduce instead of DDP buckets")
     ap.add_argument("--train-graph", action="store_true", help="config 4: whole step as one HIP graph")
+    ap.add_argument("--conv-variant", type=int, default=0, help="diagnostics: dua_set_option(1, v) before the run (same-box A/B of launch policies)")
     args = ap.parse_args()
     defaults = {2: (200, 20), 3: (1, 0), 4: (5, 2), 5: (100, 10)}[args.config]
     args.steps = defaults[0] if args.steps is None else args.steps
@@ -633,6 +635,9 @@ def main():
         # two short child runs of this script under rocprofv3 --pmc, started before this process initialises the GPU
         args.traffic = measure_traffic(args.dtype)
     D = Dist(args)
+    if args.conv_variant:
+        from diff_unet_amos_amd import _native as nv
+        nv.check(nv.lib().dua_set_option(1, args.conv_variant), "dua_set_option")
     {2: run_config2, 3: run_config3, 4: run_config4, 5: run_config5}[args.config](args, D)
     D.finish()
 

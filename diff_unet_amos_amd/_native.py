@@ -125,6 +125,7 @@ _SIGS = {
     "dua_denoiser_step": (C.c_int, [C.POINTER(DenoiserPlan), _P]),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_step_begin_clear": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_long, _P]),
     "dua_conv3d_k3_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P, _P, C.c_long, _P]),
     "dua_conv3d_k3_wgrad_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),

@@ -130,24 +130,64 @@ __device__ __forceinline__ void stats_read(const stat_t* stats, int n, int c_pad
   Q = (double)w[2] + (double)w[3] * (1.0 / STAT_FRAC);
 }
 
-// Preamble: threads cooperatively compute scale/shift/add for channels [0, C) into LDS arrays.
+// The same sums read by a WHOLE WAVE for 16 channels at once: lane = (part = lane >> 4, channel c0 + (lane & 15)); every lane
+// loads the 4 words of TWO replica rows (8 independent 8-byte loads, all in flight together), the four parts are combined
+// with cross-lane adds.  One memory round trip -- the per-thread form above, 32 loads in a register-starved kernel, was
+// compiled into ~14 dependent round trips: 14 000 cycles at the head of every workgroup that normalises its input
+// (in-kernel stamps, tools/stamp_conv.py).  Call with all 64 lanes active; `c` may be clamped for lanes without a channel.
+__device__ __forceinline__ void stats_read_wave16(const stat_t* stats, int n, int c_pad, int c, double& S, double& Q) {
+  const int part = (threadIdx.x & 63) >> 4;
+  const stat_t* p = stats + ((long)n * STAT_REPLICAS + 2 * part) * STAT_WORDS * c_pad + c;
+  stat_t v[2 * STAT_WORDS];
+#pragma unroll
+  for (int k = 0; k < 2 * STAT_WORDS; ++k) v[k] = p[(long)k * c_pad];
+#ifdef DUA_STATS_F64     // diagnostic build: the words hold doubles added with fp64 atomics (the pre-round-3 arithmetic)
+  S = __longlong_as_double(v[0]) + __longlong_as_double(v[STAT_WORDS]);
+  Q = __longlong_as_double(v[2]) + __longlong_as_double(v[STAT_WORDS + 2]);
+  S += __shfl_xor(S, 16); S += __shfl_xor(S, 32);
+  Q += __shfl_xor(Q, 16); Q += __shfl_xor(Q, 32);
+#else
+  stat_t w[STAT_WORDS];
+#pragma unroll
+  for (int k = 0; k < STAT_WORDS; ++k) {
+    w[k] = v[k] + v[STAT_WORDS + k];
+    w[k] += __shfl_xor(w[k], 16);
+    w[k] += __shfl_xor(w[k], 32);
+  }
+  S = (double)w[0] + (double)w[1] * (1.0 / STAT_FRAC);
+  Q = (double)w[2] + (double)w[3] * (1.0 / STAT_FRAC);
+#endif
+}
+
+// Preamble: the workgroup's waves compute scale/shift/add for channels [c_begin, C) into LDS arrays, 16 channels per wave
+// and pass.  blockDim.x must be a multiple of 64.
 __device__ __forceinline__ void xform_preamble(const InXform& xf, int n, int C, float* sc, float* sh, float* ad,
                                                int c_begin = 0) {
-  for (int c = c_begin + threadIdx.x; c < C; c += blockDim.x) {
-    if (!xf.stats) {                      // no producer statistics: the input is already materialised (identity)
+  if (!xf.stats) {                        // no producer statistics: the input is already materialised (identity)
+    for (int c = c_begin + threadIdx.x; c < C; c += blockDim.x) {
       sc[c] = 1.f; sh[c] = 0.f;
       ad[c] = xf.add ? xf.add[(long)n * xf.add_stride + c] : 0.f;
-      continue;
     }
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int c0 = c_begin + wave * 16; c0 < C; c0 += nw * 16) {          // wave-uniform trip count
+    const int c = c0 + (lane & 15);
+    const bool ok = c < C;
+    const int cc = ok ? c : C - 1;                                      // clamped address, masked store
+    const float gam = xf.gamma[cc], bet = xf.beta[cc];
+    const float add = xf.add ? xf.add[(long)n * xf.add_stride + cc] : 0.f;
     double S, Q;
-    stats_read(xf.stats, n, xf.c_pad, c, S, Q);
+    stats_read_wave16(xf.stats, n, xf.c_pad, cc, S, Q);
     const double mean = S * (double)xf.inv_count;
     double var = Q * (double)xf.inv_count - mean * mean;
     var = var > 0 ? var : 0;
-    const float g = xf.gamma[c] * (float)(1.0 / sqrt(var + (double)xf.eps));
-    sc[c] = g;
-    sh[c] = xf.beta[c] - (float)mean * g;
-    ad[c] = xf.add ? xf.add[(long)n * xf.add_stride + c] : 0.f;
+    const float g = gam * (float)(1.0 / sqrt(var + (double)xf.eps));
+    if (ok && lane < 16) {
+      sc[c] = g;
+      sh[c] = bet - (float)mean * g;
+      ad[c] = add;
+    }
   }
 }
 
@@ -168,12 +208,22 @@ static inline InXform make_xform(const dua_in_norm* in, int C) {
 // Epilogue side: one (sum, sum of squares) contribution per (n, c) from a workgroup.
 __device__ __forceinline__ void stats_add(stat_t* stats, int n, int c_pad, int replica, int c, double S, double Q) {
   unsigned long long* p = (unsigned long long*)stats + ((long)n * STAT_REPLICAS + replica) * STAT_WORDS * c_pad + c;
+#ifdef DUA_STATS_F64
+  unsafeAtomicAdd((double*)p, S);
+  unsafeAtomicAdd((double*)(p + 2L * c_pad), Q);
+  return;
+#endif
   const double Si = rint(S), Qi = rint(Q);
-  // two's-complement adds: negative parts wrap, the integer sum is exact either way
-  __hip_atomic_fetch_add(p, (unsigned long long)(long long)Si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add(p + c_pad, (unsigned long long)(long long)rint((S - Si) * STAT_FRAC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add(p + 2L * c_pad, (unsigned long long)(long long)Qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add(p + 3L * c_pad, (unsigned long long)(long long)rint((Q - Qi) * STAT_FRAC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // two's-complement adds: negative parts wrap, the integer sum is exact either way.  SYSTEM scope on purpose: on gfx950
+  // an agent-scope integer read-modify-write carries no sc bit and executes in the issuing XCD's own L2; the eight L2s are
+  // not coherent with each other, so two XCDs adding into one line (any grid whose workgroups of one replica row are not
+  // all on one XCD: every level below 16^3) each update their own copy and one write-back wins -- sums came out wrong
+  // depending on timing (found by a bit-equality test of repeated graph replays; fp64 atomics, which execute at the
+  // memory side, never showed it).  sc1 sends the add to the memory side, where all XCDs meet.
+  __hip_atomic_fetch_add(p, (unsigned long long)(long long)Si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_fetch_add(p + c_pad, (unsigned long long)(long long)rint((S - Si) * STAT_FRAC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_fetch_add(p + 2L * c_pad, (unsigned long long)(long long)Qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_fetch_add(p + 3L * c_pad, (unsigned long long)(long long)rint((Q - Qi) * STAT_FRAC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <typename T>

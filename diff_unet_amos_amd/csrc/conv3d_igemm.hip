@@ -88,12 +88,19 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // HALF: the last Cin chunk holds at most one k-step (16 channels) of real input (Cin = 48 = 32 + 16, the Swin-UNETR widths):
 // its second k-step per tap would multiply zero padding and is skipped.  A separate instantiation, so that the common
 // kernel keeps its schedule.
-template <typename T, int TDP = 4, int NKS = 2, bool HALF = false>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
+// BIG (layers that cannot put two workgroups on every CU: <= 24^3): ONE workgroup per CU with most of the LDS.  Weights
+// arrive as whole kd planes (9 taps, 36 KB) by LDS-DMA into a ring of three -- no staging registers, no store phase, the
+// plane after next in flight while this one multiplies -- so a phase is 18 k-steps between two barriers instead of 6, and
+// with a single wave per SIMD the fragment reads run three k-steps ahead of the MFMAs (2x8x8 tiles: the two MFMAs of a
+// k-step are shorter than one LDS round trip; measured with in-kernel stamps, 1010 cycles per 384-cycle phase).
+template <typename T, int TDP = 4, int NKS = 2, bool HALF = false, bool BIG = false>
+__global__ __launch_bounds__(256, BIG ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   using namespace c3v2;
   constexpr int TD = TDP, HD = TDP + 2, MB = TDP == 2 ? 1 : 2;
   constexpr int NW = 4, NTHR = 64 * NW;
-  constexpr int HALO_BYTES = HD * PS, LDS_MAIN = HALO_BYTES + 2 * SLAB;
+  constexpr int BSLAB = 3 * SLAB;                                            // one kd plane of the packed weights
+  constexpr int HALO_BYTES = HD * PS, LDS_MAIN = HALO_BYTES + (BIG ? 3 * BSLAB : 2 * SLAB);
+  static_assert(!BIG || (NKS == 2 && !HALF), "the kd-plane form is the plain 32-channel-chunk kernel");
   constexpr int NITEMS = HD * HH * HW * KG, NIT = (NITEMS + NTHR - 1) / NTHR;
   constexpr int NPIECE = SLAB / 16, NSL = (NPIECE + NTHR - 1) / NTHR;      // 16-byte pieces of a weight slab per thread
   using Frag = typename Elem<T>::Frag;
@@ -127,7 +134,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
     int gd = d0 + hd - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
     bool ok = it < NITEMS && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
     goff[j] = ok ? (((long)gd * a.H + gh) * a.W + gw) * a.Cin_stride + kg_t * EPG : -1;
+#ifndef DUA_HALO_BRANCHFREE
     loff[j] = it < NITEMS ? hd * PS + hy * RS + hx * VS + kg_t * 16 : -1;
+#else
+    loff[j] = it < NITEMS ? hd * PS + hy * RS + hx * VS + kg_t * 16 : HW * VS;     // beyond the halo: the pad bytes of row 0
+#endif
   }
   const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB;
   // Weight slabs go global -> registers (issued one slab ahead, 3 x 16 B per thread) -> LDS.  LDS-DMA
@@ -149,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
       if (NPIECE % NTHR == 0 || tid + NTHR * j < NPIECE) *(f32x4*)(dst + j * NTHR * 16) = wreg[set][j];
   };
   Frag hv_[NIT];
+#ifndef DUA_HALO_BRANCHFREE     // default; -DDUA_HALO_BRANCHFREE selects the select-based form below (hipcc 7.2 fails to compile it with -fPIC)
   auto load_halo = [&](int ch) {
     const bool cok = ch * CK + kg_t * EPG < a.Cin;
 #pragma unroll
@@ -173,6 +185,50 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
     for (int j = 0; j < NIT; ++j)
       if (loff[j] >= 0) *(Frag*)(halo + loff[j]) = hv_[j];
   };
+#else
+  // Branch-free staging: every item loads (out-of-volume / padding-channel items from a clamped, always valid address), is
+  // transformed, and is zeroed by a select afterwards -- under a lane-dependent branch hipcc gives every load a basic
+  // block of its own (the loads then issue one by one); items beyond the halo store into the pad bytes of halo row 0.
+  auto load_halo = [&](int ch) {
+    const bool cok = ch * CK + kg_t * EPG < a.Cin;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) hv_[j] = *(const Frag*)(xin + (goff[j] >= 0 && cok ? goff[j] + ch * CK : 0));
+  };
+  auto store_halo = [&](int ch) {
+    const int c0 = ch * CK + kg_t * EPG;
+    const bool cok = c0 < a.Cin;
+    float sc[EPG], sh[EPG], ad[EPG];
+#pragma unroll
+    for (int e = 0; e < EPG; ++e) { sc[e] = 1.f; sh[e] = 0.f; ad[e] = 0.f; }
+    if (fused && cok) {
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      Frag v = hv_[j];
+      if (fused) v = xform_frag<T>(v, sc, sh, ad, a.xf.slope);
+      const bool ok = goff[j] >= 0 && cok;
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) v[e] = ok ? v[e] : (T)0.f;
+      if (NITEMS % NTHR == 0 || tid + NTHR * j < NITEMS) *(Frag*)(halo + loff[j]) = v;
+    }
+  };
+#endif
+
+  // BIG: one kd plane (36 pieces of 1 KB: 9 per wave) straight into ring slot `slot`.  Inline assembly (M0 saved and restored
+  // inside the statement): hipcc neither counts these transfers nor waits for them; the loop below does (counted vmcnt,
+  // then the barrier, then the reads).
+  auto dma_unit = [&](int u, int slot) {
+    const char* src = wsrc + (long)u * BSLAB + (wave * 9) * 1024 + lane * 16;
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(wbuf + slot * BSLAB + (wave * 9) * 1024);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src + j * 1024), "s"(__builtin_amdgcn_readfirstlane(dst + j * 1024)) : "memory");
+    }
+  };
 
   // accumulators start at the bias of the lane's output channel (split-K adds it in the finish kernel instead)
   f32x16 acc[MB][2];
@@ -194,25 +250,87 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
   DUA_STAMP_AT(0, true);
   DUA_STAMP_AT(2, false);
   // ---- prologue ----
+  if constexpr (BIG) {
+    load_halo(u0 / 3);
+    dma_unit(u0, 0);
+    if (u0 + 1 < u1) dma_unit(u0 + 1, 1);
+    DUA_STAMP_AT(59, false);
+    if (fused) {
+      xform_preamble(a.xf, n, min(a.Cin, ((u1 + 2) / 3) * CK), xsc, xsh, xad, (u0 / 3) * CK);
+      __syncthreads();
+    }
+    DUA_STAMP_AT(60, false);
+    DUA_STAMP_AT(61, false);
+    store_halo(u0 / 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // both planes have landed (this wave's pieces; the barrier: everyone's)
+    __syncthreads();
+  } else {
   load_slab(g0, 0);
   load_slab(g0 + 1, 1);
   load_slab(g0 + 2, 2);
   load_halo(u0 / 3);
+  DUA_STAMP_AT(59, false);
   if (fused) {     // only the Cin chunks this workgroup walks (all of them unless split-K)
     xform_preamble(a.xf, n, min(a.Cin, ((u1 + 2) / 3) * CK), xsc, xsh, xad, (u0 / 3) * CK);
     __syncthreads();
   }
+  DUA_STAMP_AT(60, false);
   store_slab(g0, 0);
+  DUA_STAMP_AT(61, false);
   store_halo(u0 / 3);
   if constexpr (NKS < 2) {       // tap block of this cout tile: [4 k-groups of 8 taps][64 couts][16 B], behind the slabs
     const char* wt = (const char*)a.w + (long)gridDim.y * a.nchunks * 9 * SLAB + (long)ct * 4096;
     *(f32x4*)(smem + LDS_MAIN + tid * 16) = *(const f32x4*)(wt + tid * 16);
   }
   __syncthreads();
+  }
 
   DUA_STAMP_AT(3, false);
   const int a_base = dwave * PS + (hbase + (r >> 3)) * RS + (r & 7) * VS + hh * 16;
   const int b_base = (hh * BN + r) * 16;
+  if constexpr (BIG) {
+    constexpr int NTB = 9 * NKS, PF = MB == 1 ? 3 : 1;     // k-steps per plane; fragment prefetch distance
+    for (int u = u0; u < u1; ++u) {
+      const int kd = u % 3, slot = (u - u0) % 3;
+      const bool next_chunk = kd == 2 && u + 1 < u1;
+      if (next_chunk) load_halo(u / 3 + 1);                 // older than the transfers below: the counted wait covers it
+      const bool ahead = u + 2 < u1;
+      if (ahead) dma_unit(u + 2, (u - u0 + 2) % 3);         // that slot was last read before the previous barrier
+      const char* ap = halo + a_base + kd * PS;
+      const char* wb = wbuf + slot * BSLAB + b_base;
+      Frag fa0[PF + 1], fa1[PF + 1], fb0[PF + 1], fb1[PF + 1];
+      auto ldb = [&](int t, int b) {
+        const int tap = t / NKS, ks = t % NKS, kh = tap / 3, kw = tap % 3;
+        fa0[b] = *(const Frag*)(ap + kh * RS + kw * VS + ks * 32);
+        fb0[b] = *(const Frag*)(wb + (tap * KG + 2 * ks) * BN * 16);
+        fb1[b] = *(const Frag*)(wb + (tap * KG + 2 * ks) * BN * 16 + 32 * 16);
+        if (MB == 2) fa1[b] = *(const Frag*)(ap + 4 * RS + kh * RS + kw * VS + ks * 32);
+      };
+#pragma unroll
+      for (int t = 0; t < PF; ++t) ldb(t, t);
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) {
+        if (t + PF < NTB) ldb(t + PF, (t + PF) % (PF + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma32(acc[0][0], fa0[t % (PF + 1)], fb0[t % (PF + 1)]);
+        mma32(acc[0][1], fa0[t % (PF + 1)], fb1[t % (PF + 1)]);
+        if constexpr (MB == 2) {
+          mma32(acc[1][0], fa1[t % (PF + 1)], fb0[t % (PF + 1)]);
+          mma32(acc[1][1], fa1[t % (PF + 1)], fb1[t % (PF + 1)]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // plane u + 1 (requested a whole phase ago) must have landed before anyone reads it; plane u + 2 stays in flight
+      if (ahead) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (u - u0 < 55) DUA_STAMP_AT(4 + (u - u0), false);
+      if (next_chunk) {
+        store_halo(u / 3 + 1);
+        __syncthreads();
+      }
+    }
+  } else
   for (int u = u0; u < u1; ++u) {
     const int kd = u % 3;
     const bool next_chunk = kd == 2 && u + 1 < u1;     // the unit after this one starts a new Cin chunk
@@ -255,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_v2_kernel(Conv3Args a) {
         }
       }
       __syncthreads();   // next slab visible and everyone is done with this one
-      DUA_STAMP_AT(4 + (g - g0), false);
+      if (g - g0 < 55) DUA_STAMP_AT(4 + (g - g0), false);
     }
     if (next_chunk) {
       store_halo(u / 3 + 1);
@@ -414,17 +532,30 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
       f32x4 acc = b4;
       const float* pp = part + ((long)n * vox + v) * cout_pad + c;
       const long kstride = (long)N * vox * cout_pad;
+      // The partial tiles of one output element are read in batches of up to 16 independent 16-byte loads (one memory round
+      // trip per batch: the kernel is a few microseconds of dependent latency, not bandwidth), and summed in a fixed order.
       int k = 0;
-      for (; k + 4 <= ksplit; k += 4) {          // four independent loads in flight
-        const f32x4 p0 = *(const f32x4*)(pp + (k + 0) * kstride), p1 = *(const f32x4*)(pp + (k + 1) * kstride);
-        const f32x4 p2 = *(const f32x4*)(pp + (k + 2) * kstride), p3 = *(const f32x4*)(pp + (k + 3) * kstride);
+      for (; k + 16 <= ksplit; k += 16) {
+        f32x4 pv[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += (p0[e] + p1[e]) + (p2[e] + p3[e]);
+        for (int j = 0; j < 16; ++j) pv[j] = *(const f32x4*)(pp + (k + j) * kstride);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += pv[j][e];
       }
-      for (; k < ksplit; ++k) {
-        const f32x4 p = *(const f32x4*)(pp + k * kstride);
+      if (k < ksplit) {
+        f32x4 pv[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += p[e];
+        for (int j = 0; j < 16; ++j) {
+          const int kk = k + j < ksplit ? k + j : ksplit - 1;          // clamped address, masked use: branch-free loads
+          pv[j] = *(const f32x4*)(pp + kk * kstride);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (k + j < ksplit)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += pv[j][e];
       }
       T o[4];
 #pragma unroll
@@ -455,10 +586,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 }
 
 
-static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups) {
+static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups, int target = 320) {
   *ksplit = 1; *ups = units;
   if (base_wgs > 64 || units <= 1) return;        // 24^3 and up: the partial-tile round trip costs more than it buys
-  int want = (320 + base_wgs - 1) / base_wgs;      // ~one workgroup per CU, each keeping >= a few units of work
+  int want = target == 320 ? (320 + base_wgs - 1) / base_wgs : target / base_wgs;   // ~one workgroup per CU, each keeping >= a few units of work
+  if (want < 1) want = 1;
   if (want > units) want = units;
   *ups = (units + want - 1) / want;
   *ksplit = (units + *ups - 1) / *ups;
@@ -492,6 +624,10 @@ static int ensure_lds_attr() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             c3v2::LDS_MAIN + 3 * 4 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return (int)e;
   done[dev] = true;
   return 0;
@@ -533,29 +669,33 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
       return (int)hipGetLastError();
     }
   }
-  if (ws != nullptr && g_conv_variant == 0) {
+  const bool big = g_conv_variant == 5;          // experiment switch: kd-plane form for the layers that cannot fill the chip twice
+  if (ws != nullptr && (g_conv_variant == 0 || big)) {
     int ks, ups;
-    choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups);
+    choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups, big ? 256 : 320);
     if (ks > 1 && (long)ks * d->N * vox * a.cout_pad * 4 <= ws_bytes) { a.ksplit = ks; a.units_per_split = ups; a.part = ws; }
   }
   // 24^3-sized layers (too few 4x8x8 tiles for 256 CUs, too big for split-K to pay): 2x8x8 tiles, twice the workgroups
-  if (a.ksplit == 1 && ((g_conv_variant == 0 && a.ntiles * nct * d->N < 200 && a.ntiles * nct * d->N > 64) || g_conv_variant == 3)) {
+  if (a.ksplit == 1 && (((g_conv_variant == 0 || big) && a.ntiles * nct * d->N < 200 && a.ntiles * nct * d->N > 64) || g_conv_variant == 3)) {
     const int td2 = (d->D + 1) / 2;
     a.ntiles = td2 * a.tiles_h * a.tiles_w;
     dim3 grid2(a.ntiles, nct, d->N);
     constexpr int LDS2 = 4 * c3::HH * c3::RS + 2 * c3v2::SLAB;
-    hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2>), grid2, dim3(256), LDS2 + xf_bytes, s, a);
+    if (big) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2, 2, false, true>), grid2, dim3(256), 4 * c3::HH * c3::RS + 9 * c3v2::SLAB + xf_bytes, s, a);
+    else hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2>), grid2, dim3(256), LDS2 + xf_bytes, s, a);
     return (int)hipGetLastError();
   }
   dim3 grid(a.ntiles, nct, d->N * a.ksplit);
   if (a.ksplit > 1) {
-    hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
+    if (big) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 2, false, true>), grid, dim3(256), c3::HALO_BYTES + 9 * c3v2::SLAB + xf_bytes, s, a);
+    else hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
     if (g_skip_splitk_finish) return (int)hipGetLastError();
     const int G = a.cout_pad / 4 > 256 ? 256 : a.cout_pad / 4;       // channel groups handled per block pass
     if (a.cout_pad / 4 > 256) return DUA_ERR_ARG;
     const int VL = 256 / G;
     int ITER = 8;
-    while (ITER > 1 && (vox + (long)VL * ITER - 1) / ((long)VL * ITER) < 128) ITER >>= 1;   // >= ~128 blocks; fewer blocks = fewer fp64 atomics
+    while (ITER > 1 && (vox + (long)VL * ITER - 1) / ((long)VL * ITER) < 512) ITER >>= 1;   // each iteration is a dependent memory
+                                                                                            // round trip: few of them, >= ~512 blocks
     dim3 fgrid((unsigned)((vox + (long)VL * ITER - 1) / ((long)VL * ITER)), d->N);
     hipLaunchKernelGGL(splitk_finish_kernel<T>, fgrid, dim3(256), 0, s, (const float*)ws, a.ksplit, d->N, vox, a.cout_pad,
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
@@ -586,7 +726,7 @@ long dua_debug_stamps(void* host, long bytes) {
 #endif
 
 int dua_set_option(int key, int value) {
-  if (key == 1 && (value == 0 || value == 2 || value == 3)) { dua::g_conv_variant = value; return 0; }
+  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 5)) { dua::g_conv_variant = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
 #ifdef DUA_ABLATE
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only

@@ -10,11 +10,11 @@
 
 extern "C" int dua_denoiser_step(const dua_denoiser_plan* p, void* stream) {
   if (!p || p->N <= 0 || !p->ops || p->n_ops <= 0 || !p->stat_arena || p->stat_bytes <= 0 || !p->tail_raw) return DUA_ERR_ARG;
-  int rc = dua_step_begin(p->N, p->P, p->temb_table, p->table_rows, p->rows_per_sample, p->row_of_step, p->nsteps,
-                          p->coef_table, p->counter, p->cur_add, p->cur_coef, p->step_word, p->err_word, stream);
+  // step begin and the clear of the statistics arena are ONE launch (see step_begin_kernel: a memset node is not)
+  int rc = dua_step_begin_clear(p->N, p->P, p->temb_table, p->table_rows, p->rows_per_sample, p->row_of_step, p->nsteps,
+                                p->coef_table, p->counter, p->cur_add, p->cur_coef, p->step_word, p->err_word,
+                                p->stat_arena, p->stat_bytes, stream);
   if (rc) return rc;
-  hipError_t e = hipMemsetAsync(p->stat_arena, 0, (size_t)p->stat_bytes, (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
   for (int i = 0; i < p->n_ops; ++i) {
     const dua_step_op& o = p->ops[i];
     const dua_in_norm* in = o.has_norm ? &o.norm : nullptr;

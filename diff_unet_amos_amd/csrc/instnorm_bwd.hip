@@ -13,18 +13,25 @@
 
 namespace dua {
 
-// mean / rstd / gamma / beta of channels [0, C) into LDS
+// mean / rstd / gamma / beta of channels [0, C) into LDS (16 channels per wave and pass, see stats_read_wave16)
 __device__ __forceinline__ void norm_preamble(const InXform& xf, int n, int C, float* mu, float* rs, float* ga, float* be) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int c0 = wave * 16; c0 < C; c0 += nw * 16) {
+    const int c = c0 + (lane & 15);
+    const bool ok = c < C;
+    const int cc = ok ? c : C - 1;
+    const float gam = xf.gamma[cc], bet = xf.beta[cc];
     double S, Q;
-    stats_read(xf.stats, n, xf.c_pad, c, S, Q);
+    stats_read_wave16(xf.stats, n, xf.c_pad, cc, S, Q);
     const double mean = S * (double)xf.inv_count;
     double var = Q * (double)xf.inv_count - mean * mean;
     var = var > 0 ? var : 0;
-    mu[c] = (float)mean;
-    rs[c] = (float)(1.0 / sqrt(var + (double)xf.eps));
-    ga[c] = xf.gamma[c];
-    be[c] = xf.beta[c];
+    if (ok && lane < 16) {
+      mu[c] = (float)mean;
+      rs[c] = (float)(1.0 / sqrt(var + (double)xf.eps));
+      ga[c] = gam;
+      be[c] = bet;
+    }
   }
 }
 

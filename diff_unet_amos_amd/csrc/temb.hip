@@ -66,7 +66,17 @@ __global__ __launch_bounds__(256) void step_begin_kernel(int N, int P, const flo
                                                          const int* __restrict__ row_of_step, int nsteps,
                                                          const float* __restrict__ coef_table, int* counter,
                                                          float* __restrict__ cur_add, float* __restrict__ cur_coef,
-                                                         int* step_word, int* err_word) {
+                                                         int* step_word, int* err_word, f32x4* __restrict__ zero,
+                                                         long zero_pieces) {
+  // Blocks 1.. clear the statistics arena of the evaluation (16-byte pieces); block 0 does the step's bookkeeping.  The clear
+  // used to be a hipMemsetAsync node in the captured step: replayed back to back, that runtime blit was seen starting before
+  // the previous replay's tail kernel had finished (late workgroups of the tail then normalised with zeroed sums -- results
+  // that depended on how far the host ran ahead).  As part of this kernel it is ordered like any other launch.
+  if (blockIdx.x > 0) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (blockIdx.x - 1) * 256L + threadIdx.x; i < zero_pieces; i += (gridDim.x - 1) * 256L) zero[i] = z;
+    return;
+  }
   // Every index that comes from device memory is range-checked here: an out-of-range timestep or step counter must
   // not turn into a wild read (a GPU memory fault can reset the node).  Offenders are clamped and reported.
   int k = 0;
@@ -107,15 +117,27 @@ int dua_temb_table(int count, const int* timesteps, const float* freqs, int half
   return (int)hipGetLastError();
 }
 
-int dua_step_begin(int N, int P, const float* table, int table_rows, const int* rows_per_sample, const int* row_of_step,
-                   int nsteps, const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
-                   int* err_word, void* stream) {
+int dua_step_begin_clear(int N, int P, const float* table, int table_rows, const int* rows_per_sample, const int* row_of_step,
+                         int nsteps, const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
+                         int* err_word, void* clear, long clear_bytes, void* stream) {
   if (N <= 0 || P <= 0 || !table || table_rows <= 0 || !cur_add) return DUA_ERR_ARG;
   if (!rows_per_sample && (!row_of_step || !counter || nsteps <= 0)) return DUA_ERR_ARG;
   if (coef_table && !cur_coef) return DUA_ERR_ARG;
-  hipLaunchKernelGGL(dua::step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, N, P, table, table_rows,
-                     rows_per_sample, row_of_step, nsteps, coef_table, counter, cur_add, cur_coef, step_word, err_word);
+  if (clear_bytes < 0 || clear_bytes % 16 || (clear_bytes > 0 && (!clear || ((size_t)clear & 15)))) return DUA_ERR_ARG;
+  const long pieces = clear_bytes / 16;
+  long zb = (pieces + 1023) / 1024;                 // four pieces per thread
+  if (zb > 1024) zb = 1024;
+  hipLaunchKernelGGL(dua::step_begin_kernel, dim3(1 + (unsigned)zb), dim3(256), 0, (hipStream_t)stream, N, P, table, table_rows,
+                     rows_per_sample, row_of_step, nsteps, coef_table, counter, cur_add, cur_coef, step_word, err_word,
+                     (dua::f32x4*)clear, pieces);
   return (int)hipGetLastError();
+}
+
+int dua_step_begin(int N, int P, const float* table, int table_rows, const int* rows_per_sample, const int* row_of_step,
+                   int nsteps, const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
+                   int* err_word, void* stream) {
+  return dua_step_begin_clear(N, P, table, table_rows, rows_per_sample, row_of_step, nsteps, coef_table, counter, cur_add,
+                              cur_coef, step_word, err_word, nullptr, 0, stream);
 }
 
 }  // extern "C"

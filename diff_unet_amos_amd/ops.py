@@ -715,9 +715,10 @@ def temb_table(timesteps, freqs, w0, b0, w1, b1, w_cat, b_cat, out=None):
 
 
 def step_begin(N, table, cur_add, rows_per_sample=None, row_of_step=None, counter=None, coef_table=None,
-               cur_coef=None, step_word=None, err_word=None):
+               cur_coef=None, step_word=None, err_word=None, clear=None):
     """``err_word`` (int32[1] device, optional): set to 1 by the kernel when a timestep row / step counter read from
-    device memory is outside the tables (the offender is clamped, nothing faults)."""
+    device memory is outside the tables (the offender is clamped, nothing faults).  ``clear``: a contiguous device tensor
+    (the statistics arena of the evaluation that starts here) zeroed by the same launch."""
     T, P = table.shape
     assert table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()
     assert cur_add.numel() >= N * P
@@ -729,9 +730,15 @@ def step_begin(N, table, cur_add, rows_per_sample=None, row_of_step=None, counte
         nsteps = row_of_step.numel()
         if coef_table is not None:
             assert coef_table.numel() >= 8 * nsteps
-    nv.check(nv.lib().dua_step_begin(N, P, nv.ptr(table), T, nv.ptr(rows_per_sample), nv.ptr(row_of_step), nsteps,
-                                     nv.ptr(coef_table), nv.ptr(counter), nv.ptr(cur_add), nv.ptr(cur_coef),
-                                     nv.ptr(step_word), nv.ptr(err_word), nv.stream_ptr()), "dua_step_begin")
+    cbytes = 0
+    if clear is not None:
+        assert clear.is_cuda and clear.is_contiguous()
+        cbytes = clear.numel() * clear.element_size()
+        assert cbytes % 16 == 0 and clear.data_ptr() % 16 == 0
+    nv.check(nv.lib().dua_step_begin_clear(N, P, nv.ptr(table), T, nv.ptr(rows_per_sample), nv.ptr(row_of_step), nsteps,
+                                           nv.ptr(coef_table), nv.ptr(counter), nv.ptr(cur_add), nv.ptr(cur_coef),
+                                           nv.ptr(step_word), nv.ptr(err_word), nv.ptr(clear), cbytes, nv.stream_ptr()),
+             "dua_step_begin_clear")
 
 
 def denoiser_step(plan_struct):

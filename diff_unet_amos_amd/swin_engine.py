@@ -445,11 +445,13 @@ class SwinPlan:
             ops.to_channels_last(e.detach().float().contiguous(), self.e_enc[k], 0, e.shape[1])
         self.emb_token += 1
 
-    def denoiser_body(self):
+    def denoiser_body(self, zero_stats=True):
         """SwinUNETRDenoiser.forward from the staged input (self.xin) to channels-last logits; self.cur_add holds the
-        t_proj rows of this evaluation."""
+        t_proj rows of this evaluation.  ``zero_stats=False``: the caller's step_begin(clear=self.den_stats) already
+        zeroed the statistics arena in its own launch."""
         f = self.f
-        self.den_stats.zero_()
+        if zero_stats:
+            self.den_stats.zero_()
         cat, dec, hs = self.cat, self.dec, self.hs
         outs = [(hs[0], 0), (hs[1], 0), (hs[2], 0), (cat[4], 8 * f), (hs[4], 0)]
         # Two streams.  The coarse Swin stages (12^3 and 6^3 tokens), encoder10 and decoder5..3 are a chain of ~150 launches of
@@ -544,8 +546,8 @@ class SwinPlan:
         if not on_host:
             self.err_word.zero_()
         ops.to_channels_last(x.detach().float().contiguous(), self.xin, 0, self.C)
-        ops.step_begin(N, self.temb_table, self.cur_add, rows_per_sample=rows, err_word=self.err_word)
-        self.denoiser_body()
+        ops.step_begin(N, self.temb_table, self.cur_add, rows_per_sample=rows, err_word=self.err_word, clear=self.den_stats)
+        self.denoiser_body(zero_stats=False)
         out = torch.empty((N, self.C, *self.dims), dtype=torch.float32, device=self.dev)
         self.tail(nv.MODE_LOGITS, logits=out)
         if not on_host and int(self.err_word.item()):
@@ -588,8 +590,9 @@ class SwinPlan:
 
         def one_step(eps):
             ops.step_begin(N, self.temb_table, self.cur_add, row_of_step=row_of_step, counter=self.counter,
-                           coef_table=coef_table, cur_coef=self.cur_coef, step_word=self.step_word, err_word=self.err_word)
-            self.denoiser_body()
+                           coef_table=coef_table, cur_coef=self.cur_coef, step_word=self.step_word, err_word=self.err_word,
+                           clear=self.den_stats)
+            self.denoiser_body(zero_stats=False)
             self.tail(mode, noise=eps, use_sum=True)
 
         if not use_graph:

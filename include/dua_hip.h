@@ -297,6 +297,11 @@ int dua_temb_table(int count, const int* timesteps, const float* freqs, int half
 int dua_step_begin(int N, int P, const float* table, int table_rows, const int* rows_per_sample, const int* row_of_step,
                    int nsteps, const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
                    int* err_word, void* stream);
+/* The same, and the same launch also zeroes `clear_bytes` (a multiple of 16; `clear` 16-byte aligned) at `clear`: the
+ * statistics arena of the evaluation that starts here (what the per-step .zero_() / memset node did). */
+int dua_step_begin_clear(int N, int P, const float* table, int table_rows, const int* rows_per_sample, const int* row_of_step,
+                         int nsteps, const float* coef_table, int* counter, float* cur_add, float* cur_coef, int* step_word,
+                         int* err_word, void* clear, long clear_bytes, void* stream);
 
 /* ---- one denoiser evaluation as ONE entry point -----------------------------------------------------------------
  * BasicUNetRDenoiser.forward (models/basic_unet/denoiser.py:284-312) + the sampler update that consumes it

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a conv3d_k3 workgroup spends its cycles: per-phase shader-clock stamps from the DIAGNOSTIC build
 (tools/build_diag.sh stamp -DDUA_STAMP; run with DUA_HIP_LIB=tools/diag/stamp/libdua_hip.so).
-usage: stamp_conv.py [shape indices of tools/bench_conv.py SHAPES, comma list] [--hot SECONDS]
+usage: stamp_conv.py [shape indices of tools/bench_conv.py SHAPES, comma list] [--hot SECONDS] [--variant V]
 Per shape: workgroups, in-kernel clock (delta s_memtime / delta s_memrealtime x 100 MHz, median over workgroups), and the
 median cycles of prologue / each K phase / epilogue.  --hot: launch the layer back to back for that long first (the clock
 a chip holds under sustained MFMA load, MI355X_MICROARCH.md 'DVFS give-back' item 6)."""
@@ -27,6 +27,8 @@ def main():
     host = np.zeros(nbytes // 8, dtype=np.uint64)
     only = [int(i) for i in sys.argv[1].split(",")] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else range(len(SHAPES))
     hot = float(sys.argv[sys.argv.index("--hot") + 1]) if "--hot" in sys.argv else 0.0
+    if "--variant" in sys.argv:
+        nv.check(L.dua_set_option(1, int(sys.argv[sys.argv.index("--variant") + 1])), "dua_set_option")
     dev, dt = "cuda", torch.float16
     for idx in only:
         S, cin, cout, fused = SHAPES[idx]
@@ -66,7 +68,7 @@ def main():
         clock = np.median(cyc / rt)                                       # GHz
         span = (st[:, 1].max() - st[:, 0].min()) * 0.01                   # us, first start to last end
         pro = np.median(st[:, 3] - st[:, 2])
-        nph = int(((st[0, 4:62] != 0).sum()))
+        nph = int(((st[0, 4:59] != 0).sum()))
         ph = np.array([np.median(st[:, 4 + i] - (st[:, 3 + i] if i else st[:, 3])) for i in range(nph)])
         last = st[:, 3 + nph] if nph else st[:, 3]
         tailc = np.median(st[:, 62] - last)
@@ -75,6 +77,8 @@ def main():
         print(f"{S}^3 {cin}->{cout}{' fused' if fused else ''}: event {us:.1f} us, stamped span {span:.1f} us, {len(st)} workgroups, "
               f"clock {clock:.3f} GHz, workgroup lifetime median {life / clock / 1e3:.2f} us (start spread "
               f"{(st[:, 0].max() - st[:, 0].min()) * 0.01:.1f} us)")
+        print(f"    prologue split: issue loads {np.median(st[:, 59] - st[:, 2]):.0f} | statistics preamble {np.median(st[:, 60] - st[:, 59]):.0f} | "
+              f"first slab to LDS (waits for it) {np.median(st[:, 61] - st[:, 60]):.0f} | halo transform + store + barrier {np.median(st[:, 3] - st[:, 61]):.0f}")
         print(f"    cycles: prologue {pro:.0f} | {nph} phases: mean {ph.mean() if nph else 0:.0f} min {ph.min() if nph else 0:.0f} max "
               f"{ph.max() if nph else 0:.0f} | post-loop {tailc:.0f} | epilogue {epi:.0f}")
         if nph:

@@ -33,7 +33,8 @@ constexpr int HALO_BYTES = HD * PS;        // 39360
 constexpr int BN = 64;                     // output channels per workgroup
 }  // namespace c3
 
-// 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones); 2 forces 4x8x8 tiles without split-K, 3 forces 2x8x8
+// 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones, both in the kd-plane form); 2 forces 4x8x8 tiles without
+// split-K, 3 forces 2x8x8 (slab form), 6 = the automatic policy with the slab form everywhere (same-process A/B)
 int g_conv_variant = 0;
 
 // ---- diagnostic build only (-DDUA_STAMP, tools/build_diag.sh -> a separate library selected with DUA_HIP_LIB): lane 0 of
@@ -669,14 +670,15 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
       return (int)hipGetLastError();
     }
   }
-  const bool big = g_conv_variant == 5;          // experiment switch: kd-plane form for the layers that cannot fill the chip twice
-  if (ws != nullptr && (g_conv_variant == 0 || big)) {
+  const bool autop = g_conv_variant == 0 || g_conv_variant == 6;       // the automatic policy; 6 = without the kd-plane form (A/B)
+  const bool big = g_conv_variant == 0;          // kd-plane form for the layers that cannot put two workgroups on every CU
+  if (ws != nullptr && autop) {
     int ks, ups;
     choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups, big ? 256 : 320);
     if (ks > 1 && (long)ks * d->N * vox * a.cout_pad * 4 <= ws_bytes) { a.ksplit = ks; a.units_per_split = ups; a.part = ws; }
   }
   // 24^3-sized layers (too few 4x8x8 tiles for 256 CUs, too big for split-K to pay): 2x8x8 tiles, twice the workgroups
-  if (a.ksplit == 1 && (((g_conv_variant == 0 || big) && a.ntiles * nct * d->N < 200 && a.ntiles * nct * d->N > 64) || g_conv_variant == 3)) {
+  if (a.ksplit == 1 && ((autop && a.ntiles * nct * d->N < 200 && a.ntiles * nct * d->N > 64) || g_conv_variant == 3)) {
     const int td2 = (d->D + 1) / 2;
     a.ntiles = td2 * a.tiles_h * a.tiles_w;
     dim3 grid2(a.ntiles, nct, d->N);
@@ -694,8 +696,9 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     if (a.cout_pad / 4 > 256) return DUA_ERR_ARG;
     const int VL = 256 / G;
     int ITER = 8;
-    while (ITER > 1 && (vox + (long)VL * ITER - 1) / ((long)VL * ITER) < 512) ITER >>= 1;   // each iteration is a dependent memory
-                                                                                            // round trip: few of them, >= ~512 blocks
+    while (ITER > 1 && (vox + (long)VL * ITER - 1) / ((long)VL * ITER) < 128) ITER >>= 1;   // >= ~128 blocks; every block ends with
+                                                                                            // 16 atomic instructions (measured: 432
+                                                                                            // blocks 14.8 us, 216 blocks 10.9 us at 12^3)
     dim3 fgrid((unsigned)((vox + (long)VL * ITER - 1) / ((long)VL * ITER)), d->N);
     hipLaunchKernelGGL(splitk_finish_kernel<T>, fgrid, dim3(256), 0, s, (const float*)ws, a.ksplit, d->N, vox, a.cout_pad,
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
@@ -726,7 +729,7 @@ long dua_debug_stamps(void* host, long bytes) {
 #endif
 
 int dua_set_option(int key, int value) {
-  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 5)) { dua::g_conv_variant = value; return 0; }
+  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 6)) { dua::g_conv_variant = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
 #ifdef DUA_ABLATE
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only

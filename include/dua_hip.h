@@ -165,7 +165,7 @@ int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, 
                       int dlogits_stride, void* stream);
 
 /* Tuning/diagnostic switch: key 1 = conv3d_k3 launch shape (0 automatic policy, 2 = 4x8x8 tiles without split-K,
- * 3 = 2x8x8 tiles);
+ * 3 = 2x8x8 tiles, 6 = the automatic policy without the kd-plane / LDS-DMA form of the small layers);
  * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid);
  * key 3: ablation mask of the weight-gradient kernel (accepted by diagnostic builds, -DDUA_ABLATE, only);
  * key 4: weight-gradient launch shape (bit 0 = plain block order, bits 1-4 = workgroups per CU over the launch,

@@ -64,18 +64,18 @@ def _producer(raw, dtype, g, add=None):
 @pytest.fixture
 def conv_variant(request):
     """Force one of the conv3d_k3 launch shapes (0: automatic policy with split-K / 2x8x8 tiles where they pay,
-    2: 4x8x8 tiles without split-K, 3: 2x8x8 tiles, 5: the policy with the kd-plane / LDS-DMA form switched on for the
-    layers that cannot fill the chip)."""
+    2: 4x8x8 tiles without split-K, 3: 2x8x8 tiles, 6: the policy with the kd-plane / LDS-DMA form of the small layers
+    switched off)."""
     from diff_unet_amos_amd import _native as nv
     nv.check(nv.lib().dua_set_option(1, request.param), "dua_set_option")
     yield request.param
     nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
 
 
-@pytest.mark.parametrize("conv_variant", [0, 2, 3, 5], indirect=True)
+@pytest.mark.parametrize("conv_variant", [0, 2, 3, 6], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [
-    (1, 64, 128, 24, 24, 24),    # a 24^3-sized layer: 108 workgroups of 4x8x8 -> the 2x8x8 forms (kd planes under variant 5)
+    (1, 64, 128, 24, 24, 24),    # a 24^3-sized layer: 108 workgroups of 4x8x8 -> the 2x8x8 forms (kd planes by default)
     (2, 40, 72, 16, 24, 24),     # the same regime, ragged channel counts, two samples
     (1, 64, 128, 24, 24, 24),    # auto picks 2x8x8 tiles (108 workgroups of 4x8x8 would half-fill the chip)
     (1, 40, 72, 22, 20, 26),     # the same path with ragged edges in every axis
@@ -124,7 +124,7 @@ def test_conv3_raw_and_stats(dtype, shape, conv_variant):
     assert torch.allclose(shift.cpu().double(), sh_ref, **ftol)
 
 
-@pytest.mark.parametrize("conv_variant", [0, 5], indirect=True)
+@pytest.mark.parametrize("conv_variant", [0, 6], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [(1, 128, 256, 12, 12, 12), (2, 72, 136, 6, 6, 6), (1, 136, 64, 8, 16, 16)])
 def test_conv3_split_k(dtype, shape, conv_variant):

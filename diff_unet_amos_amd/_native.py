@@ -121,6 +121,7 @@ _SIGS = {
     "dua_instnorm_stats": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
     "dua_gelu": (C.c_int, [C.c_int, C.c_long, _P, _P]),
     "dua_token_linear": (C.c_int, [C.POINTER(TokenLinearDesc), _P]),
+    "dua_token_gemm": (C.c_int, [C.POINTER(TokenLinearDesc), _P]),
     "dua_swin_mlp": (C.c_int, [C.c_long, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dua_denoiser_step": (C.c_int, [C.POINTER(DenoiserPlan), _P]),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
@@ -172,6 +173,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         _lib = L
+        if os.environ.get("DUA_CONV_VARIANT"):        # diagnostics: dua_set_option(1, v) for the whole process
+            check(L.dua_set_option(1, int(os.environ["DUA_CONV_VARIANT"])), "dua_set_option")
     return _lib
 
 

@@ -978,6 +978,35 @@ def token_linear(A, W, bias=None, mode="plain", out=None, out_off=0, x=None, sta
     return out if mode in ("plain", "gelu", "stats") else x
 
 
+def token_gemm(A, W, bias=None, mode="plain", out=None, out_off=0, x=None):
+    """dua_token_gemm: the tiled MFMA GEMM of the coarse Swin stages -- fp16 A [tokens, K] (row stride A.stride(0)) times the
+    nn.Linear weight W [N, K] (any K, N that are multiples of 8), "plain" / "gelu" -> out[:, out_off:out_off+N] (fp16), or
+    "residual": x += result on the fp32 stream."""
+    assert A.is_cuda and A.dtype == torch.float16 and A.dim() == 2 and A.stride(1) == 1
+    assert W.is_cuda and W.dtype == torch.float16 and W.is_contiguous() and W.dim() == 2 and W.shape[1] == A.shape[1]
+    M, K = A.shape
+    N = W.shape[0]
+    assert K % 8 == 0 and N % 8 == 0 and A.stride(0) % 8 == 0
+    code = {"plain": nv.TOKLIN_PLAIN, "gelu": nv.TOKLIN_GELU, "residual": nv.TOKLIN_RESIDUAL}[mode]
+    d = nv.TokenLinearDesc()
+    d.A, d.lda, d.M, d.K, d.N, d.W = A.data_ptr(), A.stride(0), M, K, N, W.data_ptr()
+    if bias is not None:
+        _f32c(bias, "bias")
+        assert bias.numel() == N
+        d.bias = bias.data_ptr()
+    d.mode, d.samples = code, 1
+    if mode == "residual":
+        assert x is not None and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == M * N
+        d.x = x.data_ptr()
+    else:
+        assert out is not None and out.is_cuda and out.dtype == torch.float16 and out.is_contiguous()
+        ldc = out.shape[-1]
+        assert out.numel() == M * ldc and out_off + N <= ldc and ldc % 8 == 0 and out_off % 8 == 0
+        d.out, d.ldc, d.out_off = out.data_ptr(), ldc, out_off
+    nv.check(nv.lib().dua_token_gemm(C.byref(d), nv.stream_ptr()), "dua_token_gemm")
+    return x if mode == "residual" else out
+
+
 def swin_mlp(ln2, w1, b1, w2, b2, x):
     """x += linear2(GELU(linear1(ln2))) in one launch (dua_swin_mlp): ln2 fp16 [tokens, C], w1 fp16 [4C, C], w2 fp16 [C, 4C],
     biases fp32, x the fp32 stream [tokens, C] (updated in place).  C = 48 or 96."""

@@ -169,10 +169,14 @@ class SwinPlan:
         # stage 0 only (110 592 tokens x 48): at stage 1 (13 824 x 96) a launch has ~100 tiles and the library's 10 us GEMMs
         # beat the per-workgroup weight staging of the fused kernels (same-process A/B, tools/bench_swin_ab.py)
         self.fused_max_c = 48
+        # Stages 1-3 and the wide 1x1x1 convolutions: the tiled MFMA GEMM of swin_gemm_wide.hip (fp16 operands) instead of the
+        # ~60 hipBLASLt launches per step of round 2; the fp32 parity mode keeps torch's GEMMs.
+        self.wide_gemm = dtype == torch.float16
         if self.fused_linear:
             self.qkv_buf = torch.zeros(3 * tok_max, dtype=dtype, device=device)
             self.hid_buf = torch.zeros(4 * tok_max, dtype=dtype, device=device)
             self.red_buf = torch.zeros(tok_max // 4 + 8, dtype=dtype, device=device)
+            self.po_buf = torch.zeros(tok_max, dtype=dtype, device=device)
         # ---- sampler state
         self.x_state = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
         self.x_sum = torch.zeros((N, *S[0], self.cx), dtype=torch.float32, device=device)
@@ -338,8 +342,11 @@ class SwinPlan:
             x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
             if self.fused_linear and self.tl_conv3 and r.cout <= 64 and cin <= 384:
                 ops.token_linear(x2, r.w3, None, "stats", out=res.view(-1, r.cout), stats=r.st[2], samples=N)   # conv3 + norm3 sums
+            elif self.wide_gemm:
+                ops.token_gemm(x2, r.w3, None, "plain", out=res.view(-1, r.cout))    # 1x1x1 conv3 on the tiled MFMA GEMM
+                ops.instnorm_stats(res, r.cout, r.st[2])
             else:
-                torch.matmul(x2, r.w3.t(), out=res.view(-1, r.cout))                 # 1x1x1 conv3 = library GEMM
+                torch.matmul(x2, r.w3.t(), out=res.view(-1, r.cout))                 # fp32 parity mode: library GEMM
                 ops.instnorm_stats(res, r.cout, r.st[2])
             if defer:
                 return raw2, n2, res, n3
@@ -369,7 +376,8 @@ class SwinPlan:
             ln2 = self.ln2[:ntok * C_].view(ntok, C_)
             y = None
             fused = self.fused_linear and C_ <= self.fused_max_c     # tall token GEMMs with fused epilogues (swin_gemm.hip)
-            if fused:
+            wide = self.wide_gemm and not fused
+            if fused or wide:
                 qkv_buf = self.qkv_buf[:ntok_w * 3 * C_].view(N * g["nw"], g["n"], 3 * C_)
                 hid = self.hid_buf[:ntok * 4 * C_].view(ntok, 4 * C_)
             for k, b in enumerate(st["blocks"]):
@@ -378,6 +386,8 @@ class SwinPlan:
                 ops.window_gather_norm(x, geom, b["g1"], b["b1"], win, y=y)
                 if fused and self.tl_qkv:
                     qkv = ops.token_linear(win.view(-1, C_), b["wqkv"], b["fqkv"], "plain", out=qkv_buf)
+                elif wide:
+                    qkv = ops.token_gemm(win.view(-1, C_), b["wqkv"], b["fqkv"], "plain", out=qkv_buf)
                 else:
                     qkv = F.linear(win, b["wqkv"], b["bqkv"])
                 ops.window_attention(qkv, HEADS[i], None, region_ids=g["region"] if shifted else None,
@@ -393,6 +403,12 @@ class SwinPlan:
                     else:
                         ops.token_linear(ln2, b["w1"], b["f1"], "gelu", out=hid)
                         ops.token_linear(hid, b["w2"], b["f2"], "residual", x=x)   # x + mlp(norm2(x)) lands in the stream
+                elif wide:
+                    po = self.po_buf[:ntok_w * C_].view(N * g["nw"], g["n"], C_)
+                    ops.token_gemm(att.view(-1, C_), b["wproj"], b["fproj"], "plain", out=po)
+                    ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)
+                    ops.token_gemm(ln2, b["w1"], b["f1"], "gelu", out=hid)                       # linear1 + GELU
+                    ops.token_gemm(hid, b["w2"], b["f2"], "residual", x=x.view(-1, C_))         # x + mlp(norm2(x)) on the stream
                 else:
                     po = F.linear(att, b["wproj"], b["bproj"])
                     ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)
@@ -406,6 +422,9 @@ class SwinPlan:
             if fused and 8 * C_ <= 384 and self.fused_reduction:
                 red = ops.token_linear(merged.view(-1, 8 * C_), st["wred"], None, "plain",
                                        out=self.red_buf[:merged.numel() // 4].view(-1, 2 * C_))
+            elif self.wide_gemm:
+                red = ops.token_gemm(merged.view(-1, 8 * C_), st["wred"], None, "plain",
+                                     out=self.red_buf[:merged.numel() // 4].view(-1, 2 * C_))
             else:
                 red = F.linear(merged.view(-1, 8 * C_), st["wred"])
             ops.stage_out(red, N, 2 * C_, outs[i + 1][0], outs[i + 1][1], tadd=tadd(i + 1),

@@ -645,3 +645,34 @@ def test_diff_swin_unetr_long_ddpm_run_is_finite_and_follows_the_torch_seed():
         assert torch.equal(a, c)                           # same noise field, order-independent statistics: the same bits
         with pytest.raises((RuntimeError, AssertionError, ValueError)):
             net(image=image, x=xT, step=torch.tensor([1000]), pred_type="denoise")
+
+
+@pytest.mark.gpu
+def test_token_gemm_matches_torch_linear():
+    """dua_token_gemm (the tiled MFMA GEMM of the coarse Swin stages: qkv / proj / linear1 + GELU / linear2 + residual /
+    reduction / wide conv3, attention.py:97-120, transformer.py:433-435, patch.py:89-92, blocks.py:311-314) against
+    F.linear on the same fp16 operands: token counts that are not multiples of the 64-row tile, N = 96 (one and a half
+    column tiles), K = 96 (one and a half K steps), K = 3072, a strided A (a channel slice of a wider buffer)."""
+    import torch.nn.functional as F
+    from diff_unet_amos_amd import ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(41)
+    for M, K, N, mode, bias in ((343, 3072, 768, "plain", False), (2744, 192, 576, "plain", True), (1728, 768, 192, "gelu", True),
+                                (21952, 96, 288, "plain", True), (1000, 96, 96, "gelu", True), (216, 1536, 384, "residual", True),
+                                (13824, 384, 96, "residual", True)):
+        A = torch.randn(M, K + 16, generator=g).half().to(dev)
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+        b = torch.randn(N, generator=g).to(dev) if bias else None
+        want = F.linear(A[:, :K].float(), W.float(), b)
+        scale = max(1.0, float(want.abs().max()))
+        if mode == "residual":
+            x = torch.randn(M, N, generator=g).to(dev)
+            got = ops.token_gemm(A[:, :K], W, b, "residual", x=x.clone())
+            assert (got - (x + want)).abs().max() < 2e-3 * scale, (M, K, N, mode)
+            continue
+        out = torch.full((M, N + 8), 7.0, dtype=torch.float16, device=dev)
+        ops.token_gemm(A[:, :K], W, b, mode, out=out, out_off=8)
+        if mode == "gelu":
+            want = F.gelu(want)
+        assert float((out[:, :8].float() - 7).abs().max()) == 0.0
+        assert (out[:, 8:].float() - want).abs().max() < 4e-3 * scale, (M, K, N, mode, float((out[:, 8:].float() - want).abs().max()))

@@ -164,6 +164,11 @@ int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, 
                       const double* sums, const float* gscale, float w_mse, float w_bce, float w_dice, void* dlogits,
                       int dlogits_stride, void* stream);
 
+/* Measurement aid (bench.py roofline.measured_mfma_ceiling): `workgroups` x 4 waves (one per SIMD at one workgroup per CU)
+ * issue iters * 16 back-to-back v_mfma_f32_32x32x16_f16 (32 768 FLOP each) on random register operands.  stamps (or NULL):
+ * 2 words per workgroup = (s_memtime cycles, s_memrealtime 100 MHz ticks) spent in the loop.  sink: any device float. */
+int dua_mfma_probe(int workgroups, int iters, float* sink, unsigned long long* stamps, void* stream);
+
 /* Tuning/diagnostic switch: key 1 = conv3d_k3 launch shape (0 automatic policy, 2 = 4x8x8 tiles without split-K,
  * 3 = 2x8x8 tiles, 6 = the automatic policy without the kd-plane / LDS-DMA form of the small layers);
  * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid);

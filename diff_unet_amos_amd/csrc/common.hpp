@@ -171,22 +171,36 @@ __device__ __forceinline__ void xform_preamble(const InXform& xf, int n, int C, 
     return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int c0 = c_begin + wave * 16; c0 < C; c0 += nw * 16) {          // wave-uniform trip count
-    const int c = c0 + (lane & 15);
-    const bool ok = c < C;
-    const int cc = ok ? c : C - 1;                                      // clamped address, masked store
-    const float gam = xf.gamma[cc], bet = xf.beta[cc];
-    const float add = xf.add ? xf.add[(long)n * xf.add_stride + cc] : 0.f;
-    double S, Q;
-    stats_read_wave16(xf.stats, n, xf.c_pad, cc, S, Q);
-    const double mean = S * (double)xf.inv_count;
-    double var = Q * (double)xf.inv_count - mean * mean;
-    var = var > 0 ? var : 0;
-    const float g = gam * (float)(1.0 / sqrt(var + (double)xf.eps));
-    if (ok && lane < 16) {
-      sc[c] = g;
-      sh[c] = bet - (float)mean * g;
-      ad[c] = add;
+  // up to UN groups of 16 channels per wave are in flight together (wide layers: 512 channels = 8 groups per wave would
+  // otherwise be 8 dependent round trips to lines that the producers' atomics left outside L2)
+  constexpr int UN = 4;
+  for (int c0 = c_begin + wave * 16; c0 < C; c0 += UN * nw * 16) {     // wave-uniform trip count
+    double S[UN], Q[UN];
+    float gam[UN], bet[UN], add[UN];
+    int cc[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int c = c0 + u * nw * 16 + (lane & 15);
+      cc[u] = c < C ? c : C - 1;                                       // clamped address, masked store
+      gam[u] = xf.gamma[cc[u]]; bet[u] = xf.beta[cc[u]];
+      add[u] = xf.add ? xf.add[(long)n * xf.add_stride + cc[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (c0 + u * nw * 16 < C) stats_read_wave16(xf.stats, n, xf.c_pad, cc[u], S[u], Q[u]);     // wave-uniform condition
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int c = c0 + u * nw * 16 + (lane & 15);
+      if (c0 + u * nw * 16 >= C) break;
+      const double mean = S[u] * (double)xf.inv_count;
+      double var = Q[u] * (double)xf.inv_count - mean * mean;
+      var = var > 0 ? var : 0;
+      const float g = gam[u] * (float)(1.0 / sqrt(var + (double)xf.eps));
+      if (c < C && lane < 16) {
+        sc[c] = g;
+        sh[c] = bet[u] - (float)mean * g;
+        ad[c] = add[u];
+      }
     }
   }
 }

@@ -215,7 +215,7 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
 // RES: the residual form -- the activation is assembled from the last UnetResBlock's two branches and the reverse-attention
 // term instead of being read back from a materialised tensor (three 16-byte loads per fragment, two voxel blocks in flight).
 template <int KS, bool RES = false>
-__global__ __launch_bounds__(256) void final_conv_sampler_mfma_kernel(TailArgs a) {
+__global__ __launch_bounds__(256, RES ? 2 : 3) void final_conv_sampler_mfma_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // scale[K], shift[K], add[K] (+ the same of the residual branch)
   const int n = blockIdx.y, K = a.K;
   float* sc_l = wl; float* sh_l = wl + K;

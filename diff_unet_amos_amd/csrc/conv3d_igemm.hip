@@ -512,234 +512,6 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Arg
   DUA_STAMP_AT(1, true);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Persistent form of the 4x8x8 kernel for the layers that fill the chip several times over (96^3 and 48^3: 432 .. 3456
-// tiles on 512 workgroup slots).  Same tile, fragment maps, slab pipeline and epilogue as conv3d_k3_v2_kernel; a
-// workgroup walks tiles b, b + G, b + 2G, ... and
-//   * derives the producer's scale / shift ONCE (the statistics preamble is two dependent memory round trips),
-//     (requesting the NEXT tile's operands under the last phases of the current one was built too: the registers that carry
-//     them across the epilogue -- 40 for the halo chunk -- spill, 196-252 bytes of scratch per lane, so a tile still starts
-//     with its own loads).
-// Plain 32-channel chunks only (no tap form, no half chunk, no split-K).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_pers_kernel(Conv3Args a) {
-  using namespace c3v2;
-  constexpr int MB = 2, NW = 4, NTHR = 256;
-  constexpr int NITEMS = HD * HH * HW * KG, NIT = (NITEMS + NTHR - 1) / NTHR;
-  constexpr int NPIECE = SLAB / 16, NSL = NPIECE / NTHR;
-  static_assert(NPIECE % NTHR == 0, "a slab is a whole number of 16-byte pieces per thread");
-  using Frag = typename Elem<T>::Frag;
-  constexpr int EPG = Elem<T>::EPG;
-  constexpr int CK = KG * EPG;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* halo = smem;
-  char* wbuf = smem + HALO_BYTES;
-  float* xsc = (float*)(smem + LDS_MAIN);
-  float* xsh = xsc + a.nchunks * CK;
-  float* xad = xsh + a.nchunks * CK;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, hh = lane >> 5;
-  const int ct = blockIdx.y, n = blockIdx.z;
-  const bool fused = a.xf.stats != nullptr;
-  const int kg_t = tid & (KG - 1);
-  const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off;
-  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB;
-  const int g1 = a.nchunks * 9, u1 = a.nchunks * 3;
-
-  int goff[NIT];                  // element offsets inside one sample: < 2^31 (the launcher checks)
-  int d0 = 0, h0 = 0, w0 = 0;
-  auto set_tile = [&](int vb) {                      // tile coordinates and the halo items' global offsets
-    const int tile = xcd_remap(vb, a.ntiles);
-    const int tw_ = tile % a.tiles_w, th_ = (tile / a.tiles_w) % a.tiles_h, td_ = tile / (a.tiles_w * a.tiles_h);
-    d0 = td_ * TD; h0 = th_ * TH; w0 = tw_ * TW;
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));       // opaque: the item -> (plane, row, column) arithmetic is redone per tile instead of being
-                                           // hoisted out of the tile loop into 30 more live registers
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      const int it = tid_o + NTHR * j;
-      const int hv = it >> 2;
-      const int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
-      const int gd = d0 + hd - 1, gh = h0 + hy - 1, gw = w0 + hx - 1;
-      const bool ok = it < NITEMS && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-      goff[j] = ok ? ((gd * a.H + gh) * a.W + gw) * a.Cin_stride + kg_t * EPG : -1;
-    }
-  };
-  f32x4 wreg[3][NSL];
-  auto load_slab = [&](int g, int set) {
-    const char* src = wsrc + (long)g * SLAB + tid * 16;
-#pragma unroll
-    for (int j = 0; j < NSL; ++j) wreg[set][j] = *(const f32x4*)(src + j * NTHR * 16);
-  };
-  auto store_slab = [&](int g, int set) {
-    char* dst = wbuf + (g & 1) * SLAB + tid * 16;
-#pragma unroll
-    for (int j = 0; j < NSL; ++j) *(f32x4*)(dst + j * NTHR * 16) = wreg[set][j];
-  };
-  Frag hv_[NIT];
-  auto load_halo = [&](int ch) {
-    const bool cok = ch * CK + kg_t * EPG < a.Cin;
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      if (goff[j] >= 0 && cok) hv_[j] = *(const Frag*)(xin + goff[j] + ch * CK);
-      else
-#pragma unroll
-        for (int e = 0; e < EPG; ++e) hv_[j][e] = (T)0.f;
-    }
-  };
-  auto store_halo = [&](int ch) {
-    const int c0 = ch * CK + kg_t * EPG;
-    if (fused && c0 < a.Cin) {
-      float sc[EPG], sh[EPG], ad[EPG];
-#pragma unroll
-      for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
-#pragma unroll
-      for (int j = 0; j < NIT; ++j)
-        if (goff[j] >= 0) hv_[j] = xform_frag<T>(hv_[j], sc, sh, ad, a.xf.slope);
-    }
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));       // the LDS offsets are recomputed here rather than kept live through the MFMA phases
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      const int it = tid_o + NTHR * j;
-      const int hv = it >> 2;
-      const int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
-      if (it < NITEMS) *(Frag*)(halo + hd * PS + hy * RS + hx * VS + kg_t * 16) = hv_[j];
-    }
-  };
-
-  // ---- once per workgroup: the statistics preamble (under the first tile's loads) ----
-  int vb = blockIdx.x;
-  set_tile(vb);
-  load_slab(0, 0);
-  load_slab(1, 1);
-  load_slab(2, 2);
-  load_halo(0);
-  if (fused) xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);      // visible after the barrier below
-
-  const int a_base = wave * PS + (r >> 3) * RS + (r & 7) * VS + hh * 16;
-  const int b_base = (hh * BN + r) * 16;
-  float bias0[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int bc = ct * BN + q * 32 + r;
-    bias0[q] = bc >= a.Cout ? 0.f : a.bias[bc];
-  }
-  for (;;) {
-    const int vb_next = vb + gridDim.x;
-    const bool more = vb_next < a.ntiles;
-    f32x16 acc[MB][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][q][i] = bias0[q];
-    if (vb != (int)blockIdx.x) {         // a later tile: its operands are requested here (holding them in registers across
-      set_tile(vb);                      // the previous tile's epilogue spilled 50 registers)
-      load_slab(0, 0);
-      load_slab(1, 1);
-      load_slab(2, 2);
-      load_halo(0);
-    }
-    __syncthreads();                     // preamble results (first tile) / nobody still reads the epilogue's staging tile
-    store_slab(0, 0);
-    store_halo(0);
-    // the output tile's coordinates: store_halo was the last user of this tile's goff as such; keep them for the epilogue
-    const int od0 = d0, oh0 = h0, ow0 = w0;
-    __syncthreads();
-
-    for (int u = 0; u < u1; ++u) {
-      const int kd = u % 3;
-      const bool next_chunk = kd == 2 && u + 1 < u1;
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int g = u * 3 + kh;
-        if (g + 1 < g1) store_slab(g + 1, (kh + 1) % 3);
-        if (g + 3 < g1) load_slab(g + 3, kh);
-        if (kh == 0 && next_chunk) load_halo(u / 3 + 1);
-        const char* ap = halo + a_base + kd * PS + kh * RS;
-        const char* wb = wbuf + (g & 1) * SLAB + b_base;
-        constexpr int NT = 6;
-        Frag fa0[2], fa1[2], fb0[2], fb1[2];
-        auto ld = [&](int t, int b) {
-          const int kw = t / 2, ks = t % 2;
-          fa0[b] = *(const Frag*)(ap + kw * VS + ks * 32);
-          fb0[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16);
-          fb1[b] = *(const Frag*)(wb + (kw * KG + 2 * ks) * BN * 16 + 32 * 16);
-          fa1[b] = *(const Frag*)(ap + 4 * RS + kw * VS + ks * 32);
-        };
-        ld(0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (t + 1 < NT) ld(t + 1, (t + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
-          mma32(acc[0][0], fa0[t & 1], fb0[t & 1]);
-          mma32(acc[0][1], fa0[t & 1], fb1[t & 1]);
-          mma32(acc[1][0], fa1[t & 1], fb0[t & 1]);
-          mma32(acc[1][1], fa1[t & 1], fb1[t & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-      }
-      if (next_chunk) {
-        store_halo(u / 3 + 1);
-        __syncthreads();
-      }
-    }
-    // ---- epilogue of this tile (as conv3d_k3_v2_kernel) ----
-    constexpr int OS = 32 * (int)sizeof(T) + 16;
-    char* ot = smem + wave * (32 * MB) * OS;
-    float* ex = (float*)(smem + NW * (32 * MB) * OS);
-    const int gd = od0 + wave;
-    const bool dok = gd < a.D;
-    const bool full = od0 + TD <= a.D && oh0 + TH <= a.H && ow0 + TW <= a.W;
-    T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int co = q * 32 + r;
-      float s_ = 0.f, ss = 0.f;
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
-          const bool ok = full || (dok && (oh0 + hl < a.H) && (ow0 + wl < a.W));
-          const float v = ok ? acc[m][q][i] : 0.f;
-          s_ += v;
-          ss = fmaf(v, v, ss);
-          *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = (T)v;
-        }
-      s_ += __shfl_xor(s_, 32);
-      ss += __shfl_xor(ss, 32);
-      if (hh == 0) { ex[(wave * BN + co) * 2] = s_; ex[(wave * BN + co) * 2 + 1] = ss; }
-      __syncthreads();
-      if (dok) {
-        constexpr int GPV = 32 / EPG;
-        constexpr int VPI = 64 / GPV;
-#pragma unroll
-        for (int it = 0; it < (32 * MB) / VPI; ++it) {
-          const int v = it * VPI + lane / GPV, cg = lane % GPV;
-          const int gh = oh0 + (v >> 3), gw = ow0 + (v & 7);
-          if ((full || (gh < a.H && gw < a.W)) && ct * BN + q * 32 + cg * EPG < a.Cout)
-            *(Frag*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + q * 32 + cg * EPG) =
-                *(const Frag*)(ot + v * OS + cg * 16);
-        }
-      }
-      if (q == 0) __syncthreads();
-    }
-    if (wave == 0) {
-      double S = 0, Q = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
-      if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
-    }
-    if (!more) break;
-    vb = vb_next;
-  }
-}
-
 // ---- split-K finish: y = sum_k part[k] + bias (stored as T), and this layer's InstanceNorm sums ----
 // block = 256 threads = VL voxel lanes x G channel groups of 4; each thread walks ITER voxels.
 template <typename T>
@@ -853,9 +625,6 @@ static int ensure_lds_attr() {
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             c3v2::LDS_MAIN + 3 * 4 * 1024);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)conv3d_k3_pers_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            c3v2::LDS_MAIN + 3 * 4 * 1024);
-  if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -900,9 +669,8 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
       return (int)hipGetLastError();
     }
   }
-  const bool autop = g_conv_variant == 0 || g_conv_variant == 6 || g_conv_variant == 7;   // the automatic policy; 6 = without the
-                                                 // kd-plane form, 7 = without the persistent form (same-process A/B)
-  const bool big = g_conv_variant == 0 || g_conv_variant == 7;   // kd-plane form for the layers that cannot put two workgroups on every CU
+  const bool autop = g_conv_variant == 0 || g_conv_variant == 6;       // the automatic policy; 6 = without the kd-plane form (A/B)
+  const bool big = g_conv_variant == 0;          // kd-plane form for the layers that cannot put two workgroups on every CU
   if (ws != nullptr && autop) {
     int ks, ups;
     choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups, big ? 256 : 320);
@@ -935,17 +703,6 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
                        d->Cout, bias, (T*)y, d->Cout_stride, d->Cout_off, stats, G, VL, ITER);
     return (int)hipGetLastError();
   }
-  const long slots = 512;                        // two workgroups per CU
-  if (g_conv_variant == 0 && !d->background && (long)a.ntiles * nct * d->N >= 2 * slots && vox * d->Cin_stride < (1L << 31) &&
-      !(sizeof(T) == 2 && d->Cin - (a.nchunks - 1) * CK <= CK / 2)) {
-    // persistent form: G workgroups per (cout tile, sample) walk the tiles; G a multiple of 8 (one run of tiles per XCD)
-    long G = slots / ((long)nct * d->N);
-    G = G < 8 ? 8 : (G / 8) * 8;
-    if (G > a.ntiles) G = a.ntiles;
-    dim3 gridp((unsigned)G, nct, d->N);
-    hipLaunchKernelGGL(conv3d_k3_pers_kernel<T>, gridp, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
-    return (int)hipGetLastError();
-  }
   if (sizeof(T) == 2 && d->Cin - (a.nchunks - 1) * CK <= CK / 2)       // e.g. Cin = 48: the last chunk is half padding
     hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 2, true>), grid, dim3(256), c3v2::LDS_MAIN + xf_bytes + bg_pad, s, a);
   else
@@ -971,7 +728,7 @@ long dua_debug_stamps(void* host, long bytes) {
 #endif
 
 int dua_set_option(int key, int value) {
-  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 6 || value == 7)) { dua::g_conv_variant = value; return 0; }
+  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 6)) { dua::g_conv_variant = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
 #ifdef DUA_ABLATE
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only

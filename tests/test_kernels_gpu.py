@@ -124,40 +124,6 @@ def test_conv3_raw_and_stats(dtype, shape, conv_variant):
     assert torch.allclose(shift.cpu().double(), sh_ref, **ftol)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("shape", [(1, 64, 64, 64, 64, 64), (2, 40, 72, 36, 52, 60), (1, 128, 64, 48, 48, 48)])
-def test_conv3_persistent_form_equals_the_per_tile_form(dtype, shape):
-    """Layers with >= 1024 tiles run as persistent workgroups (conv3d_k3_pers_kernel: statistics preamble once per
-    workgroup, tiles walked with stride gridDim.x); dua_set_option(1, 7) launches one workgroup per tile instead.  Same
-    arithmetic in the same order: raw output and statistics words must be IDENTICAL, with a fused producer transform,
-    ragged extents (partial tiles on every axis), two samples and two cout tiles; and the result matches torch."""
-    from diff_unet_amos_amd import _native as nv
-    ops = _ops()
-    N, Cin, Cout, D, H, W = shape
-    g = torch.Generator().manual_seed(sum(shape))
-    raw = torch.randn(N, Cin, D, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
-    b = torch.randn(Cout, generator=g)
-    norm, act = _producer(raw, dtype, g, add=torch.randn(N, Cin, generator=g))
-    wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), dtype)
-    xcl = _cl(raw, dtype)
-    outs = []
-    for variant in (0, 7):
-        nv.check(nv.lib().dua_set_option(1, variant), "dua_set_option")
-        try:
-            y = torch.zeros((N, D, H, W, Cout), dtype=dtype, device="cuda")
-            st = ops.stats_buffer(N, Cout, "cuda")
-            ops.conv3d_k3(xcl, Cin, 0, wp, bp, Cout, y, 0, st, norm=norm)
-            outs.append((y, st))
-        finally:
-            nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1].sum(1), outs[1][1].sum(1))          # replica rows differ (block index), their integer sums do not
-    ref = F.conv3d(act.to(dtype).float(), w.to(dtype).float(), b, padding=1)
-    got = ops.from_channels_last(outs[0][0], Cout).cpu()
-    assert torch.allclose(got, ref, **TOL[dtype]), float((got - ref).abs().max())
-
-
 @pytest.mark.parametrize("conv_variant", [0, 6], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [(1, 128, 256, 12, 12, 12), (2, 72, 136, 6, 6, 6), (1, 136, 64, 8, 16, 16)])

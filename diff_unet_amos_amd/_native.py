@@ -122,7 +122,8 @@ _SIGS = {
     "dua_instnorm_stats": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
     "dua_gelu": (C.c_int, [C.c_int, C.c_long, _P, _P]),
     "dua_token_linear": (C.c_int, [C.POINTER(TokenLinearDesc), _P]),
-    "dua_token_gemm": (C.c_int, [C.POINTER(TokenLinearDesc), _P]),
+    "dua_token_gemm": (C.c_int, [C.POINTER(TokenLinearDesc), _P, C.c_long, _P]),
+    "dua_token_gemm_workspace": (C.c_long, [C.c_long, C.c_int, C.c_int]),
     "dua_swin_mlp": (C.c_int, [C.c_long, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dua_denoiser_step": (C.c_int, [C.POINTER(DenoiserPlan), _P]),
     "dua_temb_table": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),

@@ -31,9 +31,13 @@ struct GemmArgs {
   const f16* W; const float* bias;
   f16* out; int ldc, out_off;
   float* x; int ldx;
+  float* part; int kper, ksplit;        // split K: slice z contracts [z * kper, (z + 1) * kper) into part[z][M][N] (fp32)
 };
 
-template <int MODE>
+// SPLIT: the small-token layers (27 .. 343 tokens against K up to 3072: a few dozen tiles, each walking 24 - 48 dependent K
+// steps of ~1 us) divide K over gridDim.z; fp32 partial tiles go to a workspace and token_gemm_finish_kernel applies the
+// epilogue (52.8 us -> ~8 us for the 27-token x 3072 -> 768 reduction of the last patch merging).
+template <int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(256) void token_gemm_kernel(GemmArgs a) {
   using namespace wg_;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE > 64 * OROW32 ? 2 * TILE : 64 * OROW32];
@@ -71,12 +75,14 @@ __global__ __launch_bounds__(256) void token_gemm_kernel(GemmArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  load_step(0);
-  for (int k0 = 0; k0 < a.K; k0 += BK) {
+  const int kbeg = SPLIT ? blockIdx.z * a.kper : 0;
+  const int kend = SPLIT ? (kbeg + a.kper < a.K ? kbeg + a.kper : a.K) : a.K;
+  load_step(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();                        // everyone is done reading the previous step's tiles
     store_step();
     __syncthreads();
-    if (k0 + BK < a.K) load_step(k0 + BK);  // in flight while this step multiplies
+    if (k0 + BK < kend) load_step(k0 + BK); // in flight while this step multiplies
     const char* wrow = Ws + (wn * 32 + r) * ROW + hh * 16;
     const char* arow = As + (wm * 32 + r) * ROW + hh * 16;
 #pragma unroll
@@ -87,6 +93,23 @@ __global__ __launch_bounds__(256) void token_gemm_kernel(GemmArgs a) {
     }
   }
   __syncthreads();
+  if constexpr (SPLIT) {
+    // fp32 partial tile, as it stands, through LDS for 16-byte rows
+    char* ot = smem;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *(f32x4*)(ot + (wm * 32 + r) * OROW32 + (wn * 32 + 8 * j + 4 * hh) * 4) = f32x4{acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+    __syncthreads();
+    float* pz = a.part + (long)blockIdx.z * a.M * a.N;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 16 + (tid >> 4), c4 = tid & 15;
+      const long m = m0 + row;
+      const int n = n0 + c4 * 4;
+      if (m < a.M && n < a.N) *(f32x4*)(pz + m * a.N + n) = *(const f32x4*)(ot + row * OROW32 + c4 * 16);
+    }
+    return;
+  }
   // ---- epilogue: register quad j of a lane = channels n0 + wn*32 + 8j + 4hh + (0..3) of token m0 + wm*32 + r ----
   float v[16];
 #pragma unroll
@@ -136,16 +159,83 @@ __global__ __launch_bounds__(256) void token_gemm_kernel(GemmArgs a) {
   }
 }
 
+// sum of the K slices + bias, then the epilogue of MODE; one thread = four consecutive channels of one token
+template <int MODE>
+__global__ __launch_bounds__(256) void token_gemm_finish_kernel(GemmArgs a) {
+  const long q = blockIdx.x * 256L + threadIdx.x, nq = a.N / 4;
+  if (q >= a.M * nq) return;
+  const long m = q / nq;
+  const int n = (int)(q - m * nq) * 4;
+  f32x4 pv[16];
+#pragma unroll
+  for (int z = 0; z < 16; ++z) {
+    const int zz = z < a.ksplit ? z : a.ksplit - 1;                  // clamped address, masked use
+    pv[z] = *(const f32x4*)(a.part + ((long)zz * a.M + m) * a.N + n);
+  }
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = a.bias ? a.bias[n + e] : 0.f;
+#pragma unroll
+  for (int z = 0; z < 16; ++z)
+    if (z < a.ksplit)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += pv[z][e];
+  if (MODE == DUA_TOKLIN_RESIDUAL) {
+    float* xp = a.x + m * a.ldx + n;
+    f32x4 xv = *(const f32x4*)xp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] += v[e];
+    *(f32x4*)xp = xv;
+  } else {
+    if (MODE == DUA_TOKLIN_GELU)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    *(f16x4*)(a.out + m * a.ldc + a.out_off + n) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  }
+}
+
 }  // namespace dua
 
-extern "C" int dua_token_gemm(const dua_token_linear_desc* d, void* stream) {
+// K slices a launch of dua_token_gemm would use for (M, K, N), and the workspace bytes that enables them (0: no split)
+extern "C" long dua_token_gemm_workspace(long M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return DUA_ERR_ARG;
+  const long tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  const int ksteps = (K + 63) / 64;
+  if (tiles >= 128 || ksteps < 8) return 0;
+  long z = 256 / tiles;
+  if (z > ksteps / 2) z = ksteps / 2;
+  if (z > 16) z = 16;
+  if (z < 2) return 0;
+  return z * M * N * 4;
+}
+
+extern "C" int dua_token_gemm(const dua_token_linear_desc* d, void* workspace, long workspace_bytes, void* stream) {
   using namespace dua;
   if (!d || !d->A || !d->W || d->M <= 0 || d->K <= 0 || d->K % 8 || d->N <= 0 || d->N % 8 || d->lda < d->K || d->lda % 8) return DUA_ERR_ARG;
   if (d->M > 65535L * 64 || d->N > 65535 * 64) return DUA_ERR_ARG;
   GemmArgs a{};
   a.A = (const f16*)d->A; a.lda = d->lda; a.M = d->M; a.K = d->K; a.N = d->N; a.W = (const f16*)d->W; a.bias = d->bias;
   a.out = (f16*)d->out; a.ldc = d->ldc; a.out_off = d->out_off; a.x = d->x; a.ldx = d->N;
+  a.part = nullptr; a.kper = d->K; a.ksplit = 1;
   dim3 grid((unsigned)((d->M + 63) / 64), (unsigned)((d->N + 63) / 64));
+  const long need = dua_token_gemm_workspace(d->M, d->K, d->N);
+  if (need > 0 && workspace && workspace_bytes >= need && d->N % 4 == 0 &&
+      (d->mode == DUA_TOKLIN_PLAIN || d->mode == DUA_TOKLIN_GELU || d->mode == DUA_TOKLIN_RESIDUAL)) {
+    if (d->mode != DUA_TOKLIN_RESIDUAL && (!d->out || d->ldc % 8 || d->out_off % 8 || d->ldc < d->out_off + d->N)) return DUA_ERR_ARG;
+    if (d->mode == DUA_TOKLIN_RESIDUAL && !d->x) return DUA_ERR_ARG;
+    const int z = (int)(need / (d->M * d->N * 4));
+    const int ksteps = (d->K + 63) / 64;
+    a.part = (float*)workspace; a.ksplit = z; a.kper = ((ksteps + z - 1) / z) * 64;
+    a.ksplit = (d->K + a.kper - 1) / a.kper;                          // slices that actually hold work
+    grid.z = a.ksplit;
+    hipLaunchKernelGGL((token_gemm_kernel<DUA_TOKLIN_PLAIN, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    const long quads = d->M * (d->N / 4);
+    dim3 fg((unsigned)((quads + 255) / 256));
+    if (d->mode == DUA_TOKLIN_PLAIN) hipLaunchKernelGGL(token_gemm_finish_kernel<DUA_TOKLIN_PLAIN>, fg, dim3(256), 0, (hipStream_t)stream, a);
+    else if (d->mode == DUA_TOKLIN_GELU) hipLaunchKernelGGL(token_gemm_finish_kernel<DUA_TOKLIN_GELU>, fg, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(token_gemm_finish_kernel<DUA_TOKLIN_RESIDUAL>, fg, dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   switch (d->mode) {
     case DUA_TOKLIN_PLAIN:
     case DUA_TOKLIN_GELU:

@@ -978,6 +978,21 @@ def token_linear(A, W, bias=None, mode="plain", out=None, out_off=0, x=None, sta
     return out if mode in ("plain", "gelu", "stats") else x
 
 
+_GEMM_WS = {}
+
+
+def _gemm_ws(nbytes, device):
+    """Grow-only fp32 scratch per (device, stream) for the K-split token GEMMs (retired, never freed: graphs bake its address)."""
+    key = (torch.device(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = _GEMM_WS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        if buf is not None:
+            _WGRAD_WS_RETIRED.append(buf)
+        buf = torch.empty(max(int(nbytes), 16 << 20) // 4, dtype=torch.float32, device=device)
+        _GEMM_WS[key] = buf
+    return buf
+
+
 def token_gemm(A, W, bias=None, mode="plain", out=None, out_off=0, x=None):
     """dua_token_gemm: the tiled MFMA GEMM of the coarse Swin stages -- fp16 A [tokens, K] (row stride A.stride(0)) times the
     nn.Linear weight W [N, K] (any K, N that are multiples of 8), "plain" / "gelu" -> out[:, out_off:out_off+N] (fp16), or
@@ -1003,7 +1018,10 @@ def token_gemm(A, W, bias=None, mode="plain", out=None, out_off=0, x=None):
         ldc = out.shape[-1]
         assert out.numel() == M * ldc and out_off + N <= ldc and ldc % 8 == 0 and out_off % 8 == 0
         d.out, d.ldc, d.out_off = out.data_ptr(), ldc, out_off
-    nv.check(nv.lib().dua_token_gemm(C.byref(d), nv.stream_ptr()), "dua_token_gemm")
+    need = int(nv.lib().dua_token_gemm_workspace(M, K, N))
+    ws = _gemm_ws(need, A.device) if need > 0 else None
+    nv.check(nv.lib().dua_token_gemm(C.byref(d), nv.ptr(ws), ws.numel() * 4 if ws is not None else 0, nv.stream_ptr()),
+             "dua_token_gemm")
     return x if mode == "residual" else out
 
 

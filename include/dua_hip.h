@@ -455,8 +455,12 @@ int dua_token_linear(const dua_token_linear_desc* d, void* stream);
 /* The same contraction for the COARSE Swin stages and the wide 1x1x1 convolutions (stages 1-3: qkv / proj / linear1 / linear2 /
  * reduction, attention.py:97-120, transformer.py:433-435, patch.py:89-92; conv3 of UnetResBlock, blocks.py:311-314) as a
  * tiled MFMA GEMM that streams BOTH operands (any K and N that are multiples of 8; M <= 4 M tokens): modes PLAIN, GELU
- * (out, ldc, out_off as above) and RESIDUAL (x [M][N] fp32 += result).  samples, stats, geom, gamma, beta, ln_out unused. */
-int dua_token_gemm(const dua_token_linear_desc* d, void* stream);
+ * (out, ldc, out_off as above) and RESIDUAL (x [M][N] fp32 += result).  samples, stats, geom, gamma, beta, ln_out unused.
+ * workspace (may be NULL): fp32 scratch that lets the launcher divide K over workgroups for the small-token layers (a few
+ * dozen tiles walking thousands of K) and finish with a second launch; dua_token_gemm_workspace gives the bytes (0: the
+ * shape is not split). */
+long dua_token_gemm_workspace(long M, int K, int N);
+int dua_token_gemm(const dua_token_linear_desc* d, void* workspace, long workspace_bytes, void* stream);
 
 /* The MLP of a Swin block in one launch (fp16 operands, C = 48 or 96, hidden = 4 C): x[token] += linear2(GELU(linear1(ln2[token])))
  * on the fp32 stream (MONAI MLPBlock; transformer.py:376,433-434,477-480).  ln2: fp16 [tokens][C] (norm2 of the stream, from

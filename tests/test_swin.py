@@ -652,12 +652,14 @@ def test_token_gemm_matches_torch_linear():
     """dua_token_gemm (the tiled MFMA GEMM of the coarse Swin stages: qkv / proj / linear1 + GELU / linear2 + residual /
     reduction / wide conv3, attention.py:97-120, transformer.py:433-435, patch.py:89-92, blocks.py:311-314) against
     F.linear on the same fp16 operands: token counts that are not multiples of the 64-row tile, N = 96 (one and a half
-    column tiles), K = 96 (one and a half K steps), K = 3072, a strided A (a channel slice of a wider buffer)."""
+    column tiles), K = 96 (one and a half K steps), K = 3072, a strided A (a channel slice of a wider buffer); the small-token
+    shapes take the K-split path (partial tiles + finish launch)."""
     import torch.nn.functional as F
     from diff_unet_amos_amd import ops
     dev = "cuda"
     g = torch.Generator().manual_seed(41)
-    for M, K, N, mode, bias in ((343, 3072, 768, "plain", False), (2744, 192, 576, "plain", True), (1728, 768, 192, "gelu", True),
+    for M, K, N, mode, bias in ((343, 3072, 768, "plain", False), (27, 3072, 768, "gelu", True), (27, 3072, 768, "plain", False),
+                                (2744, 192, 576, "plain", True), (1728, 768, 192, "gelu", True),
                                 (21952, 96, 288, "plain", True), (1000, 96, 96, "gelu", True), (216, 1536, 384, "residual", True),
                                 (13824, 384, 96, "residual", True)):
         A = torch.randn(M, K + 16, generator=g).half().to(dev)

@@ -46,12 +46,18 @@ struct Args {
 // meant to run under.  The loop below waits for its transfers itself (s_waitcnt vmcnt(0) + barrier before a buffer is read).
 __device__ __forceinline__ void wg_glds16(const void* g, void* lds_wave_base) {
   const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
-  // M0 (the LDS base of the transfer) is compiler-reserved and not preserved around an asm statement: it is saved, written
-  // and restored inside the SAME statement, so no other M0 user (movrel, another LDS-DMA builtin, sendmsg) can see a stale
-  // value.  (M0 holds a full LDS byte address; the second buffer of this kernel starts above 64 KB.)
+  // M0 (the LDS base of the transfer) is compiler-reserved and not preserved around an asm statement, so it is written in
+  // the SAME statement that reads it (cdna_hip_programming.md 5.7).  Nothing else in this kernel uses M0 (no movrel, no
+  // LDS-DMA builtin, no sendmsg), so it is not saved and restored: that form (kept under -DDUA_GLDS_SAVE_M0, and used by the
+  // conv kernel's weight ring) costs this kernel 1-4 % (646 vs 622 us on 96^3 64->64, same box).  M0 holds a full LDS
+  // byte address; the second buffer of this kernel starts above 64 KB.
+#ifdef DUA_GLDS_SAVE_M0
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(base)) : "memory");
+#else
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(__builtin_amdgcn_readfirstlane(base)) : "memory");
+#endif
 }
 
 // DMA (f16, 12 waves): the tiles go from global memory straight into one of TWO LDS buffers (global_load_lds), issued one

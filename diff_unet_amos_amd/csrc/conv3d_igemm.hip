@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include "../../include/dua_hip.h"
 #include "conv3_args.hpp"
+#include <algorithm>
 
 namespace dua {
 
@@ -512,6 +513,294 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Arg
   DUA_STAMP_AT(1, true);
 }
 
+// ------------------------------------------------------------------------------------------------
+// First layer of the denoiser (16 noisy-label channels + the conditioning image -> 64, models/basic_unet/denoiser.py:298
+// torch.cat([image, x]) into conv_0): K = 27 taps x 16 channels + 27 image taps is so short that the slab pipeline above
+// spends its time in barriers (nine per tile for 116 MFMAs per wave).  Here ALL 27 taps of the 16 ordinary channels stay
+// resident in LDS (54 KB, loaded once by a PERSISTENT workgroup that walks tiles), the image-tap weight block lives in
+// registers, and a tile is: halo (prefetched into registers under the previous tile's MFMAs) -> LDS, one barrier, 116
+// MFMAs per wave with no barrier between them, epilogue.  Two workgroups per CU (79.5 KB of LDS each) overlap one's
+// epilogue with the other's MFMAs.
+//
+// Halo image: 32 B per voxel (the 16 ordinary channels; the image channel goes to an fp16 array of its own), 12 voxel slots
+// per row (10 used), and the two 16-byte halves of a voxel swapped on odd halo rows: with that the four 16-lane groups of
+// every ds_read_b128 fragment read cover all 64 banks once (rows r>>3 = 0..3 of a 32-voxel block land on 16-byte slots
+// {0,2,4,6}+8k / {1,3,5,7}+8k).
+namespace c3f {
+using namespace c3;
+constexpr int VSF = 32, RSF = 12 * VSF, PSF = HH * RSF;      // 384-byte rows, 3840-byte planes
+constexpr int HALO_F = HD * PSF;                              // 23040
+constexpr int WRES = 27 * 2 * BN * 16;                        // 55296: [tap][k-half][64 couts][16 B]
+constexpr int IMG_F = 1216;                                   // 600 fp16 of the image halo (+ pad)
+constexpr int LDS_F = WRES + HALO_F + IMG_F;                  // 79552: two workgroups per CU
+constexpr int NV = HD * HH * HW;                              // 600 halo voxels
+}  // namespace c3f
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_first_kernel(Conv3Args a, int items) {
+  using namespace c3f;
+  using T = f16;
+  constexpr int NTHR = 256, NW = 4, MB = 2;
+  constexpr int NIT = (NV * 2 + NTHR - 1) / NTHR;             // 16-byte halo pieces per thread (5)
+  constexpr int NIM = (NV + NTHR - 1) / NTHR;                 // image halo values per thread (3)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wres = smem;
+  char* halo = smem + WRES;
+  char* img = smem + WRES + HALO_F;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int ct = blockIdx.y;
+
+  DUA_STAMP_AT(0, true);
+  DUA_STAMP_AT(2, false);
+  // ---- once per workgroup: resident weights (k-groups 0 and 1 of every tap of the packed slabs) by LDS-DMA, 54 pieces of
+  // 1 KB = [64 couts][16 B], all in flight together (inline assembly as in the kd-plane form above: the explicit
+  // s_waitcnt before the first barrier covers them), and the image-tap block ----
+  {
+    const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * c3v2::SLAB + lane * 16;
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wres;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const int s2 = wave + NW * j;                           // piece = (tap, k-half)
+      if (s2 < 54) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(wsrc + ((s2 >> 1) * KG + (s2 & 1)) * 1024), "s"(__builtin_amdgcn_readfirstlane(dst + s2 * 1024)) : "memory");
+      }
+    }
+  }
+  f16x8 tb[2][2];                                             // image-tap weights: [k-step][cout half], this lane's B fragments
+  {
+    const char* wt = (const char*)a.w + (long)gridDim.y * a.nchunks * 9 * c3v2::SLAB + (long)ct * 4096;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) tb[s][q] = *(const f16x8*)(wt + ((2 * s + hh) * BN + q * 32 + r) * 16);
+  }
+
+  // ---- per-thread halo items (tile independent): piece it = (voxel, half).  Branch-free: every thread loads every item
+  // (out-of-volume ones from a clamped address, zeroed by a select before the LDS store); threads without an item store
+  // into the unused voxel slots 10 / 11 of halo row 0 and the pad of the image array. ----
+  int hrel[NIT], loff[NIT];                                   // packed (hd, hy, hx) / LDS offset
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int it = tid + NTHR * j, hv = it >> 1, p = it & 1;
+    const int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
+    hrel[j] = it < NV * 2 ? hd | (hy << 8) | (hx << 16) : 0x7fffffff;        // no item: out of every volume
+    loff[j] = it < NV * 2 ? hd * PSF + hy * RSF + hx * VSF + ((p ^ (hy & 1)) << 4) : HW * VSF + (p << 4);
+  }
+  int irel[NIM], ioff[NIM];
+#pragma unroll
+  for (int j = 0; j < NIM; ++j) {
+    const int hv = tid + NTHR * j;
+    const int hd = hv / (HH * HW), rem = hv - hd * (HH * HW), hy = rem / HW, hx = rem - hy * HW;
+    irel[j] = hv < NV ? (hd | (hy << 8) | (hx << 16)) : 0x7fffffff;
+    ioff[j] = (hv < NV ? hv : NV + (tid & 7)) * 2;
+  }
+  const int p_t = tid & 1;
+
+  f16x8 hreg[NIT];
+  f16 ireg[NIM];
+  unsigned okmask = 0;                                        // bit j: piece j is inside the volume; bit 8 + j: image value j
+  auto tile_of = [&](int item, int& n, int& d0, int& h0, int& w0) {
+    n = item / a.ntiles;
+    const int tile = xcd_remap(item - n * a.ntiles, a.ntiles);
+    const int tw_ = tile % a.tiles_w, th_ = (tile / a.tiles_w) % a.tiles_h, td_ = tile / (a.tiles_w * a.tiles_h);
+    d0 = td_ * TD; h0 = th_ * TH; w0 = tw_ * TW;
+  };
+  auto load_halo = [&](int item) {
+    int n, d0, h0, w0;
+    tile_of(item, n, d0, h0, w0);
+    const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off;
+    okmask = 0;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int gd = d0 + (hrel[j] & 255) - 1, gh = h0 + ((hrel[j] >> 8) & 255) - 1, gw = w0 + (hrel[j] >> 16) - 1;
+      const bool ok = (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+      const long off = ok ? (((long)gd * a.H + gh) * a.W + gw) * a.Cin_stride + p_t * 8 : 0;
+      hreg[j] = *(const f16x8*)(xin + off);
+      okmask |= ok ? 1u << j : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NIM; ++j) {
+      const int gd = d0 + (irel[j] & 255) - 1, gh = h0 + ((irel[j] >> 8) & 255) - 1, gw = w0 + (irel[j] >> 16) - 1;
+      const bool ok = (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+      const long off = ok ? (((long)gd * a.H + gh) * a.W + gw) * a.Cin_stride + a.tap_ch : 0;
+      ireg[j] = xin[off];
+      okmask |= ok ? 256u << j : 0u;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const f32x4 raw = __builtin_bit_cast(f32x4, hreg[j]);
+      const bool ok = (okmask >> j) & 1;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ok ? raw[e] : 0.f;
+      *(f32x4*)(halo + loff[j]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NIM; ++j) *(T*)(img + ioff[j]) = ((okmask >> (8 + j)) & 1) ? ireg[j] : (T)0.f;
+  };
+
+  // fragment addresses: wave = depth slice, lane row r = (h = r >> 3, w = r & 7) of block m (h + 4 m), k-half hh
+  const int sw = (r >> 3) & 1;
+  const int a_base = wave * PSF + (r >> 3) * RSF + (r & 7) * VSF;
+  const int a_even = a_base + ((hh ^ sw) << 4), a_odd = a_base + ((hh ^ sw ^ 1) << 4);     // halo row parity of h + kh
+  const int b_base = (hh * BN + r) * 16;
+  const int i_base = (wave * (HH * HW) + (r >> 3) * HW + (r & 7)) * 2;
+
+  float bias_q[2];                                            // read once: a load inside the tile loop would have to wait for
+#pragma unroll                                                // the halo prefetch issued before it (vmcnt counts in order)
+  for (int q = 0; q < 2; ++q) {
+    const int bc = ct * BN + q * 32 + r;
+    bias_q[q] = bc >= a.Cout ? 0.f : a.bias[bc];
+  }
+  int item = blockIdx.x;
+  if (item < items) load_halo(item);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the weight pieces (not counted by the compiler) and the halo
+  store_halo();
+  __syncthreads();
+  DUA_STAMP_AT(3, false);
+  int slot = 4;                                               // stamp build: 4 slots per tile (MFMAs | barrier | epilogue | next halo)
+  for (; item < items; item += gridDim.x) {
+    int n, d0, h0, w0;
+    tile_of(item, n, d0, h0, w0);
+    const bool more = item + (int)gridDim.x < items;
+    if (more) load_halo(item + gridDim.x);                   // lands under the MFMAs below
+    f32x16 acc[MB][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][q][i] = bias_q[q];
+    // image taps of this lane's two voxel rows: k = 32 taps (27 real; the weights of the rest are zero, any finite value serves)
+    f16x8 ta[MB][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int t0 = s * 16 + e, t1 = t0 + 8;
+        const int o0 = ((t0 / 9) * (HH * HW) + ((t0 / 3) % 3) * HW + t0 % 3) * 2;
+        const int o1 = t1 < 27 ? ((t1 / 9) * (HH * HW) + ((t1 / 3) % 3) * HW + t1 % 3) * 2 : 0;
+        const int o = i_base + (hh ? o1 : o0);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) ta[m][s][e] = *(const f16*)(img + o + m * 4 * HW * 2);
+      }
+    {
+      constexpr int NT = 27, PF = 2;
+      f16x8 fa0[PF + 1], fa1[PF + 1], fb0[PF + 1], fb1[PF + 1];
+      auto ld = [&](int t, int b) {
+        const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+        const char* ap = halo + ((kh & 1) ? a_odd : a_even) + kd * PSF + kh * RSF + kw * VSF;
+        fa0[b] = *(const f16x8*)ap;
+        fa1[b] = *(const f16x8*)(ap + 4 * RSF);
+        fb0[b] = *(const f16x8*)(wres + b_base + t * 2 * BN * 16);
+        fb1[b] = *(const f16x8*)(wres + b_base + t * 2 * BN * 16 + 32 * 16);
+      };
+#pragma unroll
+      for (int t = 0; t < PF; ++t) ld(t, t);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t + PF < NT) ld(t + PF, (t + PF) % (PF + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma32(acc[0][0], fa0[t % (PF + 1)], fb0[t % (PF + 1)]);
+        mma32(acc[0][1], fa0[t % (PF + 1)], fb1[t % (PF + 1)]);
+        mma32(acc[1][0], fa1[t % (PF + 1)], fb0[t % (PF + 1)]);
+        mma32(acc[1][1], fa1[t % (PF + 1)], fb1[t % (PF + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        mma32(acc[m][0], ta[m][s], tb[s][0]);
+        mma32(acc[m][1], ta[m][s], tb[s][1]);
+      }
+    if (slot < 56) DUA_STAMP_AT(slot, false);
+    __syncthreads();                                          // everyone is done with the halo: the epilogue stages through it
+    if (slot < 56) DUA_STAMP_AT(slot + 1, false);
+
+    // ---- epilogue: statistics from the fp32 accumulators; each wave stages one 32-voxel block at a time in rows of its own
+    // (32 x 128 B: whole 128-byte voxel lines leave in one store instruction, eight voxels each) -- no workgroup barrier
+    // inside, ds operations of one wave execute in order ----
+    char* ot = halo + wave * 4096;
+    float* ex = (float*)(smem + LDS_F);                       // [NW waves][64 couts][2], beyond the image halo
+    const int gd = d0 + wave;
+    const bool dok = gd < a.D;
+    const bool full = d0 + TD <= a.D && h0 + TH <= a.H && w0 + TW <= a.W;
+    T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
+    float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      if (full) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float v = acc[m][q][i];
+            s[q] += v;
+            ss[q] = fmaf(v, v, ss[q]);
+            *(T*)(ot + acc_row(i, hh) * 128 + (q * 32 + r) * 2) = (T)v;
+          }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int hl = 4 * m + (i >> 2), wl = (i & 3) + 4 * hh;
+            const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
+            const float v = ok ? acc[m][q][i] : 0.f;
+            s[q] += v;
+            ss[q] = fmaf(v, v, ss[q]);
+            *(T*)(ot + acc_row(i, hh) * 128 + (q * 32 + r) * 2) = (T)v;
+          }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (dok) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int v = it * 8 + (lane >> 3), cg = lane & 7;
+          const int gh = h0 + 4 * m + (v >> 3), gw = w0 + (v & 7);
+          if ((full || (gh < a.H && gw < a.W)) && ct * BN + cg * 8 < a.Cout)
+            *(f16x8*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + cg * 8) = *(const f16x8*)(ot + v * 128 + cg * 16);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      s[q] += __shfl_xor(s[q], 32);
+      ss[q] += __shfl_xor(ss[q], 32);
+      if (hh == 0) { ex[(wave * BN + q * 32 + r) * 2] = s[q]; ex[(wave * BN + q * 32 + r) * 2 + 1] = ss[q]; }
+    }
+    if (slot < 56) DUA_STAMP_AT(slot + 2, false);
+    __syncthreads();                                          // every wave is done with its staging rows; ex is complete
+    if (wave == 0) {
+      double S = 0, Q = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
+      if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, item & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
+    }
+    if (more) {
+      store_halo();
+      __syncthreads();
+    }
+    if (slot < 56) DUA_STAMP_AT(slot + 3, false);
+    slot += 4;
+  }
+  DUA_STAMP_AT(62, false);
+  DUA_STAMP_AT(63, false);
+  DUA_STAMP_AT(1, true);
+}
+
 // ---- split-K finish: y = sum_k part[k] + bias (stored as T), and this layer's InstanceNorm sums ----
 // block = 256 threads = VL voxel lanes x G channel groups of 4; each thread walks ITER voxels.
 template <typename T>
@@ -601,6 +890,8 @@ static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups, 
 // main stream's workgroups (two of them per CU leave no room: the co-running launches then wait for retiring workgroups).
 constexpr int PARTIAL_LDS_PAD = 36 * 1024;
 
+static int g_cus[64] = {};      // compute units per device (the persistent first-layer launch sizes its grid with it)
+
 // hipFuncSetAttribute is per device: remember which devices have the dynamic-LDS limit raised
 template <typename T>
 static int ensure_lds_attr() {
@@ -620,6 +911,13 @@ static int ensure_lds_attr() {
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD);
+  }
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)conv3d_k3_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c3f::LDS_F + 2048);
+  if (e == hipSuccess) {
+    int cus = 0;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    g_cus[dev] = cus;
   }
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -664,6 +962,15 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     else {
       if (a.nchunks != 1 || (in && in->stats) || (a.tap_ch != 0 && a.tap_ch != 16) || d->Cin != a.tap_ch + 8) return DUA_ERR_ARG;
       dim3 grid(a.ntiles, nct, d->N);
+      if (a.tap_ch == 16 && g_conv_variant == 0 && bg_pad == 0) {
+        // resident-weight form: two persistent workgroups per CU walk the (sample, tile) items
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || g_cus[dev] <= 0) return DUA_ERR_ARG;
+        const int items = a.ntiles * d->N;
+        const int wgs = std::max(1, 2 * g_cus[dev] / nct);
+        hipLaunchKernelGGL(conv3d_k3_first_kernel, dim3(std::min(items, wgs), nct, 1), dim3(256), c3f::LDS_F + 2048, s, a, items);
+        return (int)hipGetLastError();
+      }
       if (a.tap_ch == 16) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 1>), grid, dim3(256), c3v2::LDS_MAIN + 4096 + bg_pad, s, a);
       else hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 0>), grid, dim3(256), c3v2::LDS_MAIN + 4096 + bg_pad, s, a);
       return (int)hipGetLastError();

@@ -183,13 +183,17 @@ def test_conv3_fused_input_transform_and_channel_slices(dtype, conv_variant):
     assert float((ybuf[..., :8].float() + 5).abs().max()) == 0 and float((ybuf[..., 48:].float() + 5).abs().max()) == 0
 
 
-@pytest.mark.parametrize("classes,shape", [(16, (1, 16, 24, 8)), (16, (2, 10, 9, 13)), (0, (1, 8, 16, 16))])
-def test_conv3_single_channel_tap_form(classes, shape):
+@pytest.mark.parametrize("classes,shape,cout", [(16, (1, 16, 24, 8), 64), (16, (2, 10, 9, 13), 64), (0, (1, 8, 16, 16), 64),
+                                                (16, (1, 40, 72, 72), 64),      # 810 tiles: persistent workgroups take two
+                                                (16, (3, 12, 20, 16), 8), (16, (1, 9, 17, 8), 96)])
+def test_conv3_single_channel_tap_form(classes, shape, cout):
     """First layers: the lone image channel behind 16 (denoiser) or 0 (encoder) ordinary channels contracted as two
-    k-steps over its 27 taps; against torch conv3d on the fp16-rounded operands and against the ordinary form."""
+    k-steps over its 27 taps; against torch conv3d on the fp16-rounded operands and against the ordinary form.  With 16
+    channels the default is the resident-weight kernel (persistent workgroups); conv_variant 6 keeps the slab pipeline."""
     ops = _ops()
+    from diff_unet_amos_amd import _native as nv
     N, D, H, W = shape
-    cin_src, cout, cin_p = classes + 1, 64, classes + 8
+    cin_src, cin_p = classes + 1, classes + 8
     g = torch.Generator().manual_seed(classes + D)
     x = torch.randn(N, cin_src, D, H, W, generator=g)                    # reference channel order [image | x_t]
     w = torch.randn(cout, cin_src, 3, 3, 3, generator=g) / (27 * cin_src) ** 0.5
@@ -199,18 +203,28 @@ def test_conv3_single_channel_tap_form(classes, shape):
     xp[..., :classes] = x[:, 1:].permute(0, 2, 3, 4, 1).half()
     xp[..., classes] = x[:, 0].half()
     outs = []
-    for tap in (None, classes):
-        wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), torch.float16, cin_packed=cin_p, perm=perm, tap_channel=tap)
-        y = torch.zeros(N, D, H, W, cout, dtype=torch.float16, device="cuda")
-        st = ops.stats_buffer(N, cout, "cuda")
-        ops.conv3d_k3(xp, cin_p, 0, wp, bp, cout, y, 0, st, tap_channel=tap)
-        outs.append((ops.from_channels_last(y, cout).cpu(), ops.stats_decode(st).cpu()))
-    want = F.conv3d(x.half().float(), w.half().float(), b, padding=1)
+    try:
+        for tap, variant in ((None, 0), (classes, 0), (classes, 6)):
+            nv.check(nv.lib().dua_set_option(1, variant), "dua_set_option")
+            wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), torch.float16, cin_packed=cin_p, perm=perm, tap_channel=tap)
+            y = torch.full((N, D, H, W, cout + 8), -5.0, dtype=torch.float16, device="cuda")
+            st = ops.stats_buffer(N, cout, "cuda")
+            ops.conv3d_k3(xp, cin_p, 0, wp, bp, cout, y, 0, st, tap_channel=tap)
+            assert float((y[..., cout:].float() + 5).abs().max()) == 0          # nothing written past Cout
+            outs.append((ops.from_channels_last(y, cout).cpu(), ops.stats_decode(st).cpu()))
+    finally:
+        nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
+    want = F.conv3d(x.half().float().cuda(), w.half().float().cuda(), b.cuda(), padding=1).cpu()
     for got, st in outs:
         assert (got - want).abs().max() < 2e-2, float((got - want).abs().max())
         gd = got.double().permute(1, 0, 2, 3, 4).reshape(cout, N, -1).permute(1, 0, 2)
-        assert torch.allclose(st[..., 0], gd.sum(-1), rtol=1e-5, atol=2e-2)
+        # the sums are taken from the fp32 accumulators, the stored values are their fp16 roundings (a random walk over the voxels)
+        walk = 1e-3 * (D * H * W) ** 0.5
+        assert torch.allclose(st[:, :cout, 0], gd.sum(-1), rtol=1e-5, atol=max(2e-2, walk))
+        assert torch.allclose(st[:, :cout, 1], (gd * gd).sum(-1), rtol=2e-3, atol=max(2e-2, walk))
+        assert float(st[:, cout:].abs().max() if st.shape[1] > cout else 0) == 0
     assert (outs[0][0] - outs[1][0]).abs().max() < 4e-3      # same products, different summation order
+    assert (outs[1][0] - outs[2][0]).abs().max() < 4e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])

@@ -33,8 +33,14 @@ def main():
     for idx in only:
         S, cin, cout, fused = SHAPES[idx]
         x = torch.randn(1, S, S, S, cin, device=dev).to(dt)
-        w = torch.randn(cout, cin, 3, 3, 3, device=dev) / (27 * cin) ** 0.5
-        wp, bp = ops.pack_conv3_weights(w, torch.zeros(cout, device=dev), dt)
+        tap = 16 if cin == 24 else None                     # the denoiser's first layer (tools/bench_conv.py)
+        if tap:
+            w = torch.randn(cout, 17, 3, 3, 3, device=dev) / (27 * 17) ** 0.5
+            wp, bp = ops.pack_conv3_weights(w, torch.zeros(cout, device=dev), dt, cin_packed=24,
+                                            perm=list(range(1, 17)) + [0] + [-1] * 7, tap_channel=tap)
+        else:
+            w = torch.randn(cout, cin, 3, 3, 3, device=dev) / (27 * cin) ** 0.5
+            wp, bp = ops.pack_conv3_weights(w, torch.zeros(cout, device=dev), dt)
         y = torch.empty(1, S, S, S, cout, device=dev, dtype=dt)
         stats = ops.stats_buffer(1, cout, dev)
         nb = ops.conv3_workspace_bytes(dt, 1, S, S, S, cin, cout)
@@ -45,7 +51,7 @@ def main():
             sums[..., 1] = float(S ** 3)
             norm = ops.Norm(ops.stats_encode(sums), torch.ones(cin, device=dev), torch.zeros(cin, device=dev), S ** 3,
                             add=torch.zeros(cin, device=dev))
-        run = lambda: ops.conv3d_k3(x, cin, 0, wp, bp, cout, y, 0, stats, norm=norm, workspace=ws)  # noqa: E731
+        run = lambda: ops.conv3d_k3(x, cin, 0, wp, bp, cout, y, 0, stats, norm=norm, workspace=ws, tap_channel=tap)  # noqa: E731
         for _ in range(3):
             run()
         torch.cuda.synchronize()

@@ -12,6 +12,8 @@
 
 namespace dua {
 
+extern int g_conv_variant;
+
 namespace dc {
 constexpr int TM = 256, BN = 64, KG = 4;
 constexpr int VS = KG * 16 + 16;          // 80 B per voxel: conflict-free for 32 consecutive rows
@@ -137,22 +139,176 @@ __global__ __launch_bounds__(256) void deconv_k2s2_kernel(DeconvArgs a) {
   }
 }
 
-// All eight taps in one workgroup (large inputs): the 256-voxel input tile is staged once with its full channel
-// depth (the one-tap kernel above re-reads and re-normalises it for every tap), then the workgroup walks the taps:
-// weights of tap t+1 are prefetched while tap t multiplies, every tap ends with its own pixel-shuffle store.
+// Small inputs (<= 24^3: few voxels, many input channels): the kernel above gives a workgroup 256 voxels and walks the Cin
+// chunks one after the other between two barriers each -- at 6^3 that is 32 workgroups x 16 chunks of ~2 000 cycles of staging
+// and transform arithmetic around 8 MFMAs.  Here a workgroup owns 64 voxels x 64 output channels x one tap and its four
+// waves SPLIT the Cin chunks (wave w: chunks w, w + 4, ...): every wave requests all its chunks at once (at most MC = 4:
+// Cin <= 512), stages each in rows of its own (no workgroup barrier in the K loop; ds operations of one wave execute in
+// order), and the four partial tiles are added in a fixed order through LDS (deterministic) before the pixel-shuffle store.
+// Four times the workgroups, a quarter of the per-thread staging work, one memory round trip.
+namespace dcs {
+constexpr int TMS = 64, MC = 4;
+constexpr int STAGE = TMS * dc::VS + dc::W_BYTES;            // 5120 + 4096 per wave
+constexpr int RS = dc::BN * 4 + 16;                          // fp32 partial row: 272 B
+constexpr int RED = 4 * TMS * RS;                            // 69632: the staging rows live inside it
+}  // namespace dcs
+
 template <typename T>
-__global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) {
+__global__ __launch_bounds__(256, 2) void deconv_k2s2_ksplit_kernel(DeconvArgs a) {
   using namespace dc;
+  using namespace dcs;
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
   constexpr int CK = KG * EPG;
-  constexpr int OSQ = 32 * (int)sizeof(T) + 16;             // staging row: one 32-channel half
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xsc = (float*)(smem + RED);
+  float* xsh = xsc + a.nchunks * CK;
+  float* xad = xsh + a.nchunks * CK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const long vox = (long)a.D * a.H * a.W;
+  const long v0 = (long)blockIdx.x * TMS;
+  const int tap = blockIdx.y / a.nct, ct = blockIdx.y % a.nct, n = blockIdx.z;
+  const T* xin = (const T*)a.x + (long)n * vox * a.Cin_stride + a.Cin_off;
+  const char* wsrc = (const char*)a.w + ((long)tap * a.nct + ct) * a.nchunks * W_BYTES;
+  char* alds = smem + wave * STAGE;
+  char* wlds = alds + TMS * VS;
+  const int kg_t = lane & 3;
+  const bool fused = a.xf.stats != nullptr;
+
+  // every chunk of this wave is requested before anything waits
+  Frag pa[MC][4];
+  f32x4 pw[MC][4];
+#pragma unroll
+  for (int c = 0; c < MC; ++c) {
+    const int ch = wave + 4 * c;
+    const int c0 = ch * CK + kg_t * EPG;
+    const bool cok = ch < a.nchunks && c0 < a.Cin;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long v = v0 + (lane >> 2) + 16 * j;
+      pa[c][j] = *(const Frag*)(xin + (v < vox && cok ? v * a.Cin_stride + c0 : 0));
+      pw[c][j] = *(const f32x4*)(wsrc + (ch < a.nchunks ? (long)ch * W_BYTES + (lane + 64 * j) * 16 : 0));
+    }
+  }
+  if (fused) xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < MC; ++c) {
+    const int ch = wave + 4 * c;
+    if (ch >= a.nchunks) break;                              // wave-uniform
+    const int c0 = ch * CK + kg_t * EPG;
+    const bool cok = c0 < a.Cin;
+    float sc[EPG], sh[EPG], ad[EPG];
+    if (fused && cok) {
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int vl = (lane >> 2) + 16 * j;
+      const bool ok = v0 + vl < vox && cok;
+      Frag f = pa[c][j];
+      if (fused && cok) f = xform_frag<T>(f, sc, sh, ad, a.xf.slope);
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) f[e] = ok ? f[e] : (T)0.f;
+      *(Frag*)(alds + vl * VS + kg_t * 16) = f;
+      *(f32x4*)(wlds + (lane + 64 * j) * 16) = pw[c][j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ks = 0; ks < KG / 2; ++ks) {
+      const Frag a0 = *(const Frag*)(alds + r * VS + (2 * ks + hh) * 16);
+      const Frag a1 = *(const Frag*)(alds + (32 + r) * VS + (2 * ks + hh) * 16);
+      const Frag b0 = *(const Frag*)(wlds + ((2 * ks + hh) * BN + r) * 16);
+      const Frag b1 = *(const Frag*)(wlds + ((2 * ks + hh) * BN + 32 + r) * 16);
+      mma32(acc[0][0], a0, b0);
+      mma32(acc[0][1], a0, b1);
+      mma32(acc[1][0], a1, b0);
+      mma32(acc[1][1], a1, b1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __syncthreads();                                           // the partial tiles overwrite everybody's staging rows
+  float* red = (float*)(smem + wave * TMS * RS);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[(m * 32 + acc_row(i, hh)) * (RS / 4) + q * 32 + r] = acc[m][q][i];
+  __syncthreads();
+  // thread = (voxel row, 8 output channels): partials of waves 0..3 in that order, + bias, pixel-shuffle store
+  const int ti = tap >> 2, tj = (tap >> 1) & 1, tk = tap & 1;
+  const int H2 = 2 * a.H, W2 = 2 * a.W;
+  T* yout = (T*)a.y + (long)n * vox * 8 * a.Cout_stride + a.Cout_off + ct * BN;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = tid + 256 * it, vl = item >> 3, cg = item & 7;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* p = (const float*)(smem + w * TMS * RS) + vl * (RS / 4) + cg * 8;
+      const f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] += lo[e]; o[4 + e] += hi[e]; }
+    }
+    const long v = v0 + vl;
+    if (v < vox && ct * BN + cg * 8 < a.Cout) {
+      const int w = (int)(v % a.W); const long t = v / a.W;
+      const int h = (int)(t % a.H), d = (int)(t / a.H);
+      const long ov = ((long)(2 * d + ti) * H2 + (2 * h + tj)) * W2 + (2 * w + tk);
+      T* dst = yout + ov * a.Cout_stride + cg * 8;
+      if constexpr (sizeof(T) == 2) {
+        Frag f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (T)(o[e] + a.bias[ct * BN + cg * 8 + e]);
+        *(Frag*)dst = f;
+      } else {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          Frag f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = (T)(o[4 * g + e] + a.bias[ct * BN + cg * 8 + 4 * g + e]);
+          *(Frag*)(dst + 4 * g) = f;
+        }
+      }
+    }
+  }
+}
+
+// All eight taps in one workgroup (large inputs): the 256-voxel input tile is staged once with its full channel
+// depth (the one-tap kernel above re-reads and re-normalises it for every tap), then the workgroup walks the taps:
+// weights of tap t+1 are prefetched while tap t multiplies, every tap ends with its own pixel-shuffle store.
+template <typename T, int MBLK>
+__global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) {
+  using namespace dc;
+  constexpr int TM = 64 * MBLK * 2, WR = 32 * MBLK;          // voxels per workgroup / per wave (MBLK 32-row MFMA blocks each)
+  using Frag = typename Elem<T>::Frag;
+  constexpr int EPG = Elem<T>::EPG;
+  constexpr int CK = KG * EPG;
+  constexpr int RB = 32 * (int)sizeof(T) + 16;              // staging row: one 32-channel half
+  constexpr int GPV = 32 / EPG, VPI = 64 / GPV, NST = WR / VPI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int VSA = a.nchunks * 64 + 16;                      // bytes per staged voxel (odd multiple of 16: conflict-free)
   char* alds = smem;
   char* wlds = alds + TM * VSA;                             // 2 x nchunks x 4 KB
-  char* stg = wlds + 2 * a.nchunks * W_BYTES;               // 256 x OSQ
-  float* xsc = (float*)(stg + TM * OSQ);
+  char* stg = wlds + 2 * a.nchunks * W_BYTES;               // TM x RB
+  float* xsc = (float*)(stg + TM * RB);
   float* xsh = xsc + a.nchunks * CK;
   float* xad = xsh + a.nchunks * CK;
 
@@ -165,12 +321,30 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
   const char* wsrc = (const char*)a.w + (long)ct * wtap;    // tap t: + t * nct * wtap
   const int kg_t = tid & 3;
 
+  // ---- the whole input tile (every chunk: nchunks <= 4) and the weights of tap 0 are requested before anything waits:
+  // one memory round trip in front of the first MFMA instead of one per chunk plus the statistics preamble's ----
+  constexpr int MCH = 4;
+  Frag f[MCH][TM / 64];
+#pragma unroll
+  for (int ch = 0; ch < MCH; ++ch) {
+    const int c0 = ch * CK + kg_t * EPG;
+    const bool cok = ch < a.nchunks && c0 < a.Cin;
+#pragma unroll
+    for (int j = 0; j < TM / 64; ++j) {
+      const long v = v0 + (tid >> 2) + 64 * j;
+      f[ch][j] = *(const Frag*)(xin + (v < vox && cok ? v * a.Cin_stride + c0 : 0));
+    }
+  }
+  f32x4 w0[MCH];
+#pragma unroll
+  for (int j = 0; j < MCH; ++j) w0[j] = *(const f32x4*)(wsrc + (j < a.nchunks ? (tid + 256 * j) * 16 : 0));
   if (a.xf.stats != nullptr) {
     xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
     __syncthreads();
   }
-  // ---- stage the input tile, every chunk ----
-  for (int ch = 0; ch < a.nchunks; ++ch) {
+#pragma unroll
+  for (int ch = 0; ch < MCH; ++ch) {
+    if (ch >= a.nchunks) break;
     const int c0 = ch * CK + kg_t * EPG;
     const bool cok = c0 < a.Cin;
     const bool xf = a.xf.stats != nullptr && cok;
@@ -179,84 +353,82 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
 #pragma unroll
       for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
     }
-    Frag f[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long v = v0 + (tid >> 2) + 64 * j;
-      f[j] = *(const Frag*)(xin + (v < vox && cok ? v * a.Cin_stride + c0 : 0));
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TM / 64; ++j) {
       const int vl = (tid >> 2) + 64 * j;
       const bool ok = v0 + vl < vox && cok;
-      Frag g = f[j];
+      Frag g = f[ch][j];
       if (xf) g = xform_frag<T>(g, sc, sh, ad, a.xf.slope);
 #pragma unroll
       for (int e = 0; e < EPG; ++e) g[e] = ok ? g[e] : (T)0.f;
       *(Frag*)(alds + vl * VSA + ch * 64 + kg_t * 16) = g;
     }
   }
-  // weights of tap 0
-  for (int i = tid; i < wtap / 16; i += 256) *(f32x4*)(wlds + i * 16) = *(const f32x4*)(wsrc + i * 16);
+#pragma unroll
+  for (int j = 0; j < MCH; ++j)
+    if (j < a.nchunks) *(f32x4*)(wlds + (tid + 256 * j) * 16) = w0[j];
   __syncthreads();
 
   const int H2 = 2 * a.H, W2 = 2 * a.W;
   T* yout = (T*)a.y + (long)n * vox * 8 * a.Cout_stride + a.Cout_off + ct * BN;
   const float bq0 = a.bias[ct * BN + r], bq1 = a.bias[ct * BN + 32 + r];
-  char* ot = stg + wave * 64 * OSQ;
+  char* ot = stg + wave * WR * RB;
+  int ovb[NST];                                             // output voxel of tap (0, 0, 0) for this lane's staged rows, or -1
+#pragma unroll
+  for (int it = 0; it < NST; ++it) {
+    const long v = v0 + wave * WR + it * VPI + lane / GPV;
+    const int vi = (int)(v < vox ? v : 0);
+    const int w = vi % a.W, t = vi / a.W, h = t % a.H, d = t / a.H;
+    ovb[it] = v < vox ? ((2 * d) * H2 + 2 * h) * W2 + 2 * w : -1;
+  }
   for (int tap = 0; tap < 8; ++tap) {
-    // prefetch the next tap's weights into registers (at most nchunks <= 8 pieces per thread)
-    f32x4 wn[8];
+    // prefetch the next tap's weights into registers (nchunks <= 4 pieces per thread)
+    f32x4 wn[MCH];
     const char* wnext = wsrc + (long)(tap + 1) * a.nct * wtap;
     if (tap < 7) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < MCH; ++j)
         if (j < a.nchunks) wn[j] = *(const f32x4*)(wnext + (tid + 256 * j) * 16);
     }
-    f32x16 acc[2][2];
+    f32x16 acc[MBLK][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MBLK; ++m)
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc[m][0][i] = bq0; acc[m][1][i] = bq1; }
     const char* wb = wlds + (tap & 1) * wtap;
     for (int ch = 0; ch < a.nchunks; ++ch) {
 #pragma unroll
       for (int ks = 0; ks < KG / 2; ++ks) {
-        const Frag a0 = *(const Frag*)(alds + (wave * 64 + r) * VSA + ch * 64 + (2 * ks + hh) * 16);
-        const Frag a1 = *(const Frag*)(alds + (wave * 64 + 32 + r) * VSA + ch * 64 + (2 * ks + hh) * 16);
         const Frag b0 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + r) * 16);
         const Frag b1 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + 32 + r) * 16);
-        mma32(acc[0][0], a0, b0);
-        mma32(acc[0][1], a0, b1);
-        mma32(acc[1][0], a1, b0);
-        mma32(acc[1][1], a1, b1);
+#pragma unroll
+        for (int m = 0; m < MBLK; ++m) {
+          const Frag am = *(const Frag*)(alds + (wave * WR + m * 32 + r) * VSA + ch * 64 + (2 * ks + hh) * 16);
+          mma32(acc[m][0], am, b0);
+          mma32(acc[m][1], am, b1);
+        }
       }
     }
     if (tap < 7) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < MCH; ++j)
         if (j < a.nchunks) *(f32x4*)(wlds + ((tap + 1) & 1) * wtap + (tid + 256 * j) * 16) = wn[j];
     }
-    // pixel-shuffle store of this tap, one 32-channel half at a time through the wave's own staging rows
-    const int ti = tap >> 2, tj = (tap >> 1) & 1, tk = tap & 1;
+    // pixel-shuffle store of this tap, one 32-channel half at a time through the wave's own staging rows (whole 128-byte
+    // lines per instruction were measured too: the 16 KB staging tile leaves one workgroup per CU, 69 -> 102 us)
+    const int toff = ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MBLK; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) *(T*)(ot + (m * 32 + acc_row(i, hh)) * OSQ + r * (int)sizeof(T)) = (T)acc[m][q][i];
+        for (int i = 0; i < 16; ++i) *(T*)(ot + (m * 32 + acc_row(i, hh)) * RB + r * (int)sizeof(T)) = (T)acc[m][q][i];
       __builtin_amdgcn_wave_barrier();
-      constexpr int GPV = 32 / EPG, VPI = 64 / GPV;
 #pragma unroll
-      for (int it = 0; it < 64 / VPI; ++it) {
+      for (int it = 0; it < NST; ++it) {
         const int vl = it * VPI + lane / GPV, cg = lane % GPV;
-        const long v = v0 + wave * 64 + vl;
-        if (v < vox && ct * BN + q * 32 + cg * EPG < a.Cout) {
-          const int w = (int)(v % a.W); const long t = v / a.W;
-          const int h = (int)(t % a.H), d = (int)(t / a.H);
-          const long ov = ((long)(2 * d + ti) * H2 + (2 * h + tj)) * W2 + (2 * w + tk);
-          *(Frag*)(yout + ov * a.Cout_stride + q * 32 + cg * EPG) = *(const Frag*)(ot + vl * OSQ + cg * 16);
-        }
+        if (ovb[it] >= 0 && ct * BN + q * 32 + cg * EPG < a.Cout)
+          *(Frag*)(yout + (long)(ovb[it] + toff) * a.Cout_stride + q * 32 + cg * EPG) = *(const Frag*)(ot + vl * RB + cg * 16);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -278,18 +450,39 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   a.nct = (d->Cout + dc::BN - 1) / dc::BN;
   const long vox = (long)d->D * d->H * d->W;
   if (vox >= 256L * 128 && a.nchunks <= 4) {          // enough tiles to fill the chip with one workgroup per 8 taps
-    const int lds = dc::TM * (a.nchunks * 64 + 16) + 2 * a.nchunks * dc::W_BYTES + dc::TM * (32 * (int)sizeof(T) + 16) +
+    // 128-voxel tiles: two workgroups per CU (77 KB each at 128 channels), one's pixel-shuffle stores under the other's loads;
+    // variant 6 keeps the 256-voxel form (one workgroup per CU) for A/B
+    const int mblk = g_conv_variant == 6 ? 2 : 1;
+    const int tm = 128 * mblk;
+    const int lds = tm * (a.nchunks * 64 + 16) + 2 * a.nchunks * dc::W_BYTES + tm * (32 * (int)sizeof(T) + 16) +
                     (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0);
     static PerDeviceOnce once2;
     bool* attr2 = once2.flag();
     if (!attr2) return DUA_ERR_ARG;
     if (!*attr2) {
-      hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_alltaps_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_alltaps_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)deconv_k2s2_alltaps_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
       *attr2 = true;
     }
-    dim3 grid2((unsigned)((vox + dc::TM - 1) / dc::TM), a.nct, d->N);
-    hipLaunchKernelGGL(deconv_k2s2_alltaps_kernel<T>, grid2, dim3(256), lds, s, a);
+    dim3 grid2((unsigned)((vox + tm - 1) / tm), a.nct, d->N);
+    if (mblk == 2) hipLaunchKernelGGL((deconv_k2s2_alltaps_kernel<T, 2>), grid2, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((deconv_k2s2_alltaps_kernel<T, 1>), grid2, dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+  }
+  if (a.nchunks >= 8 && a.nchunks <= 4 * dcs::MC && g_conv_variant != 6) {   // Cin >= 256: waves split the Cin chunks (variant 6: the one-chunk-at-a-time kernel, A/B)
+    const int lds = dcs::RED + (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0);
+    static PerDeviceOnce once3;
+    bool* attr3 = once3.flag();
+    if (!attr3) return DUA_ERR_ARG;
+    if (!*attr3) {
+      hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_ksplit_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, dcs::RED + 3 * 4 * 1024);
+      if (e != hipSuccess) return (int)e;
+      *attr3 = true;
+    }
+    dim3 grid3((unsigned)((vox + dcs::TMS - 1) / dcs::TMS), 8 * a.nct, d->N);
+    hipLaunchKernelGGL(deconv_k2s2_ksplit_kernel<T>, grid3, dim3(256), lds, s, a);
     return (int)hipGetLastError();
   }
   dim3 grid((unsigned)((vox + dc::TM - 1) / dc::TM), 8 * a.nct, d->N);

@@ -104,6 +104,7 @@ _P = C.c_void_p
 _SIGS = {
     "dua_set_option": (C.c_int, [C.c_int, C.c_int]),
     "dua_mfma_probe": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
+    "dua_chain_probe": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P]),
     "dua_deconv_k2s2_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P]),
     "dua_q_sample": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P]),
     "dua_sampler_step": (C.c_int, [C.c_int, C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, _P]),

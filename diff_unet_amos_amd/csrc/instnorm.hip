@@ -22,7 +22,7 @@ __global__ void instnorm_finalize_kernel(InXform xf, int C, float* scale, float*
 }
 
 // One thread = one 16-byte channel group of one OUTPUT voxel (pooled: of one 2x2x2 block).
-template <typename T, bool POOL>
+template <typename T, bool POOL, bool EMB>
 __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ raw, int C, int raw_stride,
                                                           InXform xf,
                                                           const T* __restrict__ emb, int emb_stride, T* __restrict__ out,
@@ -59,12 +59,12 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
       Frag x = *(const Frag*)(raw + gv * raw_stride + cg * EPG);
       Frag o;
       Frag ev;
-      if (emb) ev = *(const Frag*)(emb + gv * emb_stride + cg * EPG);
+      if constexpr (EMB) ev = *(const Frag*)(emb + gv * emb_stride + cg * EPG);
 #pragma unroll
       for (int e = 0; e < EPG; ++e) {
         float y = fmaf((float)x[e], sc[e], sh[e]);
         y = (y > 0.f ? y : y * slope) + ad[e];
-        if (emb) y += (float)ev[e];
+        if constexpr (EMB) y += (float)ev[e];
         o[e] = (T)y;
       }
       *(Frag*)(out + gv * out_stride + out_off + cg * EPG) = o;
@@ -75,23 +75,33 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
       float mx[EPG];
 #pragma unroll
       for (int e = 0; e < EPG; ++e) mx[e] = -INFINITY;
+      // all eight voxels of the block are requested before the first is used (with the embedding test inside the loop hipcc
+      // kept the voxels in order, load - wait - store eight times over: the small levels were eight dependent round trips)
+      long gvk[8];
+      Frag xk[8], evk[EMB ? 8 : 1];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int d = 2 * pd + (k >> 2), h = 2 * ph + ((k >> 1) & 1), w = 2 * pw + (k & 1);
-        const long gv = n * vox_n + ((long)d * H + h) * W + w;
-        Frag x = *(const Frag*)(raw + gv * raw_stride + cg * EPG);
-        Frag ev;
-        if (emb) ev = *(const Frag*)(emb + gv * emb_stride + cg * EPG);
+        gvk[k] = n * vox_n + ((long)d * H + h) * W + w;
+        xk[k] = *(const Frag*)(raw + gvk[k] * raw_stride + cg * EPG);
+      }
+      if constexpr (EMB) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) evk[k] = *(const Frag*)(emb + gvk[k] * emb_stride + cg * EPG);
+      }
+      __builtin_amdgcn_sched_barrier(0);       // keep every request in front of the first use
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
         Frag o;
 #pragma unroll
         for (int e = 0; e < EPG; ++e) {
-          float y = fmaf((float)x[e], sc[e], sh[e]);
+          float y = fmaf((float)xk[k][e], sc[e], sh[e]);
           y = (y > 0.f ? y : y * slope) + ad[e];
-          if (emb) y += (float)ev[e];
+          if constexpr (EMB) y += (float)evk[k][e];
           o[e] = (T)y;
           mx[e] = fmaxf(mx[e], (float)o[e]);
         }
-        *(Frag*)(out + gv * out_stride + out_off + cg * EPG) = o;
+        *(Frag*)(out + gvk[k] * out_stride + out_off + cg * EPG) = o;
       }
       Frag po;
 #pragma unroll
@@ -114,14 +124,12 @@ static int launch_materialize(const dua_materialize_desc* d, const void* raw, co
   dim3 grid((unsigned)blocks, d->N);
   const InXform xf = make_xform(in, d->C);
   const size_t lds = 3 * sizeof(float) * d->C;
-  if (pool)
-    hipLaunchKernelGGL((materialize_kernel<T, true>), grid, dim3(256), lds, s, (const T*)raw, d->C, d->raw_stride, xf,
-                       (const T*)emb, d->emb_stride, (T*)out, d->out_stride, d->out_off, (T*)pooled,
-                       d->pool_stride, d->D, d->H, d->W, total);
-  else
-    hipLaunchKernelGGL((materialize_kernel<T, false>), grid, dim3(256), lds, s, (const T*)raw, d->C, d->raw_stride, xf,
-                       (const T*)emb, d->emb_stride, (T*)out, d->out_stride, d->out_off, (T*)nullptr,
-                       0, d->D, d->H, d->W, total);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)raw, d->C, d->raw_stride, xf, (const T*)emb, d->emb_stride,
+                       (T*)out, d->out_stride, d->out_off, (T*)pooled, pool ? d->pool_stride : 0, d->D, d->H, d->W, total);
+  };
+  if (pool) { if (emb) go(materialize_kernel<T, true, true>); else go(materialize_kernel<T, true, false>); }
+  else { if (emb) go(materialize_kernel<T, false, true>); else go(materialize_kernel<T, false, false>); }
   return (int)hipGetLastError();
 }
 

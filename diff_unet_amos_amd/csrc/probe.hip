@@ -52,7 +52,42 @@ __global__ __launch_bounds__(256, 1) void mfma_probe_kernel(int iters, float* si
   if (v == 123.456f) sink[0] = v;                      // keeps the loop alive; practically never taken
 }
 
+// The floor of one launch of a normalise -> compute -> accumulate-statistics chain (what every layer of the <= 24^3 levels
+// is): mode 0 = an empty kernel; 1 = one dependent global round trip (load, +1, store) per thread; 2 = 1 and the launch
+// ends like a convolution does (workgroup reduction, one 64-bit system-scope atomic per channel lane of wave 0); 3 = 2 behind
+// a read of the words the PREVIOUS launch's atomics wrote (the statistics preamble: a second dependent round trip, on lines
+// that the atomics left outside L2).  tools/ubench_chain.py replays a graph of 24 such launches.
+__global__ __launch_bounds__(256) void chain_probe_kernel(int mode, const float* in, float* out, unsigned long long* words) {
+  if (mode == 0) return;
+  __shared__ float red[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float scale = 1.f;
+  if (mode == 3) {
+    const unsigned long long w = words[threadIdx.x & 63];
+    scale = w == 0x7fffffffffffffffull ? 2.f : 1.f;            // depends on the loaded word; practically always 1
+  }
+  const float v = in[i] * scale + 1.f;
+  out[i] = v;
+  if (mode >= 2) {
+    float s = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const float t = red[0] + red[1] + red[2] + red[3];
+      __hip_atomic_fetch_add(words + threadIdx.x, (unsigned long long)(long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 }  // namespace dua
+
+extern "C" int dua_chain_probe(int mode, int workgroups, const float* in, float* out, unsigned long long* words, void* stream) {
+  if (mode < 0 || mode > 3 || workgroups <= 0 || !in || !out || !words) return DUA_ERR_ARG;
+  hipLaunchKernelGGL(dua::chain_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, mode, in, out, words);
+  return (int)hipGetLastError();
+}
 
 // `workgroups` x 4 waves each issue iters * 16 MFMAs of 32 x 32 x 16 (32 768 FLOP each).  stamps (or NULL): 2 words per
 // workgroup = (shader cycles, 100 MHz ticks) spent in the loop.

@@ -169,6 +169,11 @@ int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, 
  * 2 words per workgroup = (s_memtime cycles, s_memrealtime 100 MHz ticks) spent in the loop.  sink: any device float. */
 int dua_mfma_probe(int workgroups, int iters, float* sink, unsigned long long* stamps, void* stream);
 
+/* Measurement aid (tools/ubench_chain.py): one launch of a normalise -> compute -> accumulate-statistics chain reduced to
+ * its dependent memory round trips.  mode 0 empty, 1 load/store, 2 + workgroup reduction and 64 system-scope atomics,
+ * 3 + a read of the words the previous launch's atomics wrote.  in/out: workgroups * 256 floats; words: 64 x 8 bytes. */
+int dua_chain_probe(int mode, int workgroups, const float* in, float* out, unsigned long long* words, void* stream);
+
 /* Tuning/diagnostic switch: key 1 = conv3d_k3 launch shape (0 automatic policy, 2 = 4x8x8 tiles without split-K,
  * 3 = 2x8x8 tiles, 6 = the automatic policy without the kd-plane / LDS-DMA form of the small layers);
  * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid);

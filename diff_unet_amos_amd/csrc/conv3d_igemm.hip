@@ -913,7 +913,7 @@ static int ensure_lds_attr() {
                               c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD);
   }
   if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)conv3d_k3_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c3f::LDS_F + 2048);
+    e = hipFuncSetAttribute((const void*)conv3d_k3_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c3f::LDS_F + 2048 + PARTIAL_LDS_PAD);
   if (e == hipSuccess) {
     int cus = 0;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -962,13 +962,14 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     else {
       if (a.nchunks != 1 || (in && in->stats) || (a.tap_ch != 0 && a.tap_ch != 16) || d->Cin != a.tap_ch + 8) return DUA_ERR_ARG;
       dim3 grid(a.ntiles, nct, d->N);
-      if (a.tap_ch == 16 && g_conv_variant == 0 && bg_pad == 0) {
-        // resident-weight form: two persistent workgroups per CU walk the (sample, tile) items
+      if (a.tap_ch == 16 && g_conv_variant == 0) {
+        // resident-weight form: two persistent workgroups per CU walk the (sample, tile) items; a background launch takes one
+        // per CU (and the LDS pad that keeps a second one off the CU)
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || g_cus[dev] <= 0) return DUA_ERR_ARG;
         const int items = a.ntiles * d->N;
-        const int wgs = std::max(1, 2 * g_cus[dev] / nct);
-        hipLaunchKernelGGL(conv3d_k3_first_kernel, dim3(std::min(items, wgs), nct, 1), dim3(256), c3f::LDS_F + 2048, s, a, items);
+        const int wgs = std::max(1, (bg_pad ? 1 : 2) * g_cus[dev] / nct);
+        hipLaunchKernelGGL(conv3d_k3_first_kernel, dim3(std::min(items, wgs), nct, 1), dim3(256), c3f::LDS_F + 2048 + bg_pad, s, a, items);
         return (int)hipGetLastError();
       }
       if (a.tap_ch == 16) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 1>), grid, dim3(256), c3v2::LDS_MAIN + 4096 + bg_pad, s, a);

@@ -191,12 +191,15 @@ class SwinPlan:
         self.tables = {}
 
     # ---- parameter binding -------------------------------------------------------------------
-    def _res(self, name, block, level, cin_packed=None, perm=None):
+    def _res(self, name, block, level, cin_packed=None, perm=None, tap=None):
         r = _Res()
         r.name, r.block, r.level = name, block, level
         r.cout, r.cin = block.conv1.conv.weight.shape[:2]
         r.cin_packed = cin_packed or r.cin
         r.perm = perm
+        # single-channel tap form of the denoiser's first convolution (fp16, 16 ordinary channels in front of the image channel:
+        # ops.conv3d_k3 / the resident-weight kernel of conv3d_igemm.hip), as engine.py uses it for DiffUNet
+        r.tap = tap if (tap == 16 and self.dtype == torch.float16 and r.cin_packed == tap + 8) else None
         r.has3 = hasattr(block, "conv3")
         r.t_off = None
         return r
@@ -205,7 +208,7 @@ class SwinPlan:
         enc, den = self.net.embed_model, self.net.model
         self.e_res = [self._res("e1", enc.encoder1.layer, 0, cin_packed=8), self._res("e2", enc.encoder2.layer, 1),
                       self._res("e3", enc.encoder3.layer, 2), self._res("e4", enc.encoder4.layer, 3)]
-        self.d_res = [self._res("d1", den.encoder1.layer, 0, cin_packed=self.cin0, perm=self.perm0),
+        self.d_res = [self._res("d1", den.encoder1.layer, 0, cin_packed=self.cin0, perm=self.perm0, tap=self.C),
                       self._res("d2", den.encoder2.layer, 1),
                       self._res("d3", den.encoder3.layer, 2), self._res("d4", den.encoder4.layer, 3),
                       self._res("d10", den.encoder10.layer, 5)]
@@ -273,7 +276,8 @@ class SwinPlan:
             for r in self.e_res + self.d_res + self.u_res:
                 b = r.block
                 r.w1, r.b1 = ops.pack_conv3_weights(b.conv1.conv.weight.detach().float().contiguous(), None, dt,
-                                                    cin_packed=r.cin_packed if r.cin_packed != r.cin else None, perm=r.perm)
+                                                    cin_packed=r.cin_packed if r.cin_packed != r.cin else None, perm=r.perm,
+                                                    tap_channel=r.tap)
                 r.w2, r.b2 = ops.pack_conv3_weights(b.conv2.conv.weight.detach().float().contiguous(), None, dt)
                 if r.has3:
                     w3 = torch.zeros((r.cout, r.cin_packed), dtype=dt, device=dev)
@@ -334,7 +338,7 @@ class SwinPlan:
                        ops.Norm(r.st[2], r.ones, r.zeros, count, slope=SLOPE, eps=EPS))
         n1, n2, n3 = r.norms
         bg = side and self.two_streams and self.background_convs
-        ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws, background=bg)
+        ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws, background=bg, tap_channel=r.tap)
         ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=ws, background=bg)
         assert r.has3 or not defer
         if r.has3:

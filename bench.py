@@ -77,6 +77,7 @@ def conv3_flops(plan):
 
 
 _LAST_CONV_CALLS = []
+_CONV_VARIANT = 0          # --conv-variant (dua_set_option(1, v)): 0 = the shipped launch policy
 
 
 def time_conv_launches(plan, reps):
@@ -124,20 +125,32 @@ def conv_roofline(plan, dtype_flag, reps=20):
     """roofline object for the 3x3x3 convolution kernel over one denoiser evaluation of `plan` (HIP events, see
     time_conv_launches); FLOPs are algorithmic (2 * Cin * Cout * 27 * voxels * batch)."""
     fl = conv3_flops(plan)
-    avg_ms, per_step, by_launch = time_conv_launches(plan, reps)
+    _, per_step, by_launch = time_conv_launches(plan, reps)
     assert per_step == len(fl)
-    flops_per_launch = sum(fl) / len(fl)
+    # The first layer (16 noisy-label channels + image -> features[0], fp16) runs in a kernel of its own since round 3
+    # (conv3d_k3_first_kernel: resident weights, persistent workgroups); the roofline object describes the kernel the other
+    # launches share, so that its average agrees with the per-kernel line of the rocprofv3 summary.
+    own_first = (dtype_flag == "f16" and _LAST_CONV_CALLS and _LAST_CONV_CALLS[0][1].get("tap_channel") == 16
+                 and _CONV_VARIANT == 0 and os.environ.get("DUA_CONV_VARIANT", "0") in ("", "0"))
+    k0 = 1 if own_first else 0
+    flk, msk = fl[k0:], by_launch[k0:]
+    avg_ms = sum(msk) / len(msk)
+    flops_per_launch = sum(flk) / len(flk)
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
     peak = PEAK_F16_TFLOPS if dtype_flag == "f16" else PEAK_F32_TFLOPS
-    return {"bound": "mfma", "kernel": CONV_KERNEL, "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-            "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4),
-            "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 2),
-            "conv_ms_per_step": round(avg_ms * per_step, 3),
-            "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
-            "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
-            "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3",
-                               "tflops": round(max(fl) / (by_launch[fl.index(max(fl))] * 1e-3) / 1e12, 2)}}
+    out = {"bound": "mfma", "kernel": CONV_KERNEL, "achieved": round(achieved, 2), "peak": peak,
+           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+           "launches_per_step": len(flk), "avg_launch_ms": round(avg_ms, 4),
+           "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 2),
+           "conv_ms_per_step": round(sum(by_launch), 3),
+           "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
+           "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
+           "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3",
+                              "tflops": round(max(fl) / (by_launch[fl.index(max(fl))] * 1e-3) / 1e12, 2)}}
+    if own_first:
+        out["first_layer"] = {"kernel": "conv3d_k3_first_kernel", "us": round(by_launch[0] * 1e3, 1),
+                              "tflops": round(fl[0] / (by_launch[0] * 1e-3) / 1e12, 1)}
+    return out
 
 
 def mfma_ceiling(dev, seconds=2.0):
@@ -678,6 +691,8 @@ def main():
     D = Dist(args)
     if args.conv_variant:
         from diff_unet_amos_amd import _native as nv
+        global _CONV_VARIANT
+        _CONV_VARIANT = args.conv_variant
         nv.check(nv.lib().dua_set_option(1, args.conv_variant), "dua_set_option")
     {2: run_config2, 3: run_config3, 4: run_config4, 5: run_config5}[args.config](args, D)
     D.finish()

@@ -237,16 +237,57 @@ __device__ __forceinline__ void stats_add(stat_t* stats, int n, int c_pad, int r
   __hip_atomic_fetch_add(p + 3L * c_pad, (unsigned long long)(long long)rint((Q - Qi) * STAT_FRAC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The transform of one 16-byte fragment.  fp32 operands: the arithmetic as written above.  fp16 operands: LeakyReLU(t) + add =
+// max(t + add, slope * t + add) for 0 <= slope <= 1, so with the four per-channel constants xform_prep derives
+//   (sc, sh + add) and (slope * sc, slope * sh + add)
+// an element is two v_fma_mix (fp16 source, fp32 arithmetic, ONE rounding into the fp16 result half) and half a v_pk_max_f16
+// (rounding is monotonic: the maximum of the two rounded values is the rounded maximum) -- 2.5 instructions per element where
+// the convert / fma / compare / select / add / convert sequence hipcc emits for the plain form is ~9.
 template <typename T>
-__device__ __forceinline__ typename Elem<T>::Frag xform_frag(typename Elem<T>::Frag v, const float* sc,
-                                                               const float* sh, const float* ad, float slope) {
+__device__ __forceinline__ void xform_prep(float* sc, float* sh, float* ad, float* sn, float slope) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int e = 0; e < Elem<T>::EPG; ++e) {
+      sn[e] = slope * sc[e];
+      const float b = sh[e] + ad[e];
+      ad[e] = fmaf(slope, sh[e], ad[e]);
+      sh[e] = b;
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned xform_pair_mix(unsigned x, float a0, float b0, float an0, float bn0, float a1, float b1,
+                                                   float an1, float bn1) {
+  unsigned p, n, r;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(p) : "v"(x), "v"(a0), "v"(b0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p) : "v"(x), "v"(a1), "v"(b1));
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(n) : "v"(x), "v"(an0), "v"(bn0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(n) : "v"(x), "v"(an1), "v"(bn1));
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(n));
+  return r;
+}
+
+// sc / sh / ad / sn as xform_prep<T> left them
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::Frag xform_frag(typename Elem<T>::Frag v, const float* sc, const float* sh,
+                                                               const float* ad, const float* sn, float slope) {
   constexpr int E = Elem<T>::EPG;
   typename Elem<T>::Frag o;
+  if constexpr (sizeof(T) == 2) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 x = __builtin_bit_cast(u32x4, v);
+    u32x4 y;
 #pragma unroll
-  for (int j = 0; j < E; ++j) {
-    float y = fmaf((float)v[j], sc[j], sh[j]);
-    y = y > 0.f ? y : y * slope;
-    o[j] = (T)(y + ad[j]);
+    for (int j = 0; j < 4; ++j)
+      y[j] = xform_pair_mix(x[j], sc[2 * j], sh[2 * j], sn[2 * j], ad[2 * j], sc[2 * j + 1], sh[2 * j + 1], sn[2 * j + 1], ad[2 * j + 1]);
+    o = __builtin_bit_cast(typename Elem<T>::Frag, y);
+  } else {
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      float y = fmaf((float)v[j], sc[j], sh[j]);
+      y = y > 0.f ? y : y * slope;
+      o[j] = (T)(y + ad[j]);
+    }
   }
   return o;
 }

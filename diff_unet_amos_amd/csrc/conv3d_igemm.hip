@@ -176,12 +176,13 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Arg
   auto store_halo = [&](int ch) {
     const int c0 = ch * CK + kg_t * EPG;
     if (fused && c0 < a.Cin) {
-      float sc[EPG], sh[EPG], ad[EPG];
+      float sc[EPG], sh[EPG], ad[EPG], sn[EPG];
 #pragma unroll
       for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+      xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
 #pragma unroll
       for (int j = 0; j < NIT; ++j)
-        if (goff[j] >= 0) hv_[j] = xform_frag<T>(hv_[j], sc, sh, ad, a.xf.slope);
+        if (goff[j] >= 0) hv_[j] = xform_frag<T>(hv_[j], sc, sh, ad, sn, a.xf.slope);
     }
 #pragma unroll
     for (int j = 0; j < NIT; ++j)
@@ -199,17 +200,18 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Arg
   auto store_halo = [&](int ch) {
     const int c0 = ch * CK + kg_t * EPG;
     const bool cok = c0 < a.Cin;
-    float sc[EPG], sh[EPG], ad[EPG];
+    float sc[EPG], sh[EPG], ad[EPG], sn[EPG];
 #pragma unroll
     for (int e = 0; e < EPG; ++e) { sc[e] = 1.f; sh[e] = 0.f; ad[e] = 0.f; }
     if (fused && cok) {
 #pragma unroll
       for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
     }
+    xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
       Frag v = hv_[j];
-      if (fused) v = xform_frag<T>(v, sc, sh, ad, a.xf.slope);
+      if (fused) v = xform_frag<T>(v, sc, sh, ad, sn, a.xf.slope);
       const bool ok = goff[j] >= 0 && cok;
 #pragma unroll
       for (int e = 0; e < EPG; ++e) v[e] = ok ? v[e] : (T)0.f;

@@ -82,16 +82,17 @@ __global__ __launch_bounds__(256) void deconv_k2s2_kernel(DeconvArgs a) {
     __syncthreads();
     const int c0 = ch * CK + kg_t * EPG;
     const bool xf = a.xf.stats != nullptr && c0 < a.Cin;
-    float sc[EPG], sh[EPG], ad[EPG];
+    float sc[EPG], sh[EPG], ad[EPG], sn[EPG];
     if (xf) {
 #pragma unroll
       for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+      xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int vl = (tid >> 2) + 64 * j;
       Frag f = pa[j];
-      if (xf && v0 + vl < vox) f = xform_frag<T>(f, sc, sh, ad, a.xf.slope);
+      if (xf && v0 + vl < vox) f = xform_frag<T>(f, sc, sh, ad, sn, a.xf.slope);
       *(Frag*)(alds + vl * VS + kg_t * 16) = f;
     }
     *(f32x4*)(wlds + tid * 16) = pw;
@@ -207,17 +208,18 @@ __global__ __launch_bounds__(256, 2) void deconv_k2s2_ksplit_kernel(DeconvArgs a
     if (ch >= a.nchunks) break;                              // wave-uniform
     const int c0 = ch * CK + kg_t * EPG;
     const bool cok = c0 < a.Cin;
-    float sc[EPG], sh[EPG], ad[EPG];
+    float sc[EPG], sh[EPG], ad[EPG], sn[EPG];
     if (fused && cok) {
 #pragma unroll
       for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+      xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int vl = (lane >> 2) + 16 * j;
       const bool ok = v0 + vl < vox && cok;
       Frag f = pa[c][j];
-      if (fused && cok) f = xform_frag<T>(f, sc, sh, ad, a.xf.slope);
+      if (fused && cok) f = xform_frag<T>(f, sc, sh, ad, sn, a.xf.slope);
 #pragma unroll
       for (int e = 0; e < EPG; ++e) f[e] = ok ? f[e] : (T)0.f;
       *(Frag*)(alds + vl * VS + kg_t * 16) = f;
@@ -348,17 +350,18 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
     const int c0 = ch * CK + kg_t * EPG;
     const bool cok = c0 < a.Cin;
     const bool xf = a.xf.stats != nullptr && cok;
-    float sc[EPG], sh[EPG], ad[EPG];
+    float sc[EPG], sh[EPG], ad[EPG], sn[EPG];
     if (xf) {
 #pragma unroll
       for (int e = 0; e < EPG; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+      xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
     }
 #pragma unroll
     for (int j = 0; j < TM / 64; ++j) {
       const int vl = (tid >> 2) + 64 * j;
       const bool ok = v0 + vl < vox && cok;
       Frag g = f[ch][j];
-      if (xf) g = xform_frag<T>(g, sc, sh, ad, a.xf.slope);
+      if (xf) g = xform_frag<T>(g, sc, sh, ad, sn, a.xf.slope);
 #pragma unroll
       for (int e = 0; e < EPG; ++e) g[e] = ok ? g[e] : (T)0.f;
       *(Frag*)(alds + vl * VSA + ch * 64 + kg_t * 16) = g;

@@ -256,14 +256,23 @@ __device__ __forceinline__ void xform_prep(float* sc, float* sh, float* ad, floa
   }
 }
 
-__device__ __forceinline__ unsigned xform_pair_mix(unsigned x, float a0, float b0, float an0, float bn0, float a1, float b1,
-                                                   float an1, float bn1) {
-  unsigned p, n, r;
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(p) : "v"(x), "v"(a0), "v"(b0));
-  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p) : "v"(x), "v"(a1), "v"(b1));
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(n) : "v"(x), "v"(an0), "v"(bn0));
-  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(n) : "v"(x), "v"(an1), "v"(bn1));
-  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(p), "v"(n));
+// one 16-byte fragment (four registers of two fp16 each); the four instructions of a register are issued a register apart, so
+// that no v_fma_mixhi follows the v_fma_mixlo it merges with back to back (hipcc pads that pair with s_nop)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t xform_frag_mix(u32x4_t x, const float* a, const float* b, const float* an, const float* bn) {
+  u32x4_t p, n, r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(p[j]) : "v"(x[j]), "v"(a[2 * j]), "v"(b[2 * j]));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(n[j]) : "v"(x[j]), "v"(an[2 * j]), "v"(bn[2 * j]));
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p[j]) : "v"(x[j]), "v"(a[2 * j + 1]), "v"(b[2 * j + 1]));
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(n[j]) : "v"(x[j]), "v"(an[2 * j + 1]), "v"(bn[2 * j + 1]));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm("v_pk_max_f16 %0, %1, %2" : "=v"(r[j]) : "v"(p[j]), "v"(n[j]));
   return r;
 }
 
@@ -274,13 +283,7 @@ __device__ __forceinline__ typename Elem<T>::Frag xform_frag(typename Elem<T>::F
   constexpr int E = Elem<T>::EPG;
   typename Elem<T>::Frag o;
   if constexpr (sizeof(T) == 2) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 x = __builtin_bit_cast(u32x4, v);
-    u32x4 y;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      y[j] = xform_pair_mix(x[j], sc[2 * j], sh[2 * j], sn[2 * j], ad[2 * j], sc[2 * j + 1], sh[2 * j + 1], sn[2 * j + 1], ad[2 * j + 1]);
-    o = __builtin_bit_cast(typename Elem<T>::Frag, y);
+    o = __builtin_bit_cast(typename Elem<T>::Frag, xform_frag_mix(__builtin_bit_cast(u32x4_t, v), sc, sh, sn, ad));
   } else {
 #pragma unroll
     for (int j = 0; j < E; ++j) {

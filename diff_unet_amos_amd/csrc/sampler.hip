@@ -22,11 +22,19 @@
 namespace dua {
 
 // ---- Philox4x32-10 + Box-Muller (production-mode noise; parity tests inject eps instead) ----
+// 32 x 32 -> 64-bit product in ONE quarter-rate instruction (hipcc emits v_mul_hi_u32 + v_mul_lo_u32 for the C form: 40
+// quarter-rate multiplies per Philox call, ~20 us of VALU time per step in the tail kernel)
+__device__ __forceinline__ void mul_wide(uint32_t k, uint32_t x, uint32_t& hi, uint32_t& lo) {
+  unsigned long long p, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(carry) : "s"(k), "v"(x));
+  hi = (uint32_t)(p >> 32); lo = (uint32_t)p;
+}
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c[0]), l0 = 0xD2511F53u * c[0];
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c[2]), l1 = 0xCD9E8D57u * c[2];
+    uint32_t h0, l0, h1, l1;
+    mul_wide(0xD2511F53u, c[0], h0, l0);
+    mul_wide(0xCD9E8D57u, c[2], h1, l1);
     const uint32_t n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
     c[0] = n0; c[1] = l1; c[2] = n2; c[3] = l0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

@@ -403,6 +403,32 @@ def test_in_kernel_philox_noise_is_standard_normal(K):
     ops.final_conv_sampler(raw, K, z, torch.zeros(C, K, device="cuda"), torch.zeros(C, device="cuda"), C, nv.MODE_DDPM,
                            coef=coef, x_state=state, step_word=step, seed=1234)
     a = state.clone()
+    # known answer: Philox4x32-10 (Salmon et al., counter = (voxel lo, voxel hi, step, class quad), key = seed) + Box-Muller,
+    # restated in numpy; the kernel's logarithm / sine / cosine are the fast hardware forms, hence the tolerance
+    import numpy as np
+    vox = D * H * W
+    ctr = np.zeros((vox, 4, 4), dtype=np.uint64)
+    ctr[:, :, 0] = np.arange(vox, dtype=np.uint64)[:, None]
+    ctr[:, :, 2] = 5
+    ctr[:, :, 3] = np.arange(4, dtype=np.uint64)[None, :]
+    k0, k1 = np.uint64(1234), np.uint64(0)
+    M32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * ctr[..., 0]
+        p1 = np.uint64(0xCD9E8D57) * ctr[..., 2]
+        n0 = ((p1 >> np.uint64(32)) ^ ctr[..., 1] ^ k0) & M32
+        n2 = ((p0 >> np.uint64(32)) ^ ctr[..., 3] ^ k1) & M32
+        ctr = np.stack([n0, p1 & M32, n2, p0 & M32], -1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M32
+    u = ((ctr.astype(np.float32) + np.float32(0.5)) * np.float32(2.3283064365386963e-10)).astype(np.float64)
+    want = np.empty((vox, 4, 4))
+    for j in (0, 2):
+        rad = np.sqrt(-2.0 * np.log(u[..., j]))
+        want[..., j] = rad * np.cos(2 * np.pi * u[..., j + 1])
+        want[..., j + 1] = rad * np.sin(2 * np.pi * u[..., j + 1])
+    got = a.view(vox, 16).double().cpu().numpy()
+    assert np.abs(got - want.reshape(vox, 16)).max() < 5e-3, float(np.abs(got - want.reshape(vox, 16)).max())
     assert abs(float(a.mean())) < 1e-2 and abs(float(a.std()) - 1) < 1e-2
     assert abs(float((a ** 4).mean()) - 3) < 0.1
     flat = a.view(-1, 16)

@@ -392,6 +392,18 @@ static int dispatch_tail(const dua_tail_desc* d, TailArgs& a, hipStream_t s) {
   return DUA_ERR_ARG;
 }
 
+// Grid of the persistent MFMA tail: exactly the workgroups that are resident together (wgs_per_cu x CUs over the N samples),
+// each walking its share of the 256-voxel tiles.  A fixed 1024 left 256 workgroups for a second round that ran on a third of the chip.
+static inline unsigned tail_grid(long ntiles, int N, int wgs_per_cu) {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (unsigned)(ntiles < 1024 ? ntiles : 1024);
+  if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
+  long g = (long)wgs_per_cu * cus[dev] / (N > 0 ? N : 1);
+  if (g < 1) g = 1;
+  return (unsigned)(ntiles < g ? ntiles : g);
+}
+
 static inline unsigned nblk(long total) {
   long b = (total + 255) / 256;
   return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
@@ -453,7 +465,7 @@ static int tail_entry(const dua_tail_desc* d, const void* raw, const dua_in_norm
     a.res = r->res; a.res_stride = r->res_stride; a.rf = dua::make_xform(&r->res_norm, real);
     a.ra = r->ra_src; a.ra_stride = r->ra_stride; a.ra_off = r->ra_off; a.kvalid = real;
     const long ntiles = (d->voxels + 255) / 256;
-    dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024), d->N);
+    dim3 grid(dua::tail_grid(ntiles, d->N, 2), d->N);
     const size_t lds = (size_t)6 * d->K * sizeof(float);
     if (d->K == 32) hipLaunchKernelGGL((dua::final_conv_sampler_mfma_kernel<1, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((dua::final_conv_sampler_mfma_kernel<2, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
@@ -461,7 +473,7 @@ static int tail_entry(const dua_tail_desc* d, const void* raw, const dua_in_norm
   }
   if (d->dtype == DUA_F16 && d->CX == 16 && d->K % 32 == 0 && (d->K == 32 || d->K == 64 || d->K == 128)) {
     const long ntiles = (d->voxels + 255) / 256;
-    dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024), d->N);
+    dim3 grid(dua::tail_grid(ntiles, d->N, 3), d->N);
     const size_t lds = (size_t)6 * d->K * sizeof(float);
     if (d->K == 32) hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else if (d->K == 64) hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a);

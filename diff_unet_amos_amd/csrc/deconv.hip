@@ -384,15 +384,14 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
     const int w = vi % a.W, t = vi / a.W, h = t % a.H, d = t / a.H;
     ovb[it] = v < vox ? ((2 * d) * H2 + 2 * h) * W2 + 2 * w : -1;
   }
-  for (int tap = 0; tap < 8; ++tap) {
-    // prefetch the next tap's weights into registers (nchunks <= 4 pieces per thread)
-    f32x4 wn[MCH];
-    const char* wnext = wsrc + (long)(tap + 1) * a.nct * wtap;
-    if (tap < 7) {
+  // The weights of tap t + 1 travel in registers (nchunks <= 4 pieces per thread) while tap t multiplies.  They are REQUESTED
+  // before the stores of tap t - 1 are issued, not after: vmcnt counts loads and stores in issue order, so a wait for loads
+  // issued behind a tap's stores is a wait for those stores to be acknowledged by memory -- every tap paid a store round trip.
+  f32x4 wn[MCH];
 #pragma unroll
-      for (int j = 0; j < MCH; ++j)
-        if (j < a.nchunks) wn[j] = *(const f32x4*)(wnext + (tid + 256 * j) * 16);
-    }
+  for (int j = 0; j < MCH; ++j)
+    if (j < a.nchunks) wn[j] = *(const f32x4*)(wsrc + (long)a.nct * wtap + (tid + 256 * j) * 16);
+  for (int tap = 0; tap < 8; ++tap) {
     f32x16 acc[MBLK][2];
 #pragma unroll
     for (int m = 0; m < MBLK; ++m)
@@ -416,6 +415,12 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
 #pragma unroll
       for (int j = 0; j < MCH; ++j)
         if (j < a.nchunks) *(f32x4*)(wlds + ((tap + 1) & 1) * wtap + (tid + 256 * j) * 16) = wn[j];
+    }
+    if (tap < 6) {
+      const char* wnext = wsrc + (long)(tap + 2) * a.nct * wtap;
+#pragma unroll
+      for (int j = 0; j < MCH; ++j)
+        if (j < a.nchunks) wn[j] = *(const f32x4*)(wnext + (tid + 256 * j) * 16);
     }
     // pixel-shuffle store of this tap, one 32-channel half at a time through the wave's own staging rows (whole 128-byte
     // lines per instruction were measured too: the 16 KB staging tile leaves one workgroup per CU, 69 -> 102 us)

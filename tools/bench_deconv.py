@@ -14,7 +14,8 @@ SHAPES = [(6, 512, 256), (12, 256, 128), (24, 128, 64), (48, 128, 64)]       # (
 
 def main():
     alt = [a for a in sys.argv[1:] if a.startswith("lib:")]
-    rounds = int([a for a in sys.argv[1:] if not a.startswith("lib:")][0]) if len(sys.argv) > 1 + len(alt) else 9
+    nums = [a for a in sys.argv[1:] if a.isdigit()]
+    rounds = int(nums[0]) if nums else 9
     main_lib = nv.lib()
     libs = {"this": main_lib}
     if alt:
@@ -30,14 +31,15 @@ def main():
         x = torch.randn(1, S, S, S, cin, device=dev).to(dt)
         w = torch.randn(cin, cout, 2, 2, 2, device=dev) / cin ** 0.5
         wp, bp = ops.pack_deconv_weights(w, torch.zeros(cout, device=dev), dt)
-        y = torch.empty(1, 2 * S, 2 * S, 2 * S, 2 * cout, device=dev, dtype=dt)
+        dense = "--dense" in sys.argv          # the upsampled half as a tensor of its own instead of a slice of the concat buffer
+        y = torch.empty(1, 2 * S, 2 * S, 2 * S, cout if dense else 2 * cout, device=dev, dtype=dt)
         sums = torch.zeros(1, cin, 2, dtype=torch.float64, device=dev)
         sums[..., 1] = float(S ** 3)
         norm = ops.Norm(ops.stats_encode(sums), torch.ones(cin, device=dev), torch.zeros(cin, device=dev), S ** 3)
         graphs = {}
         for k, L in libs.items():
             nv._lib = L
-            run = lambda: ops.deconv_k2s2(x, cin, 0, wp, bp, cout, y, cout, norm=norm)  # noqa: E731
+            run = lambda: ops.deconv_k2s2(x, cin, 0, wp, bp, cout, y, 0 if dense else cout, norm=norm)  # noqa: E731
             run()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()

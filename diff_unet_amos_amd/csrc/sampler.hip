@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256) void final_conv_sampler_kernel(TailArgs a) {
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 // RES: the residual form -- the activation is assembled from the last UnetResBlock's two branches and the reverse-attention
 // term instead of being read back from a materialised tensor (three 16-byte loads per fragment, two voxel blocks in flight).
-template <int KS, bool RES = false>
-__global__ __launch_bounds__(256, RES ? 2 : 3) void final_conv_sampler_mfma_kernel(TailArgs a) {
+// EXTRA: the launch also writes logits / the running sum of x0^ / x0^ itself or reads injected noise (parity tests, config 3) -- a separate
+// instantiation, so that the plain sampling step does not hold their values in registers across the next tile's requests.
+template <int KS, bool RES = false, bool EXTRA = true>
+__global__ __launch_bounds__(256, (RES || KS > 2) ? 2 : 3) void final_conv_sampler_mfma_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // scale[K], shift[K], add[K] (+ the same of the residual branch)
   const int n = blockIdx.y, K = a.K;
   float* sc_l = wl; float* sh_l = wl + K;
@@ -277,6 +279,119 @@ __global__ __launch_bounds__(256, RES ? 2 : 3) void final_conv_sampler_mfma_kern
   // A workgroup walks several 256-voxel tiles: the preamble above (per-channel statistics -> scale / shift in double
   // precision, weights to registers) is a few microseconds of dependent loads, too much to pay per 77 KB of traffic.
   const long ntiles = (a.vox + 255) / 256;
+  if constexpr (!RES && KS <= 2 && !EXTRA) {
+    // The plain sampling step (no logits / x0^ outputs, in-kernel noise), software-pipelined over the tiles of a workgroup: the NEXT tile's operands are requested after this tile's arithmetic and
+    // BEFORE this tile's stores are issued.  vmcnt counts loads and stores in issue order, so loads requested behind a tile's
+    // stores would not count as landed until those stores were acknowledged by memory: every tile paid a store round trip on
+    // top of its load round trip.  With twelve waves per CU in flight it is worth 3-4 us of the 73 us launch; the forms with
+    // extra outputs (parity tests, config 3's running sum of x0^) keep the plain loop below: pipelined they need 2 waves fewer per SIMD.
+    f16x8 fr[4][KS];
+    f32x4 xt[4];
+    float ez[EXTRA ? 4 : 1][4];                              // injected noise (parity tests); the plain step draws it in place
+    auto request = [&](long tile) {
+      const long wb = (tile * 4L + wave) * 64;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const long v = wb + 16 * mb + vl;
+        const long vc = v < a.vox ? v : 0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fr[mb][ks] = kok[ks] ? *(const f16x8*)(raw + vc * a.raw_stride + 32 * ks + 8 * kq) : zero8;
+        xt[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sampling) xt[mb] = *(const f32x4*)(a.x_state + ((long)n * a.vox + vc) * 16 + 4 * kq);
+        if constexpr (EXTRA) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            ez[mb][j] = (sampling && a.noise && 4 * kq + j < a.C) ? a.noise[((long)n * a.C + 4 * kq + j) * a.vox + vc] : 0.f;
+        }
+      }
+    };
+    if ((long)blockIdx.x < ntiles) request(blockIdx.x);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const long wbase = (tile * 4L + wave) * 64;
+      f32x4a lg[EXTRA ? 4 : 1];                              // logits of classes 4 kq + j of voxel wbase + 16 mb + vl
+      f32x4 xn[4], x0[EXTRA ? 4 : 1];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        f32x4a acc = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          f16x8 y, yl;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = fmaf((float)fr[mb][ks][e], sc[ks][e], sh[ks][e]);
+            t = t > 0.f ? t : t * a.xf.slope;
+            y[e] = (f16)t;
+            yl[e] = (f16)(t - (float)y[e]);
+          }
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(awl[ks], y, acc, 0, 0, 0);    // small terms first
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks], yl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[ks], y, acc, 0, 0, 0);     // columns of voxels >= vox are never stored
+        }
+        if constexpr (EXTRA) lg[mb] = acc;
+        if (sampling) {
+          const long gv = (long)n * a.vox + wbase + 16 * mb + vl;
+          float eps[4];
+          if (!EXTRA || !a.noise) {                              // same counter as the VALU form: (voxel, step, class quad)
+            uint32_t ctr[4] = {(uint32_t)gv, (uint32_t)(gv >> 32), step, (uint32_t)kq};
+            philox4x32_10(ctr, key0, key1);
+            box_muller(ctr[0], ctr[1], eps[0], eps[1]);
+            box_muller(ctr[2], ctr[3], eps[2], eps[3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) eps[j] = ez[EXTRA ? mb : 0][j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x0j;
+            xn[mb][j] = sampler_update(a.mode, k8, acc[j], xt[mb][j], eps[j], x0j);
+            if constexpr (EXTRA) x0[mb][j] = x0j;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tile + gridDim.x < ntiles) request(tile + gridDim.x);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const long v = wbase + 16 * mb + vl;
+        if (v >= a.vox) continue;
+        const long gv = (long)n * a.vox + v;
+        if constexpr (EXTRA) {
+          if (a.logits) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (4 * kq + j < a.C) a.logits[((long)n * a.C + 4 * kq + j) * a.vox + v] = lg[mb][j];
+          }
+        }
+        if (!sampling) continue;
+        *(f32x4*)(a.x_state + gv * 16 + 4 * kq) = xn[mb];
+        if constexpr (EXTRA) {
+          if (a.xsum) {
+            f32x4 s4 = *(const f32x4*)(a.xsum + gv * 16 + 4 * kq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s4[j] += x0[mb][j];
+            *(f32x4*)(a.xsum + gv * 16 + 4 * kq) = s4;
+          }
+          if (a.xstart) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (4 * kq + j < a.C) a.xstart[((long)n * a.C + 4 * kq + j) * a.vox + v] = x0[mb][j];
+          }
+        }
+        if (a.xin) {
+          f16* xp = (f16*)a.xin + gv * a.xin_stride + 4 * kq;
+          if (4 * kq + 4 <= a.C) {
+            *(f16x4*)xp = f16x4{(f16)xn[mb][0], (f16)xn[mb][1], (f16)xn[mb][2], (f16)xn[mb][3]};
+          } else {                     // channels >= C of the slice hold the conditioning image / zero padding: leave them alone
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (4 * kq + j < a.C) xp[j] = (f16)xn[mb][j];
+          }
+        }
+      }
+    }
+    return;
+  }
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const long wbase = (tile * 4L + wave) * 64;
   // Everything this wave needs from memory is requested up front (raw fragments of all four voxel blocks, the
@@ -475,7 +590,9 @@ static int tail_entry(const dua_tail_desc* d, const void* raw, const dua_in_norm
     const long ntiles = (d->voxels + 255) / 256;
     dim3 grid(dua::tail_grid(ntiles, d->N, 3), d->N);
     const size_t lds = (size_t)6 * d->K * sizeof(float);
-    if (d->K == 32) hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    const bool extra = a.logits || a.xsum || a.xstart || a.noise || a.mode == DUA_MODE_LOGITS;
+    if (d->K == 64 && !extra) hipLaunchKernelGGL((dua::final_conv_sampler_mfma_kernel<2, false, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    else if (d->K == 32) hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else if (d->K == 64) hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(dua::final_conv_sampler_mfma_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();

@@ -817,7 +817,44 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
   if (c < Cout) b4 = *(const f32x4*)(bias + c);      // Cout is a multiple of 8, c of 4: bias needs Cout entries only
-  if (vl < VL) {
+  if (vl < VL && ITER == 2 && ksplit <= 8) {
+    // both voxels of the thread are requested before the first is stored (a thread that takes them in turn waits for the
+    // acknowledgement of its first store before its second batch of loads counts as landed: vmcnt is in issue order)
+    const long va = ((long)blockIdx.x * 2) * VL + vl, vb = va + VL;
+    const long kstride = (long)N * vox * cout_pad;
+    const float* pa = part + ((long)n * vox + (va < vox ? va : 0)) * cout_pad + c;
+    const float* pb = part + ((long)n * vox + (vb < vox ? vb : 0)) * cout_pad + c;
+    f32x4 qa[8], qb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = j < ksplit ? j : ksplit - 1;
+      qa[j] = *(const f32x4*)(pa + kk * kstride);
+      qb[j] = *(const f32x4*)(pb + kk * kstride);
+    }
+    f32x4 acc[2] = {b4, b4};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < ksplit)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[0][e] += qa[j][e]; acc[1][e] += qb[j][e]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long v = i ? vb : va;
+      if (v >= vox) break;
+      T o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (T)acc[i][e];
+        const float f = (float)o[e];
+        s[e] += f; q[e] += f * f;
+      }
+      if (c < Cout) {
+        T* yp = y + ((long)n * vox + v) * Cout_stride + Cout_off + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yp[e] = o[e];
+      }
+    }
+  } else if (vl < VL) {
     for (int i = 0; i < ITER; ++i) {
       const long v = ((long)blockIdx.x * ITER + i) * VL + vl;
       if (v >= vox) break;

@@ -186,21 +186,28 @@ __device__ __forceinline__ void xform_preamble(const InXform& xf, int n, int C, 
       add[u] = xf.add ? xf.add[(long)n * xf.add_stride + cc[u]] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < UN; ++u)
-      if (c0 + u * nw * 16 < C) stats_read_wave16(xf.stats, n, xf.c_pad, cc[u], S[u], Q[u]);     // wave-uniform condition
-#pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int c = c0 + u * nw * 16 + (lane & 15);
-      if (c0 + u * nw * 16 >= C) break;
-      const double mean = S[u] * (double)xf.inv_count;
-      double var = Q[u] * (double)xf.inv_count - mean * mean;
-      var = var > 0 ? var : 0;
-      const float g = gam[u] * (float)(1.0 / sqrt(var + (double)xf.eps));
-      if (c < C && lane < 16) {
-        sc[c] = g;
-        sh[c] = bet[u] - (float)mean * g;
-        ad[c] = add[u];
-      }
+      S[u] = 0; Q[u] = 0;
+      if (c0 + u * nw * 16 < C) stats_read_wave16(xf.stats, n, xf.c_pad, cc[u], S[u], Q[u]);     // wave-uniform condition
+    }
+    // every lane now holds the sums of all UN groups for channel (lane & 15): the 16-lane part u finishes group u, so the
+    // double-precision reciprocal square root runs ONCE per pass, not once per group (it was ~1 000 cycles per group: the
+    // preamble of a 256-channel layer was arithmetic, not the cold loads in front of it)
+    const int part = lane >> 4;
+    double Sm = S[0], Qm = Q[0];
+    float gm = gam[0], bm = bet[0], am = add[0];
+#pragma unroll
+    for (int u = 1; u < UN; ++u)
+      if (part == u) { Sm = S[u]; Qm = Q[u]; gm = gam[u]; bm = bet[u]; am = add[u]; }
+    const int c = c0 + part * nw * 16 + (lane & 15);
+    const double mean = Sm * (double)xf.inv_count;
+    double var = Qm * (double)xf.inv_count - mean * mean;
+    var = var > 0 ? var : 0;
+    const float g = gm * (float)(1.0 / sqrt(var + (double)xf.eps));
+    if (c0 + part * nw * 16 < C && c < C) {
+      sc[c] = g;
+      sh[c] = bm - (float)mean * g;
+      ad[c] = am;
     }
   }
 }

@@ -274,7 +274,10 @@ def test_materialize(dtype, pool, with_emb):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [(1, 64, 32, 3, 3, 3), (2, 40, 72, 2, 4, 6), (1, 16, 16, 6, 6, 6),
-                                   (1, 64, 64, 32, 32, 32), (1, 40, 72, 30, 34, 36)])    # the last two: all-taps kernel
+                                   (1, 64, 64, 32, 32, 32), (1, 40, 72, 30, 34, 36),      # these two: all-taps kernel
+                                   # >= 8 Cin chunks: the kernel whose waves split the chunks (ragged last chunk, ragged
+                                   # voxel tile, two output-channel tiles, the 6^3 x 512 layer of the denoiser)
+                                   (1, 256, 128, 3, 4, 5), (2, 272, 72, 2, 3, 3), (1, 512, 256, 6, 6, 6)])
 @pytest.mark.parametrize("fused", [False, True])
 def test_deconv_k2s2(dtype, shape, fused):
     ops = _ops()

@@ -431,8 +431,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (co >= Cout || cip >= Cin) continue;
     const int ci = perm ? perm[cip] : cip;
     if (ci < 0 || ci >= Cin_src) continue;
+    // The 96^3 layers have 128-256 partitions: sixteen partial sums are requested per round trip (four at a time made this
+    // kernel 32-64 dependent round trips per element: 1.1 ms per training step for ~1.5 GB of traffic).  Fixed summation order.
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int p = 0;
+    for (; p + 15 < P; p += 16) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = part[(long)(p + j) * per_p + i];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+    }
     for (; p + 3 < P; p += 4) {
       s0 += part[(long)p * per_p + i]; s1 += part[(long)(p + 1) * per_p + i];
       s2 += part[(long)(p + 2) * per_p + i]; s3 += part[(long)(p + 3) * per_p + i];

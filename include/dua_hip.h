@@ -44,7 +44,7 @@ typedef struct {
   int c_pad;                 /* channel stride of stats */
   float inv_count;           /* 1 / (D*H*W) of the producer's output */
   float eps;                 /* 1e-5 */
-  float slope;               /* LeakyReLU negative slope */
+  float slope;               /* LeakyReLU negative slope, 0 <= slope <= 1 (the fp16 kernels apply it as max(t, slope t)) */
 } dua_in_norm;
 
 /* ---- 3x3x3 convolution --------------------------------------------------------------------

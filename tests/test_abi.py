@@ -55,6 +55,11 @@ def test_argument_validation_without_a_device(lib):
     assert lib.dua_q_sample(0, 10, one, one, one, one, None) == nv.ERR_ARG
     assert lib.dua_sampler_step(7, 1, 10, one, one, one, one, one, None, None, None) == nv.ERR_ARG
     assert lib.dua_set_option(99, 1) == nv.ERR_ARG
+    # LeakyReLU slope outside [0, 1]: the fp16 kernels apply the activation as max(t, slope * t)
+    ok = nv.Conv3Desc(nv.F16, 1, 8, 8, 8, 16, 16, 0, 64, 64, 0)
+    bad = nv.InNorm(16, 16, 16, None, 0, 64, 1.0 / 512, 1e-5, 1.5)
+    assert lib.dua_conv3d_k3_fwd(C.byref(ok), one, one, one, C.byref(bad), one, one, None, 0, None) == nv.ERR_ARG
+    assert lib.dua_deconv_k2s2_fwd(C.byref(ok), one, one, one, C.byref(bad), one, None) == nv.ERR_ARG
     assert lib.dua_pack_conv3_weights(nv.F16, 64, 17, 24, None, None, None, None) == 1 * 1 * 27 * 4 * 64 * 16
 
 

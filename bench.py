@@ -33,6 +33,11 @@ Extra objects in the JSON line (config 2, rank 0, N = 1):
                   1.5-1.8 PFLOP/s on random data).  traffic = HBM bytes per launch from two
                   rocprofv3 --pmc child passes of this script (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE),
                   or null when the profiler is not available.
+  full_loop    -- config 2 end to end whatever --steps says: the whole 1000-step DDPM loop through the public API
+                  (net.diffusion.p_sample_loop(net.model, shape, model_kwargs=...)), second call (the first one captures
+                  the step graph and is reported as first_call_seconds).
+  f32          -- the parity dtype on the same workload: a short replayed pass of an fp32 plan, ms_per_step and the
+                  convolution kernel's fraction of the fp32 MFMA peak (157.3 TFLOP/s).
   cpu_baseline -- the CPU oracle (oracle/unet_ref.py, "port") timed on this box's host cores on a bounded sample
                   (1 warm-up + 2 denoiser evaluations at the same 96^3 x 16 shape).
 """
@@ -150,7 +155,78 @@ def conv_roofline(plan, dtype_flag, reps=20):
     if own_first:
         out["first_layer"] = {"kernel": "conv3d_k3_first_kernel", "us": round(by_launch[0] * 1e3, 1),
                               "tflops": round(fl[0] / (by_launch[0] * 1e-3) / 1e12, 1)}
+    # every 3x3x3 launch of the step, whichever kernel runs it (the by_launch_* arrays cover these; comparable across rounds)
+    all_tf = sum(fl) / len(fl) / (sum(by_launch) / len(by_launch) * 1e-3) / 1e12
+    out["all_conv_launches"] = {"launches_per_step": len(fl), "avg_launch_ms": round(sum(by_launch) / len(by_launch), 4),
+                                "achieved": round(all_tf, 2), "frac": round(all_tf / peak, 4)}
     return out
+
+
+def full_loop_config2(net, image, shape):
+    """BASELINE config 2 as it is worded: the whole 1000-step DDPM loop through the public API,
+    ``net.diffusion.p_sample_loop(net.model, shape, model_kwargs=...)`` (gaussian_diffusion.py:441-485 of the reference),
+    in-kernel noise, encoder pass included in neither figure.  The first call captures the step graph of this (plan, process)
+    pair; the second is what every later patch costs."""
+    out = {}
+    with torch.no_grad():
+        kw = {"image": image, "embeddings": net.embed_model(image)}
+        for key in ("first_call_seconds", "seconds"):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sample = net.diffusion.p_sample_loop(net.model, shape, model_kwargs=kw)
+            torch.cuda.synchronize()
+            out[key] = time.perf_counter() - t0
+    T = net.diffusion.num_timesteps
+    out.update(steps=T, ms_per_step=out["seconds"] / T * 1e3, voxel_steps_per_s=shape[0] * VOX * T / out["seconds"],
+               finite=bool(torch.isfinite(sample).all()), api="net.diffusion.p_sample_loop(net.model, shape, model_kwargs)")
+    return out
+
+
+def f32_pass_config2(state, image, dev, steps=20, warmup=3):
+    """The parity dtype on the same workload: `steps` replayed DDPM steps of an fp32 plan (exact-fp32 MFMA 32x32x2) and the
+    convolution kernel's roofline fraction against the fp32 MFMA peak."""
+    from diff_unet_amos_amd import _native as nv
+    from diff_unet_amos_amd import ops
+    from diff_unet_amos_amd.diff_unet import DiffUNet
+    net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES, compute_dtype=torch.float32)
+    net.load_state_dict(state)
+    net = net.to(dev).eval()
+    B = image.shape[0]
+    plan = net._rt.plan(B, (96, 96, 96), dev)
+    with torch.no_grad():
+        net.embed_model(image)
+        x_T = torch.randn(B, CLASSES, 96, 96, 96, device=dev)
+        ops.to_channels_last(x_T, plan.x_state, 0, plan.cx)
+        ops.to_channels_last(x_T, plan.xin, 0, plan.C)
+        plan.x_sum.zero_()
+        plan.refresh_weights()
+        T = net.diffusion.num_timesteps
+        order = list(range(T))[::-1]
+        coef_table = net.diffusion.ddpm_coef(torch.tensor(order)).to(dev).contiguous()
+        row_of_step = torch.tensor(order, dtype=torch.int32, device=dev)
+        plan.counter.zero_()
+        plan.new_seed(5)
+
+        def one_step():
+            plan.native_step(nv.MODE_DDPM, row_of_step=row_of_step, coef_table=coef_table, use_sum=False)
+
+        one_step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one_step()
+        for _ in range(warmup):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        roof = conv_roofline(plan, "f32", reps=5)
+    return {"ms_per_step": ms, "steps": steps, "frac": roof["frac"], "achieved": roof["achieved"], "peak": roof["peak"],
+            "unit": "TFLOP/s", "kernel": CONV_KERNEL, "largest_launch_tflops": roof["largest_launch"]["tflops"],
+            "finite": bool(torch.isfinite(plan.x_state).all())}
 
 
 def mfma_ceiling(dev, seconds=2.0):
@@ -458,6 +534,11 @@ def run_config2(args, D):
         }
         if roof is not None:
             line["roofline"] = roof
+        if world == 1 and not args.no_roofline and not args.no_graph and not args.no_full_loop:
+            # config 2 end to end, whatever --steps says: the 1000-step loop through the public sampler API
+            line["full_loop"] = full_loop_config2(net, image, (B, CLASSES, 96, 96, 96))
+            if args.dtype == "f16" and not args.no_f32:
+                line["f32"] = f32_pass_config2(state, image, dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(state, host_threads())
         print(json.dumps(line), flush=True)
@@ -671,6 +752,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-full-loop", action="store_true", help="config 2: skip the 1000-step p_sample_loop pass (full_loop object)")
+    ap.add_argument("--no-f32", action="store_true", help="config 2: skip the short fp32 pass (f32 object)")
     ap.add_argument("--batch", type=int, default=1, help="config 2: patches per GPU (BASELINE config 2 is 1)")
     ap.add_argument("--sw-batch", type=int, default=4, help="config 3: windows per sampler pass (cfg/btcv/test.yaml:4 of the reference: 4)")
     ap.add_argument("--gather-fp16", action="store_true", help="config 3: all-gather the window sums in fp16")

@@ -101,7 +101,12 @@ class TokenLinearDesc(C.Structure):
 TOKLIN_PLAIN, TOKLIN_GELU, TOKLIN_STATS, TOKLIN_RESIDUAL, TOKLIN_SCATTER = range(5)
 
 _P = C.c_void_p
+ABI_VERSION = 4          # DUA_ABI_VERSION of include/dua_hip.h this binding was written against
+
 _SIGS = {
+    "dua_abi_version": (C.c_int, []),
+    "dua_prepare": (C.c_int, []),
+    "dua_prepared_kernels": (C.c_int, []),
     "dua_set_option": (C.c_int, [C.c_int, C.c_int]),
     "dua_mfma_probe": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
     "dua_chain_probe": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P]),
@@ -175,10 +180,22 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        got = L.dua_abi_version()
+        if got != ABI_VERSION:
+            raise NativeLibraryMissing(f"{LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild the library")
         _lib = L
         if os.environ.get("DUA_CONV_VARIANT"):        # diagnostics: dua_set_option(1, v) for the whole process
             check(L.dua_set_option(1, int(os.environ["DUA_CONV_VARIANT"])), "dua_set_option")
     return _lib
+
+
+def prepare(device=None):
+    """dua_prepare() on ``device`` (default: the current one): every function attribute the library's launchers need is
+    set before the first launch -- plans and trainers call this at construction, i.e. before any stream capture and
+    before autograd's worker thread issues a launch."""
+    L = lib()
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(L.dua_prepare(), "dua_prepare")
 
 
 def ptr(t):

@@ -14,16 +14,18 @@
 #include <stdint.h>
 
 namespace dua {
-// hipFuncSetAttribute acts on the current device only: a launcher keeps one of these per kernel (a function-local static)
-// and raises the dynamic-LDS limit the first time it runs on each device of the process.
-struct PerDeviceOnce {
-  bool done[64] = {};
-  // nullptr: no current device; otherwise the flag of the current device (the caller sets it after the attribute calls)
-  bool* flag() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    return &done[dev];
-  }
+// Host-side launch state of the library (prepare.hip).  hipFuncSetAttribute acts on the current device only and is not a
+// call to make for the first time inside a stream capture or from two threads at once (torch runs backward() on a thread of
+// its own): every translation unit REGISTERS the kernels whose dynamic-LDS limit it needs raised (a namespace-scope
+// LdsAttrs object, filled in during static initialisation), and ensure_prepared() raises all of them, for the whole
+// library, the first time ANY launcher runs on a device -- under a mutex, published through an atomic flag per device.
+// dua_prepare() is the same call as a C entry point: plans and trainers run it at construction, before any capture.
+struct LdsAttr { const void* fn; int bytes; };
+void register_lds_attrs(const LdsAttr* list, int n);
+int ensure_prepared();          // 0, DUA_ERR_ARG (no current device) or the hipError_t of a failed attribute call
+int device_cus();               // compute units of the current device (cached by ensure_prepared); <= 0 before / on error
+struct LdsAttrs {
+  template <int N> explicit LdsAttrs(const LdsAttr (&list)[N]) { register_lds_attrs(list, N); }
 };
 
 

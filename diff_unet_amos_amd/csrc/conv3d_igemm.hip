@@ -929,46 +929,22 @@ static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups, 
 // main stream's workgroups (two of them per CU leave no room: the co-running launches then wait for retiring workgroups).
 constexpr int PARTIAL_LDS_PAD = 36 * 1024;
 
-static int g_cus[64] = {};      // compute units per device (the persistent first-layer launch sizes its grid with it)
-
-// hipFuncSetAttribute is per device: remember which devices have the dynamic-LDS limit raised
-template <typename T>
-static int ensure_lds_attr() {
-  static bool done[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DUA_ERR_ARG;
-  if (done[dev]) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD);
-  if constexpr (sizeof(T) == 2) {
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              c3v2::LDS_MAIN + 4096 + PARTIAL_LDS_PAD);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              c3v2::LDS_MAIN + 4096 + PARTIAL_LDS_PAD);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD);
-  }
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)conv3d_k3_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c3f::LDS_F + 2048 + PARTIAL_LDS_PAD);
-  if (e == hipSuccess) {
-    int cus = 0;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    g_cus[dev] = cus;
-  }
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            c3v2::LDS_MAIN + 3 * 4 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 4, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)conv3d_k3_v2_kernel<T, 2, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return (int)e;
-  done[dev] = true;
-  return 0;
-}
+// Kernels of this file that ask for more than 64 KB of dynamic LDS (raised once per device by ensure_prepared(), common.hpp)
+static const LdsAttr kConvLdsAttrs[] = {
+    {(const void*)conv3d_k3_v2_kernel<f16, 4>, c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD},
+    {(const void*)conv3d_k3_v2_kernel<float, 4>, c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD},
+    {(const void*)conv3d_k3_v2_kernel<f16, 4, 1>, c3v2::LDS_MAIN + 4096 + PARTIAL_LDS_PAD},
+    {(const void*)conv3d_k3_v2_kernel<f16, 4, 0>, c3v2::LDS_MAIN + 4096 + PARTIAL_LDS_PAD},
+    {(const void*)conv3d_k3_v2_kernel<f16, 4, 2, true>, c3v2::LDS_MAIN + 3 * 4 * 1024 + PARTIAL_LDS_PAD},
+    {(const void*)conv3d_k3_first_kernel, c3f::LDS_F + 2048 + PARTIAL_LDS_PAD},
+    {(const void*)conv3d_k3_v2_kernel<f16, 2>, c3v2::LDS_MAIN + 3 * 4 * 1024},
+    {(const void*)conv3d_k3_v2_kernel<float, 2>, c3v2::LDS_MAIN + 3 * 4 * 1024},
+    {(const void*)conv3d_k3_v2_kernel<f16, 4, 2, false, true>, 160 * 1024},
+    {(const void*)conv3d_k3_v2_kernel<float, 4, 2, false, true>, 160 * 1024},
+    {(const void*)conv3d_k3_v2_kernel<f16, 2, 2, false, true>, 160 * 1024},
+    {(const void*)conv3d_k3_v2_kernel<float, 2, 2, false, true>, 160 * 1024},
+};
+static const LdsAttrs kConvLdsReg(kConvLdsAttrs);
 
 template <typename T>
 static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
@@ -990,7 +966,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = nullptr; a.tap_ch = -1;
   if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
   const int xf_bytes = in && in->stats ? 3 * 4 * a.nchunks * CK : 0;
-  if (int e = ensure_lds_attr<T>()) return e;
+  if (int e = ensure_prepared()) return e;
   const long vox = (long)d->D * d->H * d->W;
   const int bg_pad = d->background ? PARTIAL_LDS_PAD : 0;     // one workgroup per CU, see PARTIAL_LDS_PAD
   if (d->tap_channel_plus1 > 0) {
@@ -1004,10 +980,10 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
       if (a.tap_ch == 16 && g_conv_variant == 0) {
         // resident-weight form: two persistent workgroups per CU walk the (sample, tile) items; a background launch takes one
         // per CU (and the LDS pad that keeps a second one off the CU)
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || g_cus[dev] <= 0) return DUA_ERR_ARG;
+        const int cus = device_cus();
+        if (cus <= 0) return DUA_ERR_ARG;
         const int items = a.ntiles * d->N;
-        const int wgs = std::max(1, (bg_pad ? 1 : 2) * g_cus[dev] / nct);
+        const int wgs = std::max(1, (bg_pad ? 1 : 2) * cus / nct);
         hipLaunchKernelGGL(conv3d_k3_first_kernel, dim3(std::min(items, wgs), nct, 1), dim3(256), c3f::LDS_F + 2048 + bg_pad, s, a, items);
         return (int)hipGetLastError();
       }

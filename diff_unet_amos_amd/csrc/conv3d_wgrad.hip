@@ -466,6 +466,19 @@ static inline int wgrad_partitions(const dua_conv3_desc* d, int* combos_out) {
   return P < 1 ? 1 : P;
 }
 
+// dynamic-LDS limits (raised once per device by ensure_prepared(), common.hpp): two (x, dy) tile images; the LDS-DMA form
+// of the 12-wave kernel keeps two such buffers
+template <typename T> constexpr int wgrad_lds() { return 2 * (wg::XV + wg::TV) * 32 * (int)sizeof(T) + 4 * 64; }
+static const LdsAttr kWgradLdsAttrs[] = {
+    {(const void*)conv3d_k3_wgrad_kernel<f16, false>, wgrad_lds<f16>()},
+    {(const void*)conv3d_k3_wgrad_kernel<f16, true>, wgrad_lds<f16>()},
+    {(const void*)conv3d_k3_wgrad_kernel<float, false>, wgrad_lds<float>()},
+    {(const void*)conv3d_k3_wgrad_kernel<float, true>, wgrad_lds<float>()},
+    {(const void*)conv3d_k3_wgrad12_kernel<f16, false>, wgrad_lds<f16>()},
+    {(const void*)conv3d_k3_wgrad12_kernel<f16, true>, 2 * wgrad_lds<f16>()},
+};
+static const LdsAttrs kWgradLdsReg(kWgradLdsAttrs);
+
 template <typename T>
 static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
                         const int* perm, float* ws, long ws_bytes, hipStream_t s) {
@@ -486,32 +499,13 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
   a.abl = g_wgrad_abl;
   a.plain_order = (g_wgrad_variant & 1) || P < 8;
   a.part = (ws && (long)P * combos * 9 * 4096 * 4 <= ws_bytes && P > 1) ? ws : nullptr;
-  const int lds = 2 * (XV + TV) * 32 * (int)sizeof(T) + 4 * 64;
-  static PerDeviceOnce once;
-  bool* attr_set = once.flag();
-  if (!attr_set) return DUA_ERR_ARG;
-  if (!*attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    *attr_set = true;
-  }
+  constexpr int lds = wgrad_lds<T>();
+  if (int e = ensure_prepared()) return e;
   const int groups = (P * a.ncombo + 7) / 8;        // groups of 8 (partition, combo) pairs, one per XCD
   const dim3 grid(a.plain_order ? P * a.ncombo * 3 : groups * 24);
   // f16 default: the 12-wave form (-5...-14 % against the 6-wave one on every layer shape, same-process A/B);
   // dua_set_option(4, 64) selects the 6-wave pipelined form, (4, 32) its compiler-scheduled k loop.  f32: 6 waves.
   if (sizeof(T) == 2 && !(g_wgrad_variant & (64 | 32))) {
-    static PerDeviceOnce once12;
-    bool* attr12 = once12.flag();
-    if (!attr12) return DUA_ERR_ARG;
-    if (!*attr12) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad12_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess && sizeof(T) == 2)
-        e = hipFuncSetAttribute((const void*)conv3d_k3_wgrad12_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds);
-      if (e != hipSuccess) return (int)e;
-      *attr12 = true;
-    }
     if constexpr (sizeof(T) == 2) {
       if (g_wgrad_variant & 128) hipLaunchKernelGGL((conv3d_k3_wgrad12_kernel<T, false>), grid, dim3(768), lds, s, a);   // register prefetch + one LDS buffer
       else hipLaunchKernelGGL((conv3d_k3_wgrad12_kernel<T, true>), grid, dim3(768), 2 * lds, s, a);

@@ -444,6 +444,21 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
   }
 }
 
+// dynamic-LDS limits (raised once per device by ensure_prepared(), common.hpp)
+template <typename T> constexpr int deconv_plain_lds() {
+  constexpr int OS = dc::BN * (int)sizeof(T) + 16;
+  return ((dc::TM * OS > dc::A_BYTES + dc::W_BYTES) ? dc::TM * OS : dc::A_BYTES + dc::W_BYTES) + 3 * 4 * 1024;
+}
+static const LdsAttr kDeconvLdsAttrs[] = {
+    {(const void*)deconv_k2s2_alltaps_kernel<f16, 2>, 160 * 1024},   {(const void*)deconv_k2s2_alltaps_kernel<f16, 1>, 160 * 1024},
+    {(const void*)deconv_k2s2_alltaps_kernel<float, 2>, 160 * 1024}, {(const void*)deconv_k2s2_alltaps_kernel<float, 1>, 160 * 1024},
+    {(const void*)deconv_k2s2_ksplit_kernel<f16>, dcs::RED + 3 * 4 * 1024},
+    {(const void*)deconv_k2s2_ksplit_kernel<float>, dcs::RED + 3 * 4 * 1024},
+    {(const void*)deconv_k2s2_kernel<f16>, deconv_plain_lds<f16>()},
+    {(const void*)deconv_k2s2_kernel<float>, deconv_plain_lds<float>()},
+};
+static const LdsAttrs kDeconvLdsReg(kDeconvLdsAttrs);
+
 template <typename T>
 static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
                          const dua_in_norm* in, void* y, hipStream_t s) {
@@ -457,6 +472,7 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   a.nchunks = (d->Cin + CK - 1) / CK;
   a.nct = (d->Cout + dc::BN - 1) / dc::BN;
   const long vox = (long)d->D * d->H * d->W;
+  if (int e = ensure_prepared()) return e;
   if (vox >= 256L * 128 && a.nchunks <= 4) {          // enough tiles to fill the chip with one workgroup per 8 taps
     // 128-voxel tiles: two workgroups per CU (77 KB each at 128 channels), one's pixel-shuffle stores under the other's loads;
     // variant 6 keeps the 256-voxel form (one workgroup per CU) for A/B
@@ -464,16 +480,7 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
     const int tm = 128 * mblk;
     const int lds = tm * (a.nchunks * 64 + 16) + 2 * a.nchunks * dc::W_BYTES + tm * (32 * (int)sizeof(T) + 16) +
                     (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0);
-    static PerDeviceOnce once2;
-    bool* attr2 = once2.flag();
-    if (!attr2) return DUA_ERR_ARG;
-    if (!*attr2) {
-      hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_alltaps_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)deconv_k2s2_alltaps_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      *attr2 = true;
-    }
+    if (lds > 160 * 1024) return DUA_ERR_ARG;
     dim3 grid2((unsigned)((vox + tm - 1) / tm), a.nct, d->N);
     if (mblk == 2) hipLaunchKernelGGL((deconv_k2s2_alltaps_kernel<T, 2>), grid2, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((deconv_k2s2_alltaps_kernel<T, 1>), grid2, dim3(256), lds, s, a);
@@ -481,14 +488,6 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   }
   if (a.nchunks >= 8 && a.nchunks <= 4 * dcs::MC && g_conv_variant != 6) {   // Cin >= 256: waves split the Cin chunks (variant 6: the one-chunk-at-a-time kernel, A/B)
     const int lds = dcs::RED + (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0);
-    static PerDeviceOnce once3;
-    bool* attr3 = once3.flag();
-    if (!attr3) return DUA_ERR_ARG;
-    if (!*attr3) {
-      hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_ksplit_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, dcs::RED + 3 * 4 * 1024);
-      if (e != hipSuccess) return (int)e;
-      *attr3 = true;
-    }
     dim3 grid3((unsigned)((vox + dcs::TMS - 1) / dcs::TMS), 8 * a.nct, d->N);
     hipLaunchKernelGGL(deconv_k2s2_ksplit_kernel<T>, grid3, dim3(256), lds, s, a);
     return (int)hipGetLastError();
@@ -498,14 +497,6 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   constexpr int LDS = (dc::TM * OS > dc::A_BYTES + dc::W_BYTES) ? dc::TM * OS : dc::A_BYTES + dc::W_BYTES;
   a.lds_base = LDS;
   if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
-  static PerDeviceOnce once;
-  bool* attr_set = once.flag();
-  if (!attr_set) return DUA_ERR_ARG;
-  if (!*attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 3 * 4 * 1024);
-    if (e != hipSuccess) return (int)e;
-    *attr_set = true;
-  }
   hipLaunchKernelGGL(deconv_k2s2_kernel<T>, grid, dim3(256), LDS + (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0), s, a);
   return (int)hipGetLastError();
 }

@@ -323,6 +323,20 @@ static inline int deconv_wgrad_partitions(const dua_conv3_desc* d, int* ncombo) 
   return (int)(P < 1 ? 1 : P);
 }
 
+// dynamic-LDS limits (raised once per device by ensure_prepared(), common.hpp)
+template <typename T> constexpr int deconv_dgrad_lds() {
+  constexpr int OS = db::BN * (int)sizeof(T) + 16;
+  return (db::TM * OS > db::A_BYTES + db::W_BYTES) ? db::TM * OS : db::A_BYTES + db::W_BYTES;
+}
+template <typename T> constexpr int deconv_wgrad_lds() { return 4 * (dwg::tile_voxels<T>() * 32 * (int)sizeof(T) + 64); }
+static const LdsAttr kDeconvBwdLdsAttrs[] = {
+    {(const void*)deconv_k2s2_dgrad_kernel<f16>, deconv_dgrad_lds<f16>()},
+    {(const void*)deconv_k2s2_dgrad_kernel<float>, deconv_dgrad_lds<float>()},
+    {(const void*)deconv_k2s2_wgrad_kernel<f16>, deconv_wgrad_lds<f16>()},
+    {(const void*)deconv_k2s2_wgrad_kernel<float>, deconv_wgrad_lds<float>()},
+};
+static const LdsAttrs kDeconvBwdLdsReg(kDeconvBwdLdsAttrs);
+
 template <typename T>
 static int launch_deconv_bwd(const dua_conv3_desc* d, const void* x, const void* dy, const void* w_packed, void* dx,
                              float* dw, float* ws, long ws_bytes, hipStream_t s) {
@@ -333,19 +347,11 @@ static int launch_deconv_bwd(const dua_conv3_desc* d, const void* x, const void*
   a.Cin = d->Cin; a.Cin_stride = d->Cin_stride; a.Cin_off = d->Cin_off;
   a.Cout = d->Cout; a.Cout_stride = d->Cout_stride; a.Cout_off = d->Cout_off;
   const long vox = (long)d->D * d->H * d->W;
+  if (int e = ensure_prepared()) return e;
   if (dx) {
     a.nchunks = (d->Cout + CK - 1) / CK;             // K chunks run over Cout
     a.nct = (d->Cin + db::BN - 1) / db::BN;          // output tiles over Cin
-    constexpr int OS = db::BN * (int)sizeof(T) + 16;
-    constexpr int LDS = (db::TM * OS > db::A_BYTES + db::W_BYTES) ? db::TM * OS : db::A_BYTES + db::W_BYTES;
-    static PerDeviceOnce once;
-    bool* attr = once.flag();
-    if (!attr) return DUA_ERR_ARG;
-    if (!*attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_dgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) return (int)e;
-      *attr = true;
-    }
+    constexpr int LDS = deconv_dgrad_lds<T>();
     dim3 grid((unsigned)((vox + db::TM - 1) / db::TM), a.nct, d->N);
     hipLaunchKernelGGL(deconv_k2s2_dgrad_kernel<T>, grid, dim3(256), LDS, s, a);
   }
@@ -359,14 +365,6 @@ static int launch_deconv_bwd(const dua_conv3_desc* d, const void* x, const void*
     if (vox * 8 > 0x7fffffffL) return DUA_ERR_ARG;                      // the kernel indexes voxels with ints
     const int lds = 4 * (TV * 32 * (int)sizeof(T) + 64);                // x and dy tile, two half images each (>= 32 KB: the
                                                                         // end-of-kernel reduction reuses it)
-    static PerDeviceOnce once2;
-    bool* attr2 = once2.flag();
-    if (!attr2) return DUA_ERR_ARG;
-    if (!*attr2) {
-      hipError_t e = hipFuncSetAttribute((const void*)deconv_k2s2_wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return (int)e;
-      *attr2 = true;
-    }
     hipLaunchKernelGGL(deconv_k2s2_wgrad_kernel<T>, dim3(P, 8 * ncombo), dim3(dwg::NT), lds, s, a);
     const long per_p = (long)ncombo * 8 * 4096;
     long nb = (per_p + 255) / 256;

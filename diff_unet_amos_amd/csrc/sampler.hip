@@ -510,11 +510,9 @@ static int dispatch_tail(const dua_tail_desc* d, TailArgs& a, hipStream_t s) {
 // Grid of the persistent MFMA tail: exactly the workgroups that are resident together (wgs_per_cu x CUs over the N samples),
 // each walking its share of the 256-voxel tiles.  A fixed 1024 left 256 workgroups for a second round that ran on a third of the chip.
 static inline unsigned tail_grid(long ntiles, int N, int wgs_per_cu) {
-  static int cus[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (unsigned)(ntiles < 1024 ? ntiles : 1024);
-  if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
-  long g = (long)wgs_per_cu * cus[dev] / (N > 0 ? N : 1);
+  (void)ensure_prepared();
+  const int cus = device_cus() > 0 ? device_cus() : 256;
+  long g = (long)wgs_per_cu * cus / (N > 0 ? N : 1);
   if (g < 1) g = 1;
   return (unsigned)(ntiles < g ? ntiles : g);
 }

@@ -19,6 +19,7 @@
 // result leaves the same way: accumulators (per LANE = TOKEN, four consecutive output channels per register quad -- bias,
 // GELU and the statistics are register arithmetic) -> LDS tile -> coalesced rows.  The scatter epilogue walks the tile
 // with 16 lanes per token (LayerNorm = a 16-lane butterfly), like window_scatter_add_norm.
+#include <mutex>
 #include "common.hpp"
 #include "../../include/dua_hip.h"
 #include "swin_geom.hpp"
@@ -486,20 +487,36 @@ int launch_patch_embed_mfma(int B, int D, int H, int W, int Cs, int Cp, const vo
   a.w_row = padded_row(K * 2); a.a_row = padded_row(((K + 15) / 16) * 32); a.o_row = padded_row(48 * 4);
   a.w_bytes = 64 * a.w_row + 16;
   const int lds = a.w_bytes + 128 * (a.a_row > a.o_row ? a.a_row : a.o_row);
-  static PerDeviceOnce once;
-  bool* raised = once.flag();
-  if (!raised) return DUA_ERR_ARG;
-  if (lds > 64 * 1024 && !*raised) {
-    if (hipFuncSetAttribute((const void*)patch_embed_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return DUA_ERR_ARG;
-    *raised = true;
-  }
+  if (lds > 160 * 1024) return DUA_ERR_ARG;
+  if (int e = ensure_prepared()) return e;
   const long tiles = ((long)B * (D / 2) * (H / 2) * (W / 2) + 127) / 128;
   dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
   hipLaunchKernelGGL(patch_embed_mfma_kernel, grid, dim3(256), lds, stream, a);
   return (int)hipGetLastError();
 }
 
+}  // namespace dua
+
+namespace dua {
+using Kern = void (*)(TokLinArgs);
+#define ROW(M_) {token_linear_kernel<M_, 1>, token_linear_kernel<M_, 2>, token_linear_kernel<M_, 3>, token_linear_kernel<M_, 4>, \
+                 token_linear_kernel<M_, 5>, token_linear_kernel<M_, 6>}
+static const Kern kTokLinTable[5][6] = {ROW(DUA_TOKLIN_PLAIN), ROW(DUA_TOKLIN_GELU), ROW(DUA_TOKLIN_STATS), ROW(DUA_TOKLIN_RESIDUAL),
+                                        ROW(DUA_TOKLIN_SCATTER)};
+#undef ROW
+// dynamic-LDS limits (raised once per device by ensure_prepared(), common.hpp): every kernel here may be asked for > 64 KB
+#define ATTR_ROW(M_) {(const void*)token_linear_kernel<M_, 1>, 160 * 1024}, {(const void*)token_linear_kernel<M_, 2>, 160 * 1024}, \
+                     {(const void*)token_linear_kernel<M_, 3>, 160 * 1024}, {(const void*)token_linear_kernel<M_, 4>, 160 * 1024}, \
+                     {(const void*)token_linear_kernel<M_, 5>, 160 * 1024}, {(const void*)token_linear_kernel<M_, 6>, 160 * 1024}
+static const LdsAttr kSwinGemmLdsAttrs[] = {
+    {(const void*)patch_embed_mfma_kernel, 160 * 1024},
+    {(const void*)swin_mlp_kernel<48>, 160 * 1024},
+    {(const void*)swin_mlp_kernel<96>, 160 * 1024},
+    ATTR_ROW(DUA_TOKLIN_PLAIN), ATTR_ROW(DUA_TOKLIN_GELU), ATTR_ROW(DUA_TOKLIN_STATS), ATTR_ROW(DUA_TOKLIN_RESIDUAL),
+    ATTR_ROW(DUA_TOKLIN_SCATTER),
+};
+#undef ATTR_ROW
+static const LdsAttrs kSwinGemmLdsReg(kSwinGemmLdsAttrs);
 }  // namespace dua
 
 extern "C" int dua_swin_mlp(long tokens, int C, const void* ln2, const void* W1, const float* b1, const void* W2, const float* b2,
@@ -512,15 +529,8 @@ extern "C" int dua_swin_mlp(long tokens, int C, const void* ln2, const void* W1,
   a.w1_row = padded_row(C * 2); a.w2_row = padded_row(192 * 2); a.a_row = padded_row(C * 2); a.o_row = padded_row(C * 4);
   const int nb2 = (C + 31) / 32;
   const int lds = 192 * a.w1_row + nb2 * 32 * a.w2_row + 128 * (a.a_row > a.o_row ? a.a_row : a.o_row);
-  static PerDeviceOnce once;
-  bool* raised = once.flag();
-  if (!raised) return DUA_ERR_ARG;
-  if (!*raised) {
-    if (hipFuncSetAttribute((const void*)swin_mlp_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)swin_mlp_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return DUA_ERR_ARG;
-    *raised = true;
-  }
+  if (lds > 160 * 1024) return DUA_ERR_ARG;
+  if (int e = ensure_prepared()) return e;
   const long tiles = (tokens + 127) / 128;
   dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
   if (C == 48) hipLaunchKernelGGL(swin_mlp_kernel<48>, grid, dim3(256), lds, (hipStream_t)stream, a);
@@ -566,33 +576,25 @@ extern "C" int dua_token_linear(const dua_token_linear_desc* d, void* stream) {
   const int tile_bytes = 128 * (a.a_row > a.o_row ? a.a_row : a.o_row);
   const int lds = a.w_bytes + tile_bytes;
   if (lds > 160 * 1024) return DUA_ERR_ARG;
-  using Kern = void (*)(TokLinArgs);
-#define ROW(M_) {token_linear_kernel<M_, 1>, token_linear_kernel<M_, 2>, token_linear_kernel<M_, 3>, token_linear_kernel<M_, 4>, \
-                 token_linear_kernel<M_, 5>, token_linear_kernel<M_, 6>}
-  static const Kern table[5][6] = {ROW(DUA_TOKLIN_PLAIN), ROW(DUA_TOKLIN_GELU), ROW(DUA_TOKLIN_STATS), ROW(DUA_TOKLIN_RESIDUAL),
-                                   ROW(DUA_TOKLIN_SCATTER)};
-#undef ROW
-  const Kern kern = table[d->mode][NB - 1];
-  if (lds > 64 * 1024) {
-    static PerDeviceOnce once[5][6];
-    bool* raised = once[d->mode][NB - 1].flag();
-    if (!raised) return DUA_ERR_ARG;
-    if (!*raised) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return DUA_ERR_ARG;
-      *raised = true;
-    }
-  }
+  const Kern kern = kTokLinTable[d->mode][NB - 1];
+  if (int e = ensure_prepared()) return e;
   // Enough workgroups to fill every CU to its occupancy limit: a wave works through load -> MFMA -> epilogue of one tile
   // at a time, so the latency of its loads is hidden by the OTHER waves of the SIMD, not inside the wave.
+  // (a pure query, cached per kernel and LDS size; the cache is shared by every thread that launches)
+  static std::mutex occ_mu;
   static int occ[5][6] = {};
   static int occ_lds[5][6] = {};
-  int& oc = occ[d->mode][NB - 1];
-  if (oc == 0 || occ_lds[d->mode][NB - 1] != lds) {
-    int nblk = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)kern, 256, lds) != hipSuccess || nblk < 1) nblk = 1;
-    oc = nblk > 8 ? 8 : nblk;
-    occ_lds[d->mode][NB - 1] = lds;
+  int oc;
+  {
+    std::lock_guard<std::mutex> lock(occ_mu);
+    int& o = occ[d->mode][NB - 1];
+    if (o == 0 || occ_lds[d->mode][NB - 1] != lds) {
+      int nblk = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)kern, 256, lds) != hipSuccess || nblk < 1) nblk = 1;
+      o = nblk > 8 ? 8 : nblk;
+      occ_lds[d->mode][NB - 1] = lds;
+    }
+    oc = o;
   }
   const long tiles = (d->M + 127) / 128;
   long cap = 256L * oc / samples;

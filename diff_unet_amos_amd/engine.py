@@ -60,6 +60,7 @@ class Plan:
             "patch extents must be multiples of 16 (four 2x poolings; the reference recommends the same)"
         assert D >= 32 and H >= 32 and W >= 32, "InstanceNorm3d needs >1 voxel at the bottom level (SURVEY F7)"
         self.net, self.N, self.dims, self.dtype, self.dev, self.f = net, N, (D, H, W), dtype, device, f
+        nv.prepare(device)            # function attributes of every kernel: before the first launch and before any capture
         self.C = net.num_classes
         self.cx = ops.state_stride(self.C)
         self.cin0 = -(-(self.C + 1) // 8) * 8           # [x_t (C) | image | zero pad]

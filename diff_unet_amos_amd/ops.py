@@ -993,10 +993,12 @@ def _gemm_ws(nbytes, device):
     return buf
 
 
-def token_gemm(A, W, bias=None, mode="plain", out=None, out_off=0, x=None):
+def token_gemm(A, W, bias=None, mode="plain", out=None, out_off=0, x=None, workspace=None):
     """dua_token_gemm: the tiled MFMA GEMM of the coarse Swin stages -- fp16 A [tokens, K] (row stride A.stride(0)) times the
     nn.Linear weight W [N, K] (any K, N that are multiples of 8), "plain" / "gelu" -> out[:, out_off:out_off+N] (fp16), or
-    "residual": x += result on the fp32 stream."""
+    "residual": x += result on the fp32 stream.  ``workspace``: a callable ``nbytes -> fp32 tensor`` that owns the K-split
+    scratch (a plan's own buffer: a captured graph bakes the address in, so two plans must not share one); default: the
+    per-(device, stream) scratch of this module."""
     assert A.is_cuda and A.dtype == torch.float16 and A.dim() == 2 and A.stride(1) == 1
     assert W.is_cuda and W.dtype == torch.float16 and W.is_contiguous() and W.dim() == 2 and W.shape[1] == A.shape[1]
     M, K = A.shape
@@ -1019,7 +1021,8 @@ def token_gemm(A, W, bias=None, mode="plain", out=None, out_off=0, x=None):
         assert out.numel() == M * ldc and out_off + N <= ldc and ldc % 8 == 0 and out_off % 8 == 0
         d.out, d.ldc, d.out_off = out.data_ptr(), ldc, out_off
     need = int(nv.lib().dua_token_gemm_workspace(M, K, N))
-    ws = _gemm_ws(need, A.device) if need > 0 else None
+    ws = (workspace(need) if workspace is not None else _gemm_ws(need, A.device)) if need > 0 else None
+    assert ws is None or (ws.is_cuda and ws.dtype == torch.float32 and ws.numel() * 4 >= need)
     nv.check(nv.lib().dua_token_gemm(C.byref(d), nv.ptr(ws), ws.numel() * 4 if ws is not None else 0, nv.stream_ptr()),
              "dua_token_gemm")
     return x if mode == "residual" else out

@@ -110,6 +110,8 @@ class SwinPlan:
             "input image size (image_size) should be divisible by stage-wise image resolution."      # denoiser.py:110-113
         assert (D // 32) * (H // 32) * (W // 32) > 1, "InstanceNorm3d needs more than one voxel at the 1/32 level"
         self.net, self.N, self.dims, self.dtype, self.dev = net, N, (D, H, W), dtype, device
+        nv.prepare(device)            # function attributes of every kernel: before the first launch and before any capture
+        self._gemm_ws, self._gemm_ws_retired = [None, None], []
         self.C = net.num_classes
         f = net.feature_size
         self.f = f
@@ -347,7 +349,8 @@ class SwinPlan:
             if self.fused_linear and self.tl_conv3 and r.cout <= 64 and cin <= 384:
                 ops.token_linear(x2, r.w3, None, "stats", out=res.view(-1, r.cout), stats=r.st[2], samples=N)   # conv3 + norm3 sums
             elif self.wide_gemm:
-                ops.token_gemm(x2, r.w3, None, "plain", out=res.view(-1, r.cout))    # 1x1x1 conv3 on the tiled MFMA GEMM
+                ops.token_gemm(x2, r.w3, None, "plain", out=res.view(-1, r.cout),
+                               workspace=self._gemm_scratch_b if side else self._gemm_scratch)    # 1x1x1 conv3 on the tiled MFMA GEMM
                 ops.instnorm_stats(res, r.cout, r.st[2])
             else:
                 torch.matmul(x2, r.w3.t(), out=res.view(-1, r.cout))                 # fp32 parity mode: library GEMM
@@ -391,7 +394,7 @@ class SwinPlan:
                 if fused and self.tl_qkv:
                     qkv = ops.token_linear(win.view(-1, C_), b["wqkv"], b["fqkv"], "plain", out=qkv_buf)
                 elif wide:
-                    qkv = ops.token_gemm(win.view(-1, C_), b["wqkv"], b["fqkv"], "plain", out=qkv_buf)
+                    qkv = ops.token_gemm(win.view(-1, C_), b["wqkv"], b["fqkv"], "plain", out=qkv_buf, workspace=self._gemm_scratch)
                 else:
                     qkv = F.linear(win, b["wqkv"], b["bqkv"])
                 ops.window_attention(qkv, HEADS[i], None, region_ids=g["region"] if shifted else None,
@@ -409,10 +412,10 @@ class SwinPlan:
                         ops.token_linear(hid, b["w2"], b["f2"], "residual", x=x)   # x + mlp(norm2(x)) lands in the stream
                 elif wide:
                     po = self.po_buf[:ntok_w * C_].view(N * g["nw"], g["n"], C_)
-                    ops.token_gemm(att.view(-1, C_), b["wproj"], b["fproj"], "plain", out=po)
+                    ops.token_gemm(att.view(-1, C_), b["wproj"], b["fproj"], "plain", out=po, workspace=self._gemm_scratch)
                     ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)
-                    ops.token_gemm(ln2, b["w1"], b["f1"], "gelu", out=hid)                       # linear1 + GELU
-                    ops.token_gemm(hid, b["w2"], b["f2"], "residual", x=x.view(-1, C_))         # x + mlp(norm2(x)) on the stream
+                    ops.token_gemm(ln2, b["w1"], b["f1"], "gelu", out=hid, workspace=self._gemm_scratch)                       # linear1 + GELU
+                    ops.token_gemm(hid, b["w2"], b["f2"], "residual", x=x.view(-1, C_), workspace=self._gemm_scratch)         # x + mlp(norm2(x)) on the stream
                 else:
                     po = F.linear(att, b["wproj"], b["bproj"])
                     ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)
@@ -428,7 +431,7 @@ class SwinPlan:
                                        out=self.red_buf[:merged.numel() // 4].view(-1, 2 * C_))
             elif self.wide_gemm:
                 red = ops.token_gemm(merged.view(-1, 8 * C_), st["wred"], None, "plain",
-                                     out=self.red_buf[:merged.numel() // 4].view(-1, 2 * C_))
+                                     out=self.red_buf[:merged.numel() // 4].view(-1, 2 * C_), workspace=self._gemm_scratch)
             else:
                 red = F.linear(merged.view(-1, 8 * C_), st["wred"])
             ops.stage_out(red, N, 2 * C_, outs[i + 1][0], outs[i + 1][1], tadd=tadd(i + 1),
@@ -519,6 +522,22 @@ class SwinPlan:
                 break
             self._res_block(self.u_res[k], cat[k], 2 * cout, dec[k], 0, ra=ra, ra_off=cout)
             src = dec[k]
+
+    def _gemm_scratch(self, nbytes, which=0):
+        """K-split scratch of the token GEMMs, owned by this plan (its graphs bake the address in); ``which`` = 1: the second
+        buffer, for launches on the side stream (reuse is ordered by the stream).  Grown by the warm-up pass that precedes
+        every capture; growing it inside a capture would put it into that graph's private memory pool."""
+        buf = self._gemm_ws[which]
+        if buf is None or buf.numel() * 4 < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("SwinPlan: the token-GEMM scratch must be sized by the warm-up pass, not inside a capture")
+            if buf is not None:
+                self._gemm_ws_retired.append(buf)          # an earlier graph of this plan may still hold its address
+            buf = self._gemm_ws[which] = torch.empty(max(int(nbytes), 16 << 20) // 4, dtype=torch.float32, device=self.dev)
+        return buf
+
+    def _gemm_scratch_b(self, nbytes):
+        return self._gemm_scratch(nbytes, 1)
 
     def capture_step(self, step_fn):
         """Record ``step_fn`` (one sampler step: step_begin + denoiser_body + tail on the current stream) into a HIP graph;

@@ -398,9 +398,24 @@ class NativeConvTrainer:
         # out of one arena that a single fill re-zeroes: gradients are 4 bytes per parameter, the rest is small
         from . import ops
         dev = self.params[0].device
+        if dev.type == "cuda":
+            from . import _native
+            _native.prepare(dev)         # every kernel's function attributes: before the first launch, before any capture, and
+                                         # before autograd's worker thread (which issues the backward launches) exists
         self.arena = ops.ZeroArena(sum(p.numel() for p in self.params) * 4 + (96 << 20), dev) if dev.type == "cuda" else None
         # weight gradients on a side stream (see _wgrad); not under the DDP reducer, whose hooks read them on the main stream
         self.wgrad_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and not self.overlap and wgrad_overlap) else None
+        # graph mode captures on a stream of this trainer's own (torch hands streams out of a pool of 32 per device, round
+        # robin: after enough Stream() calls in a process the "new" stream IS an older one -- make sure the capture stream and
+        # the weight-gradient side stream are two different HIP streams, or the captured fork / join would be a self-wait)
+        self.capture_stream = None
+        if graph and dev.type == "cuda":
+            for _ in range(64):
+                st = torch.cuda.Stream(device=dev)
+                if self.wgrad_stream is None or st.cuda_stream != self.wgrad_stream.cuda_stream:
+                    self.capture_stream = st
+                    break
+            assert self.capture_stream is not None
 
     def _allreduce(self):
         if not self.distributed or self.overlap:          # the DDP reducer already averaged them during backward
@@ -453,25 +468,29 @@ class NativeConvTrainer:
                        scale=torch.full((), self.init_scale if self.dtype == torch.float16 else 1.0, device=dev),
                        growth=torch.zeros((), dtype=torch.int32, device=dev), found_inf=torch.zeros((), device=dev))
         saved = [p.detach().clone() for p in self.params]
-        side = torch.cuda.Stream()
+        # Warm-up ON the capture stream: the per-(device, stream) scratch buffers of ops (split-K, weight-gradient partials)
+        # are then allocated here, from the ordinary pool, and the capture finds them -- allocated inside the capture they
+        # would live in this graph's private pool while the module-level cache hands them to every later capture.
+        side = self.capture_stream
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(3):                       # warm-up: lazy kernel attributes, workspaces, optimizer state tensors
+            for _ in range(3):                       # warm-up: workspaces, optimizer state tensors
                 self._g["noise"].normal_()
                 self._graph_body()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(dev)
         self.optimizer.zero_grad(set_to_none=True)
         if not self.distributed:
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, stream=self.capture_stream):
                 self._g["loss"] = self._graph_body()
         else:
             # two graphs sharing one memory pool; the gradients allocated while capturing the first stay alive (p.grad)
             # and are what the eager all-reduce and the second graph see on every replay
             self._graph, self._graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, stream=self.capture_stream):
                 self._g["loss"] = self._graph_fwd_bwd()
-            with torch.cuda.graph(self._graph2, pool=self._graph.pool()):
+            with torch.cuda.graph(self._graph2, pool=self._graph.pool(), stream=self.capture_stream):
                 self._graph_update()
         # the warm-up steps were real updates: put weights, Adam moments/step counter and the loss scale back
         with torch.no_grad():

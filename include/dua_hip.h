@@ -164,6 +164,21 @@ int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, 
                       const double* sums, const float* gscale, float w_mse, float w_bce, float w_dice, void* dlogits,
                       int dlogits_stride, void* stream);
 
+/* ---- library state ---------------------------------------------------------------------------------------------
+ * dua_abi_version(): DUA_ABI_VERSION of the library that is loaded.  It changes whenever a struct of this header, the size
+ * or layout of a buffer a caller allocates (e.g. the statistics words of dua_in_norm) or a signature changes; a binding
+ * built against another header must refuse to run (diff_unet_amos_amd/_native.py does).
+ * dua_prepare(): once per device and process, raises the dynamic-LDS limit (hipFuncSetAttribute) of every kernel of the
+ * library that needs more than 64 KB and caches the device's compute-unit count.  Every launcher runs it on first use;
+ * callers that capture launches into a hipGraph, or launch from several threads (torch's autograd runs backward() on a
+ * worker thread), call it once up front, on the device they will use, so that no such call happens inside a capture.
+ * Thread-safe.  Returns 0, DUA_ERR_ARG (no current device) or a hipError_t.
+ * dua_prepared_kernels(): how many kernels dua_prepare() configures (tests). */
+#define DUA_ABI_VERSION 4
+int dua_abi_version(void);
+int dua_prepare(void);
+int dua_prepared_kernels(void);
+
 /* Measurement aid (bench.py roofline.measured_mfma_ceiling): `workgroups` x 4 waves (one per SIMD at one workgroup per CU)
  * issue iters * 16 back-to-back v_mfma_f32_32x32x16_f16 (32 768 FLOP each) on random register operands.  stamps (or NULL):
  * 2 words per workgroup = (s_memtime cycles, s_memrealtime 100 MHz ticks) spent in the loop.  sink: any device float. */

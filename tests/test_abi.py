@@ -73,3 +73,24 @@ def test_scratch_sizes_cover_whole_tiles(lib):
     assert ws > 0 and ws % (6 * 6 * 6 * 512 * 4) == 0
     d = nv.Conv3Desc(nv.F16, 1, 96, 96, 96, 64, 64, 0, 64, 64, 0)             # the 96^3 level: never split
     assert lib.dua_conv3d_k3_workspace(C.byref(d)) == 0
+
+
+def test_abi_version_and_prepare_registry(lib):
+    """The binding refuses a library built from another header (dua_abi_version), and every kernel that needs more than the
+    default dynamic-LDS limit is registered for dua_prepare() at load time -- no device needed to count them."""
+    from diff_unet_amos_amd import _native as nv
+    src = open(HEADER).read()
+    assert int(re.search(r"#define DUA_ABI_VERSION (\d+)", src).group(1)) == nv.ABI_VERSION == lib.dua_abi_version()
+    # conv (12) + weight gradient (6) + transposed conv (8) + its backward (4) + Swin token kernels (3 + 30)
+    assert lib.dua_prepared_kernels() == 63
+
+
+def test_no_launcher_sets_function_attributes_on_its_own():
+    """hipFuncSetAttribute lives in prepare.hip only: a launcher that raised its own limit lazily could do so for the first
+    time inside a stream capture, or from autograd's worker thread while the main thread does the same."""
+    csrc = os.path.join(ROOT, "diff_unet_amos_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")) and name != "prepare.hip":
+            text = re.sub(r"//.*", "", open(os.path.join(csrc, name)).read())
+            assert "hipFuncSetAttribute" not in text, name
+            assert "PerDeviceOnce" not in text, name

@@ -701,3 +701,62 @@ def test_deconv_backward_matches_torch(dtype, shape):
     want_dx = xr.grad.permute(0, 2, 3, 4, 1)
     assert (dx.double() - want_dx).abs().max().item() <= tol * max(1.0, want_dx.abs().max().item())
     assert (dw.double() - wr.grad).abs().max().item() <= tol * max(1.0, wr.grad.abs().max().item())
+
+
+_FRESH_CAPTURE = r"""
+import sys, threading
+sys.path.insert(0, {root!r})
+import torch
+from diff_unet_amos_amd import _native as nv, ops
+dev = torch.device("cuda:0")
+errs = []
+def prep():
+    try:
+        nv.prepare(dev)
+    except Exception as e:            # noqa: BLE001
+        errs.append(e)
+ts = [threading.Thread(target=prep) for _ in range(8)]          # concurrent first use: one of them does the work
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errs, errs
+g = torch.Generator().manual_seed(5)
+N, cin, cout, S = 1, 64, 128, 24                                  # a 24^3 layer: the kd-plane form (160 KB of dynamic LDS)
+dtype = {dtype}
+x = torch.randn(N, S, S, S, cin, generator=g).to(dev, dtype)
+w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05).to(dev)
+b = torch.randn(cout, generator=g).to(dev)
+wp, bp = ops.pack_conv3_weights(w, b, dtype)
+torch.cuda.synchronize()
+def run(y, st, dw):
+    ops.conv3d_k3(x, cin, 0, wp, bp, cout, y, 0, st)
+    ops.conv3d_k3_wgrad(x, cin, 0, y, cout, 0, dw)                # y as the output gradient: any tensor of that shape
+ya, sa, dwa = torch.empty(N, S, S, S, cout, device=dev, dtype=dtype), ops.stats_buffer(N, cout, dev), torch.zeros_like(w)
+yb, sb, dwb = torch.empty_like(ya), ops.stats_buffer(N, cout, dev), torch.zeros_like(w)
+# NO warm-up launch: the very first launch of these kernels in this process is recorded into a graph
+cap = torch.cuda.Stream(dev)
+gr = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr, stream=cap):
+    run(ya, sa, dwa)
+gr.replay()
+torch.cuda.synchronize()
+run(yb, sb, dwb)
+torch.cuda.synchronize()
+assert torch.equal(ya, yb) and torch.equal(sa, sb)
+assert torch.allclose(dwa, dwb, rtol=1e-3, atol=1e-3 * float(dwb.abs().max()))
+print("fresh-capture ok", float(ya.float().abs().max()))
+"""
+
+
+@pytest.mark.parametrize("dtype", ["torch.float16", "torch.float32"])
+def test_first_launch_inside_a_capture_in_a_fresh_process(dtype):
+    """Regression guard for the training-graph crash of round 3: after dua_prepare() -- called concurrently
+    from eight threads here -- the FIRST launch of the 160 KB kd-plane convolution and of the weight-gradient kernel may be a
+    captured one; no function attribute is set lazily inside the capture.  A process of its own, so that nothing warmed the
+    kernels up."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", _FRESH_CAPTURE.format(root=root, dtype=dtype)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "fresh-capture ok" in r.stdout

@@ -17,4 +17,8 @@ struct Conv3Args {
   int tap_ch;                       // single-channel tap form: packed index of that channel, else -1
 };
 
+// conv3d_wide.hip: the 8-accumulator form (8x8x8 tiles) for fp16 layers with >= 1024 tiles of 4x8x8; D, H, W multiples of 8,
+// Cin a multiple of 16.
+int launch_conv3_wide(Conv3Args a, int D, hipStream_t s);
+
 }  // namespace dua

@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include "../../include/dua_hip.h"
 #include "conv3_args.hpp"
+#include "stamp.hpp"
 #include <algorithm>
 
 namespace dua {
@@ -38,24 +39,6 @@ constexpr int BN = 64;                     // output channels per workgroup
 // split-K, 3 forces 2x8x8 (slab form), 6 = the automatic policy with the slab form everywhere (same-process A/B)
 int g_conv_variant = 0;
 
-// ---- diagnostic build only (-DDUA_STAMP, tools/build_diag.sh -> a separate library selected with DUA_HIP_LIB): lane 0 of
-// every workgroup stamps the shader-clock counter at the phase boundaries of the convolution kernel and the 100 MHz
-// real-time counter at its start and end.  The stamps go to a buffer of their own that no kernel reads
-// (dua_debug_stamps copies it out); the shipped library contains none of this.
-#ifdef DUA_STAMP
-constexpr int STAMP_WGS = 8192, STAMP_SLOTS = 64;
-__device__ unsigned long long g_stamp[STAMP_WGS][STAMP_SLOTS];
-#define DUA_STAMP_AT(slot, rt)                                                                          \
-  do {                                                                                                   \
-    if (threadIdx.x == 0) {                                                                              \
-      const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                    \
-      if (wg_ < STAMP_WGS && (slot) < STAMP_SLOTS)                                                      \
-        g_stamp[wg_][slot] = (rt) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();    \
-    }                                                                                                    \
-  } while (0)
-#else
-#define DUA_STAMP_AT(slot, rt) do { } while (0)
-#endif
 int g_skip_splitk_finish = 0;   // diagnostics (dua_set_option(2, 1)): time the split-K main kernel alone; outputs are not finished
 extern int g_wgrad_abl;
 extern int g_wgrad_variant;
@@ -992,8 +975,14 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
       return (int)hipGetLastError();
     }
   }
-  const bool autop = g_conv_variant == 0 || g_conv_variant == 6;       // the automatic policy; 6 = without the kd-plane form (A/B)
-  const bool big = g_conv_variant == 0;          // kd-plane form for the layers that cannot put two workgroups on every CU
+  // wide-tile form (conv3d_wide.hip): fp16 layers with tiles to spare (96^3); variant 7 keeps them on the 4x8x8 kernel (A/B)
+  if constexpr (sizeof(T) == 2) {
+    if (g_conv_variant == 0 && !d->background && (long)a.ntiles * nct * d->N >= 1024 && d->D % 8 == 0 && d->H % 8 == 0 && d->W % 8 == 0 &&
+        d->Cin % 16 == 0 && d->Cin <= (in && in->stats ? 256 : 384) && vox * d->Cin_stride < 0x7fffffffL)
+      return launch_conv3_wide(a, d->D, s);
+  }
+  const bool autop = g_conv_variant == 0 || g_conv_variant == 6 || g_conv_variant == 7;       // the automatic policy; 6 = without the kd-plane form, 7 = without the wide-tile form (A/B)
+  const bool big = g_conv_variant == 0 || g_conv_variant == 7;          // kd-plane form for the layers that cannot put two workgroups on every CU
   if (ws != nullptr && autop) {
     int ks, ups;
     choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups, big ? 256 : 320);
@@ -1039,19 +1028,11 @@ extern "C" {
 
 #ifdef DUA_STAMP
 // diagnostic build: copy the stamp buffer out ([8192 workgroups][64 slots] of 64-bit counters) and clear it
-long dua_debug_stamps(void* host, long bytes) {
-  const long all = (long)sizeof(unsigned long long) * dua::STAMP_WGS * dua::STAMP_SLOTS;
-  if (!host || bytes < all) return all;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(dua::g_stamp), all) != hipSuccess) return -1;
-  void* p = nullptr;
-  if (hipGetSymbolAddress(&p, HIP_SYMBOL(dua::g_stamp)) == hipSuccess) (void)hipMemset(p, 0, all);
-  return all;
-}
+long dua_debug_stamps(void* host, long bytes) { return dua::stamps_out(host, bytes); }
 #endif
 
 int dua_set_option(int key, int value) {
-  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 6)) { dua::g_conv_variant = value; return 0; }
+  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 6 || value == 7)) { dua::g_conv_variant = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
 #ifdef DUA_ABLATE
   if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only

@@ -1,0 +1,357 @@
+// 3x3x3 convolution, wide-tile form (round 4): 8 MFMA accumulators per wave.
+//
+// Same operation, operands and packed weights as conv3d_k3_v2_kernel (conv3d_igemm.hip: nn.Conv3d k3 p1 of MONAI's
+// Convolution block, models/basic_unet/denoiser.py:56-59, with the producer's InstanceNorm + LeakyReLU + temb add fused
+// into the halo staging and this layer's InstanceNorm sums in the epilogue), for the fp16 layers that have tiles to spare
+// (96^3): there a 4x8x8-voxel workgroup spends 19 000 of its 52 000 cycles outside the K loop (statistics preamble, halo
+// staging + transform, epilogue; in-kernel stamps), and two such workgroups per CU keep the matrix pipes 53 %
+// busy.  Here a workgroup owns 8x8x8 voxels x 64 output channels and a wave 128 voxels x 64 channels = 4 x 2
+// accumulators of 32x32:
+//   * per k-step 6 fragment reads feed 8 MFMAs (4 per 4 before): 768 B of LDS reads per MFMA instead of 1024;
+//   * weights, barriers and the statistics preamble are paid once per 512 voxels instead of once per 256;
+//   * the halo is 1000 voxels for 512 outputs (1.95 per output) instead of 600 for 256 (2.34).
+// Two workgroups per CU must still fit (one alone leaves the pipes idle during every prologue / epilogue), i.e. <= 80 KB
+// of LDS and <= 256 registers per lane with 128 of them accumulators:
+//   * the input is walked in HALF chunks of 16 channels: 32-byte halo voxels (12 slots per 10-voxel row, the two 16-byte
+//     halves swapped on odd rows: the layout of the first-layer kernel, every ds_read_b128 fragment read conflict-free),
+//     38.4 KB for the 10x10x10 halo; one k-step per tap;
+//   * weights arrive as kd planes of a half chunk (9 taps x 2 k-groups x 1 KB = 18 KB) by LDS-DMA straight out of the
+//     packed slab layout into a ring of two: no staging registers, a phase is 72 MFMAs per wave between two barriers;
+//   * operand fragments are prefetched half a k-step ahead (the B pair double-buffered, the A pairs of the two depth
+//     slices alternate): 32 registers;
+//   * the next half chunk's halo (8 pieces of 16 bytes per thread) is requested at the start of a half chunk's last
+//     phase and transformed + stored after it.
+// Tile count: 96^3 gives 1728 such tiles for 512 resident workgroups (3.4 rounds); ending the launch with 4x8x8 tiles of the
+// same code (template MB = 2) to fill the last round was built and measured: the all-wide launch is faster
+// (profiles/r4_conv_wide_tile_ab.txt), so the kernel has the one form.
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+#include "conv3_args.hpp"
+#include "stamp.hpp"
+
+namespace dua {
+
+namespace c3w {
+constexpr int TH = 8, TW = 8, HH = TH + 2, HW = TW + 2;
+constexpr int VSF = 32, RSF = 12 * VSF, PSF = HH * RSF;      // 384-byte rows, 3840-byte planes
+constexpr int BN = 64;
+constexpr int WPLANE = 18 * 1024;                              // [9 taps][2 k-groups][64 couts][16 B]
+constexpr int HALO_MAX = 10 * PSF;                             // 38400: the 8-deep tile
+constexpr int LDS_FIXED = HALO_MAX + 2 * WPLANE;               // 75264
+constexpr int SLAB = 3 * 4 * BN * 16;                          // 12288: one (kd, kh) slab of the packed weights (32-channel chunk)
+}  // namespace c3w
+
+// one 1 KB piece global -> LDS (64 lanes x 16 B, LDS address = M0 base + lane * 16); M0 saved / restored in the statement
+__device__ __forceinline__ void dma_piece(const char* src_lane, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src_lane), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+
+// MB = 32-voxel blocks per wave: 4 (8x8x8 tile, wave = depth slices 2w and 2w+1) or 2 (4x8x8 tile, wave = depth slice w)
+template <int MB>
+__device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const int d0, const int h0, const int w0,
+                                          const int ct, const int n, const int replica) {
+  using namespace c3w;
+  using T = f16;
+  constexpr int TD = 2 * MB, HD = TD + 2, NH = MB / 2;         // NH half-steps (pairs of blocks) per tap
+  char* halo = smem;
+  char* wbuf = smem + HALO_MAX;
+  float* xsc = (float*)(smem + LDS_FIXED);
+  float* xsh = xsc + a.Cin;                                    // Cin is a multiple of 16 here
+  float* xad = xsh + a.Cin;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const bool fused = a.xf.stats != nullptr;
+  const int nhc = (a.Cin + 15) >> 4;                           // half chunks
+  const int U = nhc * 3;
+
+  // ---- halo pieces of this thread: thread = (position (hy, hx) inside a halo plane, 16-byte half p) -- 200 of the 256 threads
+  // -- and piece j = halo plane j: the global address advances by one plane of the volume and the LDS address by one halo
+  // plane per piece (immediate offsets), and whether plane j lies inside the volume is wave-uniform.  (Dealing the 2000
+  // pieces out evenly, 8 per thread, cost ~40 address instructions per piece, at every half chunk.) ----
+  const int p_t = tid & 1, pos = tid >> 1;
+  const int hy = pos / HW, hx = pos - hy * HW;
+  const int gh = h0 + hy - 1, gw = w0 + hx - 1;
+  const bool ok_hw = pos < HH * HW && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+  const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + a.Cin_off + p_t * 8;
+  const int voff = ok_hw ? (((d0 - 1) * a.H + gh) * a.W + gw) * a.Cin_stride : 0;      // of halo plane 0 (never read where it is outside)
+  const int pstep = a.H * a.W * a.Cin_stride;
+  // threads without a position store into the unused voxel slots 10 / 11 of row 0 of each plane
+  const int loff = pos < HH * HW ? hy * RSF + hx * VSF + ((p_t ^ (hy & 1)) << 4) : HW * VSF + (p_t << 4);
+  f16x8 hreg[HD];
+  auto load_halo = [&](int hc, int j0, int j1) {
+    const T* src = xin + hc * 16;
+#pragma unroll
+    for (int j = 0; j < HD; ++j) {
+      if (j < j0 || j >= j1) continue;
+      const bool dok = (unsigned)(d0 + j - 1) < (unsigned)a.D;       // wave-uniform
+      hreg[j] = *(const f16x8*)(src + (ok_hw && dok ? voff + j * pstep : 0));
+    }
+  };
+  auto store_halo = [&](int hc) {
+    float sc[8], sh[8], ad[8], sn[8];
+    if (fused) {
+      const int c0 = hc * 16 + p_t * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+      xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
+    }
+#pragma unroll
+    for (int j = 0; j < HD; ++j) {
+      f16x8 v = hreg[j];
+      if (fused) v = xform_frag<T>(v, sc, sh, ad, sn, a.xf.slope);
+      const f32x4 raw = __builtin_bit_cast(f32x4, v);
+      const bool ok = ok_hw && (unsigned)(d0 + j - 1) < (unsigned)a.D;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = ok ? raw[e] : 0.f;
+      *(f32x4*)(halo + loff + j * PSF) = o;
+    }
+  };
+
+  // ---- weights: kd plane `kd` of half chunk `hc` -> ring slot (18 pieces of 1 KB; wave w takes pieces w, w + 4, ...) ----
+  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB + lane * 16;
+  const unsigned wlds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wbuf;
+  auto dma_plane = [&](int u, int slot) {
+    const int hc = u / 3, kd = u - hc * 3;
+    const char* src = wsrc + (long)((hc >> 1) * 3 + kd) * 3 * SLAB + (hc & 1) * 2048;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int p = wave + 4 * j;                              // piece = (tap p >> 1, k-group p & 1)
+      if (p < 18) dma_piece(src + ((p >> 1) * 4 + (p & 1)) * 1024, wlds + slot * WPLANE + p * 1024);
+    }
+  };
+
+  // ---- prologue.  Everything that must come from memory is requested before anything waits, oldest first in the order it
+  // is needed (vmcnt retires in order): bias, the producer's statistics words (fused input), the halo, the first weight plane.
+  DUA_STAMP_AT(0, true);
+  DUA_STAMP_AT(2, false);
+  float bias_q[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int bc = ct * BN + q * 32 + r;
+    bias_q[q] = bc >= a.Cout ? 0.f : a.bias[bc];
+  }
+  // scale / shift / add tables of the fused input transform: the arithmetic of xform_preamble (common.hpp) with its loads
+  // split off, 16 channels per (wave, group u), up to UN groups per wave = 256 channels
+  constexpr int UN = 4;
+  stat_t sv[UN][2 * STAT_WORDS];
+  float gam[UN], bet[UN], addv[UN];
+  if (fused) {
+    const int part = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int c = (wave + 4 * u) * 16 + (lane & 15), cc = c < a.Cin ? c : a.Cin - 1;
+      gam[u] = a.xf.gamma[cc]; bet[u] = a.xf.beta[cc];
+      addv[u] = a.xf.add ? a.xf.add[(long)n * a.xf.add_stride + cc] : 0.f;
+      const stat_t* sp = a.xf.stats + ((long)n * STAT_REPLICAS + 2 * part) * STAT_WORDS * a.xf.c_pad + cc;
+#pragma unroll
+      for (int k = 0; k < 2 * STAT_WORDS; ++k) sv[u][k] = (wave + 4 * u) * 16 < a.Cin ? sp[(long)k * a.xf.c_pad] : 0;   // wave-uniform
+    }
+  }
+  DUA_STAMP_AT(56, false);
+  load_halo(0, 0, HD);
+  DUA_STAMP_AT(57, false);
+  dma_plane(0, 0);
+  DUA_STAMP_AT(59, false);
+  if (fused) {
+    const int part = lane >> 4;
+    double Sm = 0, Qm = 0;
+    float gm = 0.f, bm = 0.f, am = 0.f;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      stat_t w[STAT_WORDS];
+#pragma unroll
+      for (int k = 0; k < STAT_WORDS; ++k) {
+        w[k] = sv[u][k] + sv[u][STAT_WORDS + k];
+        w[k] += __shfl_xor(w[k], 16);
+        w[k] += __shfl_xor(w[k], 32);
+      }
+      if (part == u) {                     // the 16-lane part u finishes group u: one reciprocal square root per lane
+        Sm = (double)w[0] + (double)w[1] * (1.0 / STAT_FRAC);
+        Qm = (double)w[2] + (double)w[3] * (1.0 / STAT_FRAC);
+        gm = gam[u]; bm = bet[u]; am = addv[u];
+      }
+    }
+    const int c = (wave + 4 * part) * 16 + (lane & 15);
+    const double mean = Sm * (double)a.xf.inv_count;
+    double var = Qm * (double)a.xf.inv_count - mean * mean;
+    var = var > 0 ? var : 0;
+    const float g = gm * (float)(1.0 / sqrt(var + (double)a.xf.eps));
+    if (c < a.Cin) {
+      xsc[c] = g;
+      xsh[c] = bm - (float)mean * g;
+      xad[c] = am;
+    }
+    __syncthreads();
+  }
+  DUA_STAMP_AT(60, false);
+  DUA_STAMP_AT(61, false);
+  store_halo(0);
+  // ---- accumulators: [block m][cout half q]; block m = depth slice dsl + (m >> 1), h rows 4 (m & 1) .. +3; they start at
+  // the bias ----
+  const int dsl = MB == 4 ? 2 * wave : wave;
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][q][i] = bias_q[q];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's weight pieces (the compiler does not count them)
+  __syncthreads();
+  DUA_STAMP_AT(3, false);
+
+  const int sw = (r >> 3) & 1;
+  const int a_base = dsl * PSF + (r >> 3) * RSF + (r & 7) * VSF;
+  const int a_even = a_base + ((hh ^ sw) << 4), a_odd = a_base + ((hh ^ sw ^ 1) << 4);      // parity of halo row h + kh
+  const int b_base = (hh * BN + r) * 16;
+
+  // One phase = the 9 taps of kd plane `kd` of the current half chunk against ring slot `slot`: half-step h = (tap t = h / NH,
+  // block pair sub = h % NH) is 4 MFMAs on A pair (t, sub) and B pair t; the fragments of half-step h + 1 are requested
+  // before the MFMAs of half-step h issue.
+  auto phase = [&](int kd, int slot) __attribute__((always_inline)) {
+    const char* hp = halo + kd * PSF;
+    const char* wb = wbuf + slot * WPLANE + b_base;
+    f16x8 fa[2][2], fb[2][2];                                    // [buffer][block of the pair] / [buffer][cout half]
+    auto ldA = [&](int t, int sub, int b) {
+      const int kh = t / 3, kw = t - kh * 3;
+      const char* ap = hp + ((kh & 1) ? a_odd : a_even) + sub * PSF + kh * RSF + kw * VSF;
+      fa[b][0] = *(const f16x8*)ap;
+      fa[b][1] = *(const f16x8*)(ap + 4 * RSF);
+    };
+    auto ldB = [&](int t, int b) {
+      fb[b][0] = *(const f16x8*)(wb + t * 2048);
+      fb[b][1] = *(const f16x8*)(wb + t * 2048 + 512);
+    };
+    ldB(0, 0);
+    ldA(0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < 9 * NH; ++h) {
+      const int t = h / NH, sub = h % NH;
+      if (h + 1 < 9 * NH) {
+        const int t1 = (h + 1) / NH, sub1 = (h + 1) % NH;
+        if (sub1 == 0) ldB(t1, t1 & 1);
+        ldA(t1, sub1, (h + 1) & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);                         // keep the requests ahead of the MFMAs (hipcc sinks them otherwise)
+      mma32(acc[2 * sub][0], fa[h & 1][0], fb[t & 1][0]);
+      mma32(acc[2 * sub][1], fa[h & 1][0], fb[t & 1][1]);
+      mma32(acc[2 * sub + 1][0], fa[h & 1][1], fb[t & 1][0]);
+      mma32(acc[2 * sub + 1][1], fa[h & 1][1], fb[t & 1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // The next half chunk's halo pieces (each touches 32 cache lines: ten back-to-back requests hold the wave for ~3 000 cycles)
+  // are requested in three groups, at the head of the three phases of the current half chunk, behind that phase's weight
+  // pieces: planes [0, J1), [J1, J2), [J2, HD).
+  constexpr int J1 = HD == 10 ? 4 : 2, J2 = HD == 10 ? 7 : 4;
+  for (int hc = 0; hc < nhc; ++hc) {
+    const bool more = hc + 1 < nhc;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int u = hc * 3 + kd, slot = u & 1;
+      if (u + 1 < U) dma_plane(u + 1, slot ^ 1);                // that slot was last read before the previous barrier
+      if (more) load_halo(hc + 1, kd == 0 ? 0 : kd == 1 ? J1 : J2, kd == 0 ? J1 : kd == 1 ? J2 : HD);
+      phase(kd, slot);
+      // the next weight plane has landed (this wave's pieces; the barrier: everyone's); the halo pieces requested behind it may
+      // still fly, except before the store that follows the last phase
+      if (more && kd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J1) : "memory");
+      else if (more && kd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J2 - J1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (u < 26) DUA_STAMP_AT(4 + u, false);
+    }
+    if (more) {
+      store_halo(hc + 1);
+      if (hc < 7) DUA_STAMP_AT(30 + 2 * hc, false);
+      __syncthreads();
+      if (hc < 7) DUA_STAMP_AT(31 + 2 * hc, false);
+    }
+  }
+  DUA_STAMP_AT(62, false);
+
+  // ---- epilogue: statistics from the fp32 accumulators; each wave stages TWO 32-voxel blocks at a time in rows of its own
+  // (2 x 32 x 128 B: whole voxel lines leave in one store instruction) -- the loop above ended with a workgroup barrier, so the
+  // halo is free; no workgroup barrier inside ----
+  char* ot = halo + wave * 8192;
+  float* ex = (float*)wbuf;                                      // [4 waves][64 couts][2]
+  T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
+  float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+#pragma unroll
+  for (int pr = 0; pr < MB / 2; ++pr) {
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[2 * pr + mm][q][i];
+          s[q] += v;
+          ss[q] = fmaf(v, v, ss[q]);
+          *(T*)(ot + mm * 4096 + acc_row(i, hh) * 128 + (q * 32 + r) * 2) = (T)v;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int gd = d0 + dsl + pr;                                // blocks 2 pr and 2 pr + 1: depth slice dsl + pr, h rows 0..3 and 4..7
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int v = it * 8 + (lane >> 3), cg = lane & 7;         // v = 0..63: the 8 x 8 voxels of the depth slice
+      const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
+      if (ct * BN + cg * 8 < a.Cout)
+        *(f16x8*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + cg * 8) = *(const f16x8*)(ot + v * 128 + cg * 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    s[q] += __shfl_xor(s[q], 32);
+    ss[q] += __shfl_xor(ss[q], 32);
+    if (hh == 0) { ex[(wave * BN + q * 32 + r) * 2] = s[q]; ex[(wave * BN + q * 32 + r) * 2 + 1] = ss[q]; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double S = 0, Q = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
+    if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, replica, ct * BN + lane, S, Q);
+  }
+  DUA_STAMP_AT(63, false);
+  DUA_STAMP_AT(1, true);
+}
+
+// grid = (8x8x8 tiles in XCD-contiguous order, cout tiles, N)
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wide_kernel(Conv3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int per_slab = a.tiles_h * a.tiles_w;
+  const int tile = xcd_remap(blockIdx.x, a.ntiles);
+  const int td = tile / per_slab, rem = tile - td * per_slab, th = rem / a.tiles_w, tw = rem - th * a.tiles_w;
+  wide_tile<4>(a, smem, td * 8, th * 8, tw * 8, blockIdx.y, blockIdx.z, blockIdx.x & (STAT_REPLICAS - 1));
+}
+
+static const LdsAttr kWideLdsAttrs[] = {{(const void*)conv3d_k3_wide_kernel, 80 * 1024}};
+static const LdsAttrs kWideLdsReg(kWideLdsAttrs);
+
+#ifdef DUA_STAMP
+extern "C" long dua_debug_stamps_wide(void* host, long bytes) { return stamps_out(host, bytes); }
+#endif
+
+int launch_conv3_wide(Conv3Args a, int D, hipStream_t s) {
+  using namespace c3w;
+  if (int e = ensure_prepared()) return e;
+  if (D % 8 || a.H % 8 || a.W % 8 || a.Cin % 16 || (a.xf.stats && a.Cin > 256)) return DUA_ERR_ARG;
+  a.tiles_h = a.H / 8; a.tiles_w = a.W / 8;
+  a.ntiles = (D / 8) * a.tiles_h * a.tiles_w;
+  const int lds = LDS_FIXED + (a.xf.stats ? 3 * 4 * a.Cin : 0);
+  if (lds > 80 * 1024) return DUA_ERR_ARG;
+  hipLaunchKernelGGL(conv3d_k3_wide_kernel, dim3(a.ntiles, a.cout_pad / BN, a.N), dim3(256), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace dua

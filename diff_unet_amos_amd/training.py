@@ -403,19 +403,18 @@ class NativeConvTrainer:
             _native.prepare(dev)         # every kernel's function attributes: before the first launch, before any capture, and
                                          # before autograd's worker thread (which issues the backward launches) exists
         self.arena = ops.ZeroArena(sum(p.numel() for p in self.params) * 4 + (96 << 20), dev) if dev.type == "cuda" else None
-        # weight gradients on a side stream (see _wgrad); not under the DDP reducer, whose hooks read them on the main stream
-        self.wgrad_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and not self.overlap and wgrad_overlap) else None
-        # graph mode captures on a stream of this trainer's own (torch hands streams out of a pool of 32 per device, round
-        # robin: after enough Stream() calls in a process the "new" stream IS an older one -- make sure the capture stream and
-        # the weight-gradient side stream are two different HIP streams, or the captured fork / join would be a self-wait)
-        self.capture_stream = None
-        if graph and dev.type == "cuda":
-            for _ in range(64):
-                st = torch.cuda.Stream(device=dev)
-                if self.wgrad_stream is None or st.cuda_stream != self.wgrad_stream.cuda_stream:
-                    self.capture_stream = st
-                    break
-            assert self.capture_stream is not None
+        # weight gradients on a side stream (see _wgrad); not under the DDP reducer, whose hooks read them on the main stream --
+        # and NOT in graph mode: a captured fork / join makes the step a multi-branch HIP graph, and hipGraphLaunch of such a
+        # graph can fault inside the ROCm 7 runtime (hip::Graph::UpdateStreams reads past the end of the exec's parallel-stream
+        # list whenever more than one of those streams shares the launch stream's queue: which ones do depends on how many
+        # streams the process created before -- the host segfaults of test_graph_replayed_training_step_equals_eager in full
+        # test-suite runs).  The captured step is therefore a single-stream graph; the side stream was worth
+        # 0.03 ms of a 17.7 ms step there (17.67 vs 17.70, same-process A/B of round 2).
+        self.wgrad_stream = (torch.cuda.Stream(device=dev)
+                             if (dev.type == "cuda" and not self.overlap and wgrad_overlap and not graph) else None)
+        # graph mode captures on a stream of this trainer's own, after warming up on that same stream (so that the per-stream
+        # scratch buffers of ops exist before the capture and do not land in the graph's private memory pool)
+        self.capture_stream = torch.cuda.Stream(device=dev) if (graph and dev.type == "cuda") else None
 
     def _allreduce(self):
         if not self.distributed or self.overlap:          # the DDP reducer already averaged them during backward

@@ -124,6 +124,62 @@ def test_conv3_raw_and_stats(dtype, shape, conv_variant):
     assert torch.allclose(shift.cpu().double(), sh_ref, **ftol)
 
 
+@pytest.fixture
+def conv_variant_any(request):
+    from diff_unet_amos_amd import _native as nv
+    nv.check(nv.lib().dua_set_option(1, request.param), "dua_set_option")
+    yield request.param
+    nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
+
+
+@pytest.mark.parametrize("conv_variant_any", [0, 7], indirect=True)
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("shape", [
+    # N, Cin, Cout, D, H, W, input channel offset / stride, output channel offset / stride: layers with >= 1024 tiles of 4x8x8
+    (1, 64, 64, 64, 64, 64, 0, 64, 0, 64),        # a 64 -> 64 layer, 8 x 8 x 8 = 512 wide tiles
+    (1, 32, 64, 40, 64, 64, 32, 64, 64, 128),     # depth 40 = 5 slabs of 8; reads / writes halves of concat buffers
+    (2, 48, 48, 32, 64, 64, 0, 48, 0, 48),        # the Swin-UNETR width: three half chunks, 48 outputs on a 64-wide tile; two samples
+    (1, 16, 72, 64, 64, 64, 0, 16, 8, 80),        # one half chunk; two output-channel tiles, the second one 8 channels wide
+])
+def test_conv3_wide_tile_form(shape, fused, conv_variant_any):
+    """The 8-accumulator form (conv3d_wide.hip) that fp16 layers with >= 1024 tiles take: against torch conv3d on the
+    fp16-rounded operands (0), like the 4x8x8 kernel it replaces (7); statistics against the exact convolution."""
+    ops = _ops()
+    dtype = torch.float16
+    N, Cin, Cout, D, H, W, ioff, istride, ooff, ostride = shape
+    g = torch.Generator().manual_seed(sum(shape) + int(fused))
+    raw = torch.randn(N, Cin, D, H, W, generator=g) * 1.5 + 0.25
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    if fused:
+        norm, act = _producer(raw, dtype, g, add=torch.randn(N, Cin, generator=g))
+        xin = act.to(dtype).float()
+    else:
+        norm, xin = None, raw.to(dtype).float()
+    ref = F.conv3d(xin, w.to(dtype).float(), b, padding=1)
+    xbuf = torch.full((N, D, H, W, istride), 3.0, dtype=dtype, device="cuda")
+    ops.to_channels_last(raw.cuda(), xbuf, ioff, Cin)
+    ybuf = torch.full((N, D, H, W, ostride), -5.0, dtype=dtype, device="cuda")
+    wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), dtype)
+    stats = ops.stats_buffer(N, Cout, "cuda")
+    ops.conv3d_k3(xbuf, Cin, ioff, wp, bp, Cout, ybuf, ooff, stats, norm=norm)
+    got = ops.from_channels_last(ybuf, Cout, ooff).cpu()
+    assert torch.allclose(got, ref, **TOL[dtype]), float((got - ref).abs().max())
+    if ooff:
+        assert float((ybuf[..., :ooff].float() + 5).abs().max()) == 0
+    if ooff + Cout < ostride:
+        assert float((ybuf[..., ooff + Cout:].float() + 5).abs().max()) == 0
+    st = ops.stats_decode(stats).cpu()[:, :Cout]
+    rd = ref.double().flatten(2)
+    assert torch.allclose(st[..., 0], rd.sum(-1), rtol=2e-3, atol=0.5)
+    assert torch.allclose(st[..., 1], (rd * rd).sum(-1), rtol=2e-3, atol=0.5)
+    # bit-reproducible: a second launch gives the same bytes and the same statistics words
+    y2 = torch.full_like(ybuf, -5.0)
+    st2 = ops.stats_buffer(N, Cout, "cuda")
+    ops.conv3d_k3(xbuf, Cin, ioff, wp, bp, Cout, y2, ooff, st2, norm=norm)
+    assert torch.equal(y2, ybuf) and torch.equal(st2, stats)
+
+
 @pytest.mark.parametrize("conv_variant", [0, 6], indirect=True)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [(1, 128, 256, 12, 12, 12), (2, 72, 136, 6, 6, 6), (1, 136, 64, 8, 16, 16)])

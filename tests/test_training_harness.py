@@ -325,6 +325,8 @@ def test_graph_replayed_training_step_equals_eager():
         torch.manual_seed(0)
         net = DiffUNet(**KW).to(dev)
         tr = NativeConvTrainer(net, lr=1e-3, dtype=torch.float32, graph=mode, fused_optimizer=fused)
+        # a captured step must be a single-stream graph: a multi-branch one can fault inside hipGraphLaunch
+        assert (tr.wgrad_stream is None) == mode
         losses = [float(tr.step(image, labels, noise=noise, t=tk)) for tk in ts]
         runs.append((losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
 

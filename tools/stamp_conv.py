@@ -22,8 +22,9 @@ def main():
     L = nv.lib()
     if not hasattr(L, "dua_debug_stamps"):
         sys.exit("not a stamp build: DUA_HIP_LIB=tools/diag/stamp/libdua_hip.so")
-    L.dua_debug_stamps.restype, L.dua_debug_stamps.argtypes = ctypes.c_long, [ctypes.c_void_p, ctypes.c_long]
-    nbytes = L.dua_debug_stamps(None, 0)
+    stamps = L.dua_debug_stamps_wide if "--wide" in sys.argv else L.dua_debug_stamps     # --wide: the stamps of conv3d_wide.hip
+    stamps.restype, stamps.argtypes = ctypes.c_long, [ctypes.c_void_p, ctypes.c_long]
+    nbytes = stamps(None, 0)
     host = np.zeros(nbytes // 8, dtype=np.uint64)
     only = [int(i) for i in sys.argv[1].split(",")] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else range(len(SHAPES))
     hot = float(sys.argv[sys.argv.index("--hot") + 1]) if "--hot" in sys.argv else 0.0
@@ -61,12 +62,12 @@ def main():
                 for _ in range(50):
                     run()
                 torch.cuda.synchronize()
-        L.dua_debug_stamps(host.ctypes.data, nbytes)          # clears
+        stamps(host.ctypes.data, nbytes)          # clears
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); run(); e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3
-        L.dua_debug_stamps(host.ctypes.data, nbytes)
+        stamps(host.ctypes.data, nbytes)
         st = host.reshape(8192, 64).astype(np.int64)
         st = st[st[:, 0] != 0]
         rt = (st[:, 1] - st[:, 0]).astype(np.float64) * 10.0            # ns
@@ -74,7 +75,7 @@ def main():
         clock = np.median(cyc / rt)                                       # GHz
         span = (st[:, 1].max() - st[:, 0].min()) * 0.01                   # us, first start to last end
         pro = np.median(st[:, 3] - st[:, 2])
-        nph = int(((st[0, 4:59] != 0).sum()))
+        nph = int(((st[0, 4:(30 if '--wide' in sys.argv else 59)] != 0).sum()))
         ph = np.array([np.median(st[:, 4 + i] - (st[:, 3 + i] if i else st[:, 3])) for i in range(nph)])
         last = st[:, 3 + nph] if nph else st[:, 3]
         tailc = np.median(st[:, 62] - last)
@@ -89,6 +90,15 @@ def main():
               f"{ph.max() if nph else 0:.0f} | post-loop {tailc:.0f} | epilogue {epi:.0f}")
         if nph:
             print("    phases: " + " ".join(f"{p:.0f}" for p in ph))
+        if "--wide" in sys.argv and st[0, 56] != 0:
+            print(f"    prologue issue: bias + statistics requests {np.median(st[:, 56] - st[:, 2]):.0f} | halo requests "
+                  f"{np.median(st[:, 57] - st[:, 56]):.0f} | weight plane {np.median(st[:, 59] - st[:, 57]):.0f}")
+        if "--wide" in sys.argv:       # half-chunk boundaries: next halo transform + LDS store | barrier behind it
+            bd = []
+            for hc in range(7):
+                if st[0, 30 + 2 * hc] != 0 and 4 + 3 * hc + 2 < 30:
+                    bd.append(f"{np.median(st[:, 30 + 2 * hc] - st[:, 4 + 3 * hc + 2]):.0f}+{np.median(st[:, 31 + 2 * hc] - st[:, 30 + 2 * hc]):.0f}")
+            print("    boundaries (store + barrier): " + " ".join(bd))
 
 
 main()

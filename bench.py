@@ -63,7 +63,23 @@ CLASSES = 16
 FEATURES = (64, 64, 128, 256, 512, 64)
 PEAK_F16_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
-CONV_KERNEL = "conv3d_k3_v2_kernel"
+CONV_KERNEL = "conv3d_k3_v2_kernel"          # the 4x8x8 / 2x8x8 / split-K forms (every layer below 96^3; every fp32 layer)
+WIDE_KERNEL = "conv3d_k3_wide_kernel"        # round 4: the 8x8x8-tile form of the fp16 96^3 layers, 70 % of a step's FLOPs
+
+
+def conv_kernel_of(call):
+    """Which kernel launch_conv3 (csrc/conv3d_igemm.hip) picks for a recorded ops.conv3d_k3 call: the same rule, restated."""
+    a, k = call
+    x, cin, cout = a[0], a[1], a[5]
+    N, D, H, W = x.shape[:4]
+    if k.get("tap_channel") == 16 and x.dtype == torch.float16 and _CONV_VARIANT == 0:
+        return "conv3d_k3_first_kernel"
+    tiles = -(-D // 4) * -(-H // 8) * -(-W // 8) * -(-cout // 64) * N
+    fused = k.get("norm") is not None
+    if (x.dtype == torch.float16 and _CONV_VARIANT == 0 and k.get("tap_channel") is None and not k.get("background") and tiles >= 1024
+            and D % 8 == 0 and H % 8 == 0 and W % 8 == 0 and cin % 16 == 0 and cin <= (256 if fused else 384)):
+        return WIDE_KERNEL
+    return CONV_KERNEL
 
 
 def conv3_flops(plan):
@@ -127,36 +143,42 @@ def time_conv_launches(plan, reps):
 
 
 def conv_roofline(plan, dtype_flag, reps=20):
-    """roofline object for the 3x3x3 convolution kernel over one denoiser evaluation of `plan` (HIP events, see
-    time_conv_launches); FLOPs are algorithmic (2 * Cin * Cout * 27 * voxels * batch)."""
+    """roofline object for the 3x3x3 convolution of one denoiser evaluation of `plan` (HIP events, see time_conv_launches);
+    FLOPs are algorithmic (2 * Cin * Cout * 27 * voxels * batch).  The object describes the DOMINANT kernel -- the one with
+    the largest share of the step: conv3d_k3_wide_kernel in fp16 (the three 96^3 layers it runs are 74 % of the step's FLOPs),
+    conv3d_k3_v2_kernel in fp32 -- so that `avg_launch_ms` is the per-kernel average of the rocprofv3 summary; the other
+    convolution kernels of the step are listed under `other_kernels`, and `all_conv_launches` is the figure over all 18 launches
+    (comparable across rounds whatever the kernel split)."""
     fl = conv3_flops(plan)
     _, per_step, by_launch = time_conv_launches(plan, reps)
     assert per_step == len(fl)
-    # The first layer (16 noisy-label channels + image -> features[0], fp16) runs in a kernel of its own since round 3
-    # (conv3d_k3_first_kernel: resident weights, persistent workgroups); the roofline object describes the kernel the other
-    # launches share, so that its average agrees with the per-kernel line of the rocprofv3 summary.
-    own_first = (dtype_flag == "f16" and _LAST_CONV_CALLS and _LAST_CONV_CALLS[0][1].get("tap_channel") == 16
-                 and _CONV_VARIANT == 0 and os.environ.get("DUA_CONV_VARIANT", "0") in ("", "0"))
-    k0 = 1 if own_first else 0
-    flk, msk = fl[k0:], by_launch[k0:]
-    avg_ms = sum(msk) / len(msk)
-    flops_per_launch = sum(flk) / len(flk)
-    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    kern = [conv_kernel_of(c) for c in _LAST_CONV_CALLS]
     peak = PEAK_F16_TFLOPS if dtype_flag == "f16" else PEAK_F32_TFLOPS
-    out = {"bound": "mfma", "kernel": CONV_KERNEL, "achieved": round(achieved, 2), "peak": peak,
-           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-           "launches_per_step": len(flk), "avg_launch_ms": round(avg_ms, 4),
-           "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 2),
+    groups = {}
+    for name, f, ms in zip(kern, fl, by_launch):
+        g = groups.setdefault(name, [0, 0.0, 0.0])
+        g[0] += 1; g[1] += f; g[2] += ms
+    main = max(groups, key=lambda n_: groups[n_][2])
+
+    def summary(g):
+        tf = g[1] / (g[2] * 1e-3) / 1e12
+        return {"launches_per_step": g[0], "avg_launch_ms": round(g[2] / g[0], 4), "algorithmic_gflop_per_launch": round(g[1] / g[0] / 1e9, 2),
+                "ms_per_step": round(g[2], 4), "achieved": round(tf, 2), "frac": round(tf / peak, 4)}
+
+    m = summary(groups[main])
+    big = fl.index(max(fl))
+    out = {"bound": "mfma", "kernel": main, "achieved": m["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": m["frac"],
+           "traffic": None, "launches_per_step": m["launches_per_step"], "avg_launch_ms": m["avg_launch_ms"],
+           "algorithmic_gflop_per_launch": m["algorithmic_gflop_per_launch"], "kernel_ms_per_step": m["ms_per_step"],
            "conv_ms_per_step": round(sum(by_launch), 3),
            "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
            "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
-           "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3",
-                              "tflops": round(max(fl) / (by_launch[fl.index(max(fl))] * 1e-3) / 1e12, 2)}}
-    if own_first:
-        out["first_layer"] = {"kernel": "conv3d_k3_first_kernel", "us": round(by_launch[0] * 1e3, 1),
-                              "tflops": round(fl[0] / (by_launch[0] * 1e-3) / 1e12, 1)}
-    # every 3x3x3 launch of the step, whichever kernel runs it (the by_launch_* arrays cover these; comparable across rounds)
-    all_tf = sum(fl) / len(fl) / (sum(by_launch) / len(by_launch) * 1e-3) / 1e12
+           "by_launch_kernel": [{"conv3d_k3_first_kernel": "first", WIDE_KERNEL: "wide", CONV_KERNEL: "v2"}[k_] for k_ in kern],
+           "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3", "kernel": kern[big],
+                              "tflops": round(max(fl) / (by_launch[big] * 1e-3) / 1e12, 2)},
+           "other_kernels": {n_: summary(g) for n_, g in groups.items() if n_ != main}}
+    # every 3x3x3 launch of the step, whichever kernel runs it
+    all_tf = sum(fl) / (sum(by_launch) * 1e-3) / 1e12
     out["all_conv_launches"] = {"launches_per_step": len(fl), "avg_launch_ms": round(sum(by_launch) / len(by_launch), 4),
                                 "achieved": round(all_tf, 2), "frac": round(all_tf / peak, 4)}
     return out
@@ -225,7 +247,7 @@ def f32_pass_config2(state, image, dev, steps=20, warmup=3):
         ms = (time.perf_counter() - t0) / steps * 1e3
         roof = conv_roofline(plan, "f32", reps=5)
     return {"ms_per_step": ms, "steps": steps, "frac": roof["frac"], "achieved": roof["achieved"], "peak": roof["peak"],
-            "unit": "TFLOP/s", "kernel": CONV_KERNEL, "largest_launch_tflops": roof["largest_launch"]["tflops"],
+            "unit": "TFLOP/s", "kernel": roof["kernel"], "largest_launch_tflops": roof["largest_launch"]["tflops"],
             "finite": bool(torch.isfinite(plan.x_state).all())}
 
 
@@ -330,7 +352,7 @@ def cpu_training_baseline(net_state, threads):
                       f"ONE 96^3 x 16-class sample, {dt:.2f} s/sample"}
 
 
-def measure_traffic(dtype_flag):
+def measure_traffic(dtype_flag, kernel=None):
     """HBM bytes per conv launch from the PMC counters, as MI355X_MICROARCH.md (HBM / rocprofv3 sections) prescribes:
     FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes over a short eager run of this script (a child
     process: the profiler must start the program itself), FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request),
@@ -352,7 +374,7 @@ def measure_traffic(dtype_flag):
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if CONV_KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    if (kernel or CONV_KERNEL) in r["Kernel_Name"] and r["Counter_Name"] == counter:
                         vals.append(float(r["Counter_Value"]))
             if not vals:
                 return None
@@ -770,7 +792,7 @@ def main():
 
     if args.config == 2 and args.gpus == 1 and not (args.no_roofline or args.no_traffic):
         # two short child runs of this script under rocprofv3 --pmc, started before this process initialises the GPU
-        args.traffic = measure_traffic(args.dtype)
+        args.traffic = measure_traffic(args.dtype, WIDE_KERNEL if (args.dtype == "f16" and not args.conv_variant) else CONV_KERNEL)
     D = Dist(args)
     if args.conv_variant:
         from diff_unet_amos_amd import _native as nv

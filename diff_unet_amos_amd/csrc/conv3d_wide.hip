@@ -147,8 +147,14 @@ __device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const 
       gam[u] = a.xf.gamma[cc]; bet[u] = a.xf.beta[cc];
       addv[u] = a.xf.add ? a.xf.add[(long)n * a.xf.add_stride + cc] : 0.f;
       const stat_t* sp = a.xf.stats + ((long)n * STAT_REPLICAS + 2 * part) * STAT_WORDS * a.xf.c_pad + cc;
+      // one block per group (wave-uniform condition): inside a per-load conditional hipcc waits for every load on its own
+      if ((wave + 4 * u) * 16 < a.Cin) {
 #pragma unroll
-      for (int k = 0; k < 2 * STAT_WORDS; ++k) sv[u][k] = (wave + 4 * u) * 16 < a.Cin ? sp[(long)k * a.xf.c_pad] : 0;   // wave-uniform
+        for (int k = 0; k < 2 * STAT_WORDS; ++k) sv[u][k] = sp[(long)k * a.xf.c_pad];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 2 * STAT_WORDS; ++k) sv[u][k] = 0;
+      }
     }
   }
   DUA_STAMP_AT(56, false);

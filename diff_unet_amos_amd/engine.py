@@ -74,6 +74,12 @@ class Plan:
         # step and does not average out of the sum of predictions -- emulated on the oracle (tools/precision_sites.py) it was
         # 45 % of the 50-step Dice deviation of an all-fp16 pass, for ~2 ms per patch.
         self.enc_hi = dtype == torch.float16 and bool(getattr(net, "encoder_level0_fp32", True))
+        # The LAST reverse steps of a DDPM loop (p_sample_loop, BASELINE config 2) run on a companion exact-fp32 plan: as t -> 0
+        # the posterior mean turns into the clamped prediction itself (coef1 -> 1, coef2 -> 0), so the final sample carries the
+        # rounding error of the last evaluations undamped.  Measured (tools/final_steps_precision.py, 1000 steps, 32^3): worst-
+        # class 1 - Dice of the thresholded sample against the oracle 9.5e-4 all-fp16, 6.8e-4 / 4.7e-4 / 4.7e-4 / 4.1e-4 with the
+        # last 1 / 2 / 5 / 10 steps in fp32 -- two steps cost 19 ms of a 1.5 s loop at 96^3 x 16.
+        self.finish_fp32_steps = int(getattr(net, "ddpm_finish_fp32_steps", 2))
         if self.enc_hi:
             f32 = torch.float32
             self.img_in32 = z(0, 8, f32)
@@ -237,6 +243,7 @@ class Plan:
         self.refresh_weights()
         N = self.N
         assert tuple(image.shape) == (N, 1, *self.dims), f"image shape {tuple(image.shape)} != plan {(N, 1, *self.dims)}"
+        self._note_condition(image, None)
         img = image.detach().float().contiguous()
         ops.to_channels_last(img, self.img_in, 0, 8)
         ops.to_channels_last(img, self.xin, self.C, self.cin0 - self.C)     # conditioning channel of the denoiser input
@@ -262,8 +269,29 @@ class Plan:
         self.emb_token += 1
         return EmbeddingList(self, self.emb_token)
 
+    def _hi_plan(self):
+        """Companion exact-fp32 plan of an fp16 plan (same network, batch, patch), with the conditioning of the patch this plan
+        holds: its own encoder pass on the fp32 image, or the caller's embeddings."""
+        hi = getattr(self, "_hi", None)
+        if hi is None:
+            hi = self._hi = Plan(self.net, self.N, *self.dims, torch.float32, self.dev)
+        hi.refresh_weights()
+        image, emb = self._cond
+        if getattr(hi, "_cond_token", None) != self._cond_token:
+            if isinstance(emb, EmbeddingList) or emb is None:
+                hi.run_encoder(image)
+            else:
+                hi.stage_condition(image, emb)
+            hi._cond_token = self._cond_token
+        return hi
+
+    def _note_condition(self, image, embeddings):
+        self._cond = (image.detach(), embeddings)
+        self._cond_token = getattr(self, "_cond_token", 0) + 1
+
     def stage_condition(self, image, embeddings):
         """Make sure the denoiser's conditioning (image channel of xin, 5 embedding maps) is resident."""
+        self._note_condition(image, embeddings)
         if isinstance(embeddings, EmbeddingList) and embeddings.plan is self and embeddings.token == self.emb_token:
             return          # run_encoder just staged both from this image
         img = image.detach().float().contiguous()
@@ -440,8 +468,29 @@ class Plan:
         def one_step(eps):
             self.native_step(mode, row_of_step=row_of_step, coef_table=coef_table, noise=eps, use_sum=True)
 
+        # DDPM in an fp16 plan: the LAST steps run on the exact-fp32 path (see finish_fp32_steps in __init__)
+        finish = min(T, self.finish_fp32_steps) if (kind == "ddpm" and self.dtype == torch.float16) else 0
+        lo_steps = T - finish
+
+        def finish_hi(first_step):
+            """steps [first_step, T) on the companion fp32 plan: hand the sampler state over, run, hand it back"""
+            hi = self._hi_plan()
+            hi.x_state.copy_(self.x_state)
+            hi.xin[..., :self.C].copy_(self.x_state.view(N, *self.dims, self.cx)[..., :self.C])
+            hi.x_sum.copy_(self.x_sum)
+            hi.counter.copy_(self.counter)
+            hi.seed_word.copy_(self.seed_word)
+            for k in range(first_step, T):
+                eps = None if step_noise is None else step_noise[k].detach().to(self.dev).float().contiguous()
+                hi.native_step(mode, row_of_step=row_of_step, coef_table=coef_table, noise=eps, use_sum=True)
+                if snapshots and (k + 1) in snapshots:
+                    snapshots[k + 1] = ops.from_channels_last(hi.x_state, self.C)
+            self.x_state.copy_(hi.x_state)
+            self.x_sum.copy_(hi.x_sum)
+            self.counter.copy_(hi.counter)
+
         if not use_graph:
-            for k in range(T):
+            for k in range(lo_steps):
                 one_step(None if step_noise is None else step_noise[k].detach().to(self.dev).float().contiguous())
                 if snapshots and (k + 1) in snapshots:
                     snapshots[k + 1] = ops.from_channels_last(self.x_state, self.C)
@@ -460,8 +509,10 @@ class Plan:
                 ops.to_channels_last(x_T, self.xin, 0, self.C)
                 self.x_sum.zero_()
                 self.counter.zero_()
-            for _ in range(T):
+            for _ in range(lo_steps):
                 g.replay()
+        if finish:
+            finish_hi(lo_steps)
         out = {"sample": ops.from_channels_last(self.x_state, self.C),
                "sum_pred_xstart": ops.from_channels_last(self.x_sum, self.C)}
         return out

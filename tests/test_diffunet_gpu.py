@@ -347,13 +347,14 @@ def test_thousand_step_p_sample_loop_matches_oracle(dtype):
     if dtype == torch.float32:
         assert d.max() < 5e-3 and d.mean() < 2e-4, (float(d.max()), float(d.mean()))
     else:
-        assert d.max() < 0.25 and d.mean() < 1e-2, (float(d.max()), float(d.mean()))
+        # fp16 plan: 998 steps on fp16 operands, the last two on the exact-fp32 path (engine.Plan.finish_fp32_steps): measured
+        # max 3.7e-3 / mean 3.9e-4 (all-fp16: 5.1e-3 / 5.3e-4)
+        assert d.max() < 2e-2 and d.mean() < 1.5e-3, (float(d.max()), float(d.mean()))
     from oracle.unet_ref import binarise
     dice = _dice(binarise(out["sample"].cpu()), binarise(want[T]))
     print(f"[{dtype}] Dice(build, oracle) of the thresholded final sample: {dice}")
-    # The DDPM sample is not the segmentation output (that is the DDIM sum, tests above / below, held to 1e-3); with
-    # random weights ~0.15 % of the voxels end within the fp16 drift (|x| < 8e-3) of the threshold and may flip.
-    assert min(dice) > (1 - 1e-3 if dtype == torch.float32 else 1 - 3e-3), dice
+    # north_star: Dice within 1e-3 of the reference, in both dtypes (fp16 measured 1 - 4.7e-4; all-fp16 steps: 1 - 9.5e-4)
+    assert min(dice) > 1 - 1e-3, dice
     assert (via_api.cpu() - out["sample"].cpu()).abs().max() < (1e-4 if dtype == torch.float32 else 5e-2)
 
 

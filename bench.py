@@ -68,18 +68,14 @@ WIDE_KERNEL = "conv3d_k3_wide_kernel"        # round 4: the 8x8x8-tile form of t
 
 
 def conv_kernel_of(call):
-    """Which kernel launch_conv3 (csrc/conv3d_igemm.hip) picks for a recorded ops.conv3d_k3 call: the same rule, restated."""
+    """Which kernel the launcher picks for a recorded ops.conv3d_k3 call (dua_conv3d_k3_kernel_kind: the launcher's own rule)."""
+    from diff_unet_amos_amd import ops
     a, k = call
     x, cin, cout = a[0], a[1], a[5]
     N, D, H, W = x.shape[:4]
-    if k.get("tap_channel") == 16 and x.dtype == torch.float16 and _CONV_VARIANT == 0:
-        return "conv3d_k3_first_kernel"
-    tiles = -(-D // 4) * -(-H // 8) * -(-W // 8) * -(-cout // 64) * N
-    fused = k.get("norm") is not None
-    if (x.dtype == torch.float16 and _CONV_VARIANT == 0 and k.get("tap_channel") is None and not k.get("background") and tiles >= 1024
-            and D % 8 == 0 and H % 8 == 0 and W % 8 == 0 and cin % 16 == 0 and cin <= (256 if fused else 384)):
-        return WIDE_KERNEL
-    return CONV_KERNEL
+    kind = ops.conv3_kernel_kind(x.dtype, N, D, H, W, cin, x.shape[-1], cout, fused=k.get("norm") is not None,
+                                 tap_channel=k.get("tap_channel"), background=bool(k.get("background")))
+    return {ops.KIND_V2: CONV_KERNEL, ops.KIND_FIRST: "conv3d_k3_first_kernel", ops.KIND_WIDE: WIDE_KERNEL}[kind]
 
 
 def conv3_flops(plan):

@@ -28,7 +28,7 @@ class Conv3Desc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("Cin", C.c_int), ("Cin_stride", C.c_int), ("Cin_off", C.c_int),
                 ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int), ("tap_channel_plus1", C.c_int),
-                ("background", C.c_int)]
+                ("background", C.c_int), ("layout", C.c_int)]
 
 
 class InNorm(C.Structure):
@@ -40,7 +40,7 @@ class InNorm(C.Structure):
 class MaterializeDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
                 ("raw_stride", C.c_int), ("emb_stride", C.c_int), ("out_stride", C.c_int), ("out_off", C.c_int),
-                ("pool_stride", C.c_int)]
+                ("pool_stride", C.c_int), ("out_blocked", C.c_int)]
 
 
 class NormBwdDesc(C.Structure):
@@ -60,6 +60,7 @@ class TailResidual(C.Structure):
                 ("ra_stride", C.c_int), ("ra_off", C.c_int), ("channels", C.c_int)]
 
 
+IN_BLOCKED, OUT_BLOCKED = 1, 2            # dua_conv3_desc.layout bits
 MODE_LOGITS, MODE_DDPM, MODE_DDIM = 0, 1, 2
 OP_CONV3, OP_MATERIALIZE, OP_DECONV = 1, 2, 3
 
@@ -101,7 +102,7 @@ class TokenLinearDesc(C.Structure):
 TOKLIN_PLAIN, TOKLIN_GELU, TOKLIN_STATS, TOKLIN_RESIDUAL, TOKLIN_SCATTER = range(5)
 
 _P = C.c_void_p
-ABI_VERSION = 4          # DUA_ABI_VERSION of include/dua_hip.h this binding was written against
+ABI_VERSION = 5          # DUA_ABI_VERSION of include/dua_hip.h this binding was written against
 
 _SIGS = {
     "dua_abi_version": (C.c_int, []),
@@ -136,6 +137,8 @@ _SIGS = {
     "dua_step_begin": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dua_step_begin_clear": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_long, _P]),
     "dua_conv3d_k3_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
+    "dua_conv3d_k3_kernel_kind": (C.c_int, [C.POINTER(Conv3Desc), C.c_int, C.c_int]),
+    "dua_deconv_k2s2_kernel_kind": (C.c_int, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P, _P, C.c_long, _P]),
     "dua_conv3d_k3_wgrad_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_wgrad": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.c_int, _P, _P, C.c_long, _P]),

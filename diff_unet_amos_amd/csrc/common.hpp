@@ -81,6 +81,12 @@ __device__ __forceinline__ float other_half(float v) {
   return __uint_as_float((threadIdx.x & 32) ? pr[0] : pr[1]);
 }
 
+// Element offset of channel c (a multiple of 8) of voxel v inside one sample of a buffer with `stride` channels per voxel and
+// `nvox` voxels: channels-last rows, or (blk) 16-channel blocks [stride / 16][nvox][16] (dua_conv3_desc.layout).
+__device__ __forceinline__ long chan_off(bool blk, long v, int c, int stride, long nvox) {
+  return blk ? ((long)(c >> 4) * nvox + v) * 16 + (c & 15) : v * stride + c;
+}
+
 // Row of a 32x32 MFMA accumulator held in register i (0..15) of lane-half h.
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 

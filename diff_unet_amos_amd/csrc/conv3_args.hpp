@@ -15,6 +15,7 @@ struct Conv3Args {
   int ksplit, units_per_split;      // split-K over (chunk, kd) units; partial tiles go to `part` in fp32
   float* part;                      // split-K: fp32 partial tiles [ks][n][voxel][cout_pad], else null
   int tap_ch;                       // single-channel tap form: packed index of that channel, else -1
+  int in_blk, out_blk;              // 16-channel-blocked input / output buffers (wide-tile form and its producers)
 };
 
 // conv3d_wide.hip: the 8-accumulator form (8x8x8 tiles) for fp16 layers with >= 1024 tiles of 4x8x8; D, H, W multiples of 8,

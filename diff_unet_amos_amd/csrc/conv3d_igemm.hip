@@ -717,7 +717,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_first_kernel(Conv3Args a, in
     const int gd = d0 + wave;
     const bool dok = gd < a.D;
     const bool full = d0 + TD <= a.D && h0 + TH <= a.H && w0 + TW <= a.W;
-    T* yout = (T*)a.y + (long)n * a.D * a.H * a.W * a.Cout_stride + a.Cout_off + ct * BN;
+    const long nvox = (long)a.D * a.H * a.W;
+    T* yout = (T*)a.y + (long)n * nvox * a.Cout_stride;
     float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
@@ -753,7 +754,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_first_kernel(Conv3Args a, in
           const int v = it * 8 + (lane >> 3), cg = lane & 7;
           const int gh = h0 + 4 * m + (v >> 3), gw = w0 + (v & 7);
           if ((full || (gh < a.H && gw < a.W)) && ct * BN + cg * 8 < a.Cout)
-            *(f16x8*)(yout + (((long)gd * a.H + gh) * a.W + gw) * a.Cout_stride + cg * 8) = *(const f16x8*)(ot + v * 128 + cg * 16);
+            *(f16x8*)(yout + chan_off(a.out_blk, ((long)gd * a.H + gh) * a.W + gw, a.Cout_off + ct * BN + cg * 8, a.Cout_stride, nvox)) =
+                *(const f16x8*)(ot + v * 128 + cg * 16);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -929,6 +931,19 @@ static const LdsAttr kConvLdsAttrs[] = {
 };
 static const LdsAttrs kConvLdsReg(kConvLdsAttrs);
 
+// Which kernel a launch takes (also exported: dua_conv3d_k3_kernel_kind): 1 = the resident-weight first-layer kernel, 2 = the
+// wide-tile form, 0 = conv3d_k3_v2_kernel in one of its launch shapes.
+static int conv3_kernel_kind(const dua_conv3_desc* d, bool fused) {
+  if (d->dtype != DUA_F16) return 0;
+  if (d->tap_channel_plus1 > 0) return (d->tap_channel_plus1 == 17 && g_conv_variant == 0) ? 1 : 0;
+  const long tiles = (long)((d->D + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * ((d->Cout + c3::BN - 1) / c3::BN) * d->N;
+  const long vox = (long)d->D * d->H * d->W;
+  if (g_conv_variant == 0 && !d->background && tiles >= 1024 && d->D % 8 == 0 && d->H % 8 == 0 && d->W % 8 == 0 &&
+      d->Cin % 16 == 0 && d->Cin <= (fused ? 256 : 384) && vox * d->Cin_stride < 0x7fffffffL)
+    return 2;
+  return 0;
+}
+
 template <typename T>
 static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
                         const dua_in_norm* in, void* y, stat_t* stats, float* ws, long ws_bytes, hipStream_t s) {
@@ -947,7 +962,12 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   const int nct = (d->Cout + BN - 1) / BN;
   a.cout_pad = nct * BN;
   a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = nullptr; a.tap_ch = -1;
+  a.in_blk = d->layout & DUA_IN_BLOCKED ? 1 : 0; a.out_blk = d->layout & DUA_OUT_BLOCKED ? 1 : 0;
   if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
+  const int kind = conv3_kernel_kind(d, in && in->stats);
+  // 16-channel-blocked buffers: read by the wide-tile form only, written by it and by the first-layer kernel only
+  if ((a.in_blk && kind != 2) || (a.out_blk && kind == 0)) return DUA_ERR_ARG;
+  if ((a.in_blk && (d->Cin_off % 16 || d->Cin_stride % 16)) || (a.out_blk && (d->Cout_off % 16 || d->Cout_stride % 16))) return DUA_ERR_ARG;
   const int xf_bytes = in && in->stats ? 3 * 4 * a.nchunks * CK : 0;
   if (int e = ensure_prepared()) return e;
   const long vox = (long)d->D * d->H * d->W;
@@ -960,7 +980,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     else {
       if (a.nchunks != 1 || (in && in->stats) || (a.tap_ch != 0 && a.tap_ch != 16) || d->Cin != a.tap_ch + 8) return DUA_ERR_ARG;
       dim3 grid(a.ntiles, nct, d->N);
-      if (a.tap_ch == 16 && g_conv_variant == 0) {
+      if (kind == 1) {
         // resident-weight form: two persistent workgroups per CU walk the (sample, tile) items; a background launch takes one
         // per CU (and the LDS pad that keeps a second one off the CU)
         const int cus = device_cus();
@@ -977,9 +997,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   }
   // wide-tile form (conv3d_wide.hip): fp16 layers with tiles to spare (96^3); variant 7 keeps them on the 4x8x8 kernel (A/B)
   if constexpr (sizeof(T) == 2) {
-    if (g_conv_variant == 0 && !d->background && (long)a.ntiles * nct * d->N >= 1024 && d->D % 8 == 0 && d->H % 8 == 0 && d->W % 8 == 0 &&
-        d->Cin % 16 == 0 && d->Cin <= (in && in->stats ? 256 : 384) && vox * d->Cin_stride < 0x7fffffffL)
-      return launch_conv3_wide(a, d->D, s);
+    if (kind == 2) return launch_conv3_wide(a, d->D, s);
   }
   const bool autop = g_conv_variant == 0 || g_conv_variant == 6 || g_conv_variant == 7;       // the automatic policy; 6 = without the kd-plane form, 7 = without the wide-tile form (A/B)
   const bool big = g_conv_variant == 0 || g_conv_variant == 7;          // kd-plane form for the layers that cannot put two workgroups on every CU
@@ -1039,6 +1057,12 @@ int dua_set_option(int key, int value) {
 #endif
   if (key == 4 && value >= 0 && value < 256) { dua::g_wgrad_variant = value; return 0; }
   return DUA_ERR_ARG;
+}
+
+int dua_conv3d_k3_kernel_kind(const dua_conv3_desc* d, int fused, int has_workspace) {
+  if (!d) return DUA_ERR_ARG;
+  (void)has_workspace;              // split-K applies below 1024 tiles only, where the answer is 0 anyway
+  return dua::conv3_kernel_kind(d, fused != 0);
 }
 
 long dua_conv3d_k3_workspace(const dua_conv3_desc* d) {

@@ -27,6 +27,7 @@ struct DeconvArgs {
   int N, D, H, W;                  // input spatial
   int Cin, Cin_stride, Cin_off, Cout, Cout_stride, Cout_off;
   int nchunks, nct, lds_base;
+  int out_blk;                     // y in 16-channel blocks (dua_conv3_desc.layout; the all-taps kernel only)
 };
 
 template <typename T>
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
   __syncthreads();
 
   const int H2 = 2 * a.H, W2 = 2 * a.W;
-  T* yout = (T*)a.y + (long)n * vox * 8 * a.Cout_stride + a.Cout_off + ct * BN;
+  T* yout = (T*)a.y + (long)n * vox * 8 * a.Cout_stride;
   const float bq0 = a.bias[ct * BN + r], bq1 = a.bias[ct * BN + 32 + r];
   char* ot = stg + wave * WR * RB;
   int ovb[NST];                                             // output voxel of tap (0, 0, 0) for this lane's staged rows, or -1
@@ -436,7 +437,8 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
       for (int it = 0; it < NST; ++it) {
         const int vl = it * VPI + lane / GPV, cg = lane % GPV;
         if (ovb[it] >= 0 && ct * BN + q * 32 + cg * EPG < a.Cout)
-          *(Frag*)(yout + (long)(ovb[it] + toff) * a.Cout_stride + q * 32 + cg * EPG) = *(const Frag*)(ot + vl * RB + cg * 16);
+          *(Frag*)(yout + chan_off(a.out_blk, ovb[it] + toff, a.Cout_off + ct * BN + q * 32 + cg * EPG, a.Cout_stride, vox * 8)) =
+              *(const Frag*)(ot + vl * RB + cg * 16);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -459,6 +461,16 @@ static const LdsAttr kDeconvLdsAttrs[] = {
 };
 static const LdsAttrs kDeconvLdsReg(kDeconvLdsAttrs);
 
+// 2 = the all-taps kernel (large inputs: it may write 16-channel blocks), 1 = Cin chunks split over the waves, 0 = one tap per workgroup
+static int deconv_kernel_kind(const dua_conv3_desc* d) {
+  const int ck = dc::KG * (d->dtype == DUA_F16 ? 8 : 4);
+  const int nchunks = (d->Cin + ck - 1) / ck;
+  const long vox = (long)d->D * d->H * d->W;
+  if (vox >= 256L * 128 && nchunks <= 4) return 2;
+  if (nchunks >= 8 && nchunks <= 4 * dcs::MC && g_conv_variant != 6) return 1;
+  return 0;
+}
+
 template <typename T>
 static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
                          const dua_in_norm* in, void* y, hipStream_t s) {
@@ -473,6 +485,9 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   a.nct = (d->Cout + dc::BN - 1) / dc::BN;
   const long vox = (long)d->D * d->H * d->W;
   if (int e = ensure_prepared()) return e;
+  a.out_blk = d->layout & DUA_OUT_BLOCKED ? 1 : 0;
+  if (d->layout & DUA_IN_BLOCKED) return DUA_ERR_ARG;
+  if (a.out_blk && (deconv_kernel_kind(d) != 2 || d->Cout_off % 16 || d->Cout_stride % 16 || vox * 8 * 16 >= 0x7fffffffL)) return DUA_ERR_ARG;
   if (vox >= 256L * 128 && a.nchunks <= 4) {          // enough tiles to fill the chip with one workgroup per 8 taps
     // 128-voxel tiles: two workgroups per CU (77 KB each at 128 channels), one's pixel-shuffle stores under the other's loads;
     // variant 6 keeps the 256-voxel form (one workgroup per CU) for A/B
@@ -502,6 +517,11 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
 }
 
 }  // namespace dua
+
+extern "C" int dua_deconv_k2s2_kernel_kind(const dua_conv3_desc* d) {
+  if (!d || (d->dtype != DUA_F16 && d->dtype != DUA_F32)) return DUA_ERR_ARG;
+  return dua::deconv_kernel_kind(d);
+}
 
 extern "C" int dua_deconv_k2s2_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed,
                                    const float* bias_padded, const dua_in_norm* in, void* y, void* stream) {

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
                                                           InXform xf,
                                                           const T* __restrict__ emb, int emb_stride, T* __restrict__ out,
                                                           int out_stride, int out_off, T* __restrict__ pooled,
-                                                          int pool_stride, int D, int H, int W, long total) {
+                                                          int pool_stride, int D, int H, int W, long total, int out_blk) {
   using Frag = typename Elem<T>::Frag;
   constexpr int EPG = Elem<T>::EPG;
   extern __shared__ float sm[];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
         if constexpr (EMB) y += (float)ev[e];
         o[e] = (T)y;
       }
-      *(Frag*)(out + gv * out_stride + out_off + cg * EPG) = o;
+      *(Frag*)(out + n * vox_n * out_stride + chan_off(out_blk, v, out_off + cg * EPG, out_stride, vox_n)) = o;
     } else {
       const int W2 = W >> 1, H2 = H >> 1;
       const int pw = (int)(v % W2); v /= W2;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void materialize_kernel(const T* __restrict__ 
           o[e] = (T)y;
           mx[e] = fmaxf(mx[e], (float)o[e]);
         }
-        *(Frag*)(out + gvk[k] * out_stride + out_off + cg * EPG) = o;
+        *(Frag*)(out + n * vox_n * out_stride + chan_off(out_blk, gvk[k] - n * vox_n, out_off + cg * EPG, out_stride, vox_n)) = o;
       }
       Frag po;
 #pragma unroll
@@ -126,7 +126,7 @@ static int launch_materialize(const dua_materialize_desc* d, const void* raw, co
   const size_t lds = 3 * sizeof(float) * d->C;
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)raw, d->C, d->raw_stride, xf, (const T*)emb, d->emb_stride,
-                       (T*)out, d->out_stride, d->out_off, (T*)pooled, pool ? d->pool_stride : 0, d->D, d->H, d->W, total);
+                       (T*)out, d->out_stride, d->out_off, (T*)pooled, pool ? d->pool_stride : 0, d->D, d->H, d->W, total, d->out_blocked ? 1 : 0);
   };
   if (pool) { if (emb) go(materialize_kernel<T, true, true>); else go(materialize_kernel<T, true, false>); }
   else { if (emb) go(materialize_kernel<T, false, true>); else go(materialize_kernel<T, false, false>); }
@@ -150,6 +150,7 @@ int dua_materialize(const dua_materialize_desc* d, const void* raw, const dua_in
   if (!d || !raw || !in || !in->stats || !in->gamma || !in->beta || in->c_pad < d->C || !out) return DUA_ERR_ARG;
   if (d->C % 8 || d->raw_stride % 8 || d->out_stride % 8 || d->out_off % 8 || (emb && d->emb_stride % 8)) return DUA_ERR_ARG;
   if (pooled && ((d->D | d->H | d->W) & 1 || d->pool_stride % 8)) return DUA_ERR_ARG;
+  if (d->out_blocked && (d->dtype != DUA_F16 || d->out_stride % 16 || d->out_off % 16 || d->C % 16)) return DUA_ERR_ARG;
   if (d->dtype == DUA_F16) return dua::launch_materialize<dua::f16>(d, raw, in, emb, out, pooled, (hipStream_t)stream);
   if (d->dtype == DUA_F32) return dua::launch_materialize<float>(d, raw, in, emb, out, pooled, (hipStream_t)stream);
   return DUA_ERR_ARG;

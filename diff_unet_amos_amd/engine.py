@@ -234,9 +234,32 @@ class Plan:
                                   add_stride=self.P, slope=SLOPE, eps=EPS)
         return c.norm_add
 
-    def _conv(self, c, x, cin, y, level, xform_from=None, add_key=None):
+    def _conv(self, c, x, cin, y, level, xform_from=None, add_key=None, in_blocked=False, out_blocked=False):
         norm = None if xform_from is None else self._norm(xform_from, level, add_key)
-        ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, c.stats, norm=norm, workspace=self.splitk_ws, tap_channel=c.tap)
+        ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, c.stats, norm=norm, workspace=self.splitk_ws, tap_channel=c.tap,
+                      in_blocked=in_blocked, out_blocked=out_blocked)
+
+    def _level0_layout(self):
+        """Which level-0 buffers of the DENOISER are kept in 16-channel blocks (dua_conv3_desc.layout): those whose only
+        consumer is the wide-tile convolution (it walks its input 16 channels at a time) and whose producer can write
+        blocks -- asked of the launchers' own policy functions.  rawA[0]: first layer -> conv_0.conv_1; cat[0]: materialise +
+        transposed convolution -> upcat_1.conv_0; uA[0]: upcat_1.conv_0 -> upcat_1.conv_1."""
+        if getattr(self, "_l0", None) is None:
+            N, f, dt = self.N, self.f, self.dtype
+            D, H, W = self.S[0]
+            a0, b0 = self.den[0]
+            u0a, u0b = self.dec[0]
+            kind = lambda cin, cs, cout, fused, tap=None: ops.conv3_kernel_kind(dt, N, D, H, W, cin, cs, cout, fused, tap)   # noqa: E731
+            wide = ops.KIND_WIDE
+            raw_a = (dt == torch.float16 and f[0] % 16 == 0 and kind(self.cin0, self.cin0, a0.cout, False, a0.tap) == ops.KIND_FIRST
+                     and kind(a0.cout, f[0], b0.cout, True) == wide)
+            cat = (dt == torch.float16 and f[0] % 16 == 0 and (f[0] + self.up[0]) % 16 == 0
+                   and kind(f[0] + self.up[0], f[0] + self.up[0], u0a.cout, False) == wide
+                   and ops.deconv_kernel_kind(dt, N, *self.S[1], self.dec_out[1], self.up[0]) == ops.DECONV_ALLTAPS)
+            u_a = (dt == torch.float16 and self.dec_out[0] % 16 == 0 and kind(f[0] + self.up[0], f[0] + self.up[0], u0a.cout, False) == wide
+                   and kind(u0a.cout, self.dec_out[0], u0b.cout, True) == wide)
+            self._l0 = (raw_a, cat, u_a)
+        return self._l0
 
     def run_encoder(self, image):
         """BasicUNetEncoder.forward: fills self.emb[0..4] (channels-last)."""
@@ -317,14 +340,15 @@ class Plan:
         f = self.f
         if zero_stats:
             self.den_stats.zero_()
+        blk_raw, blk_cat, blk_u = self._level0_layout()
         x, cin = self.xin, self.cin0
         for l in range(5):
             a, b = self.den[l]
-            self._conv(a, x, cin, self.rawA[l], l)
-            self._conv(b, self.rawA[l], a.cout, self.rawB[l], l, xform_from=a, add_key=f"d{l}")
+            self._conv(a, x, cin, self.rawA[l], l, out_blocked=blk_raw and l == 0)
+            self._conv(b, self.rawA[l], a.cout, self.rawB[l], l, xform_from=a, add_key=f"d{l}", in_blocked=blk_raw and l == 0)
             if l < 4:
                 ops.materialize(self.rawB[l], b.cout, self._norm(b, l), self.cat[l], 0, emb=self.emb[l],
-                                pooled=self.pool[l])
+                                pooled=self.pool[l], out_blocked=blk_cat and l == 0)
                 x, cin = self.pool[l], b.cout
             else:
                 ops.materialize(self.rawB[4], b.cout, self._norm(b, 4), self.x4, 0, emb=self.emb[4])
@@ -332,10 +356,10 @@ class Plan:
         for l in (3, 2, 1, 0):
             wp, bp = self.deconv_packed[l]
             norm = self._norm(src_conv, l + 1) if src_conv is not None else None
-            ops.deconv_k2s2(src, src_c, 0, wp, bp, self.up[l], self.cat[l], f[l], norm=norm)
+            ops.deconv_k2s2(src, src_c, 0, wp, bp, self.up[l], self.cat[l], f[l], norm=norm, out_blocked=blk_cat and l == 0)
             a, b = self.dec[l]
-            self._conv(a, self.cat[l], f[l] + self.up[l], self.uA[l], l)
-            self._conv(b, self.uA[l], a.cout, self.uB[l], l, xform_from=a, add_key=f"u{l}")
+            self._conv(a, self.cat[l], f[l] + self.up[l], self.uA[l], l, in_blocked=blk_cat and l == 0, out_blocked=blk_u and l == 0)
+            self._conv(b, self.uA[l], a.cout, self.uB[l], l, xform_from=a, add_key=f"u{l}", in_blocked=blk_u and l == 0)
             src, src_c, src_conv = self.uB[l], b.cout, b
         return self.dec[0][1]
 

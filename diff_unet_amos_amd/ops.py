@@ -291,15 +291,49 @@ def conv3_workspace_bytes(dtype, N, D, H, W, cin, cout):
     return int(nv.lib().dua_conv3d_k3_workspace(C.byref(d)))
 
 
+KIND_V2, KIND_FIRST, KIND_WIDE = 0, 1, 2          # dua_conv3d_k3_kernel_kind
+DECONV_ALLTAPS = 2                                # dua_deconv_k2s2_kernel_kind
+
+
+def conv3_kernel_kind(dtype, N, D, H, W, cin, cin_stride, cout, fused=False, tap_channel=None, background=False):
+    """Which kernel the launcher picks for this 3x3x3 convolution (dua_conv3d_k3_kernel_kind: the launcher's own rule).  Only
+    KIND_WIDE reads 16-channel-blocked input; only KIND_WIDE and KIND_FIRST write blocked output."""
+    d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, cin, cin_stride, 0, cout, -(-cout // 8) * 8, 0,
+                     0 if tap_channel is None else tap_channel + 1, 1 if background else 0, 0)
+    return int(nv.lib().dua_conv3d_k3_kernel_kind(C.byref(d), 1 if fused else 0, 0))
+
+
+def deconv_kernel_kind(dtype, N, D, H, W, cin, cout):
+    """dua_deconv_k2s2_kernel_kind for an input of D x H x W voxels: DECONV_ALLTAPS is the kernel that may write blocked output."""
+    d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, cin, cin, 0, cout, cout, 0, 0, 0, 0)
+    return int(nv.lib().dua_deconv_k2s2_kernel_kind(C.byref(d)))
+
+
+def to_blocked(t):
+    """channels-last [N, D, H, W, Cs] -> the same bytes count laid out as 16-channel blocks [N][Cs / 16][voxels][16]
+    (dua_conv3_desc.layout), returned with the channels-last SHAPE (a buffer is a buffer: the kernels are told its layout)."""
+    N, D, H, W, Cs = t.shape
+    assert Cs % 16 == 0
+    return t.reshape(N, D * H * W, Cs // 16, 16).permute(0, 2, 1, 3).contiguous().view(N, D, H, W, Cs)
+
+
+def from_blocked(t):
+    """inverse of to_blocked"""
+    N, D, H, W, Cs = t.shape
+    assert Cs % 16 == 0
+    return t.reshape(N, Cs // 16, D * H * W, 16).permute(0, 2, 1, 3).contiguous().view(N, D, H, W, Cs)
+
+
 def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats, norm=None, workspace=None, tap_channel=None,
-              background=False):
+              background=False, in_blocked=False, out_blocked=False):
     """Raw 3x3x3 convolution (+bias); ``norm`` = producer descriptor of x (fused IN+LeakyReLU+add);
     accumulates this layer's InstanceNorm sums into ``out_stats`` (must be zero on entry).
     ``tap_channel`` (0 or 16, fp16, cin == tap_channel + 8): the single-channel tap form for first layers -- that packed
     channel is the last real input channel and is contracted as two k-steps over its 27 taps (weights packed with the
     same ``tap_channel``).
     ``background``: the launch runs on a second stream under a chain of small launches (one workgroup per CU, see
-    dua_conv3_desc.background)."""
+    dua_conv3_desc.background).  ``in_blocked`` / ``out_blocked``: x / y are laid out in 16-channel blocks
+    (dua_conv3_desc.layout; the launcher rejects kernels that cannot)."""
     _cl_check(x, "x"); _cl_check(y, "y")
     assert x.dtype == y.dtype and x.device == y.device
     N, D, H, W, cs_in = x.shape
@@ -317,7 +351,8 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
     assert bias_pad.numel() >= cout and bias_pad.dtype == torch.float32 and bias_pad.is_contiguous()     # the kernels read [0, cout)
     assert out_stats.dtype == torch.int64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, STAT_WORDS, nct * 64)
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off,
-                     0 if tap_channel is None else tap_channel + 1, 1 if background else 0)
+                     0 if tap_channel is None else tap_channel + 1, 1 if background else 0,
+                     (nv.IN_BLOCKED if in_blocked else 0) | (nv.OUT_BLOCKED if out_blocked else 0))
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, cin)
         _RECORD.append(nv.StepOp(nv.OP_CONV3, has, d, nv.MaterializeDesc(),
@@ -557,7 +592,7 @@ def seg_loss_grad(logits, labels, sums, gscale, names=LOSS_NAMES):
     return out
 
 
-def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None):
+def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None, out_blocked=False):
     _cl_check(raw, "raw"); _cl_check(out, "out")
     N, D, H, W, rs = raw.shape
     assert tuple(out.shape[:4]) == (N, D, H, W) and out.dtype == raw.dtype
@@ -573,7 +608,7 @@ def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None):
         assert D % 2 == 0 and H % 2 == 0 and W % 2 == 0
         assert tuple(pooled.shape[:4]) == (N, D // 2, H // 2, W // 2) and pooled.dtype == raw.dtype and pooled.shape[-1] >= Cc
         ps = pooled.shape[-1]
-    d = nv.MaterializeDesc(nv.dt_code(raw.dtype), N, D, H, W, Cc, rs, es, out.shape[-1], out_off, ps)
+    d = nv.MaterializeDesc(nv.dt_code(raw.dtype), N, D, H, W, Cc, rs, es, out.shape[-1], out_off, ps, 1 if out_blocked else 0)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, Cc)
         _RECORD.append(nv.StepOp(nv.OP_MATERIALIZE, has, nv.Conv3Desc(), d, nval, _addr(raw), None, None, _addr(out), None,
@@ -583,7 +618,7 @@ def materialize(raw, Cc, norm, out, out_off, emb=None, pooled=None):
                                       nv.ptr(pooled), nv.stream_ptr()), "dua_materialize")
 
 
-def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=None):
+def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=None, out_blocked=False):
     """ConvTranspose3d(k2,s2) of a channel slice of ``x`` into a channel slice of ``y`` (2x spatial)."""
     _cl_check(x, "x"); _cl_check(y, "y")
     N, D, H, W, cs_in = x.shape
@@ -594,7 +629,8 @@ def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=Non
     nch, nct = -(-cin // ck), -(-cout // 64)
     assert nch * ck <= 1024
     assert w_packed.numel() == 8 * nct * nch * 4 * 64 * 16 and bias_pad.numel() == nct * 64
-    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
+    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off, 0, 0,
+                     nv.OUT_BLOCKED if out_blocked else 0)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, cin)
         _RECORD.append(nv.StepOp(nv.OP_DECONV, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),

@@ -63,7 +63,25 @@ typedef struct {
                                       launches that the caller is waiting for: it asks for LDS it does not use, so that one of
                                       its workgroups fits a CU instead of two and the chain's workgroups always find free
                                       registers and LDS.  Same result, longer launch.  0 = ordinary launch. */
+  int layout;                      /* bit 0 (DUA_IN_BLOCKED): x is stored in 16-channel blocks, bit 1 (DUA_OUT_BLOCKED): y is.
+                                      A blocked buffer of Cstride channels (a multiple of 16) holds sample n as
+                                      [Cstride / 16][voxels][16] instead of [voxels][Cstride]; channel offsets must be multiples
+                                      of 16.  It exists for the wide-tile convolution (csrc/conv3d_wide.hip), which walks its
+                                      input 16 channels at a time: from channels-last rows every pass touches every 128-byte
+                                      voxel line again (2.9x the algorithmic bytes fetched, 32 cache lines per wave request).
+                                      Only the kernels named by dua_conv3d_k3_kernel_kind / dua_deconv_k2s2_kernel_kind below
+                                      read or write it; any other combination is rejected with DUA_ERR_ARG.  0 = channels-last. */
 } dua_conv3_desc;
+#define DUA_IN_BLOCKED 1
+#define DUA_OUT_BLOCKED 2
+
+/* Which kernel a launch described by d takes (the launchers' own policy, exported so that a caller that lays buffers out in
+ * 16-channel blocks decides with the rule the launcher uses).  fused = the call will pass a producer descriptor.
+ * dua_conv3d_k3_kernel_kind: 0 = conv3d_k3_v2_kernel (channels-last only), 1 = conv3d_k3_first_kernel (output may be
+ * blocked), 2 = conv3d_k3_wide_kernel (input and output may be blocked).  dua_deconv_k2s2_kernel_kind: 0 = a kernel that
+ * writes channels-last only, 2 = deconv_k2s2_alltaps_kernel (output may be blocked). */
+int dua_conv3d_k3_kernel_kind(const dua_conv3_desc* d, int fused, int has_workspace);
+int dua_deconv_k2s2_kernel_kind(const dua_conv3_desc* d);
 
 /* w_packed: from dua_pack_conv3_weights.  bias_padded: fp32, at least Cout entries (a buffer padded to
  * ceil(Cout/64)*64 works, entries behind Cout are never read).  in: NULL or the
@@ -174,7 +192,7 @@ int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, 
  * worker thread), call it once up front, on the device they will use, so that no such call happens inside a capture.
  * Thread-safe.  Returns 0, DUA_ERR_ARG (no current device) or a hipError_t.
  * dua_prepared_kernels(): how many kernels dua_prepare() configures (tests). */
-#define DUA_ABI_VERSION 4
+#define DUA_ABI_VERSION 5
 int dua_abi_version(void);
 int dua_prepare(void);
 int dua_prepared_kernels(void);
@@ -228,6 +246,8 @@ typedef struct {
   int emb_stride;               /* channel stride of emb (offset 0), ignored when emb is NULL */
   int out_stride, out_off;
   int pool_stride;              /* channel stride of pooled (offset 0); D,H,W must be even */
+  int out_blocked;              /* 1 = `out` is stored in 16-channel blocks (dua_conv3_desc.layout; out_stride, out_off
+                                   multiples of 16); raw, emb and pooled are always channels-last */
 } dua_materialize_desc;
 
 int dua_materialize(const dua_materialize_desc* d, const void* raw, const dua_in_norm* in,

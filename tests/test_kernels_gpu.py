@@ -132,18 +132,20 @@ def conv_variant_any(request):
     nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
 
 
-@pytest.mark.parametrize("conv_variant_any", [0, 7], indirect=True)
+@pytest.mark.parametrize("conv_variant_any,layout", [(0, (False, False)), (0, (True, False)), (0, (False, True)), (0, (True, True)),
+                                                     (7, (False, False))], indirect=["conv_variant_any"])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("shape", [
     # N, Cin, Cout, D, H, W, input channel offset / stride, output channel offset / stride: layers with >= 1024 tiles of 4x8x8
     (1, 64, 64, 64, 64, 64, 0, 64, 0, 64),        # a 64 -> 64 layer, 8 x 8 x 8 = 512 wide tiles
-    (1, 32, 64, 40, 64, 64, 32, 64, 64, 128),     # depth 40 = 5 slabs of 8; reads / writes halves of concat buffers
+    (2, 32, 64, 40, 64, 64, 32, 64, 64, 128),     # depth 40 = 5 slabs of 8, two samples; reads / writes halves of concat buffers
     (2, 48, 48, 32, 64, 64, 0, 48, 0, 48),        # the Swin-UNETR width: three half chunks, 48 outputs on a 64-wide tile; two samples
-    (1, 16, 72, 64, 64, 64, 0, 16, 8, 80),        # one half chunk; two output-channel tiles, the second one 8 channels wide
+    (1, 16, 72, 64, 64, 64, 0, 16, 16, 96),       # one half chunk; two output-channel tiles, the second one 8 channels wide
 ])
-def test_conv3_wide_tile_form(shape, fused, conv_variant_any):
+def test_conv3_wide_tile_form(shape, fused, conv_variant_any, layout):
     """The 8-accumulator form (conv3d_wide.hip) that fp16 layers with >= 1024 tiles take: against torch conv3d on the
-    fp16-rounded operands (0), like the 4x8x8 kernel it replaces (7); statistics against the exact convolution."""
+    fp16-rounded operands (0), like the 4x8x8 kernel it replaces (7); statistics against the exact convolution.  ``layout``:
+    input / output buffer in 16-channel blocks (dua_conv3_desc.layout) instead of channels-last rows."""
     ops = _ops()
     dtype = torch.float16
     N, Cin, Cout, D, H, W, ioff, istride, ooff, ostride = shape
@@ -159,16 +161,20 @@ def test_conv3_wide_tile_form(shape, fused, conv_variant_any):
     ref = F.conv3d(xin, w.to(dtype).float(), b, padding=1)
     xbuf = torch.full((N, D, H, W, istride), 3.0, dtype=dtype, device="cuda")
     ops.to_channels_last(raw.cuda(), xbuf, ioff, Cin)
+    in_blk, out_blk = layout
+    if in_blk:
+        xbuf = ops.to_blocked(xbuf)
     ybuf = torch.full((N, D, H, W, ostride), -5.0, dtype=dtype, device="cuda")
     wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), dtype)
     stats = ops.stats_buffer(N, Cout, "cuda")
-    ops.conv3d_k3(xbuf, Cin, ioff, wp, bp, Cout, ybuf, ooff, stats, norm=norm)
-    got = ops.from_channels_last(ybuf, Cout, ooff).cpu()
+    ops.conv3d_k3(xbuf, Cin, ioff, wp, bp, Cout, ybuf, ooff, stats, norm=norm, in_blocked=in_blk, out_blocked=out_blk)
+    ycl = ops.from_blocked(ybuf) if out_blk else ybuf
+    got = ops.from_channels_last(ycl, Cout, ooff).cpu()
     assert torch.allclose(got, ref, **TOL[dtype]), float((got - ref).abs().max())
     if ooff:
-        assert float((ybuf[..., :ooff].float() + 5).abs().max()) == 0
+        assert float((ycl[..., :ooff].float() + 5).abs().max()) == 0
     if ooff + Cout < ostride:
-        assert float((ybuf[..., ooff + Cout:].float() + 5).abs().max()) == 0
+        assert float((ycl[..., ooff + Cout:].float() + 5).abs().max()) == 0
     st = ops.stats_decode(stats).cpu()[:, :Cout]
     rd = ref.double().flatten(2)
     assert torch.allclose(st[..., 0], rd.sum(-1), rtol=2e-3, atol=0.5)
@@ -176,8 +182,25 @@ def test_conv3_wide_tile_form(shape, fused, conv_variant_any):
     # bit-reproducible: a second launch gives the same bytes and the same statistics words
     y2 = torch.full_like(ybuf, -5.0)
     st2 = ops.stats_buffer(N, Cout, "cuda")
-    ops.conv3d_k3(xbuf, Cin, ioff, wp, bp, Cout, y2, ooff, st2, norm=norm)
+    ops.conv3d_k3(xbuf, Cin, ioff, wp, bp, Cout, y2, ooff, st2, norm=norm, in_blocked=in_blk, out_blocked=out_blk)
     assert torch.equal(y2, ybuf) and torch.equal(st2, stats)
+
+
+def test_blocked_layout_is_refused_by_kernels_that_cannot():
+    """A launch that would read or write 16-channel blocks with a kernel that only knows channels-last rows fails loudly."""
+    ops = _ops()
+    dtype = torch.float16
+    x = torch.zeros(1, 16, 16, 16, 32, dtype=dtype, device="cuda")          # 16^3: far below the wide-tile form's 1024 tiles
+    w = torch.zeros(64, 32, 3, 3, 3, device="cuda")
+    wp, bp = ops.pack_conv3_weights(w, torch.zeros(64, device="cuda"), dtype)
+    y = torch.zeros(1, 16, 16, 16, 64, dtype=dtype, device="cuda")
+    assert ops.conv3_kernel_kind(dtype, 1, 16, 16, 16, 32, 32, 64) == ops.KIND_V2
+    for kw in (dict(in_blocked=True), dict(out_blocked=True)):
+        with pytest.raises(RuntimeError):
+            ops.conv3d_k3(x, 32, 0, wp, bp, 64, y, 0, ops.stats_buffer(1, 64, "cuda"), **kw)
+    assert ops.conv3_kernel_kind(dtype, 1, 96, 96, 96, 64, 64, 64, fused=True) == ops.KIND_WIDE
+    assert ops.conv3_kernel_kind(torch.float32, 1, 96, 96, 96, 64, 64, 64) == ops.KIND_V2
+    assert ops.conv3_kernel_kind(dtype, 1, 96, 96, 96, 24, 24, 64, tap_channel=16) == ops.KIND_FIRST
 
 
 @pytest.mark.parametrize("conv_variant", [0, 6], indirect=True)
@@ -281,6 +304,15 @@ def test_conv3_single_channel_tap_form(classes, shape, cout):
         assert float(st[:, cout:].abs().max() if st.shape[1] > cout else 0) == 0
     assert (outs[0][0] - outs[1][0]).abs().max() < 4e-3      # same products, different summation order
     assert (outs[1][0] - outs[2][0]).abs().max() < 4e-3
+    if classes == 16 and cout % 16 == 0:
+        # the resident-weight kernel writing a 16-channel-blocked buffer (the layout its consumer, the wide-tile form, reads)
+        wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), torch.float16, cin_packed=cin_p, perm=perm, tap_channel=classes)
+        yb = torch.full((N, D, H, W, cout + 16), -5.0, dtype=torch.float16, device="cuda")
+        ops.conv3d_k3(xp, cin_p, 0, wp, bp, cout, yb, 16, ops.stats_buffer(N, cout, "cuda"), tap_channel=classes, out_blocked=True)
+        ycl = ops.from_blocked(yb)
+        y_plain = torch.full((N, D, H, W, cout + 16), -5.0, dtype=torch.float16, device="cuda")
+        ops.conv3d_k3(xp, cin_p, 0, wp, bp, cout, y_plain, 16, ops.stats_buffer(N, cout, "cuda"), tap_channel=classes)
+        assert torch.equal(ycl, y_plain)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
@@ -326,6 +358,57 @@ def test_materialize(dtype, pool, with_emb):
     if pool:
         gp = ops.from_channels_last(pooled, C).cpu()
         assert torch.equal(gp, F.max_pool3d(got, 2))
+
+
+@pytest.mark.parametrize("pool", [False, True])
+def test_materialize_into_a_blocked_buffer(pool):
+    """materialize writing its slice of a concat buffer that is kept in 16-channel blocks (the level-0 skip half)."""
+    ops = _ops()
+    dtype = torch.float16
+    N, C, D, H, W = 2, 32, 4, 6, 8
+    g = torch.Generator().manual_seed(9)
+    raw = torch.randn(N, C, D, H, W, generator=g)
+    emb = torch.randn(N, C, D, H, W, generator=g)
+    norm, y = _producer(raw, dtype, g)
+    y = (y + emb.to(dtype).float()).to(dtype).float()
+    out = torch.full((N, D, H, W, 64), 4.0, dtype=dtype, device="cuda")
+    pooled = torch.zeros((N, D // 2, H // 2, W // 2, C), dtype=dtype, device="cuda") if pool else None
+    ops.materialize(_cl(raw, dtype), C, norm, out, 16, emb=_cl(emb, dtype), pooled=pooled, out_blocked=True)
+    ocl = ops.from_blocked(out)
+    got = ops.from_channels_last(ocl, C, 16).cpu()
+    assert torch.allclose(got, y, rtol=2e-3, atol=2e-3), float((got - y).abs().max())
+    assert float((ocl[..., :16].float() - 4).abs().max()) == 0 and float((ocl[..., 48:].float() - 4).abs().max()) == 0
+    if pool:
+        assert torch.equal(ops.from_channels_last(pooled, C).cpu(), F.max_pool3d(got, 2))
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_deconv_k2s2_into_a_blocked_buffer(fused):
+    """The all-taps transposed convolution writing its half of a concat buffer kept in 16-channel blocks; kernels that
+    cannot are refused."""
+    ops = _ops()
+    dtype = torch.float16
+    N, Cin, Cout, D, H, W = 1, 64, 64, 32, 32, 32
+    g = torch.Generator().manual_seed(21)
+    raw = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, 2, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xin, norm = raw.to(dtype).float(), None
+    if fused:
+        norm, act = _producer(raw, dtype, g)
+        xin = act.to(dtype).float()
+    ref = F.conv_transpose3d(xin, w.to(dtype).float(), b, stride=2)
+    y = torch.full((N, 2 * D, 2 * H, 2 * W, 128), 9.0, dtype=dtype, device="cuda")
+    wp, bp = ops.pack_deconv_weights(w.cuda(), b.cuda(), dtype)
+    assert ops.deconv_kernel_kind(dtype, N, D, H, W, Cin, Cout) == ops.DECONV_ALLTAPS
+    ops.deconv_k2s2(_cl(raw, dtype), Cin, 0, wp, bp, Cout, y, 64, norm=norm, out_blocked=True)
+    ycl = ops.from_blocked(y)
+    got = ops.from_channels_last(ycl, Cout, 64).cpu()
+    assert torch.allclose(got, ref, **TOL[dtype]), float((got - ref).abs().max())
+    assert float((ycl[..., :64].float() - 9).abs().max()) == 0
+    small = torch.zeros(1, 4, 4, 4, 64, dtype=dtype, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.deconv_k2s2(small, 64, 0, wp, bp, Cout, torch.zeros(1, 8, 8, 8, 128, dtype=dtype, device="cuda"), 64, out_blocked=True)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])

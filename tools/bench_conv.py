@@ -23,7 +23,13 @@ SHAPES = [  # (S, Cin, Cout, fused prologue)
 
 
 def main():
-    variants = [v if v.startswith("lib:") else int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
+    def parse(v):
+        if v.startswith("lib:"):
+            return v
+        if v.endswith("b"):                 # e.g. "0b": variant 0 reading its input as 16-channel blocks (dua_set_option(5, 1), experiment)
+            return (int(v[:-1]), 1)
+        return int(v)
+    variants = [parse(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
     main_lib = nv.lib()
     alts = {}
     for v in variants:
@@ -37,7 +43,7 @@ def main():
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     dt = torch.float16
     dev = "cuda"
-    print(f"{'shape':>22} " + " ".join(f"{(os.path.basename(v)[-12:] if isinstance(v, str) else 'v%d' % v) + ' us':>15} {'TF':>7}" for v in variants))
+    print(f"{'shape':>22} " + " ".join(f"{(os.path.basename(v)[-12:] if isinstance(v, str) else 'v' + str(v)) + ' us':>15} {'TF':>7}" for v in variants))
     for idx, (S, cin, cout, fused) in enumerate(SHAPES):
         if only is not None and idx not in only:
             continue
@@ -71,7 +77,8 @@ def main():
                 nv._lib = alts[v]
             else:
                 nv._lib = main_lib
-                nv.check(main_lib.dua_set_option(1, v), "opt")
+                nv.check(main_lib.dua_set_option(1, v[0] if isinstance(v, tuple) else v), "opt")
+                nv.check(main_lib.dua_set_option(5, v[1] if isinstance(v, tuple) else 0), "opt")
             run = lambda: ops.conv3d_k3(x, cin, 0, wp, bp, cout, y, 0, stats, norm=norm, workspace=ws, tap_channel=tap)  # noqa: E731
             run()
             torch.cuda.synchronize()
@@ -82,6 +89,7 @@ def main():
             graphs[v] = g
         nv._lib = main_lib
         nv.check(main_lib.dua_set_option(1, 0), "opt")
+        nv.check(main_lib.dua_set_option(5, 0), "opt")
         for rd in range(rounds + 1):
             for v in variants:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -26,7 +26,7 @@ def main():
     def parse(v):
         if v.startswith("lib:"):
             return v
-        if v.endswith("b"):                 # e.g. "0b": variant 0 reading its input as 16-channel blocks (dua_set_option(5, 1), experiment)
+        if v.endswith("b"):                 # e.g. "0b": variant 0 reading its input as 16-channel blocks (dua_conv3_desc.layout) where the wide-tile form runs
             return (int(v[:-1]), 1)
         return int(v)
     variants = [parse(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"])]
@@ -78,8 +78,8 @@ def main():
             else:
                 nv._lib = main_lib
                 nv.check(main_lib.dua_set_option(1, v[0] if isinstance(v, tuple) else v), "opt")
-                nv.check(main_lib.dua_set_option(5, v[1] if isinstance(v, tuple) else 0), "opt")
-            run = lambda: ops.conv3d_k3(x, cin, 0, wp, bp, cout, y, 0, stats, norm=norm, workspace=ws, tap_channel=tap)  # noqa: E731
+                blk = isinstance(v, tuple) and v[1] and ops.conv3_kernel_kind(dt, 1, S, S, S, cin, cin, cout, fused=fused, tap_channel=tap) == ops.KIND_WIDE
+            run = lambda blk=(False if isinstance(v, str) else blk): ops.conv3d_k3(x, cin, 0, wp, bp, cout, y, 0, stats, norm=norm, workspace=ws, tap_channel=tap, in_blocked=blk)  # noqa: E731
             run()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -89,7 +89,6 @@ def main():
             graphs[v] = g
         nv._lib = main_lib
         nv.check(main_lib.dua_set_option(1, 0), "opt")
-        nv.check(main_lib.dua_set_option(5, 0), "opt")
         for rd in range(rounds + 1):
             for v in variants:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

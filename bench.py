@@ -94,14 +94,14 @@ def conv3_flops(plan):
 
 
 _LAST_CONV_CALLS = []
-_CONV_VARIANT = 0          # --conv-variant (dua_set_option(1, v)): 0 = the shipped launch policy
+_CONV_VARIANT = 0          # --conv-variant (ops.CONV_POLICY): 0 = the launchers' automatic choice
 
 
 def time_conv_launches(plan, reps):
     """HIP events (torch.cuda.Event on the launch stream) around the conv3d_k3 kernel: one eager denoiser evaluation
     records the arguments of its 18 launches; each launch is then replayed `reps` times back to back between ONE event
     pair (an event pair around a single ~30 us launch reads the command-processor gaps as kernel time).  Split-K layers
-    are replayed without their finish kernel (dua_set_option(2, 1)), so the figure is the conv kernel alone, as the
+    are replayed without their finish kernel (dua_conv3_desc.policy bit DUA_POLICY_NO_FINISH), so the figure is the conv kernel alone, as the
     rocprofv3 summary lists it.  Returns (avg ms per launch, launches/step, ms by launch)."""
     from diff_unet_amos_amd import _native as nv
     from diff_unet_amos_amd import ops
@@ -121,7 +121,7 @@ def time_conv_launches(plan, reps):
     finally:
         ops.conv3d_k3 = real
     by_launch = []
-    nv.check(nv.lib().dua_set_option(2, 1), "dua_set_option")
+    ops.CONV_POLICY |= nv.POLICY_NO_FINISH
     try:
         for a, k in calls:
             for _ in range(3):
@@ -134,7 +134,7 @@ def time_conv_launches(plan, reps):
             torch.cuda.synchronize()
             by_launch.append(e0.elapsed_time(e1) / reps)
     finally:
-        nv.check(nv.lib().dua_set_option(2, 0), "dua_set_option")
+        ops.CONV_POLICY &= ~nv.POLICY_NO_FINISH
     return sum(by_launch) / len(by_launch), len(calls), by_launch
 
 
@@ -777,7 +777,7 @@ def main():
     ap.add_argument("--gather-fp16", action="store_true", help="config 3: all-gather the window sums in fp16")
     ap.add_argument("--flat-allreduce", action="store_true", help="config 4: one flat all-reduce instead of DDP buckets")
     ap.add_argument("--train-graph", action="store_true", help="config 4: whole step as one HIP graph")
-    ap.add_argument("--conv-variant", type=int, default=0, help="diagnostics: dua_set_option(1, v) before the run (same-box A/B of launch policies)")
+    ap.add_argument("--conv-variant", type=int, default=0, help="diagnostics: dua_conv3_desc.policy of every convolution launch (same-box A/B of launch forms)")
     args = ap.parse_args()
     defaults = {2: (200, 20), 3: (1, 0), 4: (5, 2), 5: (100, 10)}[args.config]
     args.steps = defaults[0] if args.steps is None else args.steps
@@ -791,10 +791,10 @@ def main():
         args.traffic = measure_traffic(args.dtype, WIDE_KERNEL if (args.dtype == "f16" and not args.conv_variant) else CONV_KERNEL)
     D = Dist(args)
     if args.conv_variant:
-        from diff_unet_amos_amd import _native as nv
+        from diff_unet_amos_amd import ops
         global _CONV_VARIANT
         _CONV_VARIANT = args.conv_variant
-        nv.check(nv.lib().dua_set_option(1, args.conv_variant), "dua_set_option")
+        ops.CONV_POLICY = args.conv_variant
     {2: run_config2, 3: run_config3, 4: run_config4, 5: run_config5}[args.config](args, D)
     D.finish()
 

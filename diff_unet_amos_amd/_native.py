@@ -13,8 +13,11 @@ import os
 import torch  # noqa: F401  (must precede CDLL: maps libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DUA_HIP_LIB: a diagnostic build of the same library (tools/build_diag.sh: stamps, ablations) instead of the shipped one
-LIB_PATH = os.environ.get("DUA_HIP_LIB") or os.path.join(_HERE, "libdua_hip.so")
+# The shipped library; with DUA_DEBUG=1 in the environment, DUA_HIP_LIB may name a diagnostic build of the same library
+# (tools/build_diag.sh: stamps, ablations) instead.  Without the debug flag the environment cannot redirect the package.
+LIB_PATH = os.path.join(_HERE, "libdua_hip.so")
+if os.environ.get("DUA_DEBUG") == "1" and os.environ.get("DUA_HIP_LIB"):
+    LIB_PATH = os.environ["DUA_HIP_LIB"]
 
 F32, F16 = 0, 1
 ERR_ARG = -22
@@ -28,7 +31,7 @@ class Conv3Desc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("Cin", C.c_int), ("Cin_stride", C.c_int), ("Cin_off", C.c_int),
                 ("Cout", C.c_int), ("Cout_stride", C.c_int), ("Cout_off", C.c_int), ("tap_channel_plus1", C.c_int),
-                ("background", C.c_int), ("layout", C.c_int)]
+                ("background", C.c_int), ("layout", C.c_int), ("policy", C.c_int)]
 
 
 class InNorm(C.Structure):
@@ -61,6 +64,7 @@ class TailResidual(C.Structure):
 
 
 IN_BLOCKED, OUT_BLOCKED = 1, 2            # dua_conv3_desc.layout bits
+POLICY_NO_FINISH = 256                    # dua_conv3_desc.policy bit: skip the split-K finish kernel (timing only)
 MODE_LOGITS, MODE_DDPM, MODE_DDIM = 0, 1, 2
 OP_CONV3, OP_MATERIALIZE, OP_DECONV = 1, 2, 3
 
@@ -108,7 +112,6 @@ _SIGS = {
     "dua_abi_version": (C.c_int, []),
     "dua_prepare": (C.c_int, []),
     "dua_prepared_kernels": (C.c_int, []),
-    "dua_set_option": (C.c_int, [C.c_int, C.c_int]),
     "dua_mfma_probe": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
     "dua_chain_probe": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P]),
     "dua_deconv_k2s2_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P]),
@@ -187,8 +190,6 @@ def lib():
         if got != ABI_VERSION:
             raise NativeLibraryMissing(f"{LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild the library")
         _lib = L
-        if os.environ.get("DUA_CONV_VARIANT"):        # diagnostics: dua_set_option(1, v) for the whole process
-            check(L.dua_set_option(1, int(os.environ["DUA_CONV_VARIANT"])), "dua_set_option")
     return _lib
 
 

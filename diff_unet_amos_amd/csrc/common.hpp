@@ -110,8 +110,10 @@ constexpr int STAT_REPLICAS = 8;   // producers spread their atomics over 8 repl
 // with 64-bit INTEGER atomics -- integer addition is associative, so any arrival order of the workgroups gives the same
 // words, and every consumer derives bit-identical scale / shift from them (two replays of a step agree bit for bit; fp64
 // atomics differed in the last place from run to run).  Row layout: [N][8 replicas][4 words][c_pad] =
-// (sum int, sum frac, sumsq int, sumsq frac).  Range: |total| < 2^62; resolution 2^-44 per contribution; up to 2^18
-// contributions per replica row.
+// (sum int, sum frac, sumsq int, sumsq frac).  Range: |total| < 2^62 for the integer words; resolution 2^-44 per
+// contribution; the fraction words (each contribution |frac| <= 2^43) hold 2^19 contributions per replica row and the consumers
+// add the 8 replica rows as int64 -- i.e. up to 2^16 contributions per row keep the 8-row sum inside int64 (a 96^3 layer at batch 4
+// makes 864 per row).  Non-finite contributions: stats_add.
 using stat_t = long long;
 constexpr int STAT_WORDS = 4;
 constexpr double STAT_FRAC = 17592186044416.0;        // 2^44
@@ -242,6 +244,11 @@ __device__ __forceinline__ void stats_add(stat_t* stats, int n, int c_pad, int r
   unsafeAtomicAdd((double*)(p + 2L * c_pad), Q);
   return;
 #endif
+  // A non-finite or out-of-range contribution (an fp16 overflow upstream) must not turn into arbitrary finite words: it is
+  // replaced by a poison value far outside anything sums of fp16 data reach, so that every consumer derives an absurd variance
+  // (scale ~ 0 or NaN) instead of a plausible one.  The fp64 atomics this replaced propagated Inf / NaN by themselves.
+  constexpr double LIM = 4.0e18;                       // < 2^62: the documented range of the fixed-point words
+  if (!(fabs(S) < LIM) || !(fabs(Q) < LIM)) { S = LIM; Q = -LIM; }      // (the comparison is false for NaN)
   const double Si = rint(S), Qi = rint(Q);
   // two's-complement adds: negative parts wrap, the integer sum is exact either way.  System scope (sc1): the adds of all
   // eight XCDs must meet in one place; an agent-scope integer read-modify-write carries no sc bit on gfx950, and unlike the

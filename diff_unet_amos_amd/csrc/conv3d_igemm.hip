@@ -35,13 +35,18 @@ constexpr int HALO_BYTES = HD * PS;        // 39360
 constexpr int BN = 64;                     // output channels per workgroup
 }  // namespace c3
 
-// 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones, both in the kd-plane form); 2 forces 4x8x8 tiles without
-// split-K, 3 forces 2x8x8 (slab form), 6 = the automatic policy with the slab form everywhere (same-process A/B)
-int g_conv_variant = 0;
+// launch form of a call (dua_conv3_desc.policy, low byte): 0 = auto (split-K for small layers, 2x8x8 tiles for mid-size ones,
+// both in the kd-plane form; the wide-tile form where there are tiles to spare); 2 forces 4x8x8 tiles without split-K, 3 forces
+// 2x8x8 (slab form), 6 = the automatic policy with the slab form everywhere, 7 = without the wide-tile form
+static inline int conv_variant_of(const dua_conv3_desc* d) { return d->policy & 0xff; }
+static inline bool conv_policy_ok(const dua_conv3_desc* d) {
+  const int v = d->policy & 0xff;
+  return (d->policy & ~(0xff | DUA_POLICY_NO_FINISH)) == 0 && (v == 0 || v == 2 || v == 3 || v == 6 || v == 7);
+}
 
-int g_skip_splitk_finish = 0;   // diagnostics (dua_set_option(2, 1)): time the split-K main kernel alone; outputs are not finished
+#ifdef DUA_ABLATE
 extern int g_wgrad_abl;
-extern int g_wgrad_variant;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // v2: same tile and fragment maps, software-pipelined.  Weights arrive as 12 KB (kd,kh) slabs, loaded to
@@ -934,6 +939,7 @@ static const LdsAttrs kConvLdsReg(kConvLdsAttrs);
 // Which kernel a launch takes (also exported: dua_conv3d_k3_kernel_kind): 1 = the resident-weight first-layer kernel, 2 = the
 // wide-tile form, 0 = conv3d_k3_v2_kernel in one of its launch shapes.
 static int conv3_kernel_kind(const dua_conv3_desc* d, bool fused) {
+  const int g_conv_variant = conv_variant_of(d);
   if (d->dtype != DUA_F16) return 0;
   if (d->tap_channel_plus1 > 0) return (d->tap_channel_plus1 == 17 && g_conv_variant == 0) ? 1 : 0;
   const long tiles = (long)((d->D + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * ((d->Cout + c3::BN - 1) / c3::BN) * d->N;
@@ -963,7 +969,8 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   a.cout_pad = nct * BN;
   a.ksplit = 1; a.units_per_split = a.nchunks * 3; a.part = nullptr; a.tap_ch = -1;
   a.in_blk = d->layout & DUA_IN_BLOCKED ? 1 : 0; a.out_blk = d->layout & DUA_OUT_BLOCKED ? 1 : 0;
-  if (a.nchunks * CK > 1024) return DUA_ERR_ARG;
+  if (a.nchunks * CK > 1024 || !conv_policy_ok(d)) return DUA_ERR_ARG;
+  const int g_conv_variant = conv_variant_of(d);
   const int kind = conv3_kernel_kind(d, in && in->stats);
   // 16-channel-blocked buffers: read by the wide-tile form only, written by it and by the first-layer kernel only
   if ((a.in_blk && kind != 2) || (a.out_blk && kind == 0)) return DUA_ERR_ARG;
@@ -1020,7 +1027,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   if (a.ksplit > 1) {
     if (big) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 4, 2, false, true>), grid, dim3(256), c3::HALO_BYTES + 9 * c3v2::SLAB + xf_bytes, s, a);
     else hipLaunchKernelGGL(conv3d_k3_v2_kernel<T>, grid, dim3(256), c3v2::LDS_MAIN + xf_bytes, s, a);
-    if (g_skip_splitk_finish) return (int)hipGetLastError();
+    if (d->policy & DUA_POLICY_NO_FINISH) return (int)hipGetLastError();
     const int G = a.cout_pad / 4 > 256 ? 256 : a.cout_pad / 4;       // channel groups handled per block pass
     if (a.cout_pad / 4 > 256) return DUA_ERR_ARG;
     const int VL = 256 / G;
@@ -1049,18 +1056,16 @@ extern "C" {
 long dua_debug_stamps(void* host, long bytes) { return dua::stamps_out(host, bytes); }
 #endif
 
-int dua_set_option(int key, int value) {
-  if (key == 1 && (value == 0 || value == 2 || value == 3 || value == 6 || value == 7)) { dua::g_conv_variant = value; return 0; }
-  if (key == 2 && (value == 0 || value == 1)) { dua::g_skip_splitk_finish = value; return 0; }
 #ifdef DUA_ABLATE
-  if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }   // diagnostic builds only
-#endif
-  if (key == 4 && value >= 0 && value < 256) { dua::g_wgrad_variant = value; return 0; }
+// diagnostic builds only (tools/build_diag.sh ... -DDUA_ABLATE): ablation mask of the weight-gradient kernel
+int dua_set_option(int key, int value) {
+  if (key == 3 && value >= 0 && value < 16) { dua::g_wgrad_abl = value; return 0; }
   return DUA_ERR_ARG;
 }
+#endif
 
 int dua_conv3d_k3_kernel_kind(const dua_conv3_desc* d, int fused, int has_workspace) {
-  if (!d) return DUA_ERR_ARG;
+  if (!d || !dua::conv_policy_ok(d)) return DUA_ERR_ARG;
   (void)has_workspace;              // split-K applies below 1024 tiles only, where the answer is 0 anyway
   return dua::conv3_kernel_kind(d, fused != 0);
 }

@@ -20,8 +20,10 @@
 #include "../../include/dua_hip.h"
 
 namespace dua {
-int g_wgrad_abl = 0;
-int g_wgrad_variant = 0;   // dua_set_option(4, v): bit 0 = plain (partition-major) block order, bits 1-4 = workgroups per CU over the launch (0 = policy), bit 5 = 6 waves + plain k loop, bit 6 = 6 waves + pipelined k loop (default: 12 waves)
+#ifdef DUA_ABLATE
+int g_wgrad_abl = 0;       // diagnostic builds: dua_set_option(3, mask)
+#endif
+// launch form of a call = dua_conv3_desc.policy: bit 0 = plain (partition-major) block order, bits 1-4 = workgroups per CU over the launch (0 = policy), bit 5 = 6 waves + plain k loop, bit 6 = 6 waves + pipelined k loop (default: 12 waves)
 namespace wg {
 constexpr int TD = 2, TH = 8, TW = 8, TV = TD * TH * TW;      // 128 output voxels per tile
 constexpr int XH = TH + 2, XW = TW + 2, XV = TD * XH * XW;    // 200 input voxels per tile and kd
@@ -56,7 +58,8 @@ __device__ __forceinline__ void wg_glds16(const void* g, void* lds_wave_base) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(__builtin_amdgcn_readfirstlane(base)) : "memory");
 #else
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(__builtin_amdgcn_readfirstlane(base)) : "memory");
+  // (s_nop 0: the one wait state the ReadM0 -> LDS-DMA hazard asks for; hipcc does not look inside an asm statement)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(__builtin_amdgcn_readfirstlane(base)) : "memory");
 #endif
 }
 
@@ -457,7 +460,7 @@ static inline int wgrad_partitions(const dua_conv3_desc* d, int* combos_out) {
   const int total = d->N * ((d->D + TD - 1) / TD) * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
   // ~3 workgroups per CU over the launch (one resident at a time): measured 1.8x faster than exactly one persistent
   // workgroup per CU on the 96^3 layers (580 vs 1035 us), 2 and 4+ per CU in between
-  const int mv = (g_wgrad_variant & 31) >> 1;        // bits 5, 6 select kernel forms, not a launch shape
+  const int mv = (d->policy & 31) >> 1;        // bits 5, 6 select kernel forms, not a launch shape
   const int mult = mv ? mv : (total < 32 ? 1 : 3);   // tiny levels: fewer partial sums
   int P = (256 * mult + combos - 1) / combos;
   if (P > total) P = total;
@@ -496,7 +499,13 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
   const int P = wgrad_partitions(d, &combos);
   a.P = P;
   a.ncombo = nct * a.ncc;
+#ifdef DUA_ABLATE
   a.abl = g_wgrad_abl;
+#else
+  a.abl = 0;
+#endif
+  const int g_wgrad_variant = d->policy;
+  if (g_wgrad_variant < 0 || g_wgrad_variant > 255) return DUA_ERR_ARG;
   a.plain_order = (g_wgrad_variant & 1) || P < 8;
   a.part = (ws && (long)P * combos * 9 * 4096 * 4 <= ws_bytes && P > 1) ? ws : nullptr;
   constexpr int lds = wgrad_lds<T>();

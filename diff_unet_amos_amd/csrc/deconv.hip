@@ -12,7 +12,6 @@
 
 namespace dua {
 
-extern int g_conv_variant;
 
 namespace dc {
 constexpr int TM = 256, BN = 64, KG = 4;
@@ -467,7 +466,7 @@ static int deconv_kernel_kind(const dua_conv3_desc* d) {
   const int nchunks = (d->Cin + ck - 1) / ck;
   const long vox = (long)d->D * d->H * d->W;
   if (vox >= 256L * 128 && nchunks <= 4) return 2;
-  if (nchunks >= 8 && nchunks <= 4 * dcs::MC && g_conv_variant != 6) return 1;
+  if (nchunks >= 8 && nchunks <= 4 * dcs::MC && d->policy != 6) return 1;
   return 0;
 }
 
@@ -485,6 +484,8 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   a.nct = (d->Cout + dc::BN - 1) / dc::BN;
   const long vox = (long)d->D * d->H * d->W;
   if (int e = ensure_prepared()) return e;
+  if (d->policy != 0 && d->policy != 6) return DUA_ERR_ARG;
+  const int g_conv_variant = d->policy;
   a.out_blk = d->layout & DUA_OUT_BLOCKED ? 1 : 0;
   if (d->layout & DUA_IN_BLOCKED) return DUA_ERR_ARG;
   if (a.out_blk && (deconv_kernel_kind(d) != 2 || d->Cout_off % 16 || d->Cout_stride % 16 || vox * 8 * 16 >= 0x7fffffffL)) return DUA_ERR_ARG;

@@ -23,7 +23,9 @@
 // keeps the 2197-entry column of its head in LDS (8.8 KB instead of 343 x 343 floats from L2) and looks up
 // table[off(q) - off(k) + centre].  Token -> coordinate uses the TABLE's grid (7, 7, 7) even for clipped windows: the
 // reference slices relative_position_index[:n, :n] of the 7^3 index (attention.py:104).
-// Fastest form (bias_tiles): the same bias, gathered once per weight version on the host side into the ACCUMULATOR's order --
+// Alternative form (bias_tiles; kept for the kernel tests, NOT used by the launch plans -- it trades the LDS gathers for a global
+// round trip per key block and measured slower at the coarse stages): the same bias, gathered once per weight
+// version on the host side into the ACCUMULATOR's order --
 // [head][query block][key block][lane][16] fp32, pre-multiplied by log2 e -- so that a key block costs four 16-byte loads per
 // lane (4 KB contiguous per wave, shared by all windows of the image: 1.45 MB at 3 heads x 343 tokens, L2 resident) instead of
 // 16 per-lane LDS gathers and their address arithmetic (LDS instructions per launch 1.08 M -> 0.22 M, VALU 14.1 M -> 11.9 M).

@@ -291,6 +291,12 @@ def conv3_workspace_bytes(dtype, N, D, H, W, cin, cout):
     return int(nv.lib().dua_conv3d_k3_workspace(C.byref(d)))
 
 
+# Launch form handed to the kernels with every call (dua_conv3_desc.policy; 0 = the launchers' automatic choice).  The kernel
+# tests and the A/B tools set these to reach forms the automatic choice would not take for their shapes; the library itself keeps
+# no option state.
+CONV_POLICY = 0          # conv3d_k3 / deconv_k2s2: 0, 2, 3, 6, 7 (| _native.POLICY_NO_FINISH)
+WGRAD_POLICY = 0         # conv3d_k3_wgrad: bit field, see include/dua_hip.h
+
 KIND_V2, KIND_FIRST, KIND_WIDE = 0, 1, 2          # dua_conv3d_k3_kernel_kind
 DECONV_ALLTAPS = 2                                # dua_deconv_k2s2_kernel_kind
 
@@ -299,13 +305,13 @@ def conv3_kernel_kind(dtype, N, D, H, W, cin, cin_stride, cout, fused=False, tap
     """Which kernel the launcher picks for this 3x3x3 convolution (dua_conv3d_k3_kernel_kind: the launcher's own rule).  Only
     KIND_WIDE reads 16-channel-blocked input; only KIND_WIDE and KIND_FIRST write blocked output."""
     d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, cin, cin_stride, 0, cout, -(-cout // 8) * 8, 0,
-                     0 if tap_channel is None else tap_channel + 1, 1 if background else 0, 0)
+                     0 if tap_channel is None else tap_channel + 1, 1 if background else 0, 0, CONV_POLICY & 0xff)
     return int(nv.lib().dua_conv3d_k3_kernel_kind(C.byref(d), 1 if fused else 0, 0))
 
 
 def deconv_kernel_kind(dtype, N, D, H, W, cin, cout):
     """dua_deconv_k2s2_kernel_kind for an input of D x H x W voxels: DECONV_ALLTAPS is the kernel that may write blocked output."""
-    d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, cin, cin, 0, cout, cout, 0, 0, 0, 0)
+    d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, cin, cin, 0, cout, cout, 0, 0, 0, 0, 6 if (CONV_POLICY & 0xff) == 6 else 0)
     return int(nv.lib().dua_deconv_k2s2_kernel_kind(C.byref(d)))
 
 
@@ -352,7 +358,7 @@ def conv3d_k3(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, out_stats,
     assert out_stats.dtype == torch.int64 and out_stats.is_contiguous() and tuple(out_stats.shape) == (N, STAT_REPLICAS, STAT_WORDS, nct * 64)
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off,
                      0 if tap_channel is None else tap_channel + 1, 1 if background else 0,
-                     (nv.IN_BLOCKED if in_blocked else 0) | (nv.OUT_BLOCKED if out_blocked else 0))
+                     (nv.IN_BLOCKED if in_blocked else 0) | (nv.OUT_BLOCKED if out_blocked else 0), CONV_POLICY)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, cin)
         _RECORD.append(nv.StepOp(nv.OP_CONV3, has, d, nv.MaterializeDesc(),
@@ -383,7 +389,7 @@ def conv3d_k3_wgrad(x, cin, cin_off, dy, cout, cout_off, dw, perm=None, workspac
         assert cin_src <= cin
     else:
         assert perm.dtype == torch.int32 and perm.numel() >= -(-cin // 64) * 64
-    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, dy.shape[-1], cout_off)
+    d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, dy.shape[-1], cout_off, 0, 0, 0, WGRAD_POLICY)
     if workspace is None:
         need = nv.lib().dua_conv3d_k3_wgrad_workspace(C.byref(d))
         workspace = _wgrad_ws(need, x.device) if need > 0 else None
@@ -630,7 +636,7 @@ def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=Non
     assert nch * ck <= 1024
     assert w_packed.numel() == 8 * nct * nch * 4 * 64 * 16 and bias_pad.numel() == nct * 64
     d = nv.Conv3Desc(nv.dt_code(x.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off, 0, 0,
-                     nv.OUT_BLOCKED if out_blocked else 0)
+                     nv.OUT_BLOCKED if out_blocked else 0, 6 if (CONV_POLICY & 0xff) == 6 else 0)
     if _RECORD is not None:
         has, nval = _norm_value(norm, N, cin)
         _RECORD.append(nv.StepOp(nv.OP_DECONV, has, d, nv.MaterializeDesc(), nval, _addr(x), _addr(w_packed), _addr(bias_pad),
@@ -783,7 +789,7 @@ def denoiser_step(plan_struct):
 
 
 def attention_bias_tiles(bias):
-    """Dense relative-position bias [heads, n, n] (query, key) -> the tile form dua_window_attention_fwd reads fastest: fp32
+    """Dense relative-position bias [heads, n, n] (query, key) -> the tile form of dua_window_attention_fwd (kernel tests only; the plans use the table form): fp32
     [heads, nb, nb, 64, 16] in the kernel's accumulator order, times log2(e), zero beyond n."""
     import math
     heads, n, _ = bias.shape

@@ -17,8 +17,12 @@ What runs where
     (deconv.hip), windowed attention (window_attention.hip), norm1 + pad + roll + window partition and its inverse with
     the residual add and norm2 (swin_tokens.hip), patch embedding, patch-merging gather + LayerNorm, the stage adds,
     GELU, the UnetResBlock tail with the embedding / reverse-attention adds (swin_ops.hip), the 1x1x1 output head.
-  * library GEMMs (torch.nn.functional.linear -> hipBLASLt): qkv / proj / MLP / patch-merging reduction Linear layers and
-    the 1x1x1 conv3 of channel-changing UnetResBlocks.
+    The Linear layers (qkv / proj / MLP / patch-merging reduction) and the 1x1x1 conv3 of channel-changing UnetResBlocks run on
+    the package's own MFMA GEMMs in fp16 plans (token_linear / swin_mlp at stage 0, token_gemm at stages 1-3:
+    swin_gemm.hip, swin_gemm_wide.hip): no library GEMM is launched.
+  * the fp32 PARITY plan (compute_dtype=torch.float32) keeps those GEMMs on torch (F.linear / torch.matmul -> hipBLASLt): the
+    token GEMM kernels are fp16-operand kernels, an fp32 form on MFMA 32x32x2 would serve the parity mode only, and the plan's
+    purpose -- checking the wiring against the oracle to 1e-5 -- does not depend on who multiplies.
 """
 from __future__ import annotations
 

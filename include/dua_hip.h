@@ -71,7 +71,19 @@ typedef struct {
                                       voxel line again (2.9x the algorithmic bytes fetched, 32 cache lines per wave request).
                                       Only the kernels named by dua_conv3d_k3_kernel_kind / dua_deconv_k2s2_kernel_kind below
                                       read or write it; any other combination is rejected with DUA_ERR_ARG.  0 = channels-last. */
+  int policy;                      /* 0 = the launcher's automatic choice of kernel form.  Non-zero values select a form by hand --
+                                      for the kernel tests (every form is exercised on shapes the automatic choice would not
+                                      give it) and same-process A/B timing; results are the same.  dua_conv3d_k3_fwd: low byte
+                                      2 = 4x8x8 tiles without split-K, 3 = 2x8x8 tiles (slab form), 6 = automatic without the
+                                      kd-plane / LDS-DMA form of the small layers, 7 = automatic without the wide-tile form;
+                                      bit 8 (DUA_POLICY_NO_FINISH) = skip the split-K finish kernel (timing the main kernel alone:
+                                      outputs are then NOT valid).  dua_deconv_k2s2_fwd: 6 = the one-tap-per-workgroup kernel
+                                      for every shape that has it, 256-voxel all-taps tiles.  dua_conv3d_k3_wgrad: bit 0 = plain
+                                      block order, bits 1-4 = workgroups per CU over the launch, bit 5 / 6 = the 6-wave forms,
+                                      bit 7 = tiles through registers.  A per-call field: the library keeps no mutable option
+                                      state.  Any other value is rejected with DUA_ERR_ARG. */
 } dua_conv3_desc;
+#define DUA_POLICY_NO_FINISH 256
 #define DUA_IN_BLOCKED 1
 #define DUA_OUT_BLOCKED 2
 
@@ -206,15 +218,6 @@ int dua_mfma_probe(int workgroups, int iters, float* sink, unsigned long long* s
  * its dependent memory round trips.  mode 0 empty, 1 load/store, 2 + workgroup reduction and 64 system-scope atomics,
  * 3 + a read of the words the previous launch's atomics wrote.  in/out: workgroups * 256 floats; words: 64 x 8 bytes. */
 int dua_chain_probe(int mode, int workgroups, const float* in, float* out, unsigned long long* words, void* stream);
-
-/* Tuning/diagnostic switch: key 1 = conv3d_k3 launch shape (0 automatic policy, 2 = 4x8x8 tiles without split-K,
- * 3 = 2x8x8 tiles, 6 = the automatic policy without the kd-plane / LDS-DMA form of the small layers);
- * key 2 = 1: skip the split-K finish kernel (timing the main kernel alone; outputs are then NOT valid);
- * key 3: ablation mask of the weight-gradient kernel (accepted by diagnostic builds, -DDUA_ABLATE, only);
- * key 4: weight-gradient launch shape (bit 0 = plain block order, bits 1-4 = workgroups per CU over the launch,
- * 0 = default policy; bit 6 = the 6-wave form instead of the 12-wave one, bit 5 = 6 waves with the compiler-scheduled
- * k loop).  Any other key/value is rejected with DUA_ERR_ARG. */
-int dua_set_option(int key, int value);
 
 /* Packs nn.Conv3d weight fp32[Cout][Cin_src][3][3][3] into the kernel's slab order
  * [cout_tile][chunk][kd][kh*3+kw][k-group][64][16 B].  in_perm (device int32[Cin_packed], may be

@@ -54,7 +54,8 @@ def test_argument_validation_without_a_device(lib):
     assert lib.dua_conv3d_k3_fwd(None, one, one, one, None, one, one, None, 0, None) == nv.ERR_ARG
     assert lib.dua_q_sample(0, 10, one, one, one, one, None) == nv.ERR_ARG
     assert lib.dua_sampler_step(7, 1, 10, one, one, one, one, one, None, None, None) == nv.ERR_ARG
-    assert lib.dua_set_option(99, 1) == nv.ERR_ARG
+    bad_policy = nv.Conv3Desc(nv.F16, 1, 8, 8, 8, 16, 16, 0, 64, 64, 0, 0, 0, 0, 5)        # not a launch form
+    assert lib.dua_conv3d_k3_fwd(C.byref(bad_policy), one, one, one, None, one, one, None, 0, None) == nv.ERR_ARG
     # LeakyReLU slope outside [0, 1]: the fp16 kernels apply the activation as max(t, slope * t)
     ok = nv.Conv3Desc(nv.F16, 1, 8, 8, 8, 16, 16, 0, 64, 64, 0)
     bad = nv.InNorm(16, 16, 16, None, 0, 64, 1.0 / 512, 1e-5, 1.5)
@@ -94,3 +95,17 @@ def test_no_launcher_sets_function_attributes_on_its_own():
             text = re.sub(r"//.*", "", open(os.path.join(csrc, name)).read())
             assert "hipFuncSetAttribute" not in text, name
             assert "PerDeviceOnce" not in text, name
+
+
+def test_the_shipped_library_keeps_no_option_state(lib):
+    """Launch forms are a per-call field (dua_conv3_desc.policy); the shipped library exports no dua_set_option and the
+    environment cannot redirect or reconfigure the package without DUA_DEBUG=1."""
+    assert not hasattr(lib, "dua_set_option")
+    src = open(os.path.join(ROOT, "diff_unet_amos_amd", "_native.py")).read()
+    assert "DUA_CONV_VARIANT" not in src
+    csrc = os.path.join(ROOT, "diff_unet_amos_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            text = re.sub(r"//.*", "", open(os.path.join(csrc, name)).read())
+            globals_ = re.findall(r"^(?:static )?int (g_\w+)", text, flags=re.M)          # namespace-scope mutable ints
+            assert [g for g in globals_ if g != "g_wgrad_abl"] == [], (name, globals_)       # g_wgrad_abl: -DDUA_ABLATE builds only

@@ -66,10 +66,10 @@ def conv_variant(request):
     """Force one of the conv3d_k3 launch shapes (0: automatic policy with split-K / 2x8x8 tiles where they pay,
     2: 4x8x8 tiles without split-K, 3: 2x8x8 tiles, 6: the policy with the kd-plane / LDS-DMA form of the small layers
     switched off)."""
-    from diff_unet_amos_amd import _native as nv
-    nv.check(nv.lib().dua_set_option(1, request.param), "dua_set_option")
+    ops = _ops()
+    ops.CONV_POLICY = request.param          # handed to the kernels with every call (dua_conv3_desc.policy)
     yield request.param
-    nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
+    ops.CONV_POLICY = 0
 
 
 @pytest.mark.parametrize("conv_variant", [0, 2, 3, 6], indirect=True)
@@ -126,10 +126,10 @@ def test_conv3_raw_and_stats(dtype, shape, conv_variant):
 
 @pytest.fixture
 def conv_variant_any(request):
-    from diff_unet_amos_amd import _native as nv
-    nv.check(nv.lib().dua_set_option(1, request.param), "dua_set_option")
+    ops = _ops()
+    ops.CONV_POLICY = request.param          # handed to the kernels with every call (dua_conv3_desc.policy)
     yield request.param
-    nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
+    ops.CONV_POLICY = 0
 
 
 @pytest.mark.parametrize("conv_variant_any,layout", [(0, (False, False)), (0, (True, False)), (0, (False, True)), (0, (True, True)),
@@ -284,7 +284,7 @@ def test_conv3_single_channel_tap_form(classes, shape, cout):
     outs = []
     try:
         for tap, variant in ((None, 0), (classes, 0), (classes, 6)):
-            nv.check(nv.lib().dua_set_option(1, variant), "dua_set_option")
+            ops.CONV_POLICY = variant
             wp, bp = ops.pack_conv3_weights(w.cuda(), b.cuda(), torch.float16, cin_packed=cin_p, perm=perm, tap_channel=tap)
             y = torch.full((N, D, H, W, cout + 8), -5.0, dtype=torch.float16, device="cuda")
             st = ops.stats_buffer(N, cout, "cuda")
@@ -292,7 +292,7 @@ def test_conv3_single_channel_tap_form(classes, shape, cout):
             assert float((y[..., cout:].float() + 5).abs().max()) == 0          # nothing written past Cout
             outs.append((ops.from_channels_last(y, cout).cpu(), ops.stats_decode(st).cpu()))
     finally:
-        nv.check(nv.lib().dua_set_option(1, 0), "dua_set_option")
+        ops.CONV_POLICY = 0
     want = F.conv3d(x.half().float().cuda(), w.half().float().cuda(), b.cuda(), padding=1).cpu()
     for got, st in outs:
         assert (got - want).abs().max() < 2e-2, float((got - want).abs().max())
@@ -618,19 +618,19 @@ def test_conv3_wgrad_matches_torch(dtype, shape):
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [32, 1, 2, 64])  # plain k loop; plain block order; one workgroup per CU; 12 waves
 def test_conv3_wgrad_launch_variants_agree(variant):
-    from diff_unet_amos_amd import _native as nv
+    ops = _ops()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(variant)
     x = torch.randn(2, 12, 16, 16, 64, generator=g, device=dev).half()
     dy = torch.randn(2, 12, 16, 16, 64, generator=g, device=dev).half()
     base = torch.zeros(64, 64, 3, 3, 3, device=dev)
     _ops().conv3d_k3_wgrad(x, 64, 0, dy, 64, 0, base)
-    nv.check(nv.lib().dua_set_option(4, variant), "opt")
+    ops.WGRAD_POLICY = variant
     try:
         other = torch.zeros(64, 64, 3, 3, 3, device=dev)
         _ops().conv3d_k3_wgrad(x, 64, 0, dy, 64, 0, other)
     finally:
-        nv.check(nv.lib().dua_set_option(4, 0), "opt")
+        ops.WGRAD_POLICY = 0
     assert (base - other).abs().max().item() <= 2e-4 * base.abs().max().item()     # fp32 summation order only
 
 

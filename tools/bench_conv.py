@@ -2,7 +2,7 @@
 """A/B timing of conv3d_k3 variants on the layer shapes of the 96^3 x 16-class denoiser
 (interleaved rounds in one process, HIP events on the launch stream).
 usage: bench_conv.py <variants> [shape indices] [rounds]
-  variants: comma list of dua_set_option(1, v) values for this build, and/or "lib:<path>" = the same entry point of ANOTHER
+  variants: comma list of launch forms (dua_conv3_desc.policy, ops.CONV_POLICY) for this build, and/or "lib:<path>" = the same entry point of ANOTHER
   build of libdua_hip.so loaded beside it (same-box, same-process comparison of two kernel generations; box-to-box
   spread is +-10 %, so nothing else ranks two builds)."""
 import ctypes
@@ -35,7 +35,7 @@ def main():
     for v in variants:
         if isinstance(v, str):
             L = ctypes.CDLL(os.path.abspath(v[4:]))
-            for name in ("dua_conv3d_k3_fwd", "dua_set_option"):
+            for name in ("dua_conv3d_k3_fwd", "dua_abi_version"):
                 fn = getattr(L, name)
                 fn.restype, fn.argtypes = nv._SIGS[name]
             alts[v] = L
@@ -75,9 +75,10 @@ def main():
         for v in variants:
             if isinstance(v, str):
                 nv._lib = alts[v]
+                ops.CONV_POLICY = 0
             else:
                 nv._lib = main_lib
-                nv.check(main_lib.dua_set_option(1, v[0] if isinstance(v, tuple) else v), "opt")
+                ops.CONV_POLICY = v[0] if isinstance(v, tuple) else v
                 blk = isinstance(v, tuple) and v[1] and ops.conv3_kernel_kind(dt, 1, S, S, S, cin, cin, cout, fused=fused, tap_channel=tap) == ops.KIND_WIDE
             run = lambda blk=(False if isinstance(v, str) else blk): ops.conv3d_k3(x, cin, 0, wp, bp, cout, y, 0, stats, norm=norm, workspace=ws, tap_channel=tap, in_blocked=blk)  # noqa: E731
             run()
@@ -88,7 +89,7 @@ def main():
                     run()
             graphs[v] = g
         nv._lib = main_lib
-        nv.check(main_lib.dua_set_option(1, 0), "opt")
+        ops.CONV_POLICY = 0
         for rd in range(rounds + 1):
             for v in variants:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

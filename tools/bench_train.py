@@ -21,7 +21,7 @@ ap.add_argument("--size", type=int, default=96)
 ap.add_argument("--dtype", default="float16")
 ap.add_argument("--graph", action="store_true", help="replay the whole training step as one HIP graph")
 ap.add_argument("--no-gc", action="store_true", help="disable the Python cyclic GC during the timed loop (diagnosis)")
-ap.add_argument("--ab-wgrad", default="", help="comma list of dua_set_option(4, v) values: time the loop once per value, same process")
+ap.add_argument("--ab-wgrad", default="", help="comma list of weight-gradient launch forms (dua_conv3_desc.policy, ops.WGRAD_POLICY): time the loop once per value, same process")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -45,9 +45,9 @@ for _ in range(a.steps):
 dt = sum(per) / len(per)
 ab = {}
 if a.ab_wgrad:
-    from diff_unet_amos_amd import _native as nv
+    from diff_unet_amos_amd import ops
     for v in [int(x) for x in a.ab_wgrad.split(",")]:
-        nv.check(nv.lib().dua_set_option(4, v), "opt")
+        ops.WGRAD_POLICY = v
         tr.step(image, labels)
         torch.cuda.synchronize()
         ts = []
@@ -57,7 +57,7 @@ if a.ab_wgrad:
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         ab.setdefault(str(v), []).append(round(sorted(ts)[len(ts) // 2] * 1e3, 2))
-    nv.check(nv.lib().dua_set_option(4, 0), "opt")
+    ops.WGRAD_POLICY = 0
 print(json.dumps({"metric": "train_step_time", "value": dt * 1e3, "unit": "ms", "median_ms": sorted(per)[len(per) // 2] * 1e3, "per_step_ms": [round(x * 1e3, 2) for x in per], "ab_wgrad_median_ms": ab, "native": True,
                   "path": "HIP conv fwd/dgrad/wgrad + fused InstanceNorm/LeakyReLU/add fwd/bwd under autograd; fused loss, pooling, 1x1-head and transposed-conv (in-place concat) kernels; AdamW = torch; " + a.dtype,
                   "graph": a.graph, "batch": a.batch,

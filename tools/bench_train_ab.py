@@ -21,10 +21,10 @@ def main():
     base = DiffUNet(in_channels=1, out_channels=16).to(dev)
     image = torch.rand(2, 1, 96, 96, 96, device=dev)
     labels = (torch.rand(2, 16, 96, 96, 96, device=dev) > 0.8).float()
-    # constructor arguments; "_option": a dua_set_option(key, value) in force while the trainer captures; "_ops": attributes of diff_unet_amos_amd.ops set while this trainer warms up and captures its graph
+    # constructor arguments; "_option": (1 | 4, value) = ops.CONV_POLICY / ops.WGRAD_POLICY in force while the trainer captures; "_ops": attributes of diff_unet_amos_amd.ops set while this trainer warms up and captures its graph
     settings = {"default": {}, "weight gradients in line with the backward chain": {"wgrad_overlap": False},
                 "no split-K scratch for the training convolutions": {"_ops": {"TRAIN_SPLITK": False}},
-                "weight-gradient tiles through registers (dua_set_option(4, 128))": {"_option": (4, 128)}}
+                "weight-gradient tiles through registers (ops.WGRAD_POLICY = 128)": {"_option": (4, 128)}}
     from diff_unet_amos_amd import ops, _native as nv
     trainers = {}
     for name, kv in settings.items():
@@ -32,7 +32,7 @@ def main():
         mod = kv.pop("_ops", {})
         opt = kv.pop("_option", None)
         if opt is not None:
-            nv.check(nv.lib().dua_set_option(*opt), "dua_set_option")
+            setattr(ops, {1: "CONV_POLICY", 4: "WGRAD_POLICY"}[opt[0]], opt[1])
         saved = {k: getattr(ops, k) for k in mod}
         for k, v in mod.items():
             setattr(ops, k, v)
@@ -42,7 +42,7 @@ def main():
         for k, v in saved.items():
             setattr(ops, k, v)
         if opt is not None:
-            nv.check(nv.lib().dua_set_option(opt[0], 0), "dua_set_option")
+            setattr(ops, {1: "CONV_POLICY", 4: "WGRAD_POLICY"}[opt[0]], 0)
         trainers[name] = tr
     res = {n: [] for n in trainers}
     for _ in range(rounds):

@@ -21,7 +21,8 @@ shapes = [(96, 64, 64), (96, 128, 64), (96, 32, 64), (48, 64, 64), (48, 128, 64)
           (12, 256, 256), (12, 512, 256), (6, 512, 512)]
 if a.abl:
     from diff_unet_amos_amd import _native as nv
-    nv.check(nv.lib().dua_set_option(3, a.abl), 'abl')
+    if a.abl:
+        nv.check(nv.lib().dua_set_option(3, a.abl), 'abl')          # diagnostic (-DDUA_ABLATE) builds only
 if a.only:
     shapes = shapes[:a.only]
 from diff_unet_amos_amd import _native as nv   # noqa: E402
@@ -33,7 +34,7 @@ for S, Cin, Cout in shapes:
     line = f"{S:3d}^3 {Cin:4d}->{Cout:4d}"
     fl = 2.0 * a.batch * S ** 3 * Cin * Cout * 27
     for v in variants:
-        nv.check(nv.lib().dua_set_option(4, v), "variant")
+        ops.WGRAD_POLICY = v
         for _ in range(2):
             ops.conv3d_k3_wgrad(x, Cin, 0, dy, Cout, 0, dw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,7 +1,9 @@
+#!/bin/bash
+# One pass over the bench lines of every BASELINE config (1 GPU): tools/measure_all.sh <out-dir>
 set -o pipefail
-mkdir -p gpurun_out/r3m
-timeout -k 10 200 python bench.py > gpurun_out/r3m/bench.json 2> gpurun_out/r3m/bench.err && cut -c1-200 gpurun_out/r3m/bench.json &&
-timeout -k 10 300 python bench.py --dtype f32 > gpurun_out/r3m/bench_f32.json 2> gpurun_out/r3m/bench_f32.err && cut -c1-200 gpurun_out/r3m/bench_f32.json &&
-timeout -k 10 400 python bench.py --config 3 > gpurun_out/r3m/sliding.json 2> gpurun_out/r3m/sliding.err && cut -c1-200 gpurun_out/r3m/sliding.json &&
-timeout -k 10 400 python bench.py --config 4 --train-graph > gpurun_out/r3m/train.json 2> gpurun_out/r3m/train.err && cut -c1-200 gpurun_out/r3m/train.json &&
-timeout -k 10 300 python bench.py --config 5 > gpurun_out/r3m/swin.json 2> gpurun_out/r3m/swin.err && cut -c1-200 gpurun_out/r3m/swin.json
+out=${1:-gpurun_out/measure}
+mkdir -p "$out"
+timeout -k 10 300 python bench.py > "$out/bench.json" 2> "$out/bench.err" && cut -c1-200 "$out/bench.json" &&
+timeout -k 10 400 python bench.py --config 3 > "$out/sliding.json" 2> "$out/sliding.err" && cut -c1-200 "$out/sliding.json" &&
+timeout -k 10 400 python bench.py --config 4 --train-graph > "$out/train.json" 2> "$out/train.err" && cut -c1-200 "$out/train.json" &&
+timeout -k 10 300 python bench.py --config 5 > "$out/swin.json" 2> "$out/swin.err" && cut -c1-200 "$out/swin.json"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a conv3d_k3 workgroup spends its cycles: per-phase shader-clock stamps from the DIAGNOSTIC build
-(tools/build_diag.sh stamp -DDUA_STAMP; run with DUA_HIP_LIB=tools/diag/stamp/libdua_hip.so).
+(tools/build_diag.sh stamp -DDUA_STAMP; run with DUA_DEBUG=1 DUA_HIP_LIB=tools/diag/stamp/libdua_hip.so).
 usage: stamp_conv.py [shape indices of tools/bench_conv.py SHAPES, comma list] [--hot SECONDS] [--variant V]
 Per shape: workgroups, in-kernel clock (delta s_memtime / delta s_memrealtime x 100 MHz, median over workgroups), and the
 median cycles of prologue / each K phase / epilogue.  --hot: launch the layer back to back for that long first (the clock
@@ -21,7 +21,7 @@ from bench_conv import SHAPES
 def main():
     L = nv.lib()
     if not hasattr(L, "dua_debug_stamps"):
-        sys.exit("not a stamp build: DUA_HIP_LIB=tools/diag/stamp/libdua_hip.so")
+        sys.exit("not a stamp build: DUA_DEBUG=1 DUA_HIP_LIB=tools/diag/stamp/libdua_hip.so")
     stamps = L.dua_debug_stamps_wide if "--wide" in sys.argv else L.dua_debug_stamps     # --wide: the stamps of conv3d_wide.hip
     stamps.restype, stamps.argtypes = ctypes.c_long, [ctypes.c_void_p, ctypes.c_long]
     nbytes = stamps(None, 0)
@@ -29,7 +29,7 @@ def main():
     only = [int(i) for i in sys.argv[1].split(",")] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else range(len(SHAPES))
     hot = float(sys.argv[sys.argv.index("--hot") + 1]) if "--hot" in sys.argv else 0.0
     if "--variant" in sys.argv:
-        nv.check(L.dua_set_option(1, int(sys.argv[sys.argv.index("--variant") + 1])), "dua_set_option")
+        ops.CONV_POLICY = int(sys.argv[sys.argv.index("--variant") + 1])
     dev, dt = "cuda", torch.float16
     for idx in only:
         S, cin, cout, fused = SHAPES[idx]

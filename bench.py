@@ -135,7 +135,44 @@ def time_conv_launches(plan, reps):
             by_launch.append(e0.elapsed_time(e1) / reps)
     finally:
         ops.CONV_POLICY &= ~nv.POLICY_NO_FINISH
+    # Launches of >= 100 us are ALSO timed where they run: event pairs around them inside eager passes of the whole evaluation
+    # (the pair's command-processor gap is ~1 % there).  Replayed back to back, a 200-350 us MFMA-bound launch holds the chip at
+    # its lowest clock and reads 5-8 % longer than the same launch between the step's light kernels, which is what rocprofv3
+    # lists for it; the in-step figure is the one reported (by_launch_us), the back-to-back one is kept beside it.
+    global _BACK_TO_BACK_MS
+    _BACK_TO_BACK_MS = list(by_launch)
+    big = [i for i, ms in enumerate(by_launch) if ms >= 0.1]
+    if big:
+        pairs = {i: [] for i in big}
+        idx = [0]
+
+        def timed(*a, **k):
+            i = idx[0]
+            idx[0] += 1
+            if i in pairs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                real(*a, **k)
+                e1.record()
+                pairs[i].append((e0, e1))
+            else:
+                real(*a, **k)
+
+        ops.conv3d_k3 = timed
+        try:
+            for _ in range(1 + max(3, reps // 4)):
+                idx[0] = 0
+                plan.denoiser_body()
+            torch.cuda.synchronize()
+        finally:
+            ops.conv3d_k3 = real
+        for i in big:
+            ts = sorted(e0.elapsed_time(e1) for e0, e1 in pairs[i][1:])
+            by_launch[i] = ts[len(ts) // 2]
     return sum(by_launch) / len(by_launch), len(calls), by_launch
+
+
+_BACK_TO_BACK_MS = []
 
 
 def conv_roofline(plan, dtype_flag, reps=20):
@@ -168,6 +205,7 @@ def conv_roofline(plan, dtype_flag, reps=20):
            "algorithmic_gflop_per_launch": m["algorithmic_gflop_per_launch"], "kernel_ms_per_step": m["ms_per_step"],
            "conv_ms_per_step": round(sum(by_launch), 3),
            "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
+           "by_launch_back_to_back_us": [round(x * 1e3, 1) for x in _BACK_TO_BACK_MS],
            "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
            "by_launch_kernel": [{"conv3d_k3_first_kernel": "first", WIDE_KERNEL: "wide", CONV_KERNEL: "v2"}[k_] for k_ in kern],
            "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3", "kernel": kern[big],
@@ -315,7 +353,7 @@ def wgrad_roofline(step_fn, reps=10):
         by_launch.append(e0.elapsed_time(e1) / reps)
         fl.append(2.0 * dw.shape[1] * cout * 27 * x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3])
     achieved = sum(fl) / (sum(by_launch) * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv3d_k3_wgrad12_kernel (+ wgrad_reduce_kernel)", "achieved": round(achieved, 2),
+    return {"bound": "mfma", "kernel": "conv3d_k3_wgrad_fo_kernel (+ wgrad_fo_reduce_kernel)", "achieved": round(achieved, 2),
             "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
             "launches_per_step": len(calls), "avg_launch_ms": round(sum(by_launch) / len(by_launch), 4),
             "algorithmic_gflop_per_launch": round(sum(fl) / len(fl) / 1e9, 2), "wgrad_ms_per_step": round(sum(by_launch), 3),

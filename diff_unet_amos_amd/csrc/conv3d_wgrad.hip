@@ -482,10 +482,20 @@ static const LdsAttr kWgradLdsAttrs[] = {
 };
 static const LdsAttrs kWgradLdsReg(kWgradLdsAttrs);
 
+// conv3d_wgrad_fo.hip: the fetch-once form (fp16): one workgroup for all 27 taps of (64 co x 32 ci)
+int launch_wgrad_fo(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src, const int* perm, float* ws,
+                    long ws_bytes, hipStream_t s);
+long wgrad_fo_workspace(const dua_conv3_desc* d);
+constexpr int WGRAD_POLICY_THREE_KD = 256;      // dua_conv3_desc.policy bit 8: the first form (a workgroup per kd plane of taps)
+
 template <typename T>
 static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, float* dw, int Cin_src,
                         const int* perm, float* ws, long ws_bytes, hipStream_t s) {
   using namespace wg;
+  if (d->policy < 0 || d->policy > 511) return DUA_ERR_ARG;
+  if constexpr (sizeof(T) == 2) {
+    if (!(d->policy & WGRAD_POLICY_THREE_KD) && ws != nullptr) return launch_wgrad_fo(d, x, dy, dw, Cin_src, perm, ws, ws_bytes, s);
+  }
   Args a;
   a.x = x; a.dy = dy; a.dw = dw; a.perm = perm;
   a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
@@ -504,8 +514,7 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
 #else
   a.abl = 0;
 #endif
-  const int g_wgrad_variant = d->policy;
-  if (g_wgrad_variant < 0 || g_wgrad_variant > 255) return DUA_ERR_ARG;
+  const int g_wgrad_variant = d->policy & 255;
   a.plain_order = (g_wgrad_variant & 1) || P < 8;
   a.part = (ws && (long)P * combos * 9 * 4096 * 4 <= ws_bytes && P > 1) ? ws : nullptr;
   constexpr int lds = wgrad_lds<T>();
@@ -537,6 +546,7 @@ static int launch_wgrad(const dua_conv3_desc* d, const void* x, const void* dy, 
 
 extern "C" long dua_conv3d_k3_wgrad_workspace(const dua_conv3_desc* d) {
   if (!d) return DUA_ERR_ARG;
+  if (d->dtype == DUA_F16 && !(d->policy & dua::WGRAD_POLICY_THREE_KD)) return dua::wgrad_fo_workspace(d);
   int combos;
   const int P = dua::wgrad_partitions(d, &combos);
   return P > 1 ? (long)P * combos * 9 * 4096 * 4 : 0;

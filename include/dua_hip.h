@@ -80,7 +80,8 @@ typedef struct {
                                       outputs are then NOT valid).  dua_deconv_k2s2_fwd: 6 = the one-tap-per-workgroup kernel
                                       for every shape that has it, 256-voxel all-taps tiles.  dua_conv3d_k3_wgrad: bit 0 = plain
                                       block order, bits 1-4 = workgroups per CU over the launch, bit 5 / 6 = the 6-wave forms,
-                                      bit 7 = tiles through registers.  A per-call field: the library keeps no mutable option
+                                      bit 7 = tiles through registers, bit 8 = the first form (a workgroup per kd plane of taps)
+                                      instead of the fetch-once form (fp16).  A per-call field: the library keeps no mutable option
                                       state.  Any other value is rejected with DUA_ERR_ARG. */
 } dua_conv3_desc;
 #define DUA_POLICY_NO_FINISH 256

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Print the kernel timeline of one replayed step from a rocprofv3 --kernel-trace CSV directory."""
+"""Print the kernel timeline of one replayed step from a rocprofv3 --kernel-trace CSV directory.
+usage: step_timeline.py <dir> [index of the step_begin launch to start from; default 100 = inside the default bench's timed
+replays (the run ends with the 1000-step loops and the fp32 pass), or the 12th from the end of a short run]"""
 import csv, glob, sys, collections
 d = sys.argv[1]
 f = (glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'step_begin' in r['Kernel_Name']]
-a, b = idx[-12], idx[-11]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else (100 if len(idx) > 140 else len(idx) - 12)
+a, b = idx[k], idx[k + 1]
 t0 = int(rows[a]['Start_Timestamp'])
 agg = collections.OrderedDict()
 for r in rows[a:b]:

@@ -293,9 +293,11 @@ __global__ __launch_bounds__(256, 2) void deconv_k2s2_ksplit_kernel(DeconvArgs a
   }
 }
 
-// All eight taps in one workgroup (large inputs): the 256-voxel input tile is staged once with its full channel
-// depth (the one-tap kernel above re-reads and re-normalises it for every tap), then the workgroup walks the taps:
-// weights of tap t+1 are prefetched while tap t multiplies, every tap ends with its own pixel-shuffle store.
+// All eight taps in one workgroup (large inputs): the input tile is staged once with its full channel depth (the one-tap
+// kernel above re-reads and re-normalises it for every tap), then the workgroup walks the taps in PAIRS (tk = 0, 1): the
+// weights of the next pair are prefetched while this pair multiplies, and a pair ends with one pixel-shuffle store of both
+// taps -- outputs 2w and 2w + 1 lie next to each other, so a store instruction writes whole runs (in the 16-channel-block
+// layout: 512 contiguous bytes per block) where one tap alone writes every other 32- or 64-byte piece.
 template <typename T, int MBLK>
 __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) {
   using namespace dc;
@@ -304,13 +306,13 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
   constexpr int EPG = Elem<T>::EPG;
   constexpr int CK = KG * EPG;
   constexpr int RB = 32 * (int)sizeof(T) + 16;              // staging row: one 32-channel half
-  constexpr int GPV = 32 / EPG, VPI = 64 / GPV, NST = WR / VPI;
+  constexpr int GPV = 32 / EPG, VPI = 64 / GPV, NST = 2 * WR / VPI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int VSA = a.nchunks * 64 + 16;                      // bytes per staged voxel (odd multiple of 16: conflict-free)
   char* alds = smem;
-  char* wlds = alds + TM * VSA;                             // 2 x nchunks x 4 KB
-  char* stg = wlds + 2 * a.nchunks * W_BYTES;               // TM x RB
-  float* xsc = (float*)(stg + TM * RB);
+  char* wlds = alds + TM * VSA;                             // 2 pairs x 2 taps x nchunks x 4 KB
+  char* stg = wlds + 4 * a.nchunks * W_BYTES;               // 2 TM x RB
+  float* xsc = (float*)(stg + 2 * TM * RB);
   float* xsh = xsc + a.nchunks * CK;
   float* xad = xsh + a.nchunks * CK;
 
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
   const char* wsrc = (const char*)a.w + (long)ct * wtap;    // tap t: + t * nct * wtap
   const int kg_t = tid & 3;
 
-  // ---- the whole input tile (every chunk: nchunks <= 4) and the weights of tap 0 are requested before anything waits:
+  // ---- the whole input tile (every chunk: nchunks <= 4) and the weights of taps 0, 1 are requested before anything waits:
   // one memory round trip in front of the first MFMA instead of one per chunk plus the statistics preamble's ----
   constexpr int MCH = 4;
   Frag f[MCH][TM / 64];
@@ -337,9 +339,22 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
       f[ch][j] = *(const Frag*)(xin + (v < vox && cok ? v * a.Cin_stride + c0 : 0));
     }
   }
-  f32x4 w0[MCH];
+  f32x4 wn[2][MCH];
+  auto load_pair = [&](int tp) {
 #pragma unroll
-  for (int j = 0; j < MCH; ++j) w0[j] = *(const f32x4*)(wsrc + (j < a.nchunks ? (tid + 256 * j) * 16 : 0));
+    for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+      for (int j = 0; j < MCH; ++j)
+        wn[tk][j] = *(const f32x4*)(wsrc + (long)(2 * tp + tk) * a.nct * wtap + (j < a.nchunks ? (tid + 256 * j) * 16 : 0));
+  };
+  auto store_pair = [&](int tp) {
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+      for (int j = 0; j < MCH; ++j)
+        if (j < a.nchunks) *(f32x4*)(wlds + ((tp & 1) * 2 + tk) * wtap + (tid + 256 * j) * 16) = wn[tk][j];
+  };
+  load_pair(0);
   if (a.xf.stats != nullptr) {
     xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
     __syncthreads();
@@ -367,81 +382,72 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
       *(Frag*)(alds + vl * VSA + ch * 64 + kg_t * 16) = g;
     }
   }
-#pragma unroll
-  for (int j = 0; j < MCH; ++j)
-    if (j < a.nchunks) *(f32x4*)(wlds + (tid + 256 * j) * 16) = w0[j];
+  store_pair(0);
   __syncthreads();
 
   const int H2 = 2 * a.H, W2 = 2 * a.W;
   T* yout = (T*)a.y + (long)n * vox * 8 * a.Cout_stride;
   const float bq0 = a.bias[ct * BN + r], bq1 = a.bias[ct * BN + 32 + r];
-  char* ot = stg + wave * WR * RB;
-  int ovb[NST];                                             // output voxel of tap (0, 0, 0) for this lane's staged rows, or -1
+  char* ot = stg + wave * 2 * WR * RB;                      // staged row 2 vl + tk: the two taps of a pair interleaved like their outputs
+  int ovb[NST];                                             // output voxel (before the pair's (ti, tj) offset) of this lane's staged rows, or -1
 #pragma unroll
   for (int it = 0; it < NST; ++it) {
-    const long v = v0 + wave * WR + it * VPI + lane / GPV;
+    const int j = it * VPI + lane / GPV;
+    const long v = v0 + wave * WR + (j >> 1);
     const int vi = (int)(v < vox ? v : 0);
     const int w = vi % a.W, t = vi / a.W, h = t % a.H, d = t / a.H;
-    ovb[it] = v < vox ? ((2 * d) * H2 + 2 * h) * W2 + 2 * w : -1;
+    ovb[it] = v < vox ? ((2 * d) * H2 + 2 * h) * W2 + 2 * w + (j & 1) : -1;
   }
-  // The weights of tap t + 1 travel in registers (nchunks <= 4 pieces per thread) while tap t multiplies.  They are REQUESTED
-  // before the stores of tap t - 1 are issued, not after: vmcnt counts loads and stores in issue order, so a wait for loads
-  // issued behind a tap's stores is a wait for those stores to be acknowledged by memory -- every tap paid a store round trip.
-  f32x4 wn[MCH];
+  // The weights of pair p + 1 travel in registers while pair p multiplies.  They are REQUESTED before the stores of pair p
+  // are issued, not after: vmcnt counts loads and stores in issue order, so a wait for loads issued behind the stores is a
+  // wait for those stores to be acknowledged by memory.
+  load_pair(1);
+  for (int tp = 0; tp < 4; ++tp) {
+    f32x16 acc[2][MBLK][2];
 #pragma unroll
-  for (int j = 0; j < MCH; ++j)
-    if (j < a.nchunks) wn[j] = *(const f32x4*)(wsrc + (long)a.nct * wtap + (tid + 256 * j) * 16);
-  for (int tap = 0; tap < 8; ++tap) {
-    f32x16 acc[MBLK][2];
-#pragma unroll
-    for (int m = 0; m < MBLK; ++m)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { acc[m][0][i] = bq0; acc[m][1][i] = bq1; }
-    const char* wb = wlds + (tap & 1) * wtap;
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-#pragma unroll
-      for (int ks = 0; ks < KG / 2; ++ks) {
-        const Frag b0 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + r) * 16);
-        const Frag b1 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + 32 + r) * 16);
-#pragma unroll
-        for (int m = 0; m < MBLK; ++m) {
-          const Frag am = *(const Frag*)(alds + (wave * WR + m * 32 + r) * VSA + ch * 64 + (2 * ks + hh) * 16);
-          mma32(acc[m][0], am, b0);
-          mma32(acc[m][1], am, b1);
-        }
-      }
-    }
-    if (tap < 7) {
-#pragma unroll
-      for (int j = 0; j < MCH; ++j)
-        if (j < a.nchunks) *(f32x4*)(wlds + ((tap + 1) & 1) * wtap + (tid + 256 * j) * 16) = wn[j];
-    }
-    if (tap < 6) {
-      const char* wnext = wsrc + (long)(tap + 2) * a.nct * wtap;
-#pragma unroll
-      for (int j = 0; j < MCH; ++j)
-        if (j < a.nchunks) wn[j] = *(const f32x4*)(wnext + (tid + 256 * j) * 16);
-    }
-    // pixel-shuffle store of this tap, one 32-channel half at a time through the wave's own staging rows (whole 128-byte
-    // lines per instruction were measured too: the 16 KB staging tile leaves one workgroup per CU, 69 -> 102 us)
-    const int toff = ((tap >> 2) * H2 + ((tap >> 1) & 1)) * W2 + (tap & 1);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int tk = 0; tk < 2; ++tk) {
 #pragma unroll
       for (int m = 0; m < MBLK; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) *(T*)(ot + (m * 32 + acc_row(i, hh)) * RB + r * (int)sizeof(T)) = (T)acc[m][q][i];
+        for (int i = 0; i < 16; ++i) { acc[tk][m][0][i] = bq0; acc[tk][m][1][i] = bq1; }
+      const char* wb = wlds + ((tp & 1) * 2 + tk) * wtap;
+      for (int ch = 0; ch < a.nchunks; ++ch) {
+#pragma unroll
+        for (int ks = 0; ks < KG / 2; ++ks) {
+          const Frag b0 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + r) * 16);
+          const Frag b1 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + 32 + r) * 16);
+#pragma unroll
+          for (int m = 0; m < MBLK; ++m) {
+            const Frag am = *(const Frag*)(alds + (wave * WR + m * 32 + r) * VSA + ch * 64 + (2 * ks + hh) * 16);
+            mma32(acc[tk][m][0], am, b0);
+            mma32(acc[tk][m][1], am, b1);
+          }
+        }
+      }
+    }
+    if (tp < 3) store_pair(tp + 1);
+    if (tp < 2) load_pair(tp + 2);
+    const int toff = ((tp >> 1) * H2 + (tp & 1)) * W2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int m = 0; m < MBLK; ++m)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            *(T*)(ot + (2 * (m * 32 + acc_row(i, hh)) + tk) * RB + r * (int)sizeof(T)) = (T)acc[tk][m][q][i];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int it = 0; it < NST; ++it) {
-        const int vl = it * VPI + lane / GPV, cg = lane % GPV;
+        const int j = it * VPI + lane / GPV, cg = lane % GPV;
         if (ovb[it] >= 0 && ct * BN + q * 32 + cg * EPG < a.Cout)
           *(Frag*)(yout + chan_off(a.out_blk, ovb[it] + toff, a.Cout_off + ct * BN + q * 32 + cg * EPG, a.Cout_stride, vox * 8)) =
-              *(const Frag*)(ot + vl * RB + cg * 16);
+              *(const Frag*)(ot + j * RB + cg * 16);
       }
       __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();      // next tap's weights are in place, this tap's buffer is free
+    __syncthreads();      // the next pair's weights are in place, this pair's buffer is free
   }
 }
 
@@ -490,12 +496,15 @@ static int launch_deconv(const dua_conv3_desc* d, const void* x, const void* w, 
   if (d->layout & DUA_IN_BLOCKED) return DUA_ERR_ARG;
   if (a.out_blk && (deconv_kernel_kind(d) != 2 || d->Cout_off % 16 || d->Cout_stride % 16 || vox * 8 * 16 >= 0x7fffffffL)) return DUA_ERR_ARG;
   if (vox >= 256L * 128 && a.nchunks <= 4) {          // enough tiles to fill the chip with one workgroup per 8 taps
-    // 128-voxel tiles: two workgroups per CU (77 KB each at 128 channels), one's pixel-shuffle stores under the other's loads;
-    // variant 6 keeps the 256-voxel form (one workgroup per CU) for A/B
-    const int mblk = g_conv_variant == 6 ? 2 : 1;
+    // 128-voxel tiles: two workgroups per CU up to 64 input channels (70 KB each), one's pixel-shuffle stores under the
+    // other's loads; policy 6 keeps the 256-voxel form (one workgroup per CU) for A/B where it fits
+    auto lds_of = [&](int tm) {
+      return tm * (a.nchunks * 64 + 16) + 4 * a.nchunks * dc::W_BYTES + 2 * tm * (32 * (int)sizeof(T) + 16) +
+             (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0);
+    };
+    const int mblk = g_conv_variant == 6 && lds_of(256) <= 160 * 1024 ? 2 : 1;
     const int tm = 128 * mblk;
-    const int lds = tm * (a.nchunks * 64 + 16) + 2 * a.nchunks * dc::W_BYTES + tm * (32 * (int)sizeof(T) + 16) +
-                    (a.xf.stats ? 3 * 4 * a.nchunks * CK : 0);
+    const int lds = lds_of(tm);
     if (lds > 160 * 1024) return DUA_ERR_ARG;
     dim3 grid2((unsigned)((vox + tm - 1) / tm), a.nct, d->N);
     if (mblk == 2) hipLaunchKernelGGL((deconv_k2s2_alltaps_kernel<T, 2>), grid2, dim3(256), lds, s, a);

@@ -73,6 +73,27 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
       for (int i = 0; i < 16; ++i) { ssum[nb][i] = 0.f; ssq[nb][i] = 0.f; }
   }
   const long tiles = (a.M + 127) / 128;
+  // conv3 with K <= 96 (one pass per tile): the NEXT tile's rows are requested as soon as this
+  // tile's are in LDS and travel under its MFMAs, epilogue and copy-out -- a tile used to be load latency + compute + store
+  // latency in a row (8.9 us per tile and workgroup on the 96^3 conv3, 3.1 TB/s with three workgroups per CU).
+  const bool single = MODE == DUA_TOKLIN_STATS && K <= 96;     // (the other epilogues lose more to the 55 extra registers -- a workgroup less per CU -- than the overlap gains: measured)
+  constexpr int PF = 128 * 12 / 256;                              // 16-byte pieces per thread of a 128 x 96 tile
+  f16x8 pf[PF];
+  const int cpr1 = K >> 3;
+  auto fetch = [&](long tok0) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int c = tid + 256 * j;
+      const int row = c / cpr1, col = c - row * cpr1;
+      const bool ok = c < 128 * cpr1 && tok0 + row < a.M;
+      pf[j] = *(const f16x8*)(A + (ok ? (tok0 + row) * a.lda + col * 8 : 0));
+      if (!ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[j][e] = (f16)0.f;
+      }
+    }
+  };
+  if (single && (long)blockIdx.x < tiles) fetch(blockIdx.x * 128L);
   for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long tok0 = tile * 128;
     f32x16 acc[NB];
@@ -83,13 +104,23 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
     for (int k0 = 0; k0 < K; k0 += 16 * KSTEPS) {
       const int kc = K - k0 < 16 * KSTEPS ? K - k0 : 16 * KSTEPS, cpr = kc >> 3;
       __syncthreads();                                            // W staged / the previous tile's copy-out is done
-      for (int c = tid; c < 128 * cpr; c += 256) {                // coalesced: consecutive lanes, consecutive 16 bytes of a row
-        const int row = c / cpr, col = c - row * cpr;
-        f16x8 v;
+      if (single) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
-        if (tok0 + row < a.M) v = *(const f16x8*)(A + (tok0 + row) * a.lda + k0 + col * 8);
-        *(f16x8*)(At + row * a.a_row + col * 16) = v;
+        for (int j = 0; j < PF; ++j) {
+          const int c = tid + 256 * j;
+          const int row = c / cpr1, col = c - row * cpr1;
+          if (c < 128 * cpr1) *(f16x8*)(At + row * a.a_row + col * 16) = pf[j];
+        }
+        if (tile + gridDim.x < tiles) fetch((tile + gridDim.x) * 128);
+      } else {
+        for (int c = tid; c < 128 * cpr; c += 256) {              // coalesced: consecutive lanes, consecutive 16 bytes of a row
+          const int row = c / cpr, col = c - row * cpr;
+          f16x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
+          if (tok0 + row < a.M) v = *(const f16x8*)(A + (tok0 + row) * a.lda + k0 + col * 8);
+          *(f16x8*)(At + row * a.a_row + col * 16) = v;
+        }
       }
       __syncthreads();
       const char* arow = At + (wave * 32 + r) * a.a_row;

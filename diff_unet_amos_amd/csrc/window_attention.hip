@@ -102,11 +102,12 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   const bool has_tiles = a.btile != nullptr;
   const bool has_table = a.table != nullptr && !has_tiles;
   const int sh_ = 2 * a.gw - 1, sd_ = (2 * a.gh - 1) * sh_;         // strides of the (dd, dh, dw) difference grid
-  // scores are kept in units of log2 e (scale, bias and mask pre-multiplied): the softmax is exp2 without a multiply per
-  // element; koff holds BYTE offsets into the table so that a lookup address is one subtraction
-  constexpr float LOG2E = 1.4426950408889634f;
+  // The score tile starts as the BIAS: the table lookups land in the accumulator registers and the MFMA adds q.k on top
+  // (q carries the scale: head dimension 16 -> 0.25, exact in fp16), so a score costs no zero, no multiply-add of its own;
+  // exp(z - m) is exp2(fma(z, log2 e, -m log2 e)).  koff holds BYTE offsets into the table: a lookup address is one subtraction.
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   if (has_table) {
-    for (int i = tid; i < a.tab_len; i += 256) tab[i] = a.table[(long)head * a.tab_len + i] * LOG2E;
+    for (int i = tid; i < a.tab_len; i += 256) tab[i] = a.table[(long)head * a.tab_len + i];
     for (int i = tid; i < nb * 32; i += 256) {
       const int t = i < n ? i : 0;
       koff[i] = (short)(4 * ((t / (a.gh * a.gw)) * sd_ + ((t / a.gw) % a.gh) * sh_ + t % a.gw));
@@ -143,9 +144,10 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) qf[e] = (f16)0.f;
   if (qok) qf = load8(base + (long)q * 3 * C + hh * 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qf[e] = (f16)((float)qf[e] * a.scale);
   const unsigned char rq = has_region ? regl[qb * 32 + r] : (unsigned char)0;
   const int qoff = has_table ? (int)koff[qc] + 4 * ((a.gd - 1) * sd_ + (a.gh - 1) * sh_ + (a.gw - 1)) : 0;   // bytes
-  const float scale2 = a.scale * LOG2E;
   f16x8 zero8, ones8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { zero8[e] = (f16)0.f; ones8[e] = (f16)1.f; }
@@ -155,12 +157,9 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     if (has_tiles) bt = *(const f32x16*)(a.btile + ((((long)head * nb + qb) * nb + kb) * 64 + lane) * 16);   // 4 x 16 B, L2 resident
     const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
     f32x16 z;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.f;
-    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, z, 0, 0, 0);
     if (has_tiles) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) z[i] = fmaf(z[i], scale2, bt[i]);
+      for (int i = 0; i < 16; ++i) z[i] = bt[i] * LN2;          // the tiles are stored x log2 e
     } else if (has_table) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {               // register quad j = keys kb*32 + 8j + 4hh + (0..3): one 8-byte read of offsets
@@ -168,23 +167,24 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
         const short4v ko = *(const short4v*)(koff + kb * 32 + 8 * j + 4 * hh);
 #pragma unroll
 #if defined(WA_ABL) && (WA_ABL & 1)
-        for (int e = 0; e < 4; ++e) z[4 * j + e] = z[4 * j + e] * scale2 + (float)ko[e] * 1e-9f;      // ablation: no table lookup
+        for (int e = 0; e < 4; ++e) z[4 * j + e] = (float)ko[e] * 1e-9f;      // ablation: no table lookup
 #else
-        for (int e = 0; e < 4; ++e) z[4 * j + e] = fmaf(z[4 * j + e], scale2, *(const float*)((const char*)tab + (qoff - (int)ko[e])));
+        for (int e = 0; e < 4; ++e) z[4 * j + e] = *(const float*)((const char*)tab + (qoff - (int)ko[e]));
 #endif
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = kb * 32 + acc_row(i, hh);
-        z[i] = fmaf(z[i], scale2, bias[(long)(key < n ? key : 0) * n + qc] * LOG2E);
+        z[i] = bias[(long)(key < n ? key : 0) * n + qc];
       }
     }
+    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, z, 0, 0, 0);
     if (mask) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = kb * 32 + acc_row(i, hh);
-        z[i] += mask[(long)(key < n ? key : 0) * n + qc] * LOG2E;
+        z[i] += mask[(long)(key < n ? key : 0) * n + qc];
       }
     }
 #if defined(WA_ABL) && (WA_ABL & 4)
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
       for (int j = 0; j < 4; ++j) {
         const unsigned rk = *(const unsigned*)(regl + kb * 32 + 8 * j + 4 * hh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) z[4 * j + e] += ((rk >> (8 * e)) & 255u) != (unsigned)rq ? -100.f * LOG2E : 0.f;
+        for (int e = 0; e < 4; ++e) z[4 * j + e] += ((rk >> (8 * e)) & 255u) != (unsigned)rq ? -100.f : 0.f;
       }
     }
     if (kb == nb - 1) {                           // only the last block holds padding keys: they never win the max
@@ -223,17 +223,18 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     const float mnew = 0.f * bm;                  // ablation: no running maximum, no rescale
 #else
     const float mnew = fmaxf(mx, bm);
-    const float alpha = __builtin_amdgcn_exp2f(mx - mnew);
+    const float alpha = __builtin_amdgcn_exp2f((mx - mnew) * LOG2E);
     mx = mnew;
 #pragma unroll
     for (int i = 0; i < 9; ++i) O[i] *= alpha;
 #endif    // dims 0..15 (registers 0..7) and the denominator row 16 (register 8, lanes hh = 0)
     f16x8 p[2];
+    const float moff = -mnew * LOG2E;
 #pragma unroll
 #if defined(WA_ABL) && (WA_ABL & 2)
-    for (int i = 0; i < 16; ++i) p[i >> 3][i & 7] = (f16)fminf(z[i] - mnew, 1.f);      // ablation: no exp2
+    for (int i = 0; i < 16; ++i) p[i >> 3][i & 7] = (f16)fminf(z[i] - mnew + 0.f * moff, 1.f);      // ablation: no exp2
 #else
-    for (int i = 0; i < 16; ++i) p[i >> 3][i & 7] = (f16)__builtin_amdgcn_exp2f(z[i] - mnew);
+    for (int i = 0; i < 16; ++i) p[i >> 3][i & 7] = (f16)__builtin_amdgcn_exp2f(fmaf(z[i], LOG2E, moff));
 #endif
 #pragma unroll
     for (int s = 0; s < 2; ++s) {

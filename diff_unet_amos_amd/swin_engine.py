@@ -146,6 +146,9 @@ class SwinPlan:
         self.raw1b, self.raw2b, self.res3b = (torch.zeros(big, dtype=dtype, device=device) for _ in range(3))   # side stream
         self.side_stream = torch.cuda.Stream(device=device)
         self.two_streams = True
+        # which encoder blocks the side stream takes once hidden_states_out[i] is enqueued (encoder_k reads hidden state k - 1;
+        # encoder1, k = 0, reads the input only)
+        self.side_plan = {2: (3, 2, 1, 0)}
         self.fused_tail = dtype == torch.float16 and self.cx == 16     # the tail assembles decoder1's output itself (MFMA tail kernel: fp16, 9..16 classes)
         self._tail_src = None
         self.background_convs = True        # side-stream 3x3x3 convolutions leave half of every CU to the main stream's chain
@@ -499,10 +502,10 @@ class SwinPlan:
             self._res_block(r, srcs[k][0], srcs[k][1], cat[k], r.cout, post_add=self.e_enc[k], side=two)
 
         def ready(i):                                   # hidden_states_out[i] has been enqueued on the main stream
-            if i == 2 and two:
+            if two and self.side_plan.get(i):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    for k in (3, 2, 1, 0):
+                    for k in self.side_plan[i]:
                         enc(k)
                         self.enc_done[k].record(side)
 

@@ -24,9 +24,16 @@ def main():
     settings = {"default": {}, "fused kernels at stage 1 too": {"fused_max_c": 96}, "fused reduction": {"fused_reduction": True},
                 "one-kernel MLP off": {"fused_mlp": False}, "one stream": {"two_streams": False}, "decoder1 output materialised for the tail": {"fused_tail": False}, "side-stream convolutions at two workgroups per CU": {"background_convs": False}, "library GEMMs": {"fused_linear": False},
                 "library qkv": {"tl_qkv": False}, "library proj + scatter kernel": {"tl_proj": False},
-                "library conv3 + stats kernel": {"tl_conv3": False}}
+                "library conv3 + stats kernel": {"tl_conv3": False},
+                "encoder1 with stage 0": {"side_plan": {0: (0,), 2: (3, 2, 1)}},
+                "encoder1 after stage 0": {"side_plan": {1: (0,), 2: (3, 2, 1)}},
+                "encoder1, 2 after stage 0": {"side_plan": {1: (0, 1), 2: (3, 2)}},
+                "encoder1 first after stage 1": {"side_plan": {2: (0, 3, 2, 1)}},
+                "encoder1 after stage 2": {"side_plan": {2: (3, 2, 1), 3: (0,)}}}
+    if len(sys.argv) > 3:
+        settings = {k: v for k, v in settings.items() if k == "default" or any(w in k for w in sys.argv[3].split(","))}
     base = {k: getattr(plan, k) for k in ("two_streams", "fused_mlp", "fused_linear", "fused_max_c", "fused_reduction", "tl_qkv",
-                                          "tl_proj", "tl_conv3", "background_convs", "fused_tail")}
+                                          "tl_proj", "tl_conv3", "background_convs", "fused_tail", "side_plan")}
     graphs = {}
     with torch.no_grad():
         net.embed_model(image)

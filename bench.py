@@ -26,13 +26,20 @@ Launch: with no WORLD_SIZE in the environment and --gpus N > 1 this script start
 and relays their output; under torch.distributed.run it is one rank (RANK / LOCAL_RANK / WORLD_SIZE from the env).
 
 Extra objects in the JSON line (config 2, rank 0, N = 1):
-  roofline     -- for the dominant kernel (conv3d_k3_v2_kernel, all 18 launches of a step): algorithmic FLOPs per launch
-                  / average launch duration, measured with HIP events on the launch stream: each of the step's 18
-                  launches replayed back to back between one event pair (split-K layers without their finish kernel);
+  roofline     -- for the DOMINANT kernel: the one with the largest share of the step's convolution time
+                  (fp16: conv3d_k3_wide_kernel, the three 96^3 layers = 74 % of the step's FLOPs; fp32:
+                  conv3d_k3_v2_kernel).  achieved = algorithmic FLOPs of its launches / their duration, avg_launch_ms =
+                  the per-kernel average the rocprofv3 --kernel-trace --stats summary of the same command shows.
+                  Durations come from HIP events on the launch stream: every launch replayed back to back between one
+                  event pair (split-K layers without their finish kernel); launches >= 100 us are timed a second time
+                  INSIDE a replayed step (event pairs around the launch as the step runs it: caches and clocks as in
+                  the step) and that figure is used -- both are listed (by_launch_us / by_launch_back_to_back_us).
+                  other_kernels = the same summary for the other convolution kernels of the step, all_conv_launches =
+                  the figure over all 18 launches (comparable across rounds whatever the kernel split).
                   peak = dense fp16 MFMA (2.5 PFLOP/s nominal: at this part's 1400 W cap the matrix pipes alone sustain
-                  1.5-1.8 PFLOP/s on random data).  traffic = HBM bytes per launch from two
-                  rocprofv3 --pmc child passes of this script (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE),
-                  or null when the profiler is not available.
+                  1.5-1.8 PFLOP/s on random data, measured_mfma_ceiling / frac_of_ceiling).
+                  traffic = HBM bytes per launch of that kernel from two rocprofv3 --pmc child passes of this script
+                  (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE), or null when the profiler is not available.
   full_loop    -- config 2 end to end whatever --steps says: the whole 1000-step DDPM loop through the public API
                   (net.diffusion.p_sample_loop(net.model, shape, model_kwargs=...)), second call (the first one captures
                   the step graph and is reported as first_call_seconds).
@@ -187,6 +194,11 @@ def conv_roofline(plan, dtype_flag, reps=20):
     assert per_step == len(fl)
     kern = [conv_kernel_of(c) for c in _LAST_CONV_CALLS]
     peak = PEAK_F16_TFLOPS if dtype_flag == "f16" else PEAK_F32_TFLOPS
+    return roofline_by_kernel(fl, by_launch, kern, peak, "upcat_1.convs.conv_0 128->64 @96^3")
+
+
+def roofline_by_kernel(fl, by_launch, kern, peak, largest_name):
+    """The roofline object from per-launch FLOPs, durations (ms) and kernel names (see conv_roofline)."""
     groups = {}
     for name, f, ms in zip(kern, fl, by_launch):
         g = groups.setdefault(name, [0, 0.0, 0.0])
@@ -208,7 +220,7 @@ def conv_roofline(plan, dtype_flag, reps=20):
            "by_launch_back_to_back_us": [round(x * 1e3, 1) for x in _BACK_TO_BACK_MS],
            "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
            "by_launch_kernel": [{"conv3d_k3_first_kernel": "first", WIDE_KERNEL: "wide", CONV_KERNEL: "v2"}[k_] for k_ in kern],
-           "largest_launch": {"layer": "upcat_1.convs.conv_0 128->64 @96^3", "kernel": kern[big],
+           "largest_launch": {"layer": largest_name, "kernel": kern[big],
                               "tflops": round(max(fl) / (by_launch[big] * 1e-3) / 1e12, 2)},
            "other_kernels": {n_: summary(g) for n_, g in groups.items() if n_ != main}}
     # every 3x3x3 launch of the step, whichever kernel runs it
@@ -771,14 +783,10 @@ def run_config5(args, D):
             # layers are charged for their padding to 32-channel chunks and 64-output tiles
             avg_ms, per_step, by_launch = time_conv_launches(plan, 20)
             fl = [2.0 * 27 * a[1] * a[5] * a[0].shape[0] * a[0].shape[1] * a[0].shape[2] * a[0].shape[3] for a, _ in _LAST_CONV_CALLS]
-            achieved = sum(fl) / (sum(by_launch) * 1e-3) / 1e12
             peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_F32_TFLOPS
-            roof = {"bound": "mfma", "kernel": CONV_KERNEL, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": per_step,
-                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_gflop_per_launch": round(sum(fl) / len(fl) / 1e9, 2),
-                    "conv_ms_per_step": round(sum(by_launch), 3), "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
-                    "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
-                    "note": "side-stream launches are timed as they are launched in the step (one workgroup per CU)"}
+            roof = roofline_by_kernel(fl, by_launch, [conv_kernel_of(c) for c in _LAST_CONV_CALLS], peak,
+                                      "decoder1 conv1 96->48 @96^3")
+            roof["note"] = "side-stream launches are timed as they are launched in the step (one workgroup per CU)"
     if rank == 0:
         ms = dt / args.steps * 1e3
         line = {

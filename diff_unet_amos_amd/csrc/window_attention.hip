@@ -53,7 +53,10 @@ struct WinAttnArgs {
   float scale;
 };
 
-template <typename T>
+// BIAS: where the relative-position bias comes from -- 0 the reference's table (production), 1 accumulator-ordered tiles, 2 a dense
+// transposed matrix (both for the kernel tests).  A template parameter: as run-time branches the three forms left the score tile
+// "undefined on the other paths", which hipcc materialises as 16 register fills per key block.
+template <typename T, int BIAS>
 __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   using namespace wa;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -99,8 +102,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) vp[e * 8] = v[e];
   }
-  const bool has_tiles = a.btile != nullptr;
-  const bool has_table = a.table != nullptr && !has_tiles;
+  constexpr bool has_tiles = BIAS == 1, has_table = BIAS == 0;
   const int sh_ = 2 * a.gw - 1, sd_ = (2 * a.gh - 1) * sh_;         // strides of the (dd, dh, dw) difference grid
   // The score tile starts as the BIAS: the table lookups land in the accumulator registers and the MFMA adds q.k on top
   // (q carries the scale: head dimension 16 -> 0.25, exact in fp16), so a score costs no zero, no multiply-add of its own;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   }
   const bool has_region = __syncthreads_or(mixed) != 0;
 
-  const float* bias = has_table ? nullptr : a.bias_t + (long)head * n * n;
+  const float* bias = BIAS == 2 ? a.bias_t + (long)head * n * n : nullptr;
   const float* mask = a.mask_t ? a.mask_t + (long)(win % a.nw) * n * n : nullptr;
   T* outp = (T*)a.out + (long)win * n * C + head * HD;
   // A wave owns query blocks blockIdx.z * 4 + wave, + 4 * gridDim.z, ...: with one workgroup per (window, head) (gridDim.z = 1,
@@ -147,20 +149,22 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) qf[e] = (f16)((float)qf[e] * a.scale);
   const unsigned char rq = has_region ? regl[qb * 32 + r] : (unsigned char)0;
-  const int qoff = has_table ? (int)koff[qc] + 4 * ((a.gd - 1) * sd_ + (a.gh - 1) * sh_ + (a.gw - 1)) : 0;   // bytes
+  // LDS byte address of this query's table entry for a key at offset 0: a lookup address is ONE subtraction (koff[key])
+  const unsigned qtab = has_table ? (unsigned)(size_t)(__attribute__((address_space(3))) char*)tab + (unsigned)((int)koff[qc] +
+                                    4 * ((a.gd - 1) * sd_ + (a.gh - 1) * sh_ + (a.gw - 1))) : 0u;
+  const int nlast = n - (nb - 1) * 32 - 4 * hh;      // last key block: accumulator rows (i & 3) + 8 (i >> 2) >= nlast are padding keys
   f16x8 zero8, ones8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { zero8[e] = (f16)0.f; ones8[e] = (f16)1.f; }
   // score tile of key block kb for this lane's query: scale * <q, k> + bias + mask (padding keys: -3e38)
   auto scores = [&](int kb) {
-    f32x16 bt;
-    if (has_tiles) bt = *(const f32x16*)(a.btile + ((((long)head * nb + qb) * nb + kb) * 64 + lane) * 16);   // 4 x 16 B, L2 resident
     const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
     f32x16 z;
-    if (has_tiles) {
+    if constexpr (has_tiles) {
+      const f32x16 bt = *(const f32x16*)(a.btile + ((((long)head * nb + qb) * nb + kb) * 64 + lane) * 16);   // 4 x 16 B, L2 resident
 #pragma unroll
       for (int i = 0; i < 16; ++i) z[i] = bt[i] * LN2;          // the tiles are stored x log2 e
-    } else if (has_table) {
+    } else if constexpr (has_table) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {               // register quad j = keys kb*32 + 8j + 4hh + (0..3): one 8-byte read of offsets
         typedef short short4v __attribute__((ext_vector_type(4)));
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 #if defined(WA_ABL) && (WA_ABL & 1)
         for (int e = 0; e < 4; ++e) z[4 * j + e] = (float)ko[e] * 1e-9f;      // ablation: no table lookup
 #else
-        for (int e = 0; e < 4; ++e) z[4 * j + e] = *(const float*)((const char*)tab + (qoff - (int)ko[e]));
+        for (int e = 0; e < 4; ++e) z[4 * j + e] = *(const __attribute__((address_space(3))) float*)(size_t)(qtab - (unsigned)(int)ko[e]);
 #endif
       }
     } else {
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
     }
     if (kb == nb - 1) {                           // only the last block holds padding keys: they never win the max
 #pragma unroll
-      for (int i = 0; i < 16; ++i) z[i] = kb * 32 + acc_row(i, hh) < n ? z[i] : -3.0e38f;
+      for (int i = 0; i < 16; ++i) z[i] = (i & 3) + 8 * (i >> 2) < nlast ? z[i] : -3.0e38f;
     }
     return z;
   };
@@ -283,8 +287,13 @@ extern "C" int dua_window_attention_fwd(int dtype, int windows, int tokens, int 
   const int lds = wa::MAXB * 32 * wa::HD * 2 + wa::MAXB * 2 * 2 * 16 * 8 * 2 +                            // K, V^T
                   wa::MAXTAB * 4 + wa::MAXB * 32 * 2 + wa::MAXB * 32;                                        // table, offsets, regions
   dim3 grid(windows, heads, (long)windows * heads >= 1024 ? 1 : (nb + 3) / 4);
-  if (dtype == DUA_F16) hipLaunchKernelGGL(window_attention_kernel<f16>, grid, dim3(256), lds, (hipStream_t)stream, a);
-  else if (dtype == DUA_F32) hipLaunchKernelGGL(window_attention_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
-  else return DUA_ERR_ARG;
+  if (dtype != DUA_F16 && dtype != DUA_F32) return DUA_ERR_ARG;
+  const int bias_mode = a.btile ? 1 : a.table ? 0 : 2;
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, a); };
+  if (dtype == DUA_F16) {
+    if (bias_mode == 0) go(window_attention_kernel<f16, 0>); else if (bias_mode == 1) go(window_attention_kernel<f16, 1>); else go(window_attention_kernel<f16, 2>);
+  } else {
+    if (bias_mode == 0) go(window_attention_kernel<float, 0>); else if (bias_mode == 1) go(window_attention_kernel<float, 1>); else go(window_attention_kernel<float, 2>);
+  }
   return (int)hipGetLastError();
 }

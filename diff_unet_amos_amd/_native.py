@@ -100,7 +100,7 @@ class TokenLinearDesc(C.Structure):
                 ("W", C.c_void_p), ("bias", C.c_void_p), ("mode", C.c_int), ("samples", C.c_int),
                 ("out", C.c_void_p), ("ldc", C.c_int), ("out_off", C.c_int), ("x", C.c_void_p),
                 ("stats", C.c_void_p), ("c_pad", C.c_int), ("geom", WindowGeom), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("eps", C.c_float), ("ln_out", C.c_void_p)]
+                ("eps", C.c_float), ("ln_out", C.c_void_p), ("background", C.c_int)]
 
 
 TOKLIN_PLAIN, TOKLIN_GELU, TOKLIN_STATS, TOKLIN_RESIDUAL, TOKLIN_SCATTER = range(5)
@@ -124,7 +124,7 @@ _SIGS = {
     "dua_patch_merge_norm": (C.c_int, [C.c_int] * 7 + [_P, _P, _P, _P, C.c_float, _P, _P]),
     "dua_residual_norm_act": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.POINTER(InNorm), _P, C.c_int,
                                         C.POINTER(InNorm), _P, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_int,
-                                        C.c_int, _P]),
+                                        C.c_int, C.c_int, _P]),
     "dua_window_gather_norm": (C.c_int, [C.c_int, C.POINTER(WindowGeom), _P, _P, _P, _P, C.c_float, _P, _P]),
     "dua_window_scatter_add_norm": (C.c_int, [C.c_int, C.POINTER(WindowGeom), _P, _P, _P, _P, C.c_float, _P, _P]),
     "dua_stage_out": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, _P, C.c_int, C.c_float, _P, _P, _P, C.c_int, C.c_int, _P]),

@@ -172,7 +172,7 @@ int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legac
 int dua_residual_norm_act(int dtype, int N, long voxels, int C, const void* raw, int raw_stride, const dua_in_norm* in,
                           const void* res, int res_stride, const dua_in_norm* res_in, void* out, int out_stride, int out_off,
                           float slope, const void* post_add, int post_stride, int post_off, const void* ra_src,
-                          int ra_stride, int ra_off, void* stream) {
+                          int ra_stride, int ra_off, int background, void* stream) {
   if (!raw || !in || !in->stats || !res || !out || N <= 0 || voxels <= 0 || C <= 0 || C % 8 || raw_stride % 8 ||
       res_stride % 8 || out_stride % 8 || out_off % 8 || C > 2048)
     return DUA_ERR_ARG;
@@ -181,7 +181,8 @@ int dua_residual_norm_act(int dtype, int N, long voxels, int C, const void* raw,
   if (ra_src && (ra_stride % 8 || ra_off % 8 || ra_stride < ra_off + C)) return DUA_ERR_ARG;
   const dua::InXform xf = dua::make_xform(in, C), rf = dua::make_xform(res_in, C);
   long b = (voxels * (C / 8) + 255) / 256;
-  dim3 grid((unsigned)(b > 4096 ? 4096 : b), N);
+  const long cap = background ? 256 : 4096;       // background: one workgroup per CU (the loop strides over the grid)
+  dim3 grid((unsigned)(b > cap ? cap : b), N);
   const size_t lds = (size_t)5 * C * sizeof(float);
   if (dtype == DUA_F16)
     hipLaunchKernelGGL(dua::residual_norm_act_kernel<dua::f16>, grid, dim3(256), lds, (hipStream_t)stream, (const dua::f16*)raw,

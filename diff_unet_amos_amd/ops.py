@@ -864,7 +864,7 @@ def patch_merge_norm(x, gamma, beta, legacy=True, eps=1e-5, y=None, dtype=None, 
 
 
 def residual_norm_act(raw, norm, res, res_norm=None, slope=0.01, out=None, out_off=0, post_add=None, post_off=0,
-                      ra_src=None, ra_off=0, res_off=0):
+                      ra_src=None, ra_off=0, res_off=0, background=False):
     """out = LeakyReLU(IN(raw) + residual) [+ post_add] [+ reverse_attention(ra_src)] (UnetResBlock tail,
     models/swin_unetr/blocks.py:308-316, and the adds of swin_unetr/denoiser.py:370-399); ``res_norm`` normalises the
     residual (conv3 + norm3 of channel-changing blocks)."""
@@ -884,7 +884,7 @@ def residual_norm_act(raw, norm, res, res_norm=None, slope=0.01, out=None, out_o
                                             res_ptr, res.shape[-1], _norm_ref(res_norm, N, Cc), nv.ptr(out), out.shape[-1],
                                             out_off, slope, nv.ptr(post_add), post_add.shape[-1] if post_add is not None else 0,
                                             post_off, nv.ptr(ra_src), ra_src.shape[-1] if ra_src is not None else 0, ra_off,
-                                            nv.stream_ptr()), "dua_residual_norm_act")
+                                            1 if background else 0, nv.stream_ptr()), "dua_residual_norm_act")
     return out
 
 
@@ -976,7 +976,7 @@ def gelu_(x):
 
 
 def token_linear(A, W, bias=None, mode="plain", out=None, out_off=0, x=None, stats=None, samples=1, geom=None, gamma=None,
-                 beta=None, ln_out=None, eps=1e-5):
+                 beta=None, ln_out=None, eps=1e-5, background=False):
     """dua_token_linear: fp16 A [tokens, K] (row stride A.stride(0)) times the nn.Linear weight W [N, K] with one fused
     epilogue -- "plain" / "gelu" (-> out[:, out_off:out_off+N]), "stats" (raw out + per-(sample, channel) sums into
     ``stats``), "residual" (x += result, fp32 stream) or "scatter" (window order -> voxel order, x += result,
@@ -999,6 +999,7 @@ def token_linear(A, W, bias=None, mode="plain", out=None, out_off=0, x=None, sta
     d = nv.TokenLinearDesc()
     d.A, d.lda, d.M, d.K, d.N, d.W, d.bias = A.data_ptr(), A.stride(0), M // samples, K, N, W.data_ptr(), (bias.data_ptr() if bias is not None else None)
     d.mode, d.samples = code, samples
+    d.background = 1 if background else 0
     if mode in ("plain", "gelu", "stats"):
         assert out is not None and out.is_cuda and out.dtype == torch.float16 and out.is_contiguous()
         ldc = out.shape[-1]

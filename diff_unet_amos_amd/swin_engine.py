@@ -149,6 +149,10 @@ class SwinPlan:
         # which encoder blocks the side stream takes once hidden_states_out[i] is enqueued (encoder_k reads hidden state k - 1;
         # encoder1, k = 0, reads the input only)
         self.side_plan = {2: (3, 2, 1, 0)}
+        # the memory-bound tail of a side-stream block (conv3 + sums, residual_norm_act) also runs one workgroup per CU: at full
+        # width encoder1's two 96^3 passes held the main stream's split-K finish kernels at 40-55 us instead of 6
+        self.background_tails = True
+        self.background_conv3 = False
         self.fused_tail = dtype == torch.float16 and self.cx == 16     # the tail assembles decoder1's output itself (MFMA tail kernel: fp16, 9..16 classes)
         self._tail_src = None
         self.background_convs = True        # side-stream 3x3x3 convolutions leave half of every CU to the main stream's chain
@@ -354,7 +358,8 @@ class SwinPlan:
             res = self._view(b3, l, r.cout)
             x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
             if self.fused_linear and self.tl_conv3 and r.cout <= 64 and cin <= 384:
-                ops.token_linear(x2, r.w3, None, "stats", out=res.view(-1, r.cout), stats=r.st[2], samples=N)   # conv3 + norm3 sums
+                ops.token_linear(x2, r.w3, None, "stats", out=res.view(-1, r.cout), stats=r.st[2], samples=N,
+                                 background=bg and self.background_conv3)            # conv3 + norm3 sums
             elif self.wide_gemm:
                 ops.token_gemm(x2, r.w3, None, "plain", out=res.view(-1, r.cout),
                                workspace=self._gemm_scratch_b if side else self._gemm_scratch)    # 1x1x1 conv3 on the tiled MFMA GEMM
@@ -365,10 +370,10 @@ class SwinPlan:
             if defer:
                 return raw2, n2, res, n3
             ops.residual_norm_act(raw2, n2, res, n3, slope=SLOPE, out=out, out_off=out_off, post_add=post_add, ra_src=ra,
-                                  ra_off=ra_off)
+                                  ra_off=ra_off, background=bg and self.background_tails)
         else:
             ops.residual_norm_act(raw2, n2, x, None, slope=SLOPE, out=out, out_off=out_off, post_add=post_add, ra_src=ra,
-                                  ra_off=ra_off)
+                                  ra_off=ra_off, background=bg and self.background_tails)
 
     def _swin(self, vit, xin, cin_packed, t_offs, emb, outs, ready=None):
         """SwinTransformer.forward (transformer.py:270-316): patch embedding, four stages, the adds between them.

@@ -435,7 +435,10 @@ int dua_patch_merge_norm(int dtype, int B, int D, int H, int W, int C, int legac
 int dua_residual_norm_act(int dtype, int N, long voxels, int C, const void* raw, int raw_stride, const dua_in_norm* in,
                           const void* res, int res_stride, const dua_in_norm* res_in, void* out, int out_stride, int out_off,
                           float slope, const void* post_add, int post_stride, int post_off, const void* ra_src,
-                          int ra_stride, int ra_off, void* stream);
+                          int ra_stride, int ra_off, int background, void* stream);
+/* background (here and in dua_token_linear_desc): 1 = the launch runs on a second stream UNDER a chain of small launches of
+ * another stream (like dua_conv3_desc.background): one workgroup per CU walks the data, so that the chain's launches find
+ * free slots and memory bandwidth at once; the launch itself takes longer. */
 
 /* ---- Swin token stream (models/swin_unetr/transformer.py) ------------------------------------
  * The residual stream x of a stage is fp32 [B][D][H][W][C]; GEMM / convolution operands are written in `dtype`.
@@ -494,6 +497,7 @@ typedef struct dua_token_linear_desc {
   float* x;
   dua_stat_word* stats; int c_pad;
   dua_window_geom geom; const float* gamma; const float* beta; float eps; void* ln_out;
+  int background;          /* see dua_residual_norm_act; dua_token_linear only */
 } dua_token_linear_desc;
 int dua_token_linear(const dua_token_linear_desc* d, void* stream);
 /* The same contraction for the COARSE Swin stages and the wide 1x1x1 convolutions (stages 1-3: qkv / proj / linear1 / linear2 /

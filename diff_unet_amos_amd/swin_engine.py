@@ -153,6 +153,7 @@ class SwinPlan:
         # width encoder1's two 96^3 passes held the main stream's split-K finish kernels at 40-55 us instead of 6
         self.background_tails = True
         self.background_conv3 = False
+        self.conv3_first = False            # conv3 ahead of the block's 3x3x3 convolutions on the side stream: +0.01 ms (A/B), off
         self.fused_tail = dtype == torch.float16 and self.cx == 16     # the tail assembles decoder1's output itself (MFMA tail kernel: fp16, 9..16 classes)
         self._tail_src = None
         self.background_convs = True        # side-stream 3x3x3 convolutions leave half of every CU to the main stream's chain
@@ -351,9 +352,18 @@ class SwinPlan:
                        ops.Norm(r.st[2], r.ones, r.zeros, count, slope=SLOPE, eps=EPS))
         n1, n2, n3 = r.norms
         bg = side and self.two_streams and self.background_convs
-        ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws, background=bg, tap_channel=r.tap)
-        ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=ws, background=bg)
         assert r.has3 or not defer
+
+        def convs():
+            ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws, background=bg, tap_channel=r.tap)
+            ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=ws, background=bg)
+
+        # conv3 reads the block's input only, so on the side stream it could go first and land under the Swin chain's small GEMMs
+        # instead of under the decoder's split-K finish kernels (which read 95 MB and crawl next to another streaming kernel);
+        # measured: +0.01 ms (tools/bench_swin_ab.py), so the order of the reference stays
+        first3 = side and self.conv3_first
+        if not first3:
+            convs()
         if r.has3:
             res = self._view(b3, l, r.cout)
             x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
@@ -367,11 +377,15 @@ class SwinPlan:
             else:
                 torch.matmul(x2, r.w3.t(), out=res.view(-1, r.cout))                 # fp32 parity mode: library GEMM
                 ops.instnorm_stats(res, r.cout, r.st[2])
+            if first3:
+                convs()
             if defer:
                 return raw2, n2, res, n3
             ops.residual_norm_act(raw2, n2, res, n3, slope=SLOPE, out=out, out_off=out_off, post_add=post_add, ra_src=ra,
                                   ra_off=ra_off, background=bg and self.background_tails)
         else:
+            if first3:
+                convs()
             ops.residual_norm_act(raw2, n2, x, None, slope=SLOPE, out=out, out_off=out_off, post_add=post_add, ra_src=ra,
                                   ra_off=ra_off, background=bg and self.background_tails)
 

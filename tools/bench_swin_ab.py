@@ -26,6 +26,7 @@ def main():
                 "library qkv": {"tl_qkv": False}, "library proj + scatter kernel": {"tl_proj": False},
                 "library conv3 + stats kernel": {"tl_conv3": False},
                 "side-stream tails at full width": {"background_tails": False},
+                "side-stream blocks: conv3 ahead of the 3x3x3 convolutions": {"conv3_first": True},
                 "side-stream tails and conv3 one workgroup per CU": {"background_conv3": True},
                 "encoder1 with stage 0": {"side_plan": {0: (0,), 2: (3, 2, 1)}},
                 "encoder1 after stage 0": {"side_plan": {1: (0,), 2: (3, 2, 1)}},
@@ -35,7 +36,7 @@ def main():
     if len(sys.argv) > 3:
         settings = {k: v for k, v in settings.items() if k == "default" or any(w in k for w in sys.argv[3].split(","))}
     base = {k: getattr(plan, k) for k in ("two_streams", "fused_mlp", "fused_linear", "fused_max_c", "fused_reduction", "tl_qkv",
-                                          "tl_proj", "tl_conv3", "background_convs", "fused_tail", "side_plan", "background_tails", "background_conv3")}
+                                          "tl_proj", "tl_conv3", "background_convs", "fused_tail", "side_plan", "background_tails", "background_conv3", "conv3_first")}
     graphs = {}
     with torch.no_grad():
         net.embed_model(image)

@@ -628,7 +628,7 @@ extern "C" int dua_token_linear(const dua_token_linear_desc* d, void* stream) {
     oc = o;
   }
   const long tiles = (d->M + 127) / 128;
-  long cap = 256L * (d->background ? 1 : oc) / samples;      // background: one workgroup per CU
+  long cap = 256L * (d->background > 0 && d->background < oc ? d->background : oc) / samples;      // background: that many workgroups per CU
   if (cap < 1) cap = 1;
   dim3 grid((unsigned)(tiles < cap ? tiles : cap), samples);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -999,7 +999,7 @@ def token_linear(A, W, bias=None, mode="plain", out=None, out_off=0, x=None, sta
     d = nv.TokenLinearDesc()
     d.A, d.lda, d.M, d.K, d.N, d.W, d.bias = A.data_ptr(), A.stride(0), M // samples, K, N, W.data_ptr(), (bias.data_ptr() if bias is not None else None)
     d.mode, d.samples = code, samples
-    d.background = 1 if background else 0
+    d.background = int(background)
     if mode in ("plain", "gelu", "stats"):
         assert out is not None and out.is_cuda and out.dtype == torch.float16 and out.is_contiguous()
         ldc = out.shape[-1]

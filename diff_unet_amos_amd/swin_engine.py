@@ -152,7 +152,7 @@ class SwinPlan:
         # the memory-bound tail of a side-stream block (conv3 + sums, residual_norm_act) also runs one workgroup per CU: at full
         # width encoder1's two 96^3 passes held the main stream's split-K finish kernels at 40-55 us instead of 6
         self.background_tails = True
-        self.background_conv3 = False
+        self.background_conv3 = 0           # workgroups per CU of a side-stream conv3 + sums launch (0: as many as fit)
         self.conv3_first = False            # conv3 ahead of the block's 3x3x3 convolutions on the side stream: +0.01 ms (A/B), off
         self.fused_tail = dtype == torch.float16 and self.cx == 16     # the tail assembles decoder1's output itself (MFMA tail kernel: fp16, 9..16 classes)
         self._tail_src = None
@@ -369,7 +369,7 @@ class SwinPlan:
             x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
             if self.fused_linear and self.tl_conv3 and r.cout <= 64 and cin <= 384:
                 ops.token_linear(x2, r.w3, None, "stats", out=res.view(-1, r.cout), stats=r.st[2], samples=N,
-                                 background=bg and self.background_conv3)            # conv3 + norm3 sums
+                                 background=self.background_conv3 if bg else 0)      # conv3 + norm3 sums
             elif self.wide_gemm:
                 ops.token_gemm(x2, r.w3, None, "plain", out=res.view(-1, r.cout),
                                workspace=self._gemm_scratch_b if side else self._gemm_scratch)    # 1x1x1 conv3 on the tiled MFMA GEMM

@@ -497,7 +497,7 @@ typedef struct dua_token_linear_desc {
   float* x;
   dua_stat_word* stats; int c_pad;
   dua_window_geom geom; const float* gamma; const float* beta; float eps; void* ln_out;
-  int background;          /* see dua_residual_norm_act; dua_token_linear only */
+  int background;          /* dua_token_linear only: n > 0 = at most n workgroups per CU (see dua_residual_norm_act) */
 } dua_token_linear_desc;
 int dua_token_linear(const dua_token_linear_desc* d, void* stream);
 /* The same contraction for the COARSE Swin stages and the wide 1x1x1 convolutions (stages 1-3: qkv / proj / linear1 / linear2 /

@@ -134,8 +134,10 @@ def test_unet_res_block_on_hip_kernels_matches_oracle(dtype, tol, cin, cout):
         assert torch.allclose(sd[:, :cout, 1], (rf * rf).sum(1).double(), rtol=1e-5, atol=1e-3)
         n3 = ops.Norm(st3, blk.norm3.weight.detach().to(dev), blk.norm3.bias.detach().to(dev), V, slope=0.01)
         out = ops.residual_norm_act(raw2, n2, r, n3, slope=0.01)
+        assert torch.equal(out, ops.residual_norm_act(raw2, n2, r, n3, slope=0.01, background=True))   # one workgroup per CU: same values
     else:
         out = ops.residual_norm_act(raw2, n2, xcl, None, slope=0.01)
+        assert torch.equal(out, ops.residual_norm_act(raw2, n2, xcl, None, slope=0.01, background=True))
     got = out.float().permute(0, 4, 1, 2, 3).cpu()
     d = (got - want).abs()
     print(f"\n[{dtype}] UnetResBlock {cin}->{cout}: max |d| {d.max():.2e} mean {d.mean():.2e}")
@@ -477,6 +479,11 @@ def test_token_linear_kernel_epilogues_match_torch():
     sd = ops.stats_decode(st)
     assert torch.allclose(sd[:, :N, 0], o.sum(1).double(), rtol=1e-4, atol=1e-2)
     assert torch.allclose(sd[:, :N, 1], (o * o).sum(1).double(), rtol=1e-4, atol=1e-2)
+    # the same launch held to one workgroup per CU (dua_token_linear_desc.background): same output, same sums up to their grouping
+    out_b, st_b = torch.empty_like(out), ops.stats_buffer(B, N, dev)
+    ops.token_linear(buf[:, :K], W, None, "stats", out=out_b, stats=st_b, samples=B, background=1)
+    assert torch.equal(out_b, out)
+    assert torch.allclose(ops.stats_decode(st_b)[:, :N], sd[:, :N], rtol=1e-6, atol=1e-3)
     # residual
     for M, K, N in ((900, 192, 48), (450, 384, 96)):
         A = torch.randn(M, K, generator=g).half().to(dev)

@@ -27,7 +27,8 @@ def main():
                 "library conv3 + stats kernel": {"tl_conv3": False},
                 "side-stream tails at full width": {"background_tails": False},
                 "side-stream blocks: conv3 ahead of the 3x3x3 convolutions": {"conv3_first": True},
-                "side-stream tails and conv3 one workgroup per CU": {"background_conv3": True},
+                "side-stream conv3 one workgroup per CU": {"background_conv3": 1},
+                "side-stream conv3 two workgroups per CU": {"background_conv3": 2},
                 "encoder1 with stage 0": {"side_plan": {0: (0,), 2: (3, 2, 1)}},
                 "encoder1 after stage 0": {"side_plan": {1: (0,), 2: (3, 2, 1)}},
                 "encoder1, 2 after stage 0": {"side_plan": {1: (0, 1), 2: (3, 2)}},

@@ -248,6 +248,40 @@ __global__ __launch_bounds__(256) void wgrad_fo_reduce_kernel(const float* __res
   }
 }
 
+// The same sum for the layers with MANY (co, ci) slabs and few partitions (the <= 12^3 levels: 32-128 slabs, dW of 7-28 MB): there the
+// one-thread-per-element kernel above spends its time on the OUTPUT -- consecutive lanes are consecutive ci, 27 floats apart in
+// dW[co][ci][tap], so a wave's read-modify-write touched ~55 lines for 256 useful bytes and every line 27 times over the launch
+// (73 us for the 6^3 512 -> 512 layer, most of that launch).  Here a workgroup owns 8 output channels x 32 input channels of one
+// slab for ALL 27 taps: a thread sums the 27 taps of its (co, ci) over the partitions (coalesced reads, fixed order), the sums
+// pass through LDS in dW's own order, and dW is updated in whole 1 KB runs.  Needs the identity channel map.
+__global__ __launch_bounds__(256) void wgrad_fo_reduce_taps_kernel(const float* __restrict__ part, int P, int ncs, int ncombo, int Cin,
+                                                                   int Cin_src, int Cout, float* __restrict__ dw) {
+  __shared__ float st[256 * 27];
+  const int combo = blockIdx.x >> 3, cob = blockIdx.x & 7, t = threadIdx.x;
+  const long per_p = (long)ncombo * 27 * 2048;
+  const float* src = part + ((long)combo * 27 * 64 + cob * 8 + (t >> 5)) * 32 + (t & 31);
+  float s[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) s[k] = 0.f;
+  for (int p = 0; p < P; ++p) {
+    float v[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) v[k] = src[(long)p * per_p + k * 2048];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) s[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) st[t * 27 + k] = s[k];          // stride 27 (odd): conflict-free
+  __syncthreads();
+  const int co0 = (combo / ncs) * 64 + cob * 8, ci0 = (combo % ncs) * 32;
+  const int nci = min(min(Cin, Cin_src) - ci0, 32);              // valid input channels of this slab
+#pragma unroll
+  for (int j = 0; j < 27; ++j) {
+    const int e = j * 256 + t, col = e / 864, w = e - col * 864;  // 864 = 32 ci x 27 taps: one output channel's run
+    if (co0 + col < Cout && w < nci * 27) dw[((long)(co0 + col) * Cin_src + ci0) * 27 + w] += st[e];
+  }
+}
+
 static const LdsAttr kWgradFoLdsAttrs[] = {{(const void*)conv3d_k3_wgrad_fo_kernel, 2 * wf::BUFB}};
 static const LdsAttrs kWgradFoLdsReg(kWgradFoLdsAttrs);
 
@@ -289,6 +323,11 @@ int launch_wgrad_fo(const dua_conv3_desc* d, const void* x, const void* dy, floa
   if (voxs * d->Cin_stride >= 0x7fffffffL || voxs * d->Cout_stride >= 0x7fffffffL) return DUA_ERR_ARG;   // 32-bit offsets inside a sample
   hipLaunchKernelGGL(conv3d_k3_wgrad_fo_kernel, dim3(a.P * a.ncombo), dim3(NT), 2 * BUFB, s, a);
   const long per_p = (long)a.ncombo * 27 * 2048;
+  if (a.ncombo >= 32 && !perm) {                                 // many slabs, few partitions: the output side decides (see the kernel)
+    hipLaunchKernelGGL(wgrad_fo_reduce_taps_kernel, dim3(a.ncombo * 8), dim3(256), 0, s, ws, a.P, a.ncs, a.ncombo, d->Cin, Cin_src,
+                       d->Cout, dw);
+    return (int)hipGetLastError();
+  }
   long nb = (per_p + 255) / 256;
   hipLaunchKernelGGL(wgrad_fo_reduce_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, s, ws, a.P, a.ncs, a.ncombo,
                      d->Cin, Cin_src, d->Cout, perm, dw);

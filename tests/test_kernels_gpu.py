@@ -597,6 +597,8 @@ def test_in_kernel_philox_noise_is_standard_normal(K):
     (1, 16, 16, 16, 128, 64),     # two ci chunks (concat input)
     (2, 4, 4, 4, 72, 136),        # ragged chunk and tile in the channel axes
     (1, 3, 5, 7, 8, 8),
+    (2, 6, 6, 6, 256, 256),       # 32 (co, ci) slabs: the fp16 form sums its partitions with the tap-gathering reduce kernel
+    (1, 4, 6, 4, 264, 520),       # 81 slabs, ragged last slab in both channel axes
 ])
 def test_conv3_wgrad_matches_torch(dtype, shape):
     N, D, H, W, Cin, Cout = shape
@@ -605,8 +607,9 @@ def test_conv3_wgrad_matches_torch(dtype, shape):
     cs_in, cs_out = Cin + 8, Cout + 16                 # strided buffers with an offset
     x = torch.randn(N, D, H, W, cs_in, generator=g, device=dev).to(dtype)
     dy = torch.randn(N, D, H, W, cs_out, generator=g, device=dev).to(dtype)
-    dw = torch.zeros(Cout, Cin, 3, 3, 3, device=dev)
+    dw = torch.full((Cout, Cin, 3, 3, 3), 0.5, device=dev)      # the kernels ADD into dw
     _ops().conv3d_k3_wgrad(x, Cin, 8, dy, Cout, 16, dw)
+    dw -= 0.5
     xr = x[..., 8:8 + Cin].permute(0, 4, 1, 2, 3).double()
     dyr = dy[..., 16:16 + Cout].permute(0, 4, 1, 2, 3).double()
     want = torch.nn.grad.conv3d_weight(xr, (Cout, Cin, 3, 3, 3), dyr, padding=1)

@@ -186,31 +186,59 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
           *(f16x8*)(a.out + ((long)sample * a.M + tok0 + row) * a.ldc + a.out_off + col * 8) = *(const f16x8*)(At + row * a.o_row + col * 16);
       }
     } else if (MODE == DUA_TOKLIN_RESIDUAL) {
+      // x += out as 16-byte read-modify-writes of the tile's rows (contiguous in x).  Every piece is REQUESTED before the first
+      // is stored: as a load - add - store loop the store of one piece and the load of the next may alias as far as the
+      // compiler knows, so the pieces went to memory one round trip after the other (4 NB of them per tile).
       const int cpr = N >> 2;
-      for (int c = tid; c < 128 * cpr; c += 256) {
+      constexpr int MAXIT = 4 * NB;
+      float* xt = a.x + tok0 * N;
+      const long left = (a.M - tok0) * cpr;                        // pieces of this tile that are rows of x
+      f32x4 xv[MAXIT];
+#pragma unroll
+      for (int j = 0; j < MAXIT; ++j) {
+        const int c = tid + 256 * j;
+        xv[j] = *(const f32x4*)(xt + (c < 128 * cpr && c < left ? c * 4 : 0));
+      }
+#pragma unroll
+      for (int j = 0; j < MAXIT; ++j) {
+        const int c = tid + 256 * j;
         const int row = c / cpr, col = c - row * cpr;
-        if (tok0 + row < a.M) {
-          float* xp = a.x + (tok0 + row) * N + col * 4;
-          f32x4 xv = *(const f32x4*)xp;
+        if (c < 128 * cpr && c < left) {
           const f32x4 dv = *(const f32x4*)(At + row * a.o_row + col * 16);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xv[e] += dv[e];
-          *(f32x4*)xp = xv;
+          for (int e = 0; e < 4; ++e) xv[j][e] += dv[e];
+          *(f32x4*)(xt + c * 4) = xv[j];
         }
       }
     } else {                                                       // DUA_TOKLIN_SCATTER: 16 lanes per token, channel = i*16 + j
       const WinGeom& g = a.g;
       const int jl = tid & 15;
       constexpr int CPL = NB * 2;                                  // N = 32 NB ... but N is 48 or 96: channels per lane = N / 16
-      for (int row = tid >> 4; row < 128; row += 16) {
-        const long tk = tok0 + row;
+      // the shortcut values of all eight rows of this lane group are requested before the first row is written back (a store
+      // to x and the next row's load from x may alias for the compiler: eight round trips per tile otherwise)
+      const int cpl = N >> 4;
+      long dstv[8];
+      float xs[8][CPL];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const long tk = tok0 + (tid >> 4) + 16 * it;
         const bool inb = tk < a.M;
         const long tkc = inb ? tk : 0;
         const int t = (int)(tkc % g.n), wi = (int)((tkc / g.n) % g.nw), b = (int)(tkc / ((long)g.n * g.nw));
         int d, h, w;
         const bool real = window_to_voxel(g, wi, t, d, h, w) && inb;
-        const long dst = ((((long)b * g.D + d) * g.H + h) * g.W + w) * N;
-        const int cpl = N >> 4;
+        dstv[it] = real ? ((((long)b * g.D + d) * g.H + h) * g.W + w) * N : -1;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) xs[it][i] = (i < cpl && real) ? a.x[dstv[it] + i * 16 + jl] : 0.f;
+      }
+      float gmv[CPL], btv[CPL];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) { gmv[i] = i < cpl ? a.gamma[i * 16 + jl] : 0.f; btv[i] = i < cpl ? a.beta[i * 16 + jl] : 0.f; }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = (tid >> 4) + 16 * it;
+        const bool real = dstv[it] >= 0;
+        const long dst = dstv[it];
         float v[CPL];
         float s = 0.f;
 #pragma unroll
@@ -218,7 +246,7 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
           v[i] = 0.f;
           if (i < cpl) {
             const int c = i * 16 + jl;
-            v[i] = *(const float*)(At + row * a.o_row + c * 4) + (real ? a.x[dst + c] : 0.f);
+            v[i] = *(const float*)(At + row * a.o_row + c * 4) + xs[it][i];
             s += v[i];
           }
         }
@@ -238,7 +266,7 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
             if (i < cpl) {
               const int c = i * 16 + jl;
               a.x[dst + c] = v[i];
-              a.ln_out[dst + c] = (f16)((v[i] - mean) * rstd * a.gamma[c] + a.beta[c]);
+              a.ln_out[dst + c] = (f16)((v[i] - mean) * rstd * gmv[i] + btv[i]);
             }
         }
       }
@@ -377,16 +405,24 @@ __global__ __launch_bounds__(256) void swin_mlp_kernel(MlpArgs a) {
       }
     }
     __syncthreads();
-    constexpr int cpr = C >> 2;
-    for (int c4 = tid; c4 < 128 * cpr; c4 += 256) {               // x += out, coalesced 16-byte read-modify-write
+    constexpr int cpr = C >> 2, MAXIT = 128 * cpr / 256;            // x += out, coalesced 16-byte read-modify-writes; every piece is
+    float* xt = a.x + tok0 * C;                                     // requested before the first is stored (see token_linear RESIDUAL)
+    const long left = (a.M - tok0) * cpr;
+    f32x4 xv[MAXIT];
+#pragma unroll
+    for (int j = 0; j < MAXIT; ++j) {
+      const int c4 = tid + 256 * j;
+      xv[j] = *(const f32x4*)(xt + (c4 < left ? c4 * 4 : 0));
+    }
+#pragma unroll
+    for (int j = 0; j < MAXIT; ++j) {
+      const int c4 = tid + 256 * j;
       const int row = c4 / cpr, col = c4 - row * cpr;
-      if (tok0 + row < a.M) {
-        float* xp = a.x + (tok0 + row) * C + col * 4;
-        f32x4 xv = *(const f32x4*)xp;
+      if (c4 < left) {
         const f32x4 dv = *(const f32x4*)(At + row * a.o_row + col * 16);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xv[e] += dv[e];
-        *(f32x4*)xp = xv;
+        for (int e = 0; e < 4; ++e) xv[j][e] += dv[e];
+        *(f32x4*)(xt + c4 * 4) = xv[j];
       }
     }
   }
@@ -471,17 +507,33 @@ __global__ __launch_bounds__(256) void patch_embed_mfma_kernel(PatchArgs a) {
       }
     __syncthreads();
     const int jl = tid & 15;
-    for (int row = tid >> 4; row < 128; row += 16) {                // 16 lanes per token, channel = i*16 + jl
-      const long tok = tok0 + row;
+    // 16 lanes per token, channel = i*16 + jl.  The embedding values and the per-sample adds of all eight rows of a lane group are
+    // requested up front: inside the row loop each of them was a dependent global round trip (eight per tile).
+    float cadd[8][3], ev[8][3];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const long tok = tok0 + (tid >> 4) + 16 * it;
       const bool ok = tok < total;
       const long tc = ok ? tok : 0;
       const int b = (int)(tc / per);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c = i * 16 + jl;
+        cadd[it][i] = a.bias[c] + (a.tadd ? a.tadd[(long)b * a.tadd_stride + c] : 0.f);
+        ev[it][i] = (a.emb && ok) ? (float)a.emb[tok * E + c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = (tid >> 4) + 16 * it;
+      const long tok = tok0 + row;
+      const bool ok = tok < total;
       float v[3];
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int c = i * 16 + jl;
-        v[i] = *(const float*)(At + row * a.o_row + c * 4) + a.bias[c] + (a.tadd ? a.tadd[(long)b * a.tadd_stride + c] : 0.f);
+        v[i] = *(const float*)(At + row * a.o_row + c * 4) + cadd[it][i];
         s += v[i];
       }
 #pragma unroll
@@ -498,8 +550,7 @@ __global__ __launch_bounds__(256) void patch_embed_mfma_kernel(PatchArgs a) {
         for (int i = 0; i < 3; ++i) {
           const int c = i * 16 + jl;
           if (a.x) a.x[tok * E + c] = v[i];
-          float o = (v[i] - mean) * rstd;
-          if (a.emb) o += (float)a.emb[tok * E + c];
+          const float o = (v[i] - mean) * rstd + ev[it][i];
           a.out[tok * a.out_stride + a.out_off + c] = (f16)o;
         }
       }

@@ -217,28 +217,34 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
       // the shortcut values of all eight rows of this lane group are requested before the first row is written back (a store
       // to x and the next row's load from x may alias for the compiler: eight round trips per tile otherwise)
       const int cpl = N >> 4;
-      long dstv[8];
-      float xs[8][CPL];
+      float gmv[CPL], btv[CPL];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int i = 0; i < CPL; ++i) { gmv[i] = i < cpl ? a.gamma[i * 16 + jl] : 0.f; btv[i] = i < cpl ? a.beta[i * 16 + jl] : 0.f; }
+      // (four rows at a time: all eight cost 55 registers and, at 110 592 tokens, the fourth workgroup per CU that lets the
+      // launch's 864 tiles run in one round)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+      long dstv[4];
+      float xs[4][CPL];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int it = half * 4 + q4;
         const long tk = tok0 + (tid >> 4) + 16 * it;
         const bool inb = tk < a.M;
         const long tkc = inb ? tk : 0;
         const int t = (int)(tkc % g.n), wi = (int)((tkc / g.n) % g.nw), b = (int)(tkc / ((long)g.n * g.nw));
         int d, h, w;
         const bool real = window_to_voxel(g, wi, t, d, h, w) && inb;
-        dstv[it] = real ? ((((long)b * g.D + d) * g.H + h) * g.W + w) * N : -1;
+        dstv[q4] = real ? ((((long)b * g.D + d) * g.H + h) * g.W + w) * N : -1;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) xs[it][i] = (i < cpl && real) ? a.x[dstv[it] + i * 16 + jl] : 0.f;
+        for (int i = 0; i < CPL; ++i) xs[q4][i] = (i < cpl && real) ? a.x[dstv[q4] + i * 16 + jl] : 0.f;
       }
-      float gmv[CPL], btv[CPL];
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) { gmv[i] = i < cpl ? a.gamma[i * 16 + jl] : 0.f; btv[i] = i < cpl ? a.beta[i * 16 + jl] : 0.f; }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int it = half * 4 + q4;
         const int row = (tid >> 4) + 16 * it;
-        const bool real = dstv[it] >= 0;
-        const long dst = dstv[it];
+        const bool real = dstv[q4] >= 0;
+        const long dst = dstv[q4];
         float v[CPL];
         float s = 0.f;
 #pragma unroll
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
           v[i] = 0.f;
           if (i < cpl) {
             const int c = i * 16 + jl;
-            v[i] = *(const float*)(At + row * a.o_row + c * 4) + xs[it][i];
+            v[i] = *(const float*)(At + row * a.o_row + c * 4) + xs[q4][i];
             s += v[i];
           }
         }
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
               a.ln_out[dst + c] = (f16)((v[i] - mean) * rstd * gmv[i] + btv[i]);
             }
         }
+      }
       }
     }
   }

@@ -48,10 +48,13 @@ __device__ __forceinline__ void group_layernorm(float (&v)[CPL], int C, float ep
   rstd = rsqrtf(group_sum<G>(q) / (float)C + eps);
 }
 
-template <typename T, int G, int CPL>
-__global__ __launch_bounds__(256) void window_gather_norm_kernel(WinGeom g, float* __restrict__ x, const T* __restrict__ y,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 float eps, T* __restrict__ out) {
+// 16-byte accesses: a lane owns NP pieces of four consecutive channels (piece = i * G + lane-in-group), G = C / (4 NP) lanes per
+// token.  (One channel per lane and request -- 12 bytes per lane in flight -- ran at 1.6 TB/s at 48^3 x 48: 20 us against 8.5.)
+template <typename T, int G, int NP>
+__global__ __launch_bounds__(256) void window_gather_norm_vec_kernel(WinGeom g, float* __restrict__ x, const T* __restrict__ y,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float eps, T* __restrict__ out) {
+  typedef T TV4 __attribute__((ext_vector_type(4)));
   const int j = threadIdx.x % G;
   const long tok = blockIdx.x * (long)(256 / G) + threadIdx.x / G;
   const long total = (long)g.B * g.nw * g.n;
@@ -62,31 +65,47 @@ __global__ __launch_bounds__(256) void window_gather_norm_kernel(WinGeom g, floa
   T* o = out + tok * g.C;
   if (!real) {                                              // F.pad after norm1: padded tokens are zeros
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) o[i * G + j] = (T)0.f;
+    for (int i = 0; i < NP; ++i) *(TV4*)(o + (i * G + j) * 4) = TV4{(T)0.f, (T)0.f, (T)0.f, (T)0.f};
     return;
   }
   const long src = ((((long)b * g.D + d) * g.H + h) * g.W + w) * g.C;
-  float v[CPL];
+  float v[4 * NP];
+  f32x4 gm[NP], bt[NP];
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) v[i] = x[src + i * G + j];
+  for (int i = 0; i < NP; ++i) {
+    const f32x4 xv = *(const f32x4*)(x + src + (i * G + j) * 4);
+    gm[i] = *(const f32x4*)(gamma + (i * G + j) * 4);
+    bt[i] = *(const f32x4*)(beta + (i * G + j) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * i + e] = xv[e];
+  }
   if (y) {
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { v[i] += (float)y[src + i * G + j]; x[src + i * G + j] = v[i]; }
+    for (int i = 0; i < NP; ++i) {
+      const TV4 yv = *(const TV4*)(y + src + (i * G + j) * 4);
+      f32x4 xv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[4 * i + e] += (float)yv[e]; xv[e] = v[4 * i + e]; }
+      *(f32x4*)(x + src + (i * G + j) * 4) = xv;
+    }
   }
   float mean, rstd;
-  group_layernorm<G, CPL>(v, g.C, eps, mean, rstd);
+  group_layernorm<G, 4 * NP>(v, g.C, eps, mean, rstd);
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    const int c = i * G + j;
-    o[c] = (T)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+  for (int i = 0; i < NP; ++i) {
+    TV4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = (T)((v[4 * i + e] - mean) * rstd * gm[i][e] + bt[i][e]);
+    *(TV4*)(o + (i * G + j) * 4) = ov;
   }
 }
 
-template <typename T, int G, int CPL>
+template <typename T, int G, int NP>
 __global__ __launch_bounds__(256) void window_scatter_add_norm_kernel(WinGeom g, float* __restrict__ x, const T* __restrict__ yw,
                                                                       const float* __restrict__ gamma,
                                                                       const float* __restrict__ beta, float eps,
                                                                       T* __restrict__ out) {
+  typedef T TV4 __attribute__((ext_vector_type(4)));
   const int j = threadIdx.x % G;
   const long tok = blockIdx.x * (long)(256 / G) + threadIdx.x / G;
   const long total = (long)g.B * g.D * g.H * g.W;
@@ -97,45 +116,66 @@ __global__ __launch_bounds__(256) void window_scatter_add_norm_kernel(WinGeom g,
   const int wi = ((ds / g.wd) * g.nwh + hs / g.wh) * g.nww + ws / g.ww;
   const int t = ((ds % g.wd) * g.wh + hs % g.wh) * g.ww + ws % g.ww;
   const long src = (((long)b * g.nw + wi) * g.n + t) * g.C, dst = tok * g.C;
-  float v[CPL];
+  float v[4 * NP];
+  f32x4 gm[NP], bt[NP];
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    v[i] = x[dst + i * G + j] + (float)yw[src + i * G + j];
-    x[dst + i * G + j] = v[i];
+  for (int i = 0; i < NP; ++i) {
+    const int c = (i * G + j) * 4;
+    f32x4 xv = *(const f32x4*)(x + dst + c);
+    const TV4 yv = *(const TV4*)(yw + src + c);
+    gm[i] = *(const f32x4*)(gamma + c);
+    bt[i] = *(const f32x4*)(beta + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xv[e] += (float)yv[e]; v[4 * i + e] = xv[e]; }
+    *(f32x4*)(x + dst + c) = xv;
   }
   float mean, rstd;
-  group_layernorm<G, CPL>(v, g.C, eps, mean, rstd);
+  group_layernorm<G, 4 * NP>(v, g.C, eps, mean, rstd);
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    const int c = i * G + j;
-    out[dst + c] = (T)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+  for (int i = 0; i < NP; ++i) {
+    TV4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = (T)((v[4 * i + e] - mean) * rstd * gm[i][e] + bt[i][e]);
+    *(TV4*)(out + dst + (i * G + j) * 4) = ov;
   }
 }
 
-template <typename T, int G, int CPL>
+template <typename T, int G, int NP>
 __global__ __launch_bounds__(256) void stage_out_kernel(long tokens, long per_sample, int C, const T* __restrict__ y,
                                                         const float* __restrict__ tadd, int tadd_stride, float eps,
                                                         const T* __restrict__ emb, float* __restrict__ x, T* __restrict__ out,
                                                         int out_stride, int out_off) {
+  typedef T TV4 __attribute__((ext_vector_type(4)));
   const int j = threadIdx.x % G;
   const long tok = blockIdx.x * (long)(256 / G) + threadIdx.x / G;
   if (tok >= tokens) return;
   const long b = tok / per_sample;
-  float v[CPL];
+  float v[4 * NP];
+  TV4 ev[NP];
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    const int c = i * G + j;
-    v[i] = (float)y[tok * C + c] + (tadd ? tadd[b * tadd_stride + c] : 0.f);
-    if (x) x[tok * C + c] = v[i];
+  for (int i = 0; i < NP; ++i) {
+    const int c = (i * G + j) * 4;
+    const TV4 yv = *(const TV4*)(y + tok * C + c);
+    f32x4 ta = {0.f, 0.f, 0.f, 0.f};
+    if (tadd) ta = *(const f32x4*)(tadd + b * tadd_stride + c);
+    if (emb) ev[i] = *(const TV4*)(emb + tok * C + c);
+    f32x4 xv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xv[e] = (float)yv[e] + ta[e]; v[4 * i + e] = xv[e]; }
+    if (x) *(f32x4*)(x + tok * C + c) = xv;
   }
   float mean, rstd;
-  group_layernorm<G, CPL>(v, C, eps, mean, rstd);
+  group_layernorm<G, 4 * NP>(v, C, eps, mean, rstd);
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    const int c = i * G + j;
-    float r = (v[i] - mean) * rstd;
-    if (emb) r += (float)emb[tok * C + c];
-    out[tok * out_stride + out_off + c] = (T)r;
+  for (int i = 0; i < NP; ++i) {
+    TV4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float r = (v[4 * i + e] - mean) * rstd;
+      if (emb) r += (float)ev[i][e];
+      ov[e] = (T)r;
+    }
+    *(TV4*)(out + tok * out_stride + out_off + (i * G + j) * 4) = ov;
   }
 }
 
@@ -253,13 +293,14 @@ __global__ __launch_bounds__(256) void gelu_kernel(T* __restrict__ x, long group
 }  // namespace dua
 
 // C -> lanes per token / channels per lane: 48 -> 16 x 3, 96 -> 32 x 3, 192 -> 64 x 3, 384 -> 64 x 6, 768 -> 64 x 12
+// lanes per token x pieces of four channels per lane (C = 4 G NP)
 #define DUA_TOKEN_DISPATCH(C_, T_, CALL)                 \
   switch (C_) {                                          \
-    case 48:  { CALL(T_, 16, 3); break; }                \
-    case 96:  { CALL(T_, 32, 3); break; }                \
-    case 192: { CALL(T_, 64, 3); break; }                \
-    case 384: { CALL(T_, 64, 6); break; }                \
-    case 768: { CALL(T_, 64, 12); break; }               \
+    case 48:  { CALL(T_, 4, 3); break; }                 \
+    case 96:  { CALL(T_, 8, 3); break; }                 \
+    case 192: { CALL(T_, 16, 3); break; }                \
+    case 384: { CALL(T_, 32, 3); break; }                \
+    case 768: { CALL(T_, 64, 3); break; }                \
     default: return DUA_ERR_ARG;                         \
   }
 
@@ -271,8 +312,8 @@ int dua_window_gather_norm(int dtype, const dua_window_geom* geom, float* x, con
   if (!geom_ok(geom) || !x || !gamma || !beta || !out) return DUA_ERR_ARG;
   const WinGeom g = make_geom(geom);
   const long total = (long)g.B * g.nw * g.n;
-#define CALL(T_, G_, CPL_)                                                                                              \
-  hipLaunchKernelGGL((window_gather_norm_kernel<T_, G_, CPL_>), dim3((unsigned)((total + 256 / G_ - 1) / (256 / G_))),   \
+#define CALL(T_, G_, NP_)                                                                                                   \
+  hipLaunchKernelGGL((window_gather_norm_vec_kernel<T_, G_, NP_>), dim3((unsigned)((total + 256 / G_ - 1) / (256 / G_))),    \
                      dim3(256), 0, (hipStream_t)stream, g, x, (const T_*)y, gamma, beta, eps, (T_*)out)
   if (dtype == DUA_F16) { DUA_TOKEN_DISPATCH(g.C, f16, CALL) }
   else if (dtype == DUA_F32) { DUA_TOKEN_DISPATCH(g.C, float, CALL) }
@@ -301,6 +342,10 @@ int dua_stage_out(int dtype, int B, long tokens_per_sample, int C, const void* y
                   float eps, const void* emb, float* x, void* out, int out_stride, int out_off, void* stream) {
   using namespace dua;
   if (B <= 0 || tokens_per_sample <= 0 || !y || !out || out_stride < out_off + C || (tadd && tadd_stride < C)) return DUA_ERR_ARG;
+  // 16-byte accesses: four-channel pieces must be aligned in every operand
+  if (out_stride % 4 || out_off % 4 || (tadd && (tadd_stride % 4 || ((size_t)tadd & 15))) || ((size_t)y & 7) || ((size_t)out & 7) ||
+      (x && ((size_t)x & 15)) || (emb && ((size_t)emb & 7)))
+    return DUA_ERR_ARG;
   const long total = (long)B * tokens_per_sample;
 #define CALL(T_, G_, CPL_)                                                                                                 \
   hipLaunchKernelGGL((stage_out_kernel<T_, G_, CPL_>), dim3((unsigned)((total + 256 / G_ - 1) / (256 / G_))), dim3(256), 0, \

@@ -453,9 +453,31 @@ __global__ __launch_bounds__(256) void patch_embed_mfma_kernel(PatchArgs a) {
   char* At = smem + a.w_bytes;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int K = 8 * a.Cp, cpt = a.Cp >> 3;                          // 16-byte chunks per tap
-  for (int i = tid; i < NB * 32 * K; i += 256) {                  // W_l[n][k] = w_packed[k][n] as fp16 (rows >= 48: zero)
-    const int n = i / K, k = i - n * K;
-    *(f16*)(Wl + n * a.w_row + k * 2) = n < E ? (f16)a.wk[(long)k * E + n] : (f16)0.f;
+  // W_l[n][k] = w_packed[k][n] as fp16 (rows >= 48: zero).  16-byte loads of four output channels, four in flight per thread: as
+  // one 4-byte load per element (48 dependent-latency iterations per thread) this staging was half of the workgroup's lifetime.
+  for (int i = tid; i < (NB * 32 - E) * K; i += 256) {
+    const int n = E + i / K, k = i % K;
+    *(f16*)(Wl + n * a.w_row + k * 2) = (f16)0.f;
+  }
+  {
+    const int pieces = K * (E / 4);                                 // piece i = (k, four channels 4q..4q+3) = wk + 4 i
+    for (int i0 = 0; i0 < pieces; i0 += 4 * 256) {
+      f32x4 wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256 + tid;
+        wv[u] = *(const f32x4*)(a.wk + (i < pieces ? (long)i * 4 : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256 + tid;
+        const int k = i / (E / 4), q = i - k * (E / 4);
+        if (i < pieces) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) *(f16*)(Wl + (4 * q + e) * a.w_row + k * 2) = (f16)wv[u][e];
+        }
+      }
+    }
   }
   const int D2 = a.D / 2, H2 = a.H / 2, W2 = a.W / 2;
   const long per = (long)D2 * H2 * W2, total = a.B * per;
@@ -470,18 +492,28 @@ __global__ __launch_bounds__(256) void patch_embed_mfma_kernel(PatchArgs a) {
       const long tc = ok ? tok : 0;
       const int w2 = (int)(tc % W2), h2 = (int)((tc / W2) % H2), d2 = (int)((tc / ((long)W2 * H2)) % D2);
       const int b = (int)(tc / per);
+      // every piece of the token's 2x2x2 gather is requested (from a clamped address) before the first is stored
+      f16x8 gv[4][4];                                               // [tap of this half][16-byte chunk], Cp <= 32
 #pragma unroll
       for (int tp = 0; tp < 4; ++tp) {
         const int tap = th * 4 + tp;
         const int d = 2 * d2 + (tap >> 2), h = 2 * h2 + ((tap >> 1) & 1), w = 2 * w2 + (tap & 1);
         const f16* p = a.in + ((((long)b * a.D + d) * a.H + h) * a.W + w) * a.Cs;
-        for (int c = 0; c < cpt; ++c) {
-          f16x8 v;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
-          if (ok) v = *(const f16x8*)(p + c * 8);
-          *(f16x8*)(At + row * a.a_row + (tap * cpt + c) * 16) = v;
-        }
+        for (int c = 0; c < 4; ++c)
+          if (c < cpt) gv[tp][c] = *(const f16x8*)(p + c * 8);
+      }
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp) {
+        const int tap = th * 4 + tp;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < cpt) {
+            f16x8 v = gv[tp][c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] : (f16)0.f;
+            *(f16x8*)(At + row * a.a_row + (tap * cpt + c) * 16) = v;
+          }
       }
     }
     __syncthreads();

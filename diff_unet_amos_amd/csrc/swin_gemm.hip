@@ -210,72 +210,62 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
           *(f32x4*)(xt + c * 4) = xv[j];
         }
       }
-    } else {                                                       // DUA_TOKLIN_SCATTER: 16 lanes per token, channel = i*16 + j
+    } else {                                                       // DUA_TOKLIN_SCATTER
+      // G = N / 12 lanes per token (4 / 8 / 16 for N = 48 / 96 / 192), each with three pieces of four consecutive channels
+      // (piece = i * G + lane-in-group): the shortcut, the stream and the LayerNorm output move as 16- and 8-byte accesses
+      // (one channel per lane and access took three times the memory instructions).  The shortcut pieces of two passes are
+      // requested before the first row is written back: a store to x and the next row's load from x may alias for the compiler.
       const WinGeom& g = a.g;
-      const int jl = tid & 15;
-      constexpr int CPL = NB * 2;                                  // N = 32 NB ... but N is 48 or 96: channels per lane = N / 16
-      // the shortcut values of all eight rows of this lane group are requested before the first row is written back (a store
-      // to x and the next row's load from x may alias for the compiler: eight round trips per tile otherwise)
-      const int cpl = N >> 4;
-      float gmv[CPL], btv[CPL];
+      const int G = N / 12, lg = G == 4 ? 2 : (G == 8 ? 3 : 4);
+      const int jl = tid & (G - 1), rpp = 256 >> lg, npass = 128 / rpp;
+      for (int p0 = 0; p0 < npass; p0 += 2) {                     // two passes at a time: 128 registers = four workgroups per CU
+        long dstv[2];
+        f32x4 xs[2][3];
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) { gmv[i] = i < cpl ? a.gamma[i * 16 + jl] : 0.f; btv[i] = i < cpl ? a.beta[i * 16 + jl] : 0.f; }
-      // (four rows at a time: all eight cost 55 registers and, at 110 592 tokens, the fourth workgroup per CU that lets the
-      // launch's 864 tiles run in one round)
+        for (int q4 = 0; q4 < 2; ++q4) {
+          const long tk = tok0 + (tid >> lg) + rpp * (p0 + q4);
+          const bool inb = p0 + q4 < npass && tk < a.M;
+          const long tkc = inb ? tk : 0;
+          const int t = (int)(tkc % g.n), wi = (int)((tkc / g.n) % g.nw), b = (int)(tkc / ((long)g.n * g.nw));
+          int d, h, w;
+          const bool real = window_to_voxel(g, wi, t, d, h, w) && inb;
+          dstv[q4] = real ? ((((long)b * g.D + d) * g.H + h) * g.W + w) * N : -1;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-      long dstv[4];
-      float xs[4][CPL];
+          for (int i = 0; i < 3; ++i) xs[q4][i] = *(const f32x4*)(a.x + (real ? dstv[q4] + (i * G + jl) * 4 : 0));
+        }
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int it = half * 4 + q4;
-        const long tk = tok0 + (tid >> 4) + 16 * it;
-        const bool inb = tk < a.M;
-        const long tkc = inb ? tk : 0;
-        const int t = (int)(tkc % g.n), wi = (int)((tkc / g.n) % g.nw), b = (int)(tkc / ((long)g.n * g.nw));
-        int d, h, w;
-        const bool real = window_to_voxel(g, wi, t, d, h, w) && inb;
-        dstv[q4] = real ? ((((long)b * g.D + d) * g.H + h) * g.W + w) * N : -1;
+        for (int q4 = 0; q4 < 2; ++q4) {
+          if (p0 + q4 >= npass) break;
+          const int row = (tid >> lg) + rpp * (p0 + q4);
+          const bool real = dstv[q4] >= 0;
+          float v[12];
+          float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) xs[q4][i] = (i < cpl && real) ? a.x[dstv[q4] + i * 16 + jl] : 0.f;
-      }
+          for (int i = 0; i < 3; ++i) {
+            const f32x4 dv = *(const f32x4*)(At + row * a.o_row + (i * G + jl) * 16);
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int it = half * 4 + q4;
-        const int row = (tid >> 4) + 16 * it;
-        const bool real = dstv[q4] >= 0;
-        const long dst = dstv[q4];
-        float v[CPL];
-        float s = 0.f;
+            for (int e = 0; e < 4; ++e) { v[4 * i + e] = dv[e] + (real ? xs[q4][i][e] : 0.f); s += v[4 * i + e]; }
+          }
+          for (int o2 = G >> 1; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2);
+          const float mean = s / (float)N;
+          float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-          v[i] = 0.f;
-          if (i < cpl) {
-            const int c = i * 16 + jl;
-            v[i] = *(const float*)(At + row * a.o_row + c * 4) + xs[q4][i];
-            s += v[i];
+          for (int i = 0; i < 12; ++i) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
+          for (int o2 = G >> 1; o2 > 0; o2 >>= 1) q += __shfl_xor(q, o2);
+          const float rstd = rsqrtf(q / (float)N + a.eps);
+          if (real) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              const int c = (i * G + jl) * 4;
+              *(f32x4*)(a.x + dstv[q4] + c) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+              const f32x4 gmv = *(const f32x4*)(a.gamma + c), btv = *(const f32x4*)(a.beta + c);    // L1 hits
+              f16x4 lo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) lo[e] = (f16)((v[4 * i + e] - mean) * rstd * gmv[e] + btv[e]);
+              *(f16x4*)(a.ln_out + dstv[q4] + c) = lo;
+            }
           }
         }
-#pragma unroll
-        for (int o2 = 8; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2);
-        const float mean = s / (float)N;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i)
-          if (i < cpl) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
-#pragma unroll
-        for (int o2 = 8; o2 > 0; o2 >>= 1) q += __shfl_xor(q, o2);
-        const float rstd = rsqrtf(q / (float)N + a.eps);
-        if (real) {
-#pragma unroll
-          for (int i = 0; i < CPL; ++i)
-            if (i < cpl) {
-              const int c = i * 16 + jl;
-              a.x[dst + c] = v[i];
-              a.ln_out[dst + c] = (f16)((v[i] - mean) * rstd * gmv[i] + btv[i]);
-            }
-        }
-      }
       }
     }
   }
@@ -545,52 +535,61 @@ __global__ __launch_bounds__(256) void patch_embed_mfma_kernel(PatchArgs a) {
         if (c0 < E) *(f32x4*)(orow + c0 * 4) = f32x4{acc[nb][4 * j], acc[nb][4 * j + 1], acc[nb][4 * j + 2], acc[nb][4 * j + 3]};
       }
     __syncthreads();
-    const int jl = tid & 15;
-    // 16 lanes per token, channel = i*16 + jl.  The embedding values and the per-sample adds of all eight rows of a lane group are
-    // requested up front: inside the row loop each of them was a dependent global round trip (eight per tile).
-    float cadd[8][3], ev[8][3];
+    // four lanes per token, three pieces of four channels each (piece = i * 4 + lane-in-group): 16-byte stream stores, 8-byte
+    // output stores; the embedding pieces and the per-sample adds of both passes are requested before the first row is reduced
+    const int jl = tid & 3;
+    f32x4 cadd[2][3];
+    f16x4 ev[2][3];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const long tok = tok0 + (tid >> 4) + 16 * it;
+    for (int it = 0; it < 2; ++it) {
+      const long tok = tok0 + (tid >> 2) + 64 * it;
       const bool ok = tok < total;
       const long tc = ok ? tok : 0;
       const int b = (int)(tc / per);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const int c = i * 16 + jl;
-        cadd[it][i] = a.bias[c] + (a.tadd ? a.tadd[(long)b * a.tadd_stride + c] : 0.f);
-        ev[it][i] = (a.emb && ok) ? (float)a.emb[tok * E + c] : 0.f;
+        const int c = (i * 4 + jl) * 4;
+        cadd[it][i] = *(const f32x4*)(a.bias + c);
+        if (a.tadd) {
+          const f32x4 ta = *(const f32x4*)(a.tadd + (long)b * a.tadd_stride + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cadd[it][i][e] += ta[e];
+        }
+        ev[it][i] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        if (a.emb) ev[it][i] = *(const f16x4*)(a.emb + tc * E + c);
       }
     }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = (tid >> 4) + 16 * it;
+    for (int it = 0; it < 2; ++it) {
+      const int row = (tid >> 2) + 64 * it;
       const long tok = tok0 + row;
       const bool ok = tok < total;
-      float v[3];
+      float v[12];
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const int c = i * 16 + jl;
-        v[i] = *(const float*)(At + row * a.o_row + c * 4) + cadd[it][i];
-        s += v[i];
+        const f32x4 dv = *(const f32x4*)(At + row * a.o_row + (i * 4 + jl) * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[4 * i + e] = dv[e] + cadd[it][i][e]; s += v[4 * i + e]; }
       }
 #pragma unroll
-      for (int o2 = 8; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2);
+      for (int o2 = 2; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2);
       const float mean = s / (float)E;
       float q = 0.f;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
+      for (int i = 0; i < 12; ++i) { const float dl = v[i] - mean; q = fmaf(dl, dl, q); }
 #pragma unroll
-      for (int o2 = 8; o2 > 0; o2 >>= 1) q += __shfl_xor(q, o2);
+      for (int o2 = 2; o2 > 0; o2 >>= 1) q += __shfl_xor(q, o2);
       const float rstd = rsqrtf(q / (float)E + a.eps);
       if (ok) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          const int c = i * 16 + jl;
-          if (a.x) a.x[tok * E + c] = v[i];
-          const float o = (v[i] - mean) * rstd + ev[it][i];
-          a.out[tok * a.out_stride + a.out_off + c] = (f16)o;
+          const int c = (i * 4 + jl) * 4;
+          if (a.x) *(f32x4*)(a.x + tok * E + c) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+          f16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = (f16)((v[4 * i + e] - mean) * rstd + (float)ev[it][i][e]);
+          *(f16x4*)(a.out + tok * a.out_stride + a.out_off + c) = ov;
         }
       }
     }
@@ -681,7 +680,8 @@ extern "C" int dua_token_linear(const dua_token_linear_desc* d, void* stream) {
       if (!d->x || d->samples != 1) return DUA_ERR_ARG;
       break;
     case DUA_TOKLIN_SCATTER:
-      if (!d->x || !d->ln_out || !d->gamma || !d->beta || !geom_ok(&d->geom) || d->geom.C != d->N || d->N % 16 || d->samples != 1) return DUA_ERR_ARG;
+      if (!d->x || !d->ln_out || !d->gamma || !d->beta || !geom_ok(&d->geom) || d->geom.C != d->N || (d->N != 48 && d->N != 96 && d->N != 192) || d->samples != 1) return DUA_ERR_ARG;
+      if (((size_t)d->gamma & 15) || ((size_t)d->beta & 15) || ((size_t)d->x & 15) || ((size_t)d->ln_out & 7)) return DUA_ERR_ARG;
       a.g = make_geom(&d->geom);
       if ((long)a.g.B * a.g.nw * a.g.n != d->M) return DUA_ERR_ARG;
       break;

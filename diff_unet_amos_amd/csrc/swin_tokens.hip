@@ -366,6 +366,9 @@ int dua_patch_embed(int dtype, int B, int D, int H, int W, int Cin_stride, int C
       Cin_packed > 32 || Cin_stride < Cin_packed || Cin_stride % 8 || !in || !w_packed || !bias || !out ||
       out_stride < out_off + E || out_stride % 8 || out_off % 8 || (tadd && tadd_stride < E))
     return DUA_ERR_ARG;
+  if (dtype == DUA_F16 && (((size_t)bias & 15) || ((size_t)w_packed & 15) || (tadd && (tadd_stride % 4 || ((size_t)tadd & 15))) ||
+                           (x && ((size_t)x & 15)) || (emb && ((size_t)emb & 7))))
+    return DUA_ERR_ARG;                                  // the MFMA form moves four-channel pieces
   const long total = (long)B * (D / 2) * (H / 2) * (W / 2);
   const size_t lds = (size_t)8 * Cin_packed * E * sizeof(float);
   dim3 grid((unsigned)((total + 255) / 256));

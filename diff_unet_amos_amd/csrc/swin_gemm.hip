@@ -54,13 +54,23 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
   char* At = smem + a.w_bytes;           // [128][a_row]     activation tile (one K chunk), then the output tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int K = a.K, N = a.N, kg = K >> 3;
-  for (int i = tid; i < NB * 32 * kg; i += 256) {
-    const int n = i / kg, g8 = i - n * kg;
-    f16x8 v;
+  for (int i0 = 0; i0 < NB * 32 * kg; i0 += 4 * 256) {           // weights: four 16-byte pieces per thread in flight (a load per
+    f16x8 wv[4];                                                  // iteration behind a row test went to memory one at a time)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
-    if (n < N) v = *(const f16x8*)(a.W + (long)n * K + g8 * 8);
-    *(f16x8*)(Wl + n * a.w_row + g8 * 16) = v;
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256 + tid;
+      const int n = i / kg, g8 = i - n * kg;
+      wv[u] = *(const f16x8*)(a.W + (n < N ? (long)n * K + g8 * 8 : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256 + tid;
+      const int n = i / kg, g8 = i - n * kg;
+      f16x8 v = wv[u];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = n < N ? v[e] : (f16)0.f;
+      if (i < NB * 32 * kg) *(f16x8*)(Wl + n * a.w_row + g8 * 16) = v;
+    }
   }
   const int sample = blockIdx.y;                                  // STATS: one grid row per sample
   const f16* A = a.A + (long)sample * a.M * a.lda;
@@ -76,7 +86,9 @@ __global__ __launch_bounds__(256) void token_linear_kernel(TokLinArgs a) {
   // conv3 with K <= 96 (one pass per tile): the NEXT tile's rows are requested as soon as this
   // tile's are in LDS and travel under its MFMAs, epilogue and copy-out -- a tile used to be load latency + compute + store
   // latency in a row (8.9 us per tile and workgroup on the 96^3 conv3, 3.1 TB/s with three workgroups per CU).
-  const bool single = MODE == DUA_TOKLIN_STATS && K <= 96;     // (the other epilogues lose more to the 55 extra registers -- a workgroup less per CU -- than the overlap gains: measured)
+  // (the other epilogues lose more to the 55 extra registers -- a workgroup less per CU -- than the overlap gains: measured; for
+  // the qkv form, which has two workgroups per CU by its LDS tile whatever its registers, it changes nothing: 20.1 vs 20.4 us)
+  const bool single = MODE == DUA_TOKLIN_STATS && K <= 96;
   constexpr int PF = 128 * 12 / 256;                              // 16-byte pieces per thread of a 128 x 96 tile
   f16x8 pf[PF];
   const int cpr1 = K >> 3;
@@ -326,13 +338,28 @@ __global__ __launch_bounds__(256) void swin_mlp_kernel(MlpArgs a) {
       const int n = i / kg, g8 = i - n * kg;
       *(f16x8*)(W1l + n * a.w1_row + g8 * 16) = *(const f16x8*)(a.W1 + (long)(p * HP + n) * C + g8 * 8);
     }
-    for (int i = tid; i < NB2 * 32 * HB * 2 * 2; i += 256) {      // W2p[c][nb][s][hh][8] <- W2[c][p*HP + nb*32 + 16 s + perm(hh, e)]
-      const int h2 = i & 1, s2 = (i >> 1) & 1, nb = (i >> 2) % HB, c = i / (4 * HB);
-      f16x8 v;
+    // W2p[c][nb][s][hh][8] <- W2[c][p*HP + nb*32 + 16 s + perm(hh, e)], perm = (e & 3) + 8 (e >> 2) + 4 hh: a 16-byte piece of a
+    // W2 row (hidden units 8 t .. 8 t + 7 of a 16-unit half block, t = 0 / 1) is elements 4 t .. 4 t + 3 of BOTH hh fragments --
+    // one 16-byte load and two 8-byte LDS writes (gathered per element it was 48 two-byte global loads per thread and launch)
+    for (int i0 = 0; i0 < NB2 * 32 * (HP / 8); i0 += 4 * 256) {
+      f16x8 wv[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        v[e] = c < C ? a.W2[(long)c * a.hidden + p * HP + nb * 32 + 16 * s2 + (e & 3) + 8 * (e >> 2) + 4 * h2] : (f16)0.f;
-      *(f16x8*)(W2l + c * a.w2_row + ((nb * 2 + s2) * 2 + h2) * 16) = v;
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256 + tid, c = i / (HP / 8), hc = i - c * (HP / 8);
+        wv[u] = *(const f16x8*)(a.W2 + (c < C ? (long)c * a.hidden + p * HP + hc * 8 : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256 + tid, c = i / (HP / 8), hc = i - c * (HP / 8);
+        if (i < NB2 * 32 * (HP / 8)) {
+          const int blk = hc >> 1, t = hc & 1;                      // blk = nb * 2 + s
+          f16x4 lo, hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { lo[e] = c < C ? wv[u][e] : (f16)0.f; hi[e] = c < C ? wv[u][4 + e] : (f16)0.f; }
+          *(f16x4*)(W2l + c * a.w2_row + (blk * 2 + 0) * 16 + t * 8) = lo;
+          *(f16x4*)(W2l + c * a.w2_row + (blk * 2 + 1) * 16 + t * 8) = hi;
+        }
+      }
     }
   };
   if constexpr (npass == 1) load_weights(0);

@@ -696,7 +696,7 @@ def test_instnorm_lrelu_backward_matches_autograd(dtype, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("shape", [(2, 16, 8, 8, 8), (1, 3, 5, 6, 7), (2, 13, 16, 8, 4)])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 8, 8), (1, 3, 5, 6, 7), (2, 13, 16, 8, 4), (1, 24, 9, 10, 11)])   # 16, 24: eight channels per read (fp16)
 def test_seg_loss_and_gradient_match_torch(dtype, shape):
     """Fused mse+bce+dice loss and its gradient against the oracle's restatement of losses/loss.py (fp64)."""
     from oracle.train_ref import RefLoss as Loss

@@ -69,6 +69,87 @@ __global__ void pack_conv3_dgrad_kernel(int Cout, int Cin, int nchunks, const fl
   }
 }
 
+// ---- the two packings above for fp16 with the identity channel map, through LDS (the training step repacks every layer's weights
+// twice per step).  One thread per OUTPUT element reads w with lanes 27 floats apart: every source line is touched by 27 different
+// waves and the 512 x 512 layer took 38 us for 42 MB.  Here a workgroup owns 8 output channels x one 32-channel chunk (forward) or
+// 32 x 8 (data gradient) for all 27 taps: the rows of w arrive as contiguous 16-byte pieces, pass through LDS as fp16 in w's own
+// order, and leave as 16-byte pieces of the packed layout, 128 contiguous bytes per (tap, k-group).  Cin % 4 == 0.
+__global__ __launch_bounds__(256) void pack_conv3_rows_kernel(int Cout, int Cin_src, int nchunks, const float* __restrict__ w,
+                                                              f16* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) f16 st[8 * 864];                     // [co 8][ci 32][27]
+  const int tid = threadIdx.x, cg = blockIdx.x & 7, ch = (blockIdx.x >> 3) % nchunks, ct = (blockIdx.x >> 3) / nchunks;
+  const int ci0 = ch * 32;
+  const int nv = Cin_src - ci0 < 0 ? 0 : (Cin_src - ci0 > 32 ? 32 : Cin_src - ci0), npc = nv * 27 / 4;   // valid pieces per row
+  f32x4 v[7];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    const int piece = tid + 256 * u, r = piece / 216, q = piece - r * 216, co = ct * 64 + cg * 8 + r;
+    const bool ok = piece < 1728 && co < Cout && q < npc;
+    v[u] = *(const f32x4*)(w + (ok ? ((long)co * Cin_src + ci0) * 27 + q * 4 : 0));
+  }
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    const int piece = tid + 256 * u, r = piece / 216, q = piece - r * 216, co = ct * 64 + cg * 8 + r;
+    const bool ok = co < Cout && q < npc;
+    if (piece < 1728) {
+      f16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = ok ? (f16)v[u][e] : (f16)0.f;
+      *(f16x4*)(st + r * 864 + q * 4) = h;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = tid + 256 * u;
+    if (p < 864) {
+      const int r = p & 7, kg = (p >> 3) & 3, tap = p >> 5;
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = st[r * 864 + (kg * 8 + e) * 27 + tap];
+      *(f16x8*)(out + ((((long)ct * nchunks + ch) * 27 + tap) * 4 + kg) * 512 + (cg * 8 + r) * 8) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_conv3_dgrad_rows_kernel(int Cout, int Cin, int nchunks, const float* __restrict__ w,
+                                                                    f16* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) f16 st[32 * 216];                    // [co 32][ci 8][27]
+  const int tid = threadIdx.x, cig = blockIdx.x & 7, ch = (blockIdx.x >> 3) % nchunks, ot = (blockIdx.x >> 3) / nchunks;
+  const int co0 = ch * 32, ci0 = ot * 64 + cig * 8;
+  const int nv = Cin - ci0 < 0 ? 0 : (Cin - ci0 > 8 ? 8 : Cin - ci0), npc = nv * 27 / 4;
+  f32x4 v[7];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    const int piece = tid + 256 * u, r = piece / 54, q = piece - r * 54, co = co0 + r;
+    const bool ok = piece < 1728 && co < Cout && q < npc;
+    v[u] = *(const f32x4*)(w + (ok ? ((long)co * Cin + ci0) * 27 + q * 4 : 0));
+  }
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    const int piece = tid + 256 * u, r = piece / 54, q = piece - r * 54, co = co0 + r;
+    const bool ok = co < Cout && q < npc;
+    if (piece < 1728) {
+      f16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = ok ? (f16)v[u][e] : (f16)0.f;
+      *(f16x4*)(st + r * 216 + q * 4) = h;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = tid + 256 * u;
+    if (p < 864) {
+      const int r = p & 7, kg = (p >> 3) & 3, tap = p >> 5;                    // r: input channel of the forward conv, tap: of the gradient conv
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = st[(kg * 8 + e) * 216 + r * 27 + 26 - tap];
+      *(f16x8*)(out + ((((long)ot * nchunks + ch) * 27 + tap) * 4 + kg) * 512 + (cig * 8 + r) * 8) = o;
+    }
+  }
+}
+
 // ---- deconv k2 s2 weights: [Cin][Cout][8] fp32 -> [tap][ct][chunk][kg][64][EPG] ----
 template <typename T>
 __global__ void pack_deconv_kernel(int Cin, int Cout, int nchunks, int nct, const float* __restrict__ w,
@@ -152,7 +233,10 @@ static long pack_conv3_common(int dtype, int Cout, int Cin_src, int Cin_packed, 
     hipLaunchKernelGGL(dua::pack_conv3_tap_kernel<dua::f16>, dim3(dua::nblocks(tap_total)), dim3(256), 0, (hipStream_t)stream,
                        Cout, Cin_src, tap_src, w, (dua::f16*)w_packed + total, tap_total);
   // in_perm must cover nchunks*ck entries when given
-  if (dtype == DUA_F16)
+  if (dtype == DUA_F16 && !in_perm && tap_channel < 0 && Cin_src % 4 == 0 && ((size_t)w & 15) == 0)
+    hipLaunchKernelGGL(dua::pack_conv3_rows_kernel, dim3(nct * nchunks * 8), dim3(256), 0, (hipStream_t)stream, Cout, Cin_src, nchunks,
+                       w, (dua::f16*)w_packed);
+  else if (dtype == DUA_F16)
     hipLaunchKernelGGL(dua::pack_conv3_kernel<dua::f16>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
                        Cout, Cin_src, nchunks, w, in_perm, (dua::f16*)w_packed, total, tap_channel);
   else
@@ -171,7 +255,10 @@ long dua_pack_conv3_weights_dgrad(int dtype, int Cout, int Cin, int Cout_packed,
   const long bytes = total * (dtype == DUA_F16 ? 2 : 4);
   if (!w_packed) return bytes;
   if (!w) return DUA_ERR_ARG;
-  if (dtype == DUA_F16)
+  if (dtype == DUA_F16 && Cin % 4 == 0 && ((size_t)w & 15) == 0)
+    hipLaunchKernelGGL(dua::pack_conv3_dgrad_rows_kernel, dim3(not_ * nchunks * 8), dim3(256), 0, (hipStream_t)stream, Cout, Cin, nchunks,
+                       w, (dua::f16*)w_packed);
+  else if (dtype == DUA_F16)
     hipLaunchKernelGGL(dua::pack_conv3_dgrad_kernel<dua::f16>, dim3(dua::nblocks(total)), dim3(256), 0, (hipStream_t)stream,
                        Cout, Cin, nchunks, w, (dua::f16*)w_packed, total);
   else

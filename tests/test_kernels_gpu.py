@@ -619,6 +619,26 @@ def test_conv3_wgrad_matches_torch(dtype, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 64, 64), (136, 72, 80), (40, 100, 128), (512, 256, 256)])   # Cout, Cin, packed input channels
+def test_fp16_weight_packing_through_lds_equals_the_elementwise_kernels(shape):
+    """dua_pack_conv3_weights / _dgrad take an LDS-transposing kernel for fp16 with the identity channel map; the one-thread-per-
+    element kernels (still used with a channel map and for fp32) must give the same bytes."""
+    ops = _ops()
+    Cout, Cin, cp = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g).cuda()
+    fast, _ = ops.pack_conv3_weights(w, None, torch.float16, cin_packed=cp, pad_bias=False)
+    slow, _ = ops.pack_conv3_weights(w, None, torch.float16, cin_packed=cp, perm=list(range(Cin)) + [-1] * (cp - Cin), pad_bias=False)
+    assert torch.equal(fast, slow)
+    # data gradient: the packing of the flipped, transposed weights
+    coutp = -(-Cout // 32) * 32
+    dg, _ = ops.pack_conv3_weights_dgrad(w, torch.float16, cout_packed=coutp)
+    wt = w.flip(2, 3, 4).transpose(0, 1).contiguous()
+    ref, _ = ops.pack_conv3_weights(wt, None, torch.float16, cin_packed=coutp, perm=list(range(Cout)) + [-1] * (coutp - Cout), pad_bias=False)
+    assert torch.equal(dg, ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", [32, 1, 2, 64])  # plain k loop; plain block order; one workgroup per CU; 12 waves
 def test_conv3_wgrad_launch_variants_agree(variant):
     ops = _ops()

@@ -192,8 +192,12 @@ class _UpCat(torch.autograd.Function):
         N, D, H, W, cs = skip.shape
         cin, cout = weight.shape[:2]
         assert lo.is_contiguous() and lo.shape[-1] == cin and cin % 8 == 0 and cout % 8 == 0 and cs % 8 == 0
-        cat = torch.empty((N, D, H, W, cs + cout), dtype=skip.dtype, device=skip.device)
-        cat[..., :cs].copy_(skip)
+        buf, off = _slice_of(skip)
+        if buf is not skip and off == 0 and buf.shape[-1] == cs + cout:
+            cat = buf                # the skip was materialised straight into its concat buffer (_ConvNormAct, cat_extra): no copy
+        else:
+            cat = torch.empty((N, D, H, W, cs + cout), dtype=skip.dtype, device=skip.device)
+            cat[..., :cs].copy_(skip)
         w32 = weight.detach().float().contiguous()
         wp, bp = ops.pack_deconv_weights(w32, bias.detach().float(), skip.dtype)
         ops.deconv_k2s2(lo, cin, 0, wp, bp, cout, cat, cs)
@@ -220,7 +224,10 @@ class _ConvNormAct(torch.autograd.Function):
     backward = norm/activation backward (reduce + apply) -> data gradient (conv kernel) + weight gradient kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False):
+    def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False, cat_extra=0):
+        """``cat_extra`` > 0: the activation is the skip of a decoder level -- it is written into channels [0, cout) of a buffer
+        with ``cat_extra`` more channels (the half the transposed convolution fills later, _UpCat) and returned as that view:
+        torch.cat((x_e, upsampled)) (denoiser.py:190) costs no copy (226 MB moved per step at level 0 otherwise)."""
         from . import ops
         N, D, H, W, cs = x.shape
         cout = weight.shape[0]
@@ -233,9 +240,13 @@ class _ConvNormAct(torch.autograd.Function):
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         a32 = add.detach().float().contiguous() if add is not None else None
         norm = ops.Norm(stats, g32, b32, D * H * W, add=a32, add_stride=cout)
-        act = torch.empty_like(raw)
+        if cat_extra:
+            cat = torch.empty((N, D, H, W, cout + cat_extra), dtype=x.dtype, device=x.device)
+            act = cat[..., :cout]
+        else:
+            cat = act = torch.empty_like(raw)
         pooled = torch.empty((N, D // 2, H // 2, W // 2, cout), dtype=x.dtype, device=x.device) if pool else None
-        ops.materialize(raw, cout, norm, act, 0, emb=emb.detach() if emb is not None else None, pooled=pooled)
+        ops.materialize(raw, cout, norm, cat, 0, emb=emb.detach() if emb is not None else None, pooled=pooled)
         ctx.save_for_backward(x, weight, raw, stats, g32, b32, act if pool else None)
         ctx.has_add, ctx.has_emb, ctx.pool = add is not None, emb is not None, pool
         return (act, pooled) if pool else act
@@ -247,7 +258,8 @@ class _ConvNormAct(torch.autograd.Function):
         N, D, H, W, cout = raw.shape
         buf, off = _slice_of(dA) if dA is not None else (None, 0)       # a concat half's gradient is read in place
         if ctx.pool and dP is not None:       # MaxPool3d(2) backward + the skip-path gradient in one pass
-            dA = buf = ops.maxpool2_bwd_add(act, 0, cout, buf, off, dP.contiguous())
+            abuf, aoff = _slice_of(act)         # the activation may live in its decoder's concat buffer (cat_extra)
+            dA = buf = ops.maxpool2_bwd_add(abuf, aoff, cout, buf, off, dP.contiguous())
             off = 0
         norm = ops.Norm(stats, g32, b32, D * H * W)
         dY = torch.empty_like(raw)
@@ -259,16 +271,18 @@ class _ConvNormAct(torch.autograd.Function):
             dw = ops.zeros(tuple(weight.shape), torch.float32, x.device)
             _wgrad(x, dY, cout, dw)
         db = ops.zeros((cout,), torch.float32, x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
-        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None
+        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None, None
 
 
-def _two_conv_cl(block, x, temb, emb=None, pool=False):
+def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0):
+    """``temb``: swish(t_embedder(t)) -- the nonlinearity every block applies to the same embedding (denoiser.py:65) is computed
+    once per evaluation by the caller; the nine blocks used to launch it (and its backward) nine times."""
     add = None
     if temb is not None:
-        add = F.linear(temb * torch.sigmoid(temb), block.temb_proj.weight, block.temb_proj.bias)
+        add = F.linear(temb, block.temb_proj.weight, block.temb_proj.bias)
     c0, c1 = block.conv_0, block.conv_1
     h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None)
-    return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb, pool)
+    return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb, pool, cat_extra)
 
 
 class _Head(torch.autograd.Function):
@@ -331,11 +345,13 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
         e, pe = (r, None) if last else r
         emb.append(e)
     temb = _time_embedding(den.temb, step)
+    temb = temb * torch.sigmoid(temb)                # swish, shared by the blocks' temb_proj (see _two_conv_cl)
     h = _cl_pad(torch.cat([image, x], dim=1), dtype)
-    x0, p0 = _two_conv_cl(den.conv_0, h, temb, emb[0], True)
-    x1, p1 = _two_conv_cl(den.down_1.convs, p0, temb, emb[1], True)
-    x2, p2 = _two_conv_cl(den.down_2.convs, p1, temb, emb[2], True)
-    x3, p3 = _two_conv_cl(den.down_3.convs, p2, temb, emb[3], True)
+    up_c = [blk.upsample.deconv.weight.shape[1] for blk in (den.upcat_1, den.upcat_2, den.upcat_3, den.upcat_4)]   # channels each
+    x0, p0 = _two_conv_cl(den.conv_0, h, temb, emb[0], True, up_c[0])                                            # decoder adds to the skip
+    x1, p1 = _two_conv_cl(den.down_1.convs, p0, temb, emb[1], True, up_c[1])
+    x2, p2 = _two_conv_cl(den.down_2.convs, p1, temb, emb[2], True, up_c[2])
+    x3, p3 = _two_conv_cl(den.down_3.convs, p2, temb, emb[3], True, up_c[3])
     x4 = _two_conv_cl(den.down_4.convs, p3, temb, emb[4])
 
     def up(block, lo, skip):

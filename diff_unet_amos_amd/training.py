@@ -157,12 +157,26 @@ class _Conv3dK3(torch.autograd.Function):
         return dx, dw, db
 
 
-def _cl_pad(x_ncdhw, dtype):
-    """NCDHW -> channels-last with the channel count padded to a multiple of 8 (zeros)."""
-    N, C = x_ncdhw.shape[:2]
+def _cl_pad(parts, dtype):
+    """torch.cat(parts, 1) (NCDHW tensors) -> channels-last with the channel count padded to a multiple of 8 (zeros).  Inputs that
+    carry no gradient (the training step's image and x_t) go through dua_to_channels_last, one pass per part; the cat / fill /
+    strided-copy route of torch stays for anything else."""
+    parts = list(parts) if isinstance(parts, (list, tuple)) else [parts]
+    N = parts[0].shape[0]
+    C = sum(p.shape[1] for p in parts)
     cp = -(-C // 8) * 8
-    out = x_ncdhw.new_zeros((N, *x_ncdhw.shape[2:], cp), dtype=dtype)
-    out[..., :C] = x_ncdhw.permute(0, 2, 3, 4, 1)
+    if all(p.is_cuda and p.dtype == torch.float32 and not p.requires_grad for p in parts):
+        from . import ops
+        out = torch.empty((N, *parts[0].shape[2:], cp), dtype=dtype, device=parts[0].device)
+        off = 0
+        for i, p in enumerate(parts):
+            last = i == len(parts) - 1
+            ops.to_channels_last(p.contiguous(), out, off, c_fill=(cp - off) if last else None)
+            off += p.shape[1]
+        return out
+    x = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+    out = x.new_zeros((N, *x.shape[2:], cp), dtype=dtype)
+    out[..., :C] = x.permute(0, 2, 3, 4, 1)
     return out
 
 
@@ -346,7 +360,7 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
         emb.append(e)
     temb = _time_embedding(den.temb, step)
     temb = temb * torch.sigmoid(temb)                # swish, shared by the blocks' temb_proj (see _two_conv_cl)
-    h = _cl_pad(torch.cat([image, x], dim=1), dtype)
+    h = _cl_pad([image, x], dtype)
     up_c = [blk.upsample.deconv.weight.shape[1] for blk in (den.upcat_1, den.upcat_2, den.upcat_3, den.upcat_4)]   # channels each
     x0, p0 = _two_conv_cl(den.conv_0, h, temb, emb[0], True, up_c[0])                                            # decoder adds to the skip
     x1, p1 = _two_conv_cl(den.down_1.convs, p0, temb, emb[1], True, up_c[1])

@@ -904,9 +904,9 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 }
 
 
-static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups, int target = 320) {
+static inline void choose_split(int base_wgs, int units, int* ksplit, int* ups, int target = 320, int max_base = 64) {
   *ksplit = 1; *ups = units;
-  if (base_wgs > 64 || units <= 1) return;        // 24^3 and up: the partial-tile round trip costs more than it buys
+  if (base_wgs > max_base || units <= 1) return;  // 24^3 and up: the partial-tile round trip costs more than it buys
   int want = target == 320 ? (320 + base_wgs - 1) / base_wgs : target / base_wgs;   // ~one workgroup per CU, each keeping >= a few units of work
   if (want < 1) want = 1;
   if (want > units) want = units;
@@ -1006,11 +1006,12 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   if constexpr (sizeof(T) == 2) {
     if (kind == 2) return launch_conv3_wide(a, d->D, s);
   }
-  const bool autop = g_conv_variant == 0 || g_conv_variant == 6 || g_conv_variant == 7;       // the automatic policy; 6 = without the kd-plane form, 7 = without the wide-tile form (A/B)
-  const bool big = g_conv_variant == 0 || g_conv_variant == 7;          // kd-plane form for the layers that cannot put two workgroups on every CU
+  const bool autop = g_conv_variant == 0 || g_conv_variant == 2 || g_conv_variant == 6 || g_conv_variant == 7;       // the automatic policy; 6 = without the kd-plane form, 7 = without the wide-tile form (A/B)
+  const bool big = g_conv_variant == 0 || g_conv_variant == 2 || g_conv_variant == 7;          // kd-plane form for the layers that cannot put two workgroups on every CU
   if (ws != nullptr && autop) {
     int ks, ups;
-    choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups, big ? 256 : 320);
+    if (g_conv_variant == 2) choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups, 512, 256);    // A/B: K split up to 256 base workgroups
+    else choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups, big ? 256 : 320);
     if (ks > 1 && (long)ks * d->N * vox * a.cout_pad * 4 <= ws_bytes) { a.ksplit = ks; a.units_per_split = ups; a.part = ws; }
   }
   // 24^3-sized layers (too few 4x8x8 tiles for 256 CUs, too big for split-K to pay): 2x8x8 tiles, twice the workgroups
@@ -1019,7 +1020,10 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     a.ntiles = td2 * a.tiles_h * a.tiles_w;
     dim3 grid2(a.ntiles, nct, d->N);
     constexpr int LDS2 = 4 * c3::HH * c3::RS + 2 * c3v2::SLAB;
-    if (big) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2, 2, false, true>), grid2, dim3(256), 4 * c3::HH * c3::RS + 9 * c3v2::SLAB + xf_bytes, s, a);
+    // the kd-plane form (nine slabs resident: one workgroup per CU) only while every workgroup has a CU of its own; with more of
+    // them (12^3 at batch 4: 384) two slab-pipeline workgroups per CU are faster (64.3 vs 79.8 us on 256 -> 256, tools/bench_conv.py)
+    const bool big2 = big && (long)a.ntiles * nct * d->N <= 256;
+    if (big2) hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2, 2, false, true>), grid2, dim3(256), 4 * c3::HH * c3::RS + 9 * c3v2::SLAB + xf_bytes, s, a);
     else hipLaunchKernelGGL((conv3d_k3_v2_kernel<T, 2>), grid2, dim3(256), LDS2 + xf_bytes, s, a);
     return (int)hipGetLastError();
   }

@@ -47,7 +47,8 @@ def main():
     for idx, (S, cin, cout, fused) in enumerate(SHAPES):
         if only is not None and idx not in only:
             continue
-        x = torch.randn(1, S, S, S, cin, device=dev).to(dt)
+        B = int(os.environ.get("BENCH_CONV_BATCH", "1"))            # samples per launch (config 3 runs 4, config 4 runs 2)
+        x = torch.randn(B, S, S, S, cin, device=dev).to(dt)
         tap = 16 if cin == 24 else None                     # the denoiser's first layer: [16 x_t | image | pad], tap form
         if tap:
             w = torch.randn(cout, 17, 3, 3, 3, device=dev) / (27 * 17) ** 0.5
@@ -56,17 +57,17 @@ def main():
         else:
             w = torch.randn(cout, cin, 3, 3, 3, device=dev) / (27 * cin) ** 0.5
             wp, bp = ops.pack_conv3_weights(w, torch.zeros(cout, device=dev), dt)
-        y = torch.empty(1, S, S, S, cout, device=dev, dtype=dt)
-        stats = ops.stats_buffer(1, cout, dev)
-        nb = ops.conv3_workspace_bytes(dt, 1, S, S, S, cin, cout)
+        y = torch.empty(B, S, S, S, cout, device=dev, dtype=dt)
+        stats = ops.stats_buffer(B, cout, dev)
+        nb = max(ops.conv3_workspace_bytes(dt, B, S, S, S, cin, cout), 8 * B * S ** 3 * 256 * 4 if S <= 24 else 0)
         ws = torch.empty(max(nb, 16) // 4, device=dev)
         norm = None
         if fused:
-            sums = torch.zeros(1, cin, 2, dtype=torch.float64, device=dev)
+            sums = torch.zeros(B, cin, 2, dtype=torch.float64, device=dev)
             sums[..., 1] = float(S ** 3)                   # mean 0, variance 1
             st = ops.stats_encode(sums)
             norm = ops.Norm(st, torch.ones(cin, device=dev), torch.zeros(cin, device=dev), S ** 3,
-                            add=torch.zeros(cin, device=dev))
+                            add=torch.zeros(B, cin, device=dev))
         res = {v: [] for v in variants}
         # every variant's launch is captured once (REP launches per graph): replay timing is free of the host's per-call cost,
         # which exceeds the run time of the small layers
@@ -79,7 +80,7 @@ def main():
             else:
                 nv._lib = main_lib
                 ops.CONV_POLICY = v[0] if isinstance(v, tuple) else v
-                blk = isinstance(v, tuple) and v[1] and ops.conv3_kernel_kind(dt, 1, S, S, S, cin, cin, cout, fused=fused, tap_channel=tap) == ops.KIND_WIDE
+                blk = isinstance(v, tuple) and v[1] and ops.conv3_kernel_kind(dt, B, S, S, S, cin, cin, cout, fused=fused, tap_channel=tap) == ops.KIND_WIDE
             run = lambda blk=(False if isinstance(v, str) else blk): ops.conv3d_k3(x, cin, 0, wp, bp, cout, y, 0, stats, norm=norm, workspace=ws, tap_channel=tap, in_blocked=blk)  # noqa: E731
             run()
             torch.cuda.synchronize()
@@ -99,7 +100,7 @@ def main():
                 torch.cuda.synchronize()
                 if rd > 0:
                     res[v].append(e0.elapsed_time(e1) / REP * 1e3)
-        fl = 2.0 * (17 if tap else cin) * cout * 27 * S ** 3
+        fl = 2.0 * (17 if tap else cin) * cout * 27 * S ** 3 * B
         out = []
         for v in variants:
             us = sorted(res[v])[len(res[v]) // 2]

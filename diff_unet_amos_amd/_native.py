@@ -105,8 +105,22 @@ class TokenLinearDesc(C.Structure):
 
 TOKLIN_PLAIN, TOKLIN_GELU, TOKLIN_STATS, TOKLIN_RESIDUAL, TOKLIN_SCATTER = range(5)
 
+TEMB_MAX_BLOCKS, ADAMW_MAX_TENSORS = 16, 64
+
+
+class TembBlocks(C.Structure):
+    """dua_temb_blocks."""
+    _fields_ = [("nblocks", C.c_int), ("cout", C.c_int * TEMB_MAX_BLOCKS), ("w", C.c_void_p * TEMB_MAX_BLOCKS),
+                ("b", C.c_void_p * TEMB_MAX_BLOCKS), ("dw", C.c_void_p * TEMB_MAX_BLOCKS), ("db", C.c_void_p * TEMB_MAX_BLOCKS)]
+
+
+class AdamWList(C.Structure):
+    """dua_adamw_list."""
+    _fields_ = [("count", C.c_int), ("numel", C.c_long * ADAMW_MAX_TENSORS), ("p", C.c_void_p * ADAMW_MAX_TENSORS),
+                ("g", C.c_void_p * ADAMW_MAX_TENSORS), ("m", C.c_void_p * ADAMW_MAX_TENSORS), ("v", C.c_void_p * ADAMW_MAX_TENSORS)]
+
 _P = C.c_void_p
-ABI_VERSION = 5          # DUA_ABI_VERSION of include/dua_hip.h this binding was written against
+ABI_VERSION = 6          # DUA_ABI_VERSION of include/dua_hip.h this binding was written against
 
 _SIGS = {
     "dua_abi_version": (C.c_int, []),
@@ -165,6 +179,15 @@ _SIGS = {
     "dua_pack_deconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_to_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dua_from_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, C.c_int, _P, _P]),
+    "dua_stats_channel_sums": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "dua_seg_loss_finish": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "dua_q_sample_affine": (C.c_int, [C.c_int, C.c_long, _P, C.c_float, C.c_float, _P, _P, C.c_int, _P, _P, _P]),
+    "dua_temb_train_fwd": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.POINTER(TembBlocks), _P, _P, _P]),
+    "dua_temb_train_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(TembBlocks), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_grads_nonfinite": (C.c_int, [C.POINTER(AdamWList), _P, _P]),
+    "dua_adamw_step": (C.c_int, [C.POINTER(AdamWList), C.c_float, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P,
+                                 C.c_int, _P]),
+    "dua_adamw_advance": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_int, _P, _P]),
 }
 
 _lib = None

@@ -451,7 +451,13 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Arg
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int co = q * 32 + r;
-    float s = 0.f, ss = 0.f;
+    // fp32 (parity) instantiations keep the lane's partial sums in double: a channel whose mean is ~100 standard deviations
+    // loses three digits of its variance to fp32 partial sums of x^2 (sum x^2 / n - mean^2), and InstanceNorm's backward
+    // amplifies that further (seen as 15 % errors on single channels of coarse-level weight gradients against an fp64 oracle
+    // where torch's CPU fp32 path shows 2e-6); each wave then adds its own contribution to the statistics words.
+    constexpr bool F32 = sizeof(T) == 4;
+    using part_t = typename std::conditional<F32, double, float>::type;
+    part_t s = 0, ss = 0;
     if (full) {
 #pragma unroll
       for (int m = 0; m < MB; ++m)
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Arg
         for (int i = 0; i < 16; ++i) {
           const float v = acc[m][q][i];
           s += v;
-          ss = fmaf(v, v, ss);
+          if constexpr (F32) ss += (double)v * (double)v; else ss = fmaf(v, v, ss);
           *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = (T)v;
         }
     } else {
@@ -471,13 +477,18 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Arg
           const bool ok = dok && (h0 + hl < a.H) && (w0 + wl < a.W);
           const float v = ok ? acc[m][q][i] : 0.f;
           s += v;
-          ss = fmaf(v, v, ss);
+          if constexpr (F32) ss += (double)v * (double)v; else ss = fmaf(v, v, ss);
           *(T*)(ot + (m * 32 + acc_row(i, hh)) * OS + r * (int)sizeof(T)) = (T)v;
         }
     }
     s += __shfl_xor(s, 32);
     ss += __shfl_xor(ss, 32);
-    if (hh == 0) { ex[(wave * BN + co) * 2] = s; ex[(wave * BN + co) * 2 + 1] = ss; }
+    if constexpr (F32) {
+      if (hh == 0 && ct * BN + co < a.Cout)
+        stats_add(a.stats, n, a.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + co, (double)s, (double)ss);
+    } else {
+      if (hh == 0) { ex[(wave * BN + co) * 2] = (float)s; ex[(wave * BN + co) * 2 + 1] = (float)ss; }
+    }
     __syncthreads();
     if (dok) {
       constexpr int GPV = 32 / EPG;            // 16-byte groups per voxel in this half
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(256, BIG ? 1 : 2) void conv3d_k3_v2_kernel(Conv3Arg
     }
     if (q == 0) __syncthreads();               // staging tile is reused by the second half
   }
-  if (wave == 0) {
+  if (wave == 0 && sizeof(T) == 2) {
     double S = 0, Q = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
@@ -800,11 +811,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                                                             int cout_pad, int Cout, const float* __restrict__ bias,
                                                             T* __restrict__ y, int Cout_stride, int Cout_off,
                                                             stat_t* stats, int G, int VL, int ITER) {
-  __shared__ float red[256][8];
+  using part_t = typename std::conditional<sizeof(T) == 4, double, float>::type;       // see the convolution epilogue
+  __shared__ part_t red[256][8];
   const int n = blockIdx.y;
   const int cg = threadIdx.x % G, vl = threadIdx.x / G;
   const int c = cg * 4;
-  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  part_t s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
   if (c < Cout) b4 = *(const f32x4*)(bias + c);      // Cout is a multiple of 8, c of 4: bias needs Cout entries only
   if (vl < VL && ITER == 2 && ksplit <= 8) {
@@ -836,7 +848,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
       for (int e = 0; e < 4; ++e) {
         o[e] = (T)acc[i][e];
         const float f = (float)o[e];
-        s[e] += f; q[e] += f * f;
+        s[e] += f; q[e] += (part_t)f * (part_t)f;
       }
       if (c < Cout) {
         T* yp = y + ((long)n * vox + v) * Cout_stride + Cout_off + c;
@@ -881,7 +893,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
       for (int e = 0; e < 4; ++e) {
         o[e] = (T)acc[e];
         const float f = (float)o[e];
-        s[e] += f; q[e] += f * f;
+        s[e] += f; q[e] += (part_t)f * (part_t)f;
       }
       if (c < Cout) {
         T* yp = y + ((long)n * vox + v) * Cout_stride + Cout_off + c;

@@ -8,6 +8,7 @@ channels-last tensors of shape [N, D, H, W, Cstride].
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import torch
 
@@ -165,6 +166,8 @@ def pack_deconv_weights(w, bias, dtype):
     if rc != nbytes:
         raise RuntimeError(f"dua_pack_deconv_weights failed ({rc})")
     cpad = -(-cout // 64) * 64
+    if bias is not None and cpad == cout and bias.dtype == torch.float32 and bias.is_contiguous():
+        return buf, bias.detach()                 # already a whole number of output tiles: no fill + copy per call
     b = torch.zeros(cpad, dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:cout] = bias.detach().float()
@@ -244,6 +247,17 @@ def stats_decode(stats):
     S = w[:, 0].double() + w[:, 1].double() / STAT_FRAC
     Q = w[:, 2].double() + w[:, 3].double() / STAT_FRAC
     return torch.stack([S, Q], -1)
+
+
+def stats_channel_sums(stats, c):
+    """fp32 [c] = sum over the samples of the decoded "sum x" words (stats_decode(stats)[:, :c, 0].sum(0).float()) in one
+    launch: a bias gradient from the statistics rows accumulated over a layer's output gradient."""
+    assert stats.is_cuda and stats.dtype == torch.int64 and stats.is_contiguous() and stats.dim() == 4
+    assert stats.shape[1] == STAT_REPLICAS and stats.shape[2] == STAT_WORDS and 0 < c <= stats.shape[3]
+    out = torch.empty(c, dtype=torch.float32, device=stats.device)
+    nv.check(nv.lib().dua_stats_channel_sums(stats.shape[0], c, stats.shape[3], nv.ptr(stats), nv.ptr(out), nv.stream_ptr()),
+             "dua_stats_channel_sums")
+    return out
 
 
 def stats_encode(sums, out=None):
@@ -450,7 +464,7 @@ def instnorm_finalize(norm, N, Cc):
     return scale, shift
 
 
-def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0, want_add=True):
+def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0, want_add=True, dadd_out=None):
     """Backward of LeakyReLU(IN(raw)) [+ add] for channels [0, Cc) of ``raw``: writes d raw into ``dY`` and returns the
     parameter gradients (dgamma [Cc], dbeta [Cc], dadd [N, Cc] or None), fp32, emitted by the apply launch itself."""
     _cl_check(dA, "dA"); _cl_check(raw, "raw"); _cl_check(dY, "dY")
@@ -466,7 +480,10 @@ def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0, want_add=True):
     nv.check(L.dua_instnorm_bwd_reduce(C.byref(d), nv.ptr(dA), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(sums), nv.stream_ptr()),
              "dua_instnorm_bwd_reduce")
     pg = zeros((2, Cc), torch.float32, raw.device)              # dgamma, dbeta (accumulated over the samples)
-    dadd = torch.empty((N, Cc), dtype=torch.float32, device=raw.device) if want_add else None
+    dadd = None
+    if want_add:
+        dadd = dadd_out if dadd_out is not None else torch.empty((N, Cc), dtype=torch.float32, device=raw.device)
+        assert dadd.dtype == torch.float32 and dadd.is_contiguous() and dadd.numel() == N * Cc
     nv.check(L.dua_instnorm_bwd_apply(C.byref(d), nv.ptr(dA), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(sums), nv.ptr(dY),
                                       nv.ptr(pg[0]), nv.ptr(pg[1]), nv.ptr(dadd), nv.stream_ptr()), "dua_instnorm_bwd_apply")
     return pg[0], pg[1], dadd
@@ -571,18 +588,11 @@ def seg_loss_reduce(logits, labels, names=LOSS_NAMES, combine="sum"):
     sums = zeros((N * Cc * 4 + 2,), torch.float64, logits.device)
     nv.check(nv.lib().dua_seg_loss_reduce(nv.dt_code(logits.dtype), N, Cc, V, nv.ptr(logits), logits.shape[-1], nv.ptr(labels),
                                           nv.ptr(sums), nv.stream_ptr()), "dua_seg_loss_reduce")
-    q = sums[:N * Cc * 4].view(N, Cc, 4)
-    M = float(N * Cc * V)
-    terms = {"mse": sums[-2] / M, "bce": sums[-1] / M,
-             "dice": (1.0 - (2.0 * q[..., 0] + 1e-5) / (q[..., 1] + q[..., 2] + 1e-5)).mean()}
-    total = sum(terms[n_] for n_ in names)
-    if len(names) == 1 or combine == "sum":          # loss.py:77-78: a single loss is returned as it is
-        L, dcomb = total, torch.ones((), dtype=torch.float64, device=logits.device)
-    elif combine == "mean":
-        L, dcomb = total / len(names), torch.full((), 1.0 / len(names), dtype=torch.float64, device=logits.device)
-    else:
-        L, dcomb = torch.log(1 + total), 1.0 / (1 + total)
-    return L.float(), sums, dcomb.float()
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)             # (L, d L / d total)
+    nv.check(nv.lib().dua_seg_loss_finish(N, Cc, V, int("mse" in names), int("bce" in names), int("dice" in names),
+                                          ("sum", "mean", "log").index(combine), nv.ptr(sums), nv.ptr(out[0:]), nv.ptr(out[1:]),
+                                          nv.stream_ptr()), "dua_seg_loss_finish")
+    return out[0], sums, out[1]
 
 
 def seg_loss_grad(logits, labels, sums, gscale, names=LOSS_NAMES):
@@ -659,6 +669,142 @@ def q_sample(x0, eps, coef, out=None):
     nv.check(nv.lib().dua_q_sample(x0.shape[0], x0[0].numel(), nv.ptr(x0), nv.ptr(eps), nv.ptr(coef), nv.ptr(out),
                                    nv.stream_ptr()), "dua_q_sample")
     return out
+
+
+def q_sample_affine(src, a, b, eps, sched, t, out=None):
+    """q_sample(a * src + b, t, eps) in one pass (train.py:258-262): sched fp32 [T, 2] = (sqrt(alphas_cumprod),
+    sqrt(1 - alphas_cumprod)), t int64 [N], both on the device."""
+    _f32c(src, "src"); _f32c(eps, "eps"); _f32c(sched, "sched")
+    assert eps.shape == src.shape and sched.dim() == 2 and sched.shape[1] == 2
+    assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == src.shape[0]
+    out = torch.empty_like(src) if out is None else out
+    _f32c(out, "out")
+    nv.check(nv.lib().dua_q_sample_affine(src.shape[0], src[0].numel(), nv.ptr(src), float(a), float(b), nv.ptr(eps), nv.ptr(sched),
+                                          sched.shape[0], nv.ptr(t), nv.ptr(out), nv.stream_ptr()), "dua_q_sample_affine")
+    return out
+
+
+_TEMB_FREQS = {}
+
+
+def temb_freqs(half, device):
+    """exp(arange(half) * -(ln 10000 / (half - 1))) as models/diffusion/utils.py:15-17 computes it (fp32), cached per device."""
+    key = (half, str(device))
+    if key not in _TEMB_FREQS:
+        _TEMB_FREQS[key] = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(device)
+    return _TEMB_FREQS[key]
+
+
+def _temb_blocks(ws, bs=None, dws=None, dbs=None):
+    assert 0 < len(ws) <= nv.TEMB_MAX_BLOCKS
+    blk = nv.TembBlocks()
+    blk.nblocks = len(ws)
+    for i, w in enumerate(ws):
+        _f32c(w, "temb_proj.weight")
+        blk.cout[i] = w.shape[0]
+        blk.w[i] = w.data_ptr()
+        for arr, src in ((blk.b, bs), (blk.dw, dws), (blk.db, dbs)):
+            if src is not None:
+                _f32c(src[i], "temb_proj operand")
+                arr[i] = src[i].data_ptr()
+    return blk
+
+
+def temb_train_fwd(t, half, w0, b0, w1, b1, proj_w, proj_b):
+    """Timestep embedding of a training step (utils.py:5-54 + denoiser.py:51-52,65) for int64 timesteps ``t`` [N]: returns
+    (add, saved): add = flat fp32, BLOCK-MAJOR (block b's [N, cout_b] rows at offset N * sum(cout[:b])); saved = the
+    activations dua_temb_train_bwd needs."""
+    assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()
+    for v in (w0, b0, w1, b1):
+        _f32c(v, "temb param")
+    N, hid = t.numel(), w1.shape[0]
+    assert tuple(w0.shape) == (hid, 2 * half) and tuple(w1.shape) == (hid, hid) and all(w.shape[1] == hid for w in proj_w)
+    P = sum(w.shape[0] for w in proj_w)
+    add = torch.empty(N * P, dtype=torch.float32, device=t.device)
+    saved = torch.empty((N, 2 * half + 4 * hid), dtype=torch.float32, device=t.device)
+    blk = _temb_blocks(proj_w, bs=proj_b)
+    nv.check(nv.lib().dua_temb_train_fwd(N, nv.ptr(t), nv.ptr(temb_freqs(half, t.device)), half, hid, nv.ptr(w0), nv.ptr(b0),
+                                         nv.ptr(w1), nv.ptr(b1), C.byref(blk), nv.ptr(add), nv.ptr(saved), nv.stream_ptr()),
+             "dua_temb_train_fwd")
+    return add, saved
+
+
+def temb_train_bwd(dadd, saved, half, w1, proj_w):
+    """Every parameter gradient of temb_train_fwd from d add (block-major like add): returns (dw0, db0, dw1, db1, [dw_b], [db_b]),
+    views of one flat fp32 buffer, written (not accumulated) by two launches."""
+    _f32c(dadd, "dadd"); _f32c(saved, "saved"); _f32c(w1, "w1")
+    N, hid = saved.shape[0], w1.shape[0]
+    ed = 2 * half
+    P = sum(w.shape[0] for w in proj_w)
+    assert dadd.numel() == N * P and saved.shape[1] == ed + 4 * hid
+    flat = torch.empty(hid * ed + hid + hid * hid + hid + P * hid + P + N * 2 * hid, dtype=torch.float32, device=saved.device)
+    pos = [0]
+
+    def take(*shape):
+        n = 1
+        for d_ in shape:
+            n *= d_
+        v = flat[pos[0]:pos[0] + n].view(*shape)
+        pos[0] += n
+        return v
+
+    dw0, db0, dw1, db1 = take(hid, ed), take(hid), take(hid, hid), take(hid)
+    dws = [take(w.shape[0], hid) for w in proj_w]
+    dbs = [take(w.shape[0]) for w in proj_w]
+    scratch = take(N, 2 * hid)
+    blk = _temb_blocks(proj_w, dws=dws, dbs=dbs)
+    nv.check(nv.lib().dua_temb_train_bwd(N, half, hid, nv.ptr(w1), C.byref(blk), nv.ptr(dadd), nv.ptr(saved), nv.ptr(scratch),
+                                         nv.ptr(dw0), nv.ptr(db0), nv.ptr(dw1), nv.ptr(db1), nv.stream_ptr()), "dua_temb_train_bwd")
+    return dw0, db0, dw1, db1, dws, dbs
+
+
+def _adamw_lists(params, grads, ms, vs):
+    """dua_adamw_list chunks (<= 64 tensors each, passed by value) over parallel lists of contiguous fp32 tensors."""
+    lists = []
+    for i0 in range(0, len(params), nv.ADAMW_MAX_TENSORS):
+        l = nv.AdamWList()
+        chunk = range(i0, min(len(params), i0 + nv.ADAMW_MAX_TENSORS))
+        l.count = len(chunk)
+        for j, i in enumerate(chunk):
+            g = grads[i]
+            assert g.is_cuda and g.dtype == torch.float32 and g.is_contiguous(), "gradients must be dense fp32 device tensors"
+            l.numel[j] = g.numel()
+            l.g[j] = g.data_ptr()
+            if params is not None and params[i] is not None:
+                p, m, v = params[i], ms[i], vs[i]
+                assert p.numel() == m.numel() == v.numel() == g.numel() and p.dtype == torch.float32 and p.is_contiguous()
+                l.p[j], l.m[j], l.v[j] = p.data_ptr(), m.data_ptr(), v.data_ptr()
+        lists.append(l)
+    return lists
+
+
+def grads_nonfinite(grads, found_inf):
+    """found_inf (fp32 device scalar, zeroed by the caller) = 1 if any element of ``grads`` is Inf / NaN -- the check of
+    torch._amp_foreach_non_finite_check_and_unscale_ without the write-back (dua_adamw_step applies 1 / scale itself)."""
+    assert found_inf.is_cuda and found_inf.dtype == torch.float32
+    L = nv.lib()
+    for l in _adamw_lists([None] * len(grads), grads, None, None):
+        nv.check(L.dua_grads_nonfinite(C.byref(l), nv.ptr(found_inf), nv.stream_ptr()), "dua_grads_nonfinite")
+
+
+def adamw_step(params, grads, ms, vs, step, lr, betas, eps, weight_decay, lr_dev=None, grad_scale=None, found_inf=None,
+               store_grad=False):
+    """One AdamW update of every tensor (torch.optim.AdamW's arithmetic, train.py:121-122) with k = step + 1; ``step``: int32
+    device scalar, not advanced here (adamw_advance)."""
+    assert step.is_cuda and step.dtype == torch.int32
+    L = nv.lib()
+    for l in _adamw_lists(params, grads, ms, vs):
+        nv.check(L.dua_adamw_step(C.byref(l), float(lr), nv.ptr(lr_dev), float(betas[0]), float(betas[1]), float(eps),
+                                  float(weight_decay), nv.ptr(grad_scale), nv.ptr(found_inf), nv.ptr(step), int(store_grad),
+                                  nv.stream_ptr()), "dua_adamw_step")
+
+
+def adamw_advance(step, found_inf=None, scale=None, growth=None, growth_factor=2.0, backoff=0.5, interval=200, seen=None):
+    """End of a step: the update counter and torch._amp_update_scale_'s loss-scale rule, on the device; ``found_inf`` is cleared
+    for the next step and its value left in ``seen`` (fp32 device scalar) for the host to read."""
+    assert step.dtype == torch.int32 and (growth is None or growth.dtype == torch.int32)
+    nv.check(nv.lib().dua_adamw_advance(nv.ptr(step), nv.ptr(found_inf), nv.ptr(scale), nv.ptr(growth), float(growth_factor),
+                                        float(backoff), int(interval), nv.ptr(seen), nv.stream_ptr()), "dua_adamw_advance")
 
 
 def sampler_step(mode, model_out, x, eps, coef, x_out=None, xstart_out=None, xstart_sum=None):

@@ -8,28 +8,63 @@ InstanceNorm + LeakyReLU + temb / embedding adds forward and backward, MaxPool f
 transposed convolution with its concat in place, the 1x1x1 head, and the fused mse/bce/dice loss.  Activations are
 channels-last [N, D, H, W, C] in the compute dtype (fp16 with fp32 master weights and dynamic loss scaling, or fp32).
 ``Diffusion.denoise`` dispatches here whenever grad mode is on, so the reference's training loop runs unchanged through
-``DiffUNet.forward``.  What is still torch: the timestep MLP (two 512-wide Linear layers on a [N, 128] input), the copy
-of the skip half into the concat buffer, AdamW.  There is no torch / MIOpen convolution path in this package.
+``DiffUNet.forward``.  The timestep embedding (TimeStepEmbedder + the nine temb_proj, forward and backward), the loss tail,
+q_sample on 2 * label - 1, the overflow check, AdamW and the loss-scale update are library kernels too (csrc/train_glue.hip);
+torch supplies the tape, the allocator, the random noise and the collectives.  There is no torch / MIOpen convolution path.
 """
 from __future__ import annotations
 
-import math
-
 import torch
-import torch.nn.functional as F
 
 uses_native_kernels = True
 
 
-def _time_embedding(temb_mod, t):
-    """models/diffusion/utils.py:6-54 (sinusoid -> Linear -> swish -> Linear) on a [N] vector of timesteps."""
-    half = temb_mod.embedding_dim // 2
-    freq = torch.exp(torch.arange(half, dtype=torch.float32, device=t.device) * -(math.log(10000) / (half - 1)))
-    arg = t.float()[:, None] * freq[None, :]
-    e = torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
-    h = F.linear(e, temb_mod.dense[0].weight, temb_mod.dense[0].bias)
-    h = h * torch.sigmoid(h)
-    return F.linear(h, temb_mod.dense[1].weight, temb_mod.dense[1].bias)
+class _TembState:
+    """What the TwoConv blocks of one evaluation share about their timestep-embedding adds: every block reads its [N, cout]
+    rows of ONE block-major buffer (ops.temb_train_fwd) and, in backward, writes the gradient of its rows into ONE buffer
+    of the same layout; the block that ran FIRST in forward -- whose backward node can only run after every other block's,
+    since all of them consume its output -- hands that buffer to autograd as the gradient of the whole add tensor (the
+    others return None: the engine counts a node's dependencies whether or not a gradient came with them).  Nine slice
+    views would have cost nine zero-fills, copies and accumulations of a [N, 1536] tensor per step instead."""
+
+    def __init__(self, N, couts):
+        self.N, self.couts = N, list(couts)
+        self.offs = [sum(self.couts[:i]) for i in range(len(self.couts))]
+        self.P = sum(self.couts)
+        self.dadd = None
+        self.next = 0          # forward call counter: block i of this evaluation
+        self.written = 0
+
+    def rows(self, flat, i):
+        a = self.N * self.offs[i]
+        return flat[a:a + self.N * self.couts[i]].view(self.N, self.couts[i])
+
+
+class _TembAdds(torch.autograd.Function):
+    """add_b = temb_proj_b(swish(TimeStepEmbedder(t))) for every TwoConv block b (models/diffusion/utils.py:5-54,
+    denoiser.py:51-52,65): three launches forward (dua_temb_train_fwd), two backward (dua_temb_train_bwd) for the eleven Linear
+    layers.  Inputs after the state: dense[0].weight, .bias, dense[1].weight, .bias, then (weight, bias) of each temb_proj."""
+
+    @staticmethod
+    def forward(ctx, t, half, state, *params):
+        from . import ops
+        w0, b0, w1, b1 = (p.detach() for p in params[:4])
+        pw = [p.detach() for p in params[4::2]]
+        pb = [p.detach() for p in params[5::2]]
+        add, saved = ops.temb_train_fwd(t.contiguous(), half, w0, b0, w1, b1, pw, pb)
+        ctx.save_for_backward(saved, w1, *pw)
+        ctx.half = half
+        return add
+
+    @staticmethod
+    def backward(ctx, dadd):
+        from . import ops
+        saved, w1, *pw = ctx.saved_tensors
+        dw0, db0, dw1, db1, dws, dbs = ops.temb_train_bwd(dadd.contiguous(), saved, ctx.half, w1, pw)
+        out = [None, None, None, dw0, db0, dw1, db1]
+        for dw, db in zip(dws, dbs):
+            out += [dw, db]
+        return tuple(out)
 
 
 def parse_losses(losses="mse,bce,dice", loss_combine="sum"):
@@ -105,7 +140,7 @@ def _channel_sums(t, c, c_off):
     from . import ops
     st = ops.stats_buffer(t.shape[0], c, t.device)
     ops.instnorm_stats(t, c, st, c_off=c_off)
-    return ops.stats_decode(st)[:, :c, 0].sum(0).float()
+    return ops.stats_channel_sums(st, c)            # decode + sum over the samples in one launch (twelve torch launches before)
 
 
 class _Conv3dK3(torch.autograd.Function):
@@ -238,8 +273,10 @@ class _ConvNormAct(torch.autograd.Function):
     backward = norm/activation backward (reduce + apply) -> data gradient (conv kernel) + weight gradient kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False, cat_extra=0):
-        """``cat_extra`` > 0: the activation is the skip of a decoder level -- it is written into channels [0, cout) of a buffer
+    def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False, cat_extra=0, temb_state=None, temb_index=0):
+        """``temb_state``: ``add`` is the block-major add buffer of the whole evaluation (_TembAdds) and this block uses rows
+        ``temb_index`` of it (_TembState); otherwise ``add`` is this block's own [N, cout] tensor or None.
+        ``cat_extra`` > 0: the activation is the skip of a decoder level -- it is written into channels [0, cout) of a buffer
         with ``cat_extra`` more channels (the half the transposed convolution fills later, _UpCat) and returned as that view:
         torch.cat((x_e, upsampled)) (denoiser.py:190) costs no copy (226 MB moved per step at level 0 otherwise)."""
         from . import ops
@@ -252,7 +289,10 @@ class _ConvNormAct(torch.autograd.Function):
         stats = ops.stats_buffer(N, cout, x.device)
         ops.conv3d_k3(x, cs, 0, wp, bp, cout, raw, 0, stats, workspace=ops.splitk_ws(x.dtype, N, D, H, W, cs, cout, x.device))
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        a32 = add.detach().float().contiguous() if add is not None else None
+        if add is not None and temb_state is not None:
+            a32 = temb_state.rows(add.detach(), temb_index)
+        else:
+            a32 = add.detach().float().contiguous() if add is not None else None
         norm = ops.Norm(stats, g32, b32, D * H * W, add=a32, add_stride=cout)
         if cat_extra:
             cat = torch.empty((N, D, H, W, cout + cat_extra), dtype=x.dtype, device=x.device)
@@ -263,6 +303,7 @@ class _ConvNormAct(torch.autograd.Function):
         ops.materialize(raw, cout, norm, cat, 0, emb=emb.detach() if emb is not None else None, pooled=pooled)
         ctx.save_for_backward(x, weight, raw, stats, g32, b32, act if pool else None)
         ctx.has_add, ctx.has_emb, ctx.pool = add is not None, emb is not None, pool
+        ctx.temb_state, ctx.temb_index = (temb_state, temb_index) if add is not None else (None, 0)
         return (act, pooled) if pool else act
 
     @staticmethod
@@ -277,7 +318,20 @@ class _ConvNormAct(torch.autograd.Function):
             off = 0
         norm = ops.Norm(stats, g32, b32, D * H * W)
         dY = torch.empty_like(raw)
-        dgamma, dbeta, dadd = ops.instnorm_bwd(buf, off, raw, cout, norm, dY, want_add=ctx.has_add)
+        ts = ctx.temb_state
+        dadd_out = None
+        if ts is not None:
+            if ts.dadd is None:
+                ts.dadd = torch.empty(ts.N * ts.P, dtype=torch.float32, device=raw.device)
+            dadd_out = ts.rows(ts.dadd, ctx.temb_index)
+        dgamma, dbeta, dadd = ops.instnorm_bwd(buf, off, raw, cout, norm, dY, want_add=ctx.has_add, dadd_out=dadd_out)
+        if ts is not None:
+            ts.written += 1
+            # the evaluation's first block runs last in backward and hands the shared buffer on (see _TembState)
+            dadd = None
+            if ctx.temb_index == 0:
+                assert ts.written == len(ts.couts), "a TwoConv block's backward ran after the first block's"
+                dadd = ts.dadd
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1])
@@ -285,17 +339,21 @@ class _ConvNormAct(torch.autograd.Function):
             dw = ops.zeros(tuple(weight.shape), torch.float32, x.device)
             _wgrad(x, dY, cout, dw)
         db = ops.zeros((cout,), torch.float32, x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
-        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None, None
+        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None, None, None, None
 
 
 def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0):
-    """``temb``: swish(t_embedder(t)) -- the nonlinearity every block applies to the same embedding (denoiser.py:65) is computed
-    once per evaluation by the caller; the nine blocks used to launch it (and its backward) nine times."""
-    add = None
+    """``temb``: None (the encoder's blocks) or (add, state): the evaluation's block-major add buffer (_TembAdds) and its
+    _TembState; the blocks take their rows in call order."""
+    add = state = None
+    index = 0
     if temb is not None:
-        add = F.linear(temb, block.temb_proj.weight, block.temb_proj.bias)
+        add, state = temb
+        index = state.next
+        state.next += 1
+        assert block.temb_proj.weight.shape[0] == state.couts[index]
     c0, c1 = block.conv_0, block.conv_1
-    h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None)
+    h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None, False, 0, state, index)
     return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb, pool, cat_extra)
 
 
@@ -358,8 +416,14 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
         r = _two_conv_cl(d.convs, pe, None, None, not last)
         e, pe = (r, None) if last else r
         emb.append(e)
-    temb = _time_embedding(den.temb, step)
-    temb = temb * torch.sigmoid(temb)                # swish, shared by the blocks' temb_proj (see _two_conv_cl)
+    # the nine blocks in the order they run: their temb_proj rows come out of one launch chain (_TembAdds)
+    blocks = [den.conv_0, den.down_1.convs, den.down_2.convs, den.down_3.convs, den.down_4.convs, den.upcat_4.convs,
+              den.upcat_3.convs, den.upcat_2.convs, den.upcat_1.convs]
+    state = _TembState(image.shape[0], [b.temb_proj.weight.shape[0] for b in blocks])
+    tparams = [den.temb.dense[0].weight, den.temb.dense[0].bias, den.temb.dense[1].weight, den.temb.dense[1].bias]
+    for b in blocks:
+        tparams += [b.temb_proj.weight, b.temb_proj.bias]
+    temb = (_TembAdds.apply(step.to(torch.int64), den.temb.embedding_dim // 2, state, *tparams), state)
     h = _cl_pad([image, x], dtype)
     up_c = [blk.upsample.deconv.weight.shape[1] for blk in (den.upcat_1, den.upcat_2, den.upcat_3, den.upcat_4)]   # channels each
     x0, p0 = _two_conv_cl(den.conv_0, h, temb, emb[0], True, up_c[0])                                            # decoder adds to the skip
@@ -395,9 +459,86 @@ class _NativeModule(torch.nn.Module):
         return native_logits_cl(self.net, images, x_t, t, self.dtype)
 
 
+class NativeAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW (train.py:121-122: lr, weight_decay; betas (0.9, 0.999), eps 1e-8) on the library's multi-tensor kernel:
+    one launch per 64 tensors instead of torch's five-per-step ``multi_tensor_apply`` launches plus a separate unscale pass;
+    1 / grad_scale is applied while the gradient is read, a set ``found_inf`` skips the update on the device, and the update
+    counter lives on the device (one int32 for all tensors), so a captured step replays it.  It is a torch ``Optimizer``:
+    param_groups drive the reference's LR scheduler (schedule.py), and ``state_dict()`` has torch.optim.AdamW's layout
+    (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter), so checkpoints move between the two (engine.py:118-135)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._count = None          # int32 device scalar: updates applied so far
+        self.lr_dev = None          # fp32 device scalar that overrides the groups' lr when set (captured steps: the host value
+                                    # would be baked into the graph)
+
+    def _counter(self, device):
+        if self._count is None:
+            self._count = torch.zeros((), dtype=torch.int32, device=device)
+        return self._count
+
+    def _moments(self, p):
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["step"] = torch.zeros((), dtype=torch.float32)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st["exp_avg"], st["exp_avg_sq"]
+
+    def materialize_state(self):
+        """Allocate the moments of every parameter now (before a stream capture, which must not allocate persistent state)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.requires_grad:
+                    self._moments(p)
+                    self._counter(p.device)
+
+    def reset_state(self):
+        for st in self.state.values():
+            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["step"].zero_()
+        if self._count is not None:
+            self._count.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=None, found_inf=None, store_grad=False, advance=True):
+        """``grad_scale`` / ``found_inf``: fp32 device scalars of a loss-scaled step (see ops.adamw_step); ``advance=False`` leaves
+        the update counter to the caller's ops.adamw_advance (which also applies the loss-scale rule)."""
+        from . import ops
+        assert closure is None
+        count = None
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            mv = [self._moments(p) for p in ps]
+            count = self._counter(ps[0].device)
+            ops.adamw_step([p.data for p in ps], [p.grad for p in ps], [m for m, _ in mv], [v for _, v in mv], count, group["lr"],
+                           group["betas"], group["eps"], group["weight_decay"], lr_dev=self.lr_dev, grad_scale=grad_scale,
+                           found_inf=found_inf, store_grad=store_grad)
+        if advance and count is not None:
+            ops.adamw_advance(count)
+
+    def state_dict(self):
+        if self._count is not None:
+            k = float(self._count.item())
+            for st in self.state.values():
+                st["step"] = torch.tensor(k, dtype=torch.float32)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+        if steps:
+            dev = next(iter(self.state)).device
+            self._counter(dev).fill_(int(steps[0]))
+
+
 class NativeConvTrainer:
     """One-process-per-GPU trainer on the native-convolution path: fp32 master weights, fp16 activations and gradients
-    with dynamic loss scaling (or plain fp32), AdamW as train.py:121-126.  Under torch.distributed the gradients are
+    with dynamic loss scaling (or plain fp32), AdamW as train.py:121-126 (``NativeAdamW``; ``fused_optimizer=False`` keeps
+    torch.optim.AdamW itself for eager steps -- the reference's exact optimizer object, used as the comparison in the tests).
+    Under torch.distributed the gradients are
     averaged by torch's DDP reducer (``overlap=True``: 32 MB buckets all-reduced while the rest of backward still
     runs; RCCL on a GPU node) or by one flat all-reduce after backward (``overlap=False``).
     ``graph=True`` replays the step from HIP graphs: one graph single-process; under torch.distributed TWO graphs
@@ -405,7 +546,7 @@ class NativeConvTrainer:
     collective stays an ordinary call, so any backend works (RCCL on a node, gloo in the tests)."""
 
     def __init__(self, net, lr=2e-4, weight_decay=1e-4, losses="mse,bce,dice", loss_combine="sum",
-                 dtype=torch.float16, init_scale=2.0 ** 12, overlap=True, graph=False, fused_optimizer=False,
+                 dtype=torch.float16, init_scale=2.0 ** 12, overlap=True, graph=False, fused_optimizer=True,
                  wgrad_overlap=True):
         import torch.distributed as dist
         self.net, self.dtype = net, dtype
@@ -420,9 +561,10 @@ class NativeConvTrainer:
             self.module = DistributedDataParallel(self.module, device_ids=[dev.index], bucket_cap_mb=32)
         self.loss_names, self.loss_combine = parse_losses(losses, loss_combine)
         self.params = [p for p in net.parameters() if p.requires_grad]
-        # graph mode always uses the fused capturable AdamW; ``fused_optimizer`` selects the same kernel for eager steps
-        self.optimizer = (torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=True, capturable=True)
-                          if fused_optimizer else torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay))
+        # graph mode always uses the library's AdamW; ``fused_optimizer=False`` selects torch.optim.AdamW for eager steps
+        self.native_opt = bool(fused_optimizer or graph)
+        self.optimizer = (NativeAdamW(self.params, lr=lr, weight_decay=weight_decay) if self.native_opt
+                          else torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay))
         self.scale, self.good_steps = (init_scale if dtype == torch.float16 else 1.0), 0
         # every zero-initialised buffer of a step (weight-gradient accumulators, statistics rows, reduction scratch) comes
         # out of one arena that a single fill re-zeroes: gradients are 4 bytes per parameter, the rest is small
@@ -460,8 +602,7 @@ class NativeConvTrainer:
         g = self._g
         self.arena.reset()
         with self.arena:
-            x_start = g["labels"] * 2 - 1
-            x_t = ops.q_sample(x_start.contiguous(), g["noise"], g["qtab"][g["t"]].contiguous())
+            x_t = ops.q_sample_affine(g["labels"], 2.0, -1.0, g["noise"], g["qtab"], g["t"])      # q_sample(label * 2 - 1, t, noise)
             self.optimizer.zero_grad(set_to_none=True)
             with torch.enable_grad():
                 loss = _SegLoss.apply(self.module(g["images"], x_t, g["t"]), g["labels"], self.loss_names, self.loss_combine)
@@ -471,12 +612,12 @@ class NativeConvTrainer:
 
     def _graph_update(self):
         g = self._g
-        grads = [p.grad for p in self.params]
-        g["found_inf"].zero_()
-        torch._amp_foreach_non_finite_check_and_unscale_(grads, g["found_inf"], g["scale"].reciprocal())
-        self.optimizer.grad_scale, self.optimizer.found_inf = None, g["found_inf"]
-        self.optimizer.step()
-        torch._amp_update_scale_(g["scale"], g["growth"], g["found_inf"], 2.0, 0.5, 200)
+        from . import ops
+        # found_inf is zero on entry (zero-initialised, cleared again by adamw_advance at the end of every step)
+        # (g["found_inf"] is what the host reads: the flag the last completed step saw)
+        ops.grads_nonfinite([p.grad for p in self.params], g["found_flag"])
+        self.optimizer.step(grad_scale=g["scale"], found_inf=g["found_flag"], advance=False)
+        ops.adamw_advance(self.optimizer._count, g["found_flag"], g["scale"], g["growth"], 2.0, 0.5, 200, seen=g["found_inf"])
 
     def _graph_body(self):
         loss = self._graph_fwd_bwd()
@@ -489,13 +630,16 @@ class NativeConvTrainer:
         assert labels.dtype == torch.float32
         dev = images.device
         d = self.net.diffusion
-        self.optimizer = torch.optim.AdamW(self.params, lr=self.lr, weight_decay=self.weight_decay, fused=True, capturable=True)
+        self.optimizer.materialize_state()
+        self.optimizer.lr_dev = torch.full((), float(self.optimizer.param_groups[0]["lr"]), dtype=torch.float32, device=dev)
+        self._lr_host = float(self.optimizer.param_groups[0]["lr"])
         self._g = dict(images=images.clone(), labels=labels.contiguous().clone(), noise=torch.zeros_like(labels),
                        t=torch.zeros(labels.shape[0], dtype=torch.long, device=dev),
                        qtab=torch.stack([torch.as_tensor(d.sqrt_alphas_cumprod), torch.as_tensor(d.sqrt_one_minus_alphas_cumprod)],
                                         dim=1).float().to(dev).contiguous(),
                        scale=torch.full((), self.init_scale if self.dtype == torch.float16 else 1.0, device=dev),
-                       growth=torch.zeros((), dtype=torch.int32, device=dev), found_inf=torch.zeros((), device=dev))
+                       growth=torch.zeros((), dtype=torch.int32, device=dev), found_inf=torch.zeros((), device=dev),
+                       found_flag=torch.zeros((), device=dev))
         saved = [p.detach().clone() for p in self.params]
         # Warm-up ON the capture stream: the per-(device, stream) scratch buffers of ops (split-K, weight-gradient partials)
         # are then allocated here, from the ordinary pool, and the capture finds them -- allocated inside the capture they
@@ -525,10 +669,8 @@ class NativeConvTrainer:
         with torch.no_grad():
             for p, q in zip(self.params, saved):
                 p.copy_(q)
-            for st in self.optimizer.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            self.optimizer.reset_state()
+            self._g["found_inf"].zero_(); self._g["found_flag"].zero_()
             self._g["scale"].fill_(self.init_scale if self.dtype == torch.float16 else 1.0)
             self._g["growth"].zero_()
 
@@ -544,6 +686,10 @@ class NativeConvTrainer:
             g["noise"].normal_()
         else:
             g["noise"].copy_(noise)
+        lr = float(self.optimizer.param_groups[0]["lr"])          # an LR scheduler's new value reaches the captured kernels here
+        if lr != self._lr_host:
+            self.optimizer.lr_dev.fill_(lr)
+            self._lr_host = lr
         self._graph.replay()
         if self._graph2 is not None:
             allreduce_mean_([p.grad for p in self.params])
@@ -571,16 +717,26 @@ class NativeConvTrainer:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         self._allreduce()
+        scale_dev = None
         if self.dtype == torch.float16:
-            # one multi-tensor kernel: grads *= 1/scale, found_inf = any non-finite
-            found_inf = torch.zeros(1, dtype=torch.float32, device=self.params[0].device)
-            inv = torch.full((1,), 1.0 / self.scale, dtype=torch.float32, device=self.params[0].device)
-            torch._amp_foreach_non_finite_check_and_unscale_([p.grad for p in self.params], found_inf, inv)
+            from . import ops
+            dev = self.params[0].device
+            found_inf = torch.zeros(1, dtype=torch.float32, device=dev)
+            grads = [p.grad for p in self.params]
+            if self.native_opt:          # read-only check; the update applies 1 / scale itself and stores the unscaled gradients
+                ops.grads_nonfinite(grads, found_inf)
+                scale_dev = torch.full((1,), self.scale, dtype=torch.float32, device=dev)
+            else:                        # torch's one multi-tensor kernel: grads *= 1/scale, found_inf = any non-finite
+                inv = torch.full((1,), 1.0 / self.scale, dtype=torch.float32, device=dev)
+                torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv)
             if bool(found_inf.item()):                                           # overflow: skip, halve the scale
                 self.scale, self.good_steps = max(self.scale / 2, 2.0 ** -14), 0
                 return loss.detach()
             self.good_steps += 1
             if self.good_steps >= 200:
                 self.scale, self.good_steps = self.scale * 2, 0
-        self.optimizer.step()
+        if self.native_opt:
+            self.optimizer.step(grad_scale=scale_dev, store_grad=scale_dev is not None)
+        else:
+            self.optimizer.step()
         return loss.detach()

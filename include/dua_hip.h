@@ -195,6 +195,74 @@ int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, 
                       const double* sums, const float* gscale, float w_mse, float w_bce, float w_dice, void* dlogits,
                       int dlogits_stride, void* stream);
 
+/* ---- the rest of the training step (train.py:214-268 around the network): everything that is not a convolution --------
+ * One launch each where torch needed five to twelve (profiles/r4_train_step_timeline_before.txt: 172 torch / hipBLASLt
+ * launches, 1.5 ms of a 15.6 ms step).
+ *
+ * dua_stats_channel_sums: out[c] = fp32( sum over samples of the decoded "sum x" word pair of channel c ), c < C -- the bias
+ *   gradient of a layer from the statistics rows dua_instnorm_stats accumulated over its output gradient.
+ * dua_seg_loss_finish: the scalar tail of losses/loss.py:64-86 from the sums of dua_seg_loss_reduce: terms
+ *   mse = sums[-2]/M, bce = sums[-1]/M, dice = mean_{n,c}(1 - (2I + 1e-5)/(S + Y + 1e-5)), M = N*C*voxels; the selected terms
+ *   (use_* = 0/1) are added; combine 0 "sum" (or a single term), 1 "mean", 2 "log" (log(1 + total)).  loss[0] = L,
+ *   dcomb[0] = dL/d(total) (1, 1/count, 1/(1 + total)); double arithmetic, fp32 results.
+ * dua_q_sample_affine: out = sqrt_ab[t[n]] * (a * src + b) + sqrt_1m_ab[t[n]] * eps  (train.py:258-262: x_start = label * 2 - 1
+ *   followed by q_sample, gaussian_diffusion.py:214-231) with sched = fp32 [T][2] (sqrt(alphas_cumprod), sqrt(1 - alphas_cumprod))
+ *   and t = int64 [N] on the device: a * src + b is rounded to fp32 before the multiply, as the two torch passes it replaces. */
+int dua_stats_channel_sums(int N, int C, int c_pad, const dua_stat_word* stats, float* out, void* stream);
+int dua_seg_loss_finish(int N, int C, long voxels, int use_mse, int use_bce, int use_dice, int combine, const double* sums,
+                        float* loss, float* dcomb, void* stream);
+int dua_q_sample_affine(int N, long per_sample, const float* src, float a, float b, const float* eps, const float* sched, int T,
+                        const long long* t, float* out, void* stream);
+
+/* Timestep embedding under training (models/diffusion/utils.py:5-54, denoiser.py:51-52,65): for sample n
+ *   e = [sin | cos](t[n] * freqs), z1 = W0 e + b0, h1 = swish(z1), z2 = W1 h1 + b1, s = swish(z2), add_b = Wp_b s + bp_b
+ * for every TwoConv block b (its temb_proj).  ``add`` / ``dadd`` are BLOCK-MAJOR: block b's [N][cout_b] rows are contiguous
+ * at float offset N * (cout_0 + .. + cout_{b-1}) -- each block reads / writes an ordinary dense [N][cout] tensor.
+ * fwd: writes add and saved = fp32 [N][2*half + 4*hidden] (e, z1, h1, z2, s).
+ * bwd: from dadd and saved, every parameter gradient in two launches: dw0 [hidden][2*half], db0, dw1 [hidden][hidden], db1 and
+ *      blocks->dw[b] [cout_b][hidden], blocks->db[b] [cout_b] (all WRITTEN, summed over the samples in a fixed order);
+ *      scratch = fp32 [N][2*hidden].  hidden: 256 or 512; 2*half <= 1024; N <= 64; sum of cout <= 4096; weights 16-byte aligned. */
+#define DUA_TEMB_MAX_BLOCKS 16
+typedef struct {
+  int nblocks;
+  int cout[DUA_TEMB_MAX_BLOCKS];
+  const float* w[DUA_TEMB_MAX_BLOCKS];   /* temb_proj.weight [cout][hidden] */
+  const float* b[DUA_TEMB_MAX_BLOCKS];   /* temb_proj.bias [cout] (fwd) */
+  float* dw[DUA_TEMB_MAX_BLOCKS];        /* bwd */
+  float* db[DUA_TEMB_MAX_BLOCKS];        /* bwd */
+} dua_temb_blocks;
+int dua_temb_train_fwd(int N, const long long* t, const float* freqs, int half_dim, int hidden, const float* w0, const float* b0,
+                       const float* w1, const float* b1, const dua_temb_blocks* blocks, float* add, float* saved, void* stream);
+int dua_temb_train_bwd(int N, int half_dim, int hidden, const float* w1, const dua_temb_blocks* blocks, const float* dadd,
+                       const float* saved, float* scratch, float* dw0, float* db0, float* dw1, float* db1, void* stream);
+
+/* AdamW over a list of fp32 tensors (train.py:121-126: torch.optim.AdamW(lr, weight_decay), betas (0.9, 0.999), eps 1e-8) with
+ * the dynamic loss scaling of torch.cuda.amp around it (train.py:264-268), device-resident so that a captured step replays it:
+ *   dua_grads_nonfinite: *found_inf = 1.0f if any gradient element is Inf / NaN (never written otherwise).
+ *   dua_adamw_step: skipped entirely when found_inf && *found_inf != 0.  g' = g * (1 / *grad_scale) (grad_scale NULL: 1);
+ *     p -= lr*wd*p;  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;  p -= (lr / (1 - b1^k)) * m / (sqrt(v)/sqrt(1 - b2^k) + eps),
+ *     k = *step + 1 (step: device int32, the number of updates applied so far; NOT advanced here -- one list may take several
+ *     calls).  lr_dev (device fp32) overrides lr when non-NULL.  store_grad != 0 writes g' back (eager steps whose caller
+ *     reads the unscaled gradients).  A list is <= DUA_ADAMW_MAX_TENSORS entries, passed BY VALUE (no device-side table to keep alive).
+ *   dua_adamw_advance: end of a step -- found_inf == 0: ++*step, ++*growth, and when *growth == interval: *scale *= growth_factor,
+ *     *growth = 0;  found_inf != 0: *scale *= backoff, *growth = 0;  then *seen = the flag (1 / 0) and *found_inf = 0
+ *     (torch._amp_update_scale_ semantics; scale / growth / found_inf / seen may be NULL). */
+#define DUA_ADAMW_MAX_TENSORS 64
+typedef struct {
+  int count;
+  long numel[DUA_ADAMW_MAX_TENSORS];
+  float* p[DUA_ADAMW_MAX_TENSORS];
+  float* g[DUA_ADAMW_MAX_TENSORS];
+  float* m[DUA_ADAMW_MAX_TENSORS];
+  float* v[DUA_ADAMW_MAX_TENSORS];
+} dua_adamw_list;
+int dua_grads_nonfinite(const dua_adamw_list* list, float* found_inf, void* stream);
+int dua_adamw_step(const dua_adamw_list* list, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                   float weight_decay, const float* grad_scale, const float* found_inf, const int* step, int store_grad,
+                   void* stream);
+int dua_adamw_advance(int* step, float* found_inf, float* scale, int* growth, float growth_factor, float backoff, int interval,
+                      float* seen, void* stream);
+
 /* ---- library state ---------------------------------------------------------------------------------------------
  * dua_abi_version(): DUA_ABI_VERSION of the library that is loaded.  It changes whenever a struct of this header, the size
  * or layout of a buffer a caller allocates (e.g. the statistics words of dua_in_norm) or a signature changes; a binding
@@ -205,7 +273,7 @@ int dua_seg_loss_grad(int dtype, int N, int C, long voxels, const void* logits, 
  * worker thread), call it once up front, on the device they will use, so that no such call happens inside a capture.
  * Thread-safe.  Returns 0, DUA_ERR_ARG (no current device) or a hipError_t.
  * dua_prepared_kernels(): how many kernels dua_prepare() configures (tests). */
-#define DUA_ABI_VERSION 5
+#define DUA_ABI_VERSION 6
 int dua_abi_version(void);
 int dua_prepare(void);
 int dua_prepared_kernels(void);

@@ -62,6 +62,21 @@ def test_argument_validation_without_a_device(lib):
     assert lib.dua_conv3d_k3_fwd(C.byref(ok), one, one, one, C.byref(bad), one, one, None, 0, None) == nv.ERR_ARG
     assert lib.dua_deconv_k2s2_fwd(C.byref(ok), one, one, one, C.byref(bad), one, None) == nv.ERR_ARG
     assert lib.dua_pack_conv3_weights(nv.F16, 64, 17, 24, None, None, None, None) == 1 * 1 * 27 * 4 * 64 * 16
+    # the training-step kernels (csrc/train_glue.hip)
+    assert lib.dua_stats_channel_sums(1, 80, 64, one, one, None) == nv.ERR_ARG                  # more channels than the rows hold
+    assert lib.dua_seg_loss_finish(1, 4, 10, 0, 0, 0, 0, one, one, one, None) == nv.ERR_ARG     # no loss term selected
+    assert lib.dua_q_sample_affine(1, 10, one, 2.0, -1.0, one, one, 0, one, one, None) == nv.ERR_ARG
+    blk = nv.TembBlocks()
+    blk.nblocks = 17
+    assert lib.dua_temb_train_fwd(2, one, one, 64, 512, one, one, one, one, C.byref(blk), one, one, None) == nv.ERR_ARG
+    blk.nblocks = 1; blk.cout[0] = 64; blk.w[0] = 16; blk.b[0] = 16
+    assert lib.dua_temb_train_fwd(2, one, one, 64, 384, one, one, one, one, C.byref(blk), one, one, None) == nv.ERR_ARG   # hidden
+    lst = nv.AdamWList()
+    lst.count = 65
+    assert lib.dua_grads_nonfinite(C.byref(lst), one, None) == nv.ERR_ARG
+    lst.count = 1; lst.numel[0] = 8; lst.g[0] = 16
+    assert lib.dua_adamw_step(C.byref(lst), 1e-3, None, 0.9, 0.999, 1e-8, 0.0, None, None, one, 0, None) == nv.ERR_ARG   # no p / m / v
+    assert lib.dua_adamw_advance(None, None, None, None, 2.0, 0.5, 200, None, None) == nv.ERR_ARG
 
 
 def test_scratch_sizes_cover_whole_tiles(lib):

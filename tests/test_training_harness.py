@@ -30,7 +30,7 @@ def _data(n, seed):
 
 def _union_batch_reference(seed_data, lr=1e-3):
     """Single process, both samples through the ORACLE network (torch autograd on the CPU), mean of the two per-sample
-    losses, one AdamW step: what two ranks with averaged gradients must reproduce."""
+    losses, one AdamW step: what two ranks with averaged gradients must reproduce.  Returns (state_dict, gradients)."""
     torch.manual_seed(0)
     init = DiffUNet(**KW).state_dict()
     ref = RefDiffUNet(**KW)
@@ -43,8 +43,9 @@ def _union_batch_reference(seed_data, lr=1e-3):
     for i in range(2):
         total = total + ref_training_step(ref, image[i:i + 1], labels[i:i + 1], crit, noise[i:i + 1], t[i:i + 1]) / 2
     total.backward()
+    grads = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
     opt.step()
-    return ref.state_dict()
+    return ref.state_dict(), grads
 
 
 def test_package_has_no_torch_convolution_path():
@@ -274,7 +275,8 @@ def _native_ddp_worker(rank, world, port, q, overlap=True, graph=False):
         image, labels, noise, t = _data(2, 7)
         sl = slice(rank, rank + 1)
         loss = tr.step(image[sl].to(dev), labels[sl].to(dev), noise=noise[sl].to(dev), t=t[sl].to(dev))
-        q.put((rank, float(loss), {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}))
+        grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}          # averaged over the ranks
+        q.put((rank, float(loss), {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}, grads))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -293,19 +295,34 @@ def test_native_trainer_two_ranks_equal_union_batch(overlap, graph):
     procs = [ctx.Process(target=_native_ddp_worker, args=(r, 2, port + int(overlap) + 2 * int(graph), q, overlap, graph)) for r in range(2)]
     for p in procs:
         p.start()
-    outs = {r: (l, sd) for r, l, sd in (q.get(timeout=300) for _ in range(2))}
+    outs = {r: (l, sd, g) for r, l, sd, g in (q.get(timeout=300) for _ in range(2))}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     for k in outs[0][1]:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
-    want_sd = _union_batch_reference(7)
+    want_sd, want_g = _union_batch_reference(7)
+    # (1) the averaged gradient IS the union batch's gradient.  Whole-gradient relative L2: a single activation that lands on the
+    # other side of LeakyReLU's kink than on the CPU (|z| ~ 1e-7: the slope there jumps between 0.1 and 1) changes one channel of
+    # one coarse layer's gradient by ~15 % of that tensor's (tiny) scale -- an fp64 oracle showed exactly that for
+    # upcat_4.convs.conv_1, channel 26, under this seed, with torch's own fp32 CPU path on the fp64 side of the kink.
+    num = sum(float(((outs[0][2][k].astype(np.float64) - v.double().numpy()) ** 2).sum()) for k, v in want_g.items())
+    den = sum(float((v.double().numpy() ** 2).sum()) for v in want_g.values())
+    assert (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5        # measured 2.2e-4 with that one kink crossing (a wrong or missing
+                                                                # average is an error of order 1)
+    # (2) the parameters after the AdamW step.  The first Adam step is lr * g / (|g| + eps): sign-like, so an element whose
+    # gradient is rounding noise (the convolution biases in front of InstanceNorm: true gradient zero) or sits in the channel
+    # described above moves by +-lr on either side; everything else must agree closely, and nothing may differ by more than 2 lr.
+    bad = total = 0
     worst = 0.0
     for k, v in want_sd.items():
         if k.endswith("conv.bias"):       # zero true gradient: Adam turns rounding noise into +-lr steps on both sides
             continue
-        worst = max(worst, float(np.abs(outs[0][1][k] - v.detach().numpy()).max()))
-    assert worst < (2e-4 if not graph else 5e-4), worst
+        gap = np.abs(outs[0][1][k] - v.detach().numpy())
+        worst = max(worst, float(gap.max()))
+        bad += int((gap > (2e-4 if not graph else 5e-4)).sum())
+        total += gap.size
+    assert worst < 2.1e-3 and bad <= 0.005 * total, (worst, bad, total)
 
 
 @pytest.mark.gpu

@@ -671,6 +671,32 @@ def q_sample(x0, eps, coef, out=None):
     return out
 
 
+def linear_f32(x, w, bias=None, gelu=False, out=None):
+    """F.linear(x, w, bias) (optionally followed by the exact GELU) on fp32 rows through dua_linear_f32 (exact-fp32 MFMA): the
+    nn.Linear layers and 1x1x1 convolutions of the Swin path's fp32 parity plan.  ``x``: [..., K] with unit stride along K and
+    one row stride (a contiguous tensor, or a channel slice of one); ``out``: [..., N] contiguous."""
+    K, Nn = x.shape[-1], w.shape[0]
+    assert x.is_cuda and x.dtype == torch.float32 and x.stride(-1) == 1 and K % 4 == 0
+    _f32c(w, "weight")
+    assert tuple(w.shape) == (Nn, K)
+    rows = x.numel() // K
+    if x.is_contiguous():
+        lda = K
+    else:
+        x2 = x.reshape(-1, K) if x.dim() != 2 else x
+        assert x2.data_ptr() == x.data_ptr() and x2.stride(1) == 1, "rows of x must share one stride"
+        lda = x2.stride(0)
+    if bias is not None:
+        _f32c(bias, "bias")
+    if out is None:
+        out = torch.empty((*x.shape[:-1], Nn), dtype=torch.float32, device=x.device)
+    _f32c(out, "out")
+    assert out.numel() == rows * Nn
+    nv.check(nv.lib().dua_linear_f32(rows, K, Nn, nv.ptr(x), lda, nv.ptr(w), nv.ptr(bias), nv.ptr(out), Nn, int(gelu),
+                                     nv.stream_ptr()), "dua_linear_f32")
+    return out
+
+
 def q_sample_affine(src, a, b, eps, sched, t, out=None):
     """q_sample(a * src + b, t, eps) in one pass (train.py:258-262): sched fp32 [T, 2] = (sqrt(alphas_cumprod),
     sqrt(1 - alphas_cumprod)), t int64 [N], both on the device."""

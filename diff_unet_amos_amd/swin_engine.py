@@ -20,16 +20,14 @@ What runs where
     The Linear layers (qkv / proj / MLP / patch-merging reduction) and the 1x1x1 conv3 of channel-changing UnetResBlocks run on
     the package's own MFMA GEMMs in fp16 plans (token_linear / swin_mlp at stage 0, token_gemm at stages 1-3:
     swin_gemm.hip, swin_gemm_wide.hip): no library GEMM is launched.
-  * the fp32 PARITY plan (compute_dtype=torch.float32) keeps those GEMMs on torch (F.linear / torch.matmul -> hipBLASLt): the
-    token GEMM kernels are fp16-operand kernels, an fp32 form on MFMA 32x32x2 would serve the parity mode only, and the plan's
-    purpose -- checking the wiring against the oracle to 1e-5 -- does not depend on who multiplies.
+  * the fp32 PARITY plan (compute_dtype=torch.float32) runs the same layers on dua_linear_f32 (gemm_f32.hip: exact-fp32 MFMA
+    32x32x2, plain 64 x 64 tiles, linear1's GELU in its epilogue): no library GEMM in either plan.
 """
 from __future__ import annotations
 
 import math
 
 import torch
-import torch.nn.functional as F
 
 from . import _native as nv
 from . import ops
@@ -184,7 +182,7 @@ class SwinPlan:
         # beat the per-workgroup weight staging of the fused kernels (same-process A/B, tools/bench_swin_ab.py)
         self.fused_max_c = 48
         # Stages 1-3 and the wide 1x1x1 convolutions: the tiled MFMA GEMM of swin_gemm_wide.hip (fp16 operands) instead of the
-        # ~60 hipBLASLt launches per step of round 2; the fp32 parity mode keeps torch's GEMMs.
+        # ~60 hipBLASLt launches per step of round 2; the fp32 parity mode runs them on dua_linear_f32 (gemm_f32.hip).
         self.wide_gemm = dtype == torch.float16
         if self.fused_linear:
             self.qkv_buf = torch.zeros(3 * tok_max, dtype=dtype, device=device)
@@ -375,7 +373,7 @@ class SwinPlan:
                                workspace=self._gemm_scratch_b if side else self._gemm_scratch)    # 1x1x1 conv3 on the tiled MFMA GEMM
                 ops.instnorm_stats(res, r.cout, r.st[2])
             else:
-                torch.matmul(x2, r.w3.t(), out=res.view(-1, r.cout))                 # fp32 parity mode: library GEMM
+                ops.linear_f32(x2, r.w3, out=res.view(-1, r.cout))                   # fp32 parity mode: the exact-fp32 MFMA kernel
                 ops.instnorm_stats(res, r.cout, r.st[2])
             if first3:
                 convs()
@@ -422,7 +420,7 @@ class SwinPlan:
                 elif wide:
                     qkv = ops.token_gemm(win.view(-1, C_), b["wqkv"], b["fqkv"], "plain", out=qkv_buf, workspace=self._gemm_scratch)
                 else:
-                    qkv = F.linear(win, b["wqkv"], b["bqkv"])
+                    qkv = ops.linear_f32(win, b["wqkv"], b["bqkv"])
                 ops.window_attention(qkv, HEADS[i], None, region_ids=g["region"] if shifted else None,
                                      windows_per_image=g["nw"], out=att, bias_table=b["table"], table_grid=WINDOW)
                 if fused:
@@ -430,7 +428,9 @@ class SwinPlan:
                         ops.token_linear(att.view(-1, C_), b["wproj"], b["fproj"], "scatter", x=x, geom=geom, gamma=b["g2"],
                                          beta=b["b2"], ln_out=ln2)
                     else:
-                        ops.window_scatter_add_norm(x, geom, F.linear(att, b["wproj"], b["bproj"]), b["g2"], b["b2"], ln2)
+                        po = self.po_buf[:ntok_w * C_].view(-1, C_)
+                        ops.token_linear(att.view(-1, C_), b["wproj"], b["fproj"], "plain", out=po)
+                        ops.window_scatter_add_norm(x, geom, po.view(N * g["nw"], g["n"], C_), b["g2"], b["b2"], ln2)
                     if self.fused_mlp:                                             # linear1 + GELU + linear2 + residual, one launch
                         ops.swin_mlp(ln2, b["w1"], b["f1"], b["w2"], b["f2"], x)
                     else:
@@ -443,11 +443,10 @@ class SwinPlan:
                     ops.token_gemm(ln2, b["w1"], b["f1"], "gelu", out=hid, workspace=self._gemm_scratch)                       # linear1 + GELU
                     ops.token_gemm(hid, b["w2"], b["f2"], "residual", x=x.view(-1, C_), workspace=self._gemm_scratch)         # x + mlp(norm2(x)) on the stream
                 else:
-                    po = F.linear(att, b["wproj"], b["bproj"])
+                    po = ops.linear_f32(att, b["wproj"], b["bproj"])
                     ops.window_scatter_add_norm(x, geom, po, b["g2"], b["b2"], ln2)
-                    h = F.linear(ln2, b["w1"], b["bb1"])
-                    ops.gelu_(h)
-                    y = F.linear(h, b["w2"], b["bb2"])
+                    h = ops.linear_f32(ln2, b["w1"], b["bb1"], gelu=True)          # linear1 + exact GELU
+                    y = ops.linear_f32(h, b["w2"], b["bb2"])
             dims = g["dims"]
             mshape = (N, (dims[0] + 1) // 2, (dims[1] + 1) // 2, (dims[2] + 1) // 2, 8 * C_)
             merged = self.merged[:mshape[0] * mshape[1] * mshape[2] * mshape[3] * mshape[4]].view(mshape)
@@ -459,7 +458,7 @@ class SwinPlan:
                 red = ops.token_gemm(merged.view(-1, 8 * C_), st["wred"], None, "plain",
                                      out=self.red_buf[:merged.numel() // 4].view(-1, 2 * C_), workspace=self._gemm_scratch)
             else:
-                red = F.linear(merged.view(-1, 8 * C_), st["wred"])
+                red = ops.linear_f32(merged.view(-1, 8 * C_), st["wred"])
             ops.stage_out(red, N, 2 * C_, outs[i + 1][0], outs[i + 1][1], tadd=tadd(i + 1),
                           emb=None if emb is None else emb[i + 1], x=self.stream[i + 1] if i < 3 else None)
             if ready is not None:

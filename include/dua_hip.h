@@ -589,6 +589,13 @@ int dua_swin_mlp(long tokens, int C, const void* ln2, const void* W1, const floa
 int dua_gelu(int dtype, long elems, void* x, void* stream);
 
 /* ---- layout / packing at the API boundary -------------------------------------------------- */
+/* nn.Linear on fp32 rows, the parity plan of the Swin path (attention.py:97-120, transformer.py:433-435, patch.py:89-92,
+ * blocks.py:311-314): out[m][n] = sum_k A[m][k] W[n][k] + bias[n] (bias may be NULL), then the exact GELU when gelu != 0.
+ * A: M rows of lda floats (first K used), W: [N][K] dense, out: M rows of ldc floats.  K and lda multiples of 4, A and W
+ * 16-byte aligned.  Exact-fp32 MFMA; no library GEMM is launched. */
+int dua_linear_f32(long M, int K, int N, const float* A, long lda, const float* W, const float* bias, float* out, long ldc,
+                   int gelu, void* stream);
+
 /* nn.ConvTranspose3d weight fp32[Cin][Cout][2][2][2] -> [tap][cout_tile][chunk][k-group][64][16 B].
  * Returns bytes needed when w_packed is NULL. */
 long dua_pack_deconv_weights(int dtype, int Cin, int Cout, const float* w, void* w_packed, void* stream);

@@ -179,6 +179,7 @@ _SIGS = {
     "dua_pack_deconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_to_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dua_from_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, C.c_int, _P, _P]),
+    "dua_to_channels_last_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_long, _P, C.c_int, _P]),
     "dua_linear_f32": (C.c_int, [C.c_long, C.c_int, C.c_int, _P, C.c_long, _P, _P, _P, C.c_long, C.c_int, _P]),
     "dua_stats_channel_sums": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_seg_loss_finish": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

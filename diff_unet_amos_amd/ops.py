@@ -73,6 +73,23 @@ def to_channels_last(src, dst, c_off=0, c_fill=None):
     return dst
 
 
+def to_channels_last_rows(parts, dst):
+    """torch.cat(parts, 1) (one or two NCDHW fp32 tensors) -> the whole rows of a dense channels-last ``dst`` (zero fill up to
+    its width) in one launch of 16-byte stores; rows of at most 64 bytes."""
+    _cl_check(dst, "dst")
+    assert 1 <= len(parts) <= 2 and dst.is_contiguous()
+    for p in parts:
+        assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.dim() == 5
+        assert tuple(p.shape[2:]) == tuple(dst.shape[1:4]) and p.shape[0] == dst.shape[0]
+    N, vox = dst.shape[0], dst.shape[1] * dst.shape[2] * dst.shape[3]
+    c0 = parts[0].shape[1]
+    c1 = parts[1].shape[1] if len(parts) == 2 else 0
+    nv.check(nv.lib().dua_to_channels_last_rows(nv.dt_code(dst.dtype), N, c0, nv.ptr(parts[0]), c1,
+                                                nv.ptr(parts[1]) if c1 else None, vox, nv.ptr(dst), dst.shape[-1], nv.stream_ptr()),
+             "dua_to_channels_last_rows")
+    return dst
+
+
 def from_channels_last(src, C_, c_off=0, out=None):
     _cl_check(src, "src")
     N, D, H, W, Cs = src.shape

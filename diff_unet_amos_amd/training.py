@@ -203,6 +203,8 @@ def _cl_pad(parts, dtype):
     if all(p.is_cuda and p.dtype == torch.float32 and not p.requires_grad for p in parts):
         from . import ops
         out = torch.empty((N, *parts[0].shape[2:], cp), dtype=dtype, device=parts[0].device)
+        if len(parts) <= 2 and cp * out.element_size() <= 64 and (cp * out.element_size()) % 16 == 0:
+            return ops.to_channels_last_rows([p.contiguous() for p in parts], out)        # whole rows, 16-byte stores, one launch
         off = 0
         for i, p in enumerate(parts):
             last = i == len(parts) - 1
@@ -552,6 +554,7 @@ class NativeConvTrainer:
         self.net, self.dtype = net, dtype
         self.lr, self.weight_decay, self.init_scale = lr, weight_decay, init_scale
         self.use_graph, self._graph, self._graph2 = graph, None, None
+        self._qtab = None
         self.module = _NativeModule(net, dtype)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.overlap = overlap and self.distributed and not graph        # the DDP reducer's hooks cannot be captured
@@ -699,11 +702,20 @@ class NativeConvTrainer:
     def step(self, images, labels, noise=None, t=None):
         if self.use_graph:
             return self._graph_step(images, labels, noise, t)
-        x_start = labels * 2 - 1
         if t is None:
-            t, _ = self.net.sampler.sample(x_start.shape[0], x_start.device)
-        noise = torch.randn_like(x_start) if noise is None else noise
-        x_t = self.net.diffusion.q_sample(x_start, t, noise)                     # HIP kernel
+            t, _ = self.net.sampler.sample(labels.shape[0], labels.device)
+        noise = torch.randn_like(labels) if noise is None else noise
+        if labels.is_cuda and labels.dtype == torch.float32:
+            from . import ops
+            if self._qtab is None:
+                d = self.net.diffusion
+                self._qtab = torch.stack([torch.as_tensor(d.sqrt_alphas_cumprod), torch.as_tensor(d.sqrt_one_minus_alphas_cumprod)],
+                                         dim=1).float().to(labels.device).contiguous()
+            # x_start = label * 2 - 1 and q_sample (train.py:258-262) in one pass
+            x_t = ops.q_sample_affine(labels.contiguous(), 2.0, -1.0, noise.float().contiguous(), self._qtab,
+                                      t.to(device=labels.device, dtype=torch.int64).contiguous())
+        else:
+            x_t = self.net.diffusion.q_sample(labels * 2 - 1, t, noise)
         self.optimizer.zero_grad(set_to_none=True)
         import contextlib
         if self.arena is not None:

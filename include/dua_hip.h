@@ -605,6 +605,11 @@ int dua_to_channels_last(int dtype, int N, int C, long voxels, const float* src,
                          int C_fill, void* stream);
 int dua_from_channels_last(int dtype, int N, int C, long voxels, const void* src, int Cstride, int C_off, float* dst,
                            void* stream);
+/* Whole rows: dst[n][v][0 .. Cstride) = (src0 channels | src1 channels | zeros), src1 may be NULL with C1 = 0 -- the network
+ * input torch.cat((image, x), dim=1) (denoiser.py:298) in one pass of 16-byte stores.  dst dense (row = Cstride elements, at
+ * most 64 bytes, a multiple of 16), 16-byte aligned. */
+int dua_to_channels_last_rows(int dtype, int N, int C0, const float* src0, int C1, const float* src1, long voxels, void* dst,
+                              int Cstride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,24 @@ def test_layout_roundtrip(dtype):
     assert float(cl[..., 5:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("c0,c1,cs", [(1, 0, 8), (1, 16, 24), (3, 2, 8), (16, 0, 16), (5, 7, 16)])
+def test_whole_row_layout_kernel_equals_the_per_channel_one(dtype, c0, c1, cs):
+    """dua_to_channels_last_rows (torch.cat((image, x), 1) -> channels-last rows in 16-byte stores) against the per-channel kernel."""
+    ops = _ops()
+    if cs * (2 if dtype == torch.float16 else 4) > 64:
+        pytest.skip("rows wider than 64 bytes take the per-channel kernel")
+    g = torch.Generator().manual_seed(c0 * 100 + c1)
+    parts = [torch.randn(2, c0, 5, 6, 7, generator=g).cuda()] + ([torch.randn(2, c1, 5, 6, 7, generator=g).cuda()] if c1 else [])
+    want = torch.full((2, 5, 6, 7, cs), 7.0, dtype=dtype, device="cuda")
+    off = 0
+    for i, p in enumerate(parts):
+        ops.to_channels_last(p, want, off, c_fill=(cs - off) if i == len(parts) - 1 else None)
+        off += p.shape[1]
+    got = ops.to_channels_last_rows(parts, torch.full((2, 5, 6, 7, cs), 7.0, dtype=dtype, device="cuda"))
+    assert torch.equal(got, want)
+
+
 def _producer(raw, dtype, g, add=None):
     """Stats + affine of a fictitious producer layer whose raw output is ``raw`` (as stored in ``dtype``):
     returns (ops.Norm, reference activation = LeakyReLU(InstanceNorm(raw)*gamma+beta) [+ add])."""

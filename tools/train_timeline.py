@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel time of ONE replayed training step (BASELINE config 4) from a rocprofv3 --kernel-trace CSV directory: the launches
-between two consecutive q_sample_kernel launches (the step's first kernel), grouped by kernel, with the share that is not this
+between two consecutive q_sample launches (the step's first kernel), grouped by kernel, with the share that is not this
 library's (torch / hipBLASLt / runtime copies) listed separately.
 usage: train_timeline.py <dir> [steps from the end; default 3] [--list]"""
 import collections
@@ -13,7 +13,7 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 3
 f = (glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'q_sample_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'q_sample' in r['Kernel_Name']]
 a, b = idx[-back - 1], idx[-back]
 t0 = int(rows[a]['Start_Timestamp'])
 

@@ -114,6 +114,11 @@ class TembBlocks(C.Structure):
                 ("b", C.c_void_p * TEMB_MAX_BLOCKS), ("dw", C.c_void_p * TEMB_MAX_BLOCKS), ("db", C.c_void_p * TEMB_MAX_BLOCKS)]
 
 
+class PackItem(C.Structure):
+    """dua_pack_item."""
+    _fields_ = [("kind", C.c_int), ("Cout", C.c_int), ("Cin", C.c_int), ("packed", C.c_int), ("w", C.c_void_p), ("out", C.c_void_p)]
+
+
 class AdamWList(C.Structure):
     """dua_adamw_list."""
     _fields_ = [("count", C.c_int), ("numel", C.c_long * ADAMW_MAX_TENSORS), ("p", C.c_void_p * ADAMW_MAX_TENSORS),
@@ -179,6 +184,7 @@ _SIGS = {
     "dua_pack_deconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "dua_to_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dua_from_channels_last": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, _P, C.c_int, C.c_int, _P, _P]),
+    "dua_pack_conv3_weights_batch": (C.c_int, [C.c_int, C.c_int, C.POINTER(PackItem), _P]),
     "dua_to_channels_last_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_long, _P, C.c_int, _P]),
     "dua_linear_f32": (C.c_int, [C.c_long, C.c_int, C.c_int, _P, C.c_long, _P, _P, _P, C.c_long, C.c_int, _P]),
     "dua_stats_channel_sums": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),

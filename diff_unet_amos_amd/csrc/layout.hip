@@ -74,10 +74,10 @@ __global__ void pack_conv3_dgrad_kernel(int Cout, int Cin, int nchunks, const fl
 // waves and the 512 x 512 layer took 38 us for 42 MB.  Here a workgroup owns 8 output channels x one 32-channel chunk (forward) or
 // 32 x 8 (data gradient) for all 27 taps: the rows of w arrive as contiguous 16-byte pieces, pass through LDS as fp16 in w's own
 // order, and leave as 16-byte pieces of the packed layout, 128 contiguous bytes per (tap, k-group).  Cin % 4 == 0.
-__global__ __launch_bounds__(256) void pack_conv3_rows_kernel(int Cout, int Cin_src, int nchunks, const float* __restrict__ w,
-                                                              f16* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) f16 st[8 * 864];                     // [co 8][ci 32][27]
-  const int tid = threadIdx.x, cg = blockIdx.x & 7, ch = (blockIdx.x >> 3) % nchunks, ct = (blockIdx.x >> 3) / nchunks;
+__device__ __forceinline__ void pack_conv3_rows_body(int bid, f16* st, int Cout, int Cin_src, int nchunks, const float* __restrict__ w,
+                                                     f16* __restrict__ out) {
+  // st: [co 8][ci 32][27]
+  const int tid = threadIdx.x, cg = bid & 7, ch = (bid >> 3) % nchunks, ct = (bid >> 3) / nchunks;
   const int ci0 = ch * 32;
   const int nv = Cin_src - ci0 < 0 ? 0 : (Cin_src - ci0 > 32 ? 32 : Cin_src - ci0), npc = nv * 27 / 4;   // valid pieces per row
   f32x4 v[7];
@@ -112,10 +112,16 @@ __global__ __launch_bounds__(256) void pack_conv3_rows_kernel(int Cout, int Cin_
   }
 }
 
-__global__ __launch_bounds__(256) void pack_conv3_dgrad_rows_kernel(int Cout, int Cin, int nchunks, const float* __restrict__ w,
-                                                                    f16* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) f16 st[32 * 216];                    // [co 32][ci 8][27]
-  const int tid = threadIdx.x, cig = blockIdx.x & 7, ch = (blockIdx.x >> 3) % nchunks, ot = (blockIdx.x >> 3) / nchunks;
+__global__ __launch_bounds__(256) void pack_conv3_rows_kernel(int Cout, int Cin_src, int nchunks, const float* __restrict__ w,
+                                                              f16* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) f16 st[6912];
+  pack_conv3_rows_body(blockIdx.x, st, Cout, Cin_src, nchunks, w, out);
+}
+
+__device__ __forceinline__ void pack_conv3_dgrad_rows_body(int bid, f16* st, int Cout, int Cin, int nchunks, const float* __restrict__ w,
+                                                           f16* __restrict__ out) {
+  // st: [co 32][ci 8][27]
+  const int tid = threadIdx.x, cig = bid & 7, ch = (bid >> 3) % nchunks, ot = (bid >> 3) / nchunks;
   const int co0 = ch * 32, ci0 = ot * 64 + cig * 8;
   const int nv = Cin - ci0 < 0 ? 0 : (Cin - ci0 > 8 ? 8 : Cin - ci0), npc = nv * 27 / 4;
   f32x4 v[7];
@@ -148,6 +154,34 @@ __global__ __launch_bounds__(256) void pack_conv3_dgrad_rows_kernel(int Cout, in
       *(f16x8*)(out + ((((long)ot * nchunks + ch) * 27 + tap) * 4 + kg) * 512 + (cig * 8 + r) * 8) = o;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void pack_conv3_dgrad_rows_kernel(int Cout, int Cin, int nchunks, const float* __restrict__ w,
+                                                                    f16* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) f16 st[6912];
+  pack_conv3_dgrad_rows_body(blockIdx.x, st, Cout, Cin, nchunks, w, out);
+}
+
+// Many layers in one launch (a training step repacks all 28 convolutions twice: 56 launches of 3-12 us each before): workgroup
+// -> (layer, its block) through the first-block table, then the body of the per-layer kernel.
+constexpr int PACK_MAX = 64;
+struct PackBatch {
+  int count;
+  int first_block[PACK_MAX + 1];
+  int kind[PACK_MAX], Cout[PACK_MAX], Cin[PACK_MAX], nchunks[PACK_MAX];
+  const float* w[PACK_MAX];
+  f16* out[PACK_MAX];
+};
+__global__ __launch_bounds__(256) void pack_conv3_batch_kernel(PackBatch b) {
+  __shared__ __attribute__((aligned(16))) f16 st[6912];
+  int lo = 0, hi = b.count;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (b.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const int bid = blockIdx.x - b.first_block[lo];
+  if (b.kind[lo] == 0) pack_conv3_rows_body(bid, st, b.Cout[lo], b.Cin[lo], b.nchunks[lo], b.w[lo], b.out[lo]);
+  else pack_conv3_dgrad_rows_body(bid, st, b.Cout[lo], b.Cin[lo], b.nchunks[lo], b.w[lo], b.out[lo]);
 }
 
 // ---- deconv k2 s2 weights: [Cin][Cout][8] fp32 -> [tap][ct][chunk][kg][64][EPG] ----
@@ -302,6 +336,29 @@ long dua_pack_conv3_weights_dgrad(int dtype, int Cout, int Cin, int Cout_packed,
                        Cout, Cin, nchunks, w, (float*)w_packed, total);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? bytes : -(long)e;
+}
+
+int dua_pack_conv3_weights_batch(int dtype, int count, const dua_pack_item* items, void* stream) {
+  if (dtype != DUA_F16 || count <= 0 || count > dua::PACK_MAX || !items) return DUA_ERR_ARG;
+  dua::PackBatch b;
+  b.count = count;
+  long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const dua_pack_item& it = items[i];
+    if ((it.kind != 0 && it.kind != 1) || it.Cout <= 0 || it.Cin <= 0 || it.Cin % 4 || !it.w || !it.out ||
+        (((size_t)it.w) & 15) || (((size_t)it.out) & 15))
+      return DUA_ERR_ARG;
+    if (it.packed < (it.kind == 0 ? it.Cin : it.Cout)) return DUA_ERR_ARG;
+    const int nchunks = (it.packed + 31) / 32, tiles = ((it.kind == 0 ? it.Cout : it.Cin) + 63) / 64;
+    b.first_block[i] = (int)blocks;
+    b.kind[i] = it.kind; b.Cout[i] = it.Cout; b.Cin[i] = it.Cin; b.nchunks[i] = nchunks;
+    b.w[i] = it.w; b.out[i] = (dua::f16*)it.out;
+    blocks += (long)tiles * nchunks * 8;
+    if (blocks > 0x7fffffffL) return DUA_ERR_ARG;
+  }
+  for (int i = count; i <= dua::PACK_MAX; ++i) b.first_block[i] = (int)blocks;
+  hipLaunchKernelGGL(dua::pack_conv3_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+  return (int)hipGetLastError();
 }
 
 long dua_pack_deconv_weights(int dtype, int Cin, int Cout, const float* w, void* w_packed, void* stream) {

@@ -171,6 +171,58 @@ def pack_conv3_weights_dgrad(w, dtype, cout_packed=None):
     return buf, zero_bias(cin, w.device)          # shared, never written
 
 
+class ConvPacks:
+    """The fp16 packings of MANY 3x3x3 convolution weights made by one launch per 64 tensors (dua_pack_conv3_weights_batch): a
+    training step packs every layer twice (forward layout for the forward pass, data-gradient layout for backward) -- 56 launches
+    of 3-12 us before.  ``add(w, kind, packed)`` registers a tensor (kind "fwd": packed = channels of the input buffer; "dgrad":
+    packed = channels of the dy buffer); ``run()`` packs everything registered into one buffer; ``get(w, kind, packed)`` hands
+    back the packed bytes or None (caller packs that layer on its own: first layers, odd channel counts, fp32)."""
+
+    def __init__(self, dtype):
+        self.dtype, self.items, self.out = dtype, [], {}
+
+    @staticmethod
+    def _key(w, kind, packed):
+        return (w.data_ptr(), kind, int(packed))
+
+    def add(self, w, kind, packed):
+        cout, cin = w.shape[:2]
+        if (self.dtype != torch.float16 or not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()) or cin % 4
+                or w.data_ptr() % 16 or packed < (cin if kind == "fwd" else cout) or self._key(w, kind, packed) in self.out):
+            return
+        L, code = nv.lib(), nv.dt_code(self.dtype)
+        if kind == "fwd":
+            nbytes = L.dua_pack_conv3_weights(code, cout, cin, packed, None, None, None, None)
+        else:
+            nbytes = L.dua_pack_conv3_weights_dgrad(code, cout, cin, packed, None, None, None)
+        self.items.append((w, kind, int(packed), int(nbytes)))
+        self.out[self._key(w, kind, packed)] = None
+
+    def run(self):
+        if not self.items:
+            return self
+        offs, total = [], 0
+        for *_, nbytes in self.items:
+            offs.append(total)
+            total += (nbytes + 255) & ~255
+        flat = torch.empty(total, dtype=torch.uint8, device=self.items[0][0].device)
+        L = nv.lib()
+        for i0 in range(0, len(self.items), 64):
+            chunk = self.items[i0:i0 + 64]
+            arr = (nv.PackItem * len(chunk))()
+            for j, (w, kind, packed, nbytes) in enumerate(chunk):
+                view = flat[offs[i0 + j]:offs[i0 + j] + nbytes]
+                arr[j] = nv.PackItem(0 if kind == "fwd" else 1, w.shape[0], w.shape[1], packed, w.data_ptr(), view.data_ptr())
+                self.out[self._key(w, kind, packed)] = view
+            nv.check(L.dua_pack_conv3_weights_batch(nv.dt_code(self.dtype), len(chunk), arr, nv.stream_ptr()),
+                     "dua_pack_conv3_weights_batch")
+        self.items = []
+        return self
+
+    def get(self, w, kind, packed):
+        return self.out.get(self._key(w, kind, packed))
+
+
 def pack_deconv_weights(w, bias, dtype):
     assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 5 and tuple(w.shape[2:]) == (2, 2, 2)
     w = w.contiguous()

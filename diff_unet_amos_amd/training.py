@@ -158,11 +158,16 @@ class _Conv3dK3(torch.autograd.Function):
         return y
 
     @staticmethod
-    def _dgrad(dy, w, cin_padded):
-        """dx [.., cin_padded] = data gradient: the forward kernel on dy with W' packed straight from w."""
+    def _dgrad(dy, w, cin_padded, packs=None):
+        """dx [.., cin_padded] = data gradient: the forward kernel on dy with W' packed straight from w (or taken from the
+        evaluation's batch-packed weights, ops.ConvPacks)."""
         from . import ops
         N, D, H, W, cs = dy.shape
-        wp, bp = ops.pack_conv3_weights_dgrad(w, dy.dtype, cout_packed=cs)
+        wp = packs.get(w, "dgrad", cs) if packs is not None else None
+        if wp is not None:
+            bp = ops.zero_bias(w.shape[1], w.device)
+        else:
+            wp, bp = ops.pack_conv3_weights_dgrad(w, dy.dtype, cout_packed=cs)
         dx = torch.empty((N, D, H, W, cin_padded), dtype=dy.dtype, device=dy.device)
         ops.conv3d_k3(dy, cs, 0, wp, bp, cin_padded, dx, 0, ops.stats_buffer(N, cin_padded, dy.device),
                       workspace=ops.splitk_ws(dy.dtype, N, D, H, W, cs, cin_padded, dy.device))
@@ -275,7 +280,7 @@ class _ConvNormAct(torch.autograd.Function):
     backward = norm/activation backward (reduce + apply) -> data gradient (conv kernel) + weight gradient kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False, cat_extra=0, temb_state=None, temb_index=0):
+    def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False, cat_extra=0, temb_state=None, temb_index=0, packs=None):
         """``temb_state``: ``add`` is the block-major add buffer of the whole evaluation (_TembAdds) and this block uses rows
         ``temb_index`` of it (_TembState); otherwise ``add`` is this block's own [N, cout] tensor or None.
         ``cat_extra`` > 0: the activation is the skip of a decoder level -- it is written into channels [0, cout) of a buffer
@@ -285,8 +290,13 @@ class _ConvNormAct(torch.autograd.Function):
         N, D, H, W, cs = x.shape
         cout = weight.shape[0]
         assert x.is_contiguous() and cs % 8 == 0 and cout % 8 == 0 and weight.shape[1] <= cs
-        wp, bp = ops.pack_conv3_weights(weight.detach().float().contiguous(), bias.detach().float(), x.dtype, cin_packed=cs,
-                                        pad_bias=False)
+        wp = packs.get(weight.detach(), "fwd", cs) if packs is not None else None          # batch-packed at the start of the evaluation
+        if wp is not None:
+            bp = bias.detach().float().contiguous()
+        else:
+            wp, bp = ops.pack_conv3_weights(weight.detach().float().contiguous(), bias.detach().float(), x.dtype, cin_packed=cs,
+                                            pad_bias=False)
+        ctx.packs = packs
         raw = torch.empty((N, D, H, W, cout), dtype=x.dtype, device=x.device)
         stats = ops.stats_buffer(N, cout, x.device)
         ops.conv3d_k3(x, cs, 0, wp, bp, cout, raw, 0, stats, workspace=ops.splitk_ws(x.dtype, N, D, H, W, cs, cout, x.device))
@@ -336,15 +346,15 @@ class _ConvNormAct(torch.autograd.Function):
                 dadd = ts.dadd
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1])
+            dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1], ctx.packs)
         if ctx.needs_input_grad[1]:
             dw = ops.zeros(tuple(weight.shape), torch.float32, x.device)
             _wgrad(x, dY, cout, dw)
         db = ops.zeros((cout,), torch.float32, x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
-        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None, None, None, None
+        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None, None, None, None, None
 
 
-def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0):
+def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0, packs=None):
     """``temb``: None (the encoder's blocks) or (add, state): the evaluation's block-major add buffer (_TembAdds) and its
     _TembState; the blocks take their rows in call order."""
     add = state = None
@@ -355,8 +365,9 @@ def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0):
         state.next += 1
         assert block.temb_proj.weight.shape[0] == state.couts[index]
     c0, c1 = block.conv_0, block.conv_1
-    h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None, False, 0, state, index)
-    return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb, pool, cat_extra)
+    h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None, False, 0, state, index, packs)
+    return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb, pool, cat_extra, None, 0,
+                              packs)
 
 
 class _Head(torch.autograd.Function):
@@ -410,17 +421,29 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
     from . import _native
     _native.lib()            # fails loudly when libdua_hip.so is missing
     enc, den = net.embed_model, net.model
+    from . import ops
+    # the nine denoiser blocks in the order they run: their temb_proj rows come out of one launch chain (_TembAdds)
+    blocks = [den.conv_0, den.down_1.convs, den.down_2.convs, den.down_3.convs, den.down_4.convs, den.upcat_4.convs,
+              den.upcat_3.convs, den.upcat_2.convs, den.upcat_1.convs]
+    # every layer's fp16 weights, forward and data-gradient layout, packed by one launch per 64 tensors; an ordinary layer's input
+    # buffer has exactly its Cin channels and its output gradient exactly its Cout (the first layers -- one or seventeen input
+    # channels in a padded buffer -- and fp32 plans pack per layer as before)
+    packs = ops.ConvPacks(dtype)
+    for blk in [enc.conv_0] + [d.convs for d in enc.down] + blocks:
+        for conv in (blk.conv_0.conv, blk.conv_1.conv):
+            w = conv.weight.detach()
+            packs.add(w, "fwd", w.shape[1])
+            if torch.is_grad_enabled():
+                packs.add(w, "dgrad", w.shape[0])
+    packs.run()
     img = _cl_pad(image, dtype)
-    e, pe = _two_conv_cl(enc.conv_0, img, None, None, True)
+    e, pe = _two_conv_cl(enc.conv_0, img, None, None, True, packs=packs)
     emb = [e]
     for i, d in enumerate(enc.down):                 # the pooled copy of each level comes out of its materialize pass
         last = i == len(enc.down) - 1
-        r = _two_conv_cl(d.convs, pe, None, None, not last)
+        r = _two_conv_cl(d.convs, pe, None, None, not last, packs=packs)
         e, pe = (r, None) if last else r
         emb.append(e)
-    # the nine blocks in the order they run: their temb_proj rows come out of one launch chain (_TembAdds)
-    blocks = [den.conv_0, den.down_1.convs, den.down_2.convs, den.down_3.convs, den.down_4.convs, den.upcat_4.convs,
-              den.upcat_3.convs, den.upcat_2.convs, den.upcat_1.convs]
     state = _TembState(image.shape[0], [b.temb_proj.weight.shape[0] for b in blocks])
     tparams = [den.temb.dense[0].weight, den.temb.dense[0].bias, den.temb.dense[1].weight, den.temb.dense[1].bias]
     for b in blocks:
@@ -428,21 +451,20 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
     temb = (_TembAdds.apply(step.to(torch.int64), den.temb.embedding_dim // 2, state, *tparams), state)
     h = _cl_pad([image, x], dtype)
     up_c = [blk.upsample.deconv.weight.shape[1] for blk in (den.upcat_1, den.upcat_2, den.upcat_3, den.upcat_4)]   # channels each
-    x0, p0 = _two_conv_cl(den.conv_0, h, temb, emb[0], True, up_c[0])                                            # decoder adds to the skip
-    x1, p1 = _two_conv_cl(den.down_1.convs, p0, temb, emb[1], True, up_c[1])
-    x2, p2 = _two_conv_cl(den.down_2.convs, p1, temb, emb[2], True, up_c[2])
-    x3, p3 = _two_conv_cl(den.down_3.convs, p2, temb, emb[3], True, up_c[3])
-    x4 = _two_conv_cl(den.down_4.convs, p3, temb, emb[4])
+    x0, p0 = _two_conv_cl(den.conv_0, h, temb, emb[0], True, up_c[0], packs)                                     # decoder adds to the skip
+    x1, p1 = _two_conv_cl(den.down_1.convs, p0, temb, emb[1], True, up_c[1], packs)
+    x2, p2 = _two_conv_cl(den.down_2.convs, p1, temb, emb[2], True, up_c[2], packs)
+    x3, p3 = _two_conv_cl(den.down_3.convs, p2, temb, emb[3], True, up_c[3], packs)
+    x4 = _two_conv_cl(den.down_4.convs, p3, temb, emb[4], packs=packs)
 
     def up(block, lo, skip):
         dc = block.upsample.deconv
-        return _two_conv_cl(block.convs, _UpCat.apply(lo, skip, dc.weight, dc.bias), temb)
+        return _two_conv_cl(block.convs, _UpCat.apply(lo, skip, dc.weight, dc.bias), temb, packs=packs)
 
     u4 = up(den.upcat_4, x4, x3)
     u3 = up(den.upcat_3, u4, x2)
     u2 = up(den.upcat_2, u3, x1)
     u1 = up(den.upcat_1, u2, x0)
-    from . import ops
     wf = den.final_conv.weight
     if wf.shape[0] <= ops.HEAD_MAX_K and u1.shape[-1] <= ops.HEAD_MAX_C:
         return _Head.apply(u1, wf, den.final_conv.bias)

@@ -596,6 +596,19 @@ int dua_gelu(int dtype, long elems, void* x, void* stream);
 int dua_linear_f32(long M, int K, int N, const float* A, long lda, const float* W, const float* bias, float* out, long ldc,
                    int gelu, void* stream);
 
+/* Many 3x3x3 weight tensors in one launch (a training step repacks every layer twice: forward and data-gradient layout).
+ * items: HOST array of count <= 64 entries.  kind 0 = dua_pack_conv3_weights(F16, Cout, Cin, packed, w, NULL, out),
+ * kind 1 = dua_pack_conv3_weights_dgrad(F16, Cout, Cin, packed, w, out); fp16 only, Cin % 4 == 0, w and out 16-byte aligned,
+ * out sized by the per-layer call with w_packed == NULL.  Anything else: DUA_ERR_ARG (pack that layer on its own). */
+typedef struct {
+  int kind;
+  int Cout, Cin;
+  int packed;              /* kind 0: Cin_packed (channels of the input buffer); kind 1: Cout_packed (channels of the dy buffer) */
+  const float* w;
+  void* out;
+} dua_pack_item;
+int dua_pack_conv3_weights_batch(int dtype, int count, const dua_pack_item* items, void* stream);
+
 /* nn.ConvTranspose3d weight fp32[Cin][Cout][2][2][2] -> [tap][cout_tile][chunk][k-group][64][16 B].
  * Returns bytes needed when w_packed is NULL. */
 long dua_pack_deconv_weights(int dtype, int Cin, int Cout, const float* w, void* w_packed, void* stream);

@@ -657,6 +657,31 @@ def test_fp16_weight_packing_through_lds_equals_the_elementwise_kernels(shape):
 
 
 @pytest.mark.gpu
+def test_batched_weight_packing_equals_the_per_layer_calls():
+    """dua_pack_conv3_weights_batch (ops.ConvPacks): 70 tensors -- both layouts of 35 layers of mixed shapes, i.e. two by-value
+    lists -- byte-equal to the per-layer packing calls; tensors the batch form does not take are refused, not mis-packed."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 64), (64, 128), (8, 8), (72, 40), (512, 256), (16, 36), (32, 32)] * 5
+    ws = [torch.randn(co, ci, 3, 3, 3, generator=g).cuda() for co, ci in shapes]
+    packs = ops.ConvPacks(torch.float16)
+    for w in ws:
+        packs.add(w, "fwd", w.shape[1] + (8 if w.shape[1] == 40 else 0))       # one layer reads a wider input buffer
+        packs.add(w, "dgrad", w.shape[0])
+    odd = torch.randn(64, 17, 3, 3, 3, generator=g).cuda()                         # Cin % 4 != 0: the per-layer path
+    packs.add(odd, "fwd", 24)
+    packs.run()
+    assert packs.get(odd, "fwd", 24) is None
+    for w in ws:
+        cp = w.shape[1] + (8 if w.shape[1] == 40 else 0)
+        want, _ = ops.pack_conv3_weights(w, None, torch.float16, cin_packed=cp, pad_bias=False)
+        assert torch.equal(packs.get(w, "fwd", cp), want), tuple(w.shape)
+        want, _ = ops.pack_conv3_weights_dgrad(w, torch.float16, cout_packed=w.shape[0])
+        assert torch.equal(packs.get(w, "dgrad", w.shape[0]), want), tuple(w.shape)
+    assert ops.ConvPacks(torch.float32).run().get(ws[0], "fwd", 64) is None
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", [32, 1, 2, 64])  # plain k loop; plain block order; one workgroup per CU; 12 waves
 def test_conv3_wgrad_launch_variants_agree(variant):
     ops = _ops()

@@ -166,86 +166,99 @@ __global__ __launch_bounds__(256) void temb_train_fwd_kernel(const long long* __
   }
 }
 
-// ---- timestep embedding, backward, part 1: the chain of one sample (16 waves) -----------------------------------------------
-// y[k] = sum_r W[r][k] d[r] for a row-major W: the rows are dealt out to the 16 waves in contiguous runs, a lane owns four
-// adjacent columns (16-byte loads, whole 1 KB row pieces per wave), the 16 partial vectors are summed in wave order.
-constexpr int TB_WAVES = 16;
-__device__ __forceinline__ void tb_rows(const float* __restrict__ w, int hid, int r_lo, int r_hi, int row0, const float* dl, int k0,
-                                        f32x4& acc) {
+// ---- timestep embedding, backward ---------------------------------------------------------------------------------------------
+// y[k] = sum_r W[r][k] d[r] for row-major W (a transposed matrix-vector product), twice in a chain (temb_proj rows -> d s, then
+// W1 -> d h1), spread over workgroups of 64 rows: a thread owns four adjacent columns and every other row of the chunk (32
+// independent 16-byte loads), the two row halves meet in LDS, the chunk's partial vector goes to scratch and the NEXT launch
+// sums the chunks in a fixed order in its prologue.  (First form: one 16-wave workgroup per sample for the whole chain: 73 us.)
+constexpr int TB_ROWS = 64;
+
+// partial[k0..k0+3] over rows [r0, r1) of a matrix whose rows are (a) the concatenated temb_proj weights or (b) w1
+template <bool BLOCKS>
+__device__ __forceinline__ f32x4 tb_partial(const dua_temb_blocks& blk, const float* __restrict__ w1, int hid, int r0, int r1, int rstep,
+                                            const float* dl, int k0) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int b = 0, off = 0;
 #pragma unroll 8
-  for (int r = r_lo; r < r_hi; ++r) {
-    const f32x4 v = *(const f32x4*)(w + (long)(r - row0) * hid + k0);
-    const float d = dl[r];
+  for (int r = r0; r < r1; r += rstep) {
+    const float* row;
+    if (BLOCKS) {
+      while (r >= off + blk.cout[b]) { off += blk.cout[b]; ++b; }
+      row = blk.w[b] + (long)(r - off) * hid;
+    } else {
+      row = w1 + (long)r * hid;
+    }
+    const f32x4 v = *(const f32x4*)(row + k0);
+    const float d = dl[r - r0];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = fmaf(v[q], d, acc[q]);
   }
+  return acc;
 }
 
-__global__ __launch_bounds__(1024) void temb_bwd_chain_kernel(int N, int half, int hid, const float* __restrict__ w1, dua_temb_blocks blk,
-                                                              int P, const float* __restrict__ dadd, const float* __restrict__ saved,
-                                                              float* __restrict__ scratch) {
-  extern __shared__ float sm[];
-  float* part = sm;                        // [16][hid]
-  float* dv = part + TB_WAVES * hid;       // [hid]   dz2 of this sample
-  float* dl = dv + hid;                    // [P]     d add of this sample, blocks concatenated
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;
+// scratch: dz2 [N][hid] | part1 [N][nch1][hid] | part2 [N][nch2][hid]
+__global__ __launch_bounds__(256) void temb_bwd_ds_kernel(int N, int hid, dua_temb_blocks blk, int P, const float* __restrict__ dadd,
+                                                          float* __restrict__ scratch, int nch1) {
+  __shared__ float dl[TB_ROWS];
+  __shared__ __attribute__((aligned(16))) float half1[512];
+  const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
+  const int r0 = chunk * TB_ROWS, r1 = min(P, r0 + TB_ROWS);
+  if (tid < r1 - r0) {                       // this sample's d add of the chunk's rows (block-major source)
+    const int r = r0 + tid;
+    int b = 0, off = 0;
+    while (r >= off + blk.cout[b]) { off += blk.cout[b]; ++b; }
+    dl[tid] = dadd[(long)N * off + (long)n * blk.cout[b] + (r - off)];
+  }
+  __syncthreads();
+  const int col = tid & 127, rg = tid >> 7, k0 = col * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (k0 < hid) acc = tb_partial<true>(blk, nullptr, hid, r0 + rg, r1, 2, dl + rg, k0);
+  if (rg == 1 && k0 < hid) *(f32x4*)(half1 + k0) = acc;
+  __syncthreads();
+  if (rg == 0 && k0 < hid) {
+    const f32x4 o = *(const f32x4*)(half1 + k0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += o[q];
+    *(f32x4*)(scratch + (long)N * hid + ((long)n * nch1 + chunk) * hid + k0) = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void temb_bwd_dh_kernel(int N, int half, int hid, const float* __restrict__ w1, const float* __restrict__ saved,
+                                                          float* __restrict__ scratch, int nch1, int nch2) {
+  __shared__ float dv[512];                   // dz2 of this sample (all of it: every workgroup needs its own 64 rows AND none else, but
+  __shared__ __attribute__((aligned(16))) float half1[512];     // the sum over part1 chunks is cheapest done once per workgroup for its rows)
+  const int tid = threadIdx.x, n = blockIdx.y, chunk = blockIdx.x;
   const int ed = 2 * half;
-  const float* sv = saved + (long)n * (ed + 4 * hid);
-  const float* z1 = sv + ed;
-  const float* z2 = sv + ed + 2 * hid;
-  {
-    int off = 0;
-    for (int b = 0; b < blk.nblocks; ++b) {
-      const int co = blk.cout[b];
-      for (int o = tid; o < co; o += 1024) dl[off + o] = dadd[(long)N * off + (long)n * co + o];
-      off += co;
-    }
-  }
-  __syncthreads();
-  const int R = (P + TB_WAVES - 1) / TB_WAVES;
-  const int r0 = wave * R, r1 = min(P, r0 + R);
-  for (int cg = 0; cg < hid / 256; ++cg) {
-    const int k0 = cg * 256 + lane * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int off = 0;
-    for (int b = 0; b < blk.nblocks; ++b) {
-      const int co = blk.cout[b];
-      const int lo = max(off, r0), hi = min(off + co, r1);
-      if (lo < hi) tb_rows(blk.w[b], hid, lo, hi, off, dl, k0, acc);
-      off += co;
-    }
-    *(f32x4*)(part + wave * hid + k0) = acc;
-  }
-  __syncthreads();
-  if (tid < hid) {
+  const float* z2 = saved + (long)n * (ed + 4 * hid) + ed + 2 * hid;
+  const float* p1 = scratch + (long)N * hid + (long)n * nch1 * hid;
+  const int r0 = chunk * TB_ROWS;             // rows of w1 = elements of dz2 this workgroup multiplies
+  if (tid < TB_ROWS) {
+    const int k = r0 + tid;
     float ds = 0.f;
-#pragma unroll
-    for (int w = 0; w < TB_WAVES; ++w) ds += part[w * hid + tid];
-    const float g = ds * tg_dswish(z2[tid]);
+    for (int c = 0; c < nch1; ++c) ds += p1[(long)c * hid + k];
+    const float g = ds * tg_dswish(z2[k]);
     dv[tid] = g;
-    scratch[(long)n * 2 * hid + tid] = g;
+    scratch[(long)n * hid + k] = g;           // dz2, for the outer-product launch
   }
   __syncthreads();
-  const int R2 = hid / TB_WAVES;
-  for (int cg = 0; cg < hid / 256; ++cg) {
-    const int k0 = cg * 256 + lane * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    tb_rows(w1, hid, wave * R2, (wave + 1) * R2, 0, dv, k0, acc);
-    *(f32x4*)(part + wave * hid + k0) = acc;
-  }
+  const int col = tid & 127, rg = tid >> 7, k0 = col * 4;
+  dua_temb_blocks none{};
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (k0 < hid) acc = tb_partial<false>(none, w1, hid, r0 + rg, r0 + TB_ROWS, 2, dv + rg, k0);
+  if (rg == 1 && k0 < hid) *(f32x4*)(half1 + k0) = acc;
   __syncthreads();
-  if (tid < hid) {
-    float dh = 0.f;
+  if (rg == 0 && k0 < hid) {
+    const f32x4 o = *(const f32x4*)(half1 + k0);
 #pragma unroll
-    for (int w = 0; w < TB_WAVES; ++w) dh += part[w * hid + tid];
-    scratch[(long)n * 2 * hid + hid + tid] = dh * tg_dswish(z1[tid]);
+    for (int q = 0; q < 4; ++q) acc[q] += o[q];
+    *(f32x4*)(scratch + (long)N * hid * (1 + nch1) + ((long)n * nch2 + chunk) * hid + k0) = acc;
   }
 }
 
-// ---- timestep embedding, backward, part 2: every parameter gradient, one workgroup per output row ------------------------------
+// ---- every parameter gradient, one workgroup per output row ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void temb_bwd_outer_kernel(int N, int half, int hid, dua_temb_blocks blk, int P,
                                                              const float* __restrict__ dadd, const float* __restrict__ saved,
-                                                             const float* __restrict__ scratch, float* __restrict__ dw0,
+                                                             const float* __restrict__ scratch, int nch1, int nch2, float* __restrict__ dw0,
                                                              float* __restrict__ db0, float* __restrict__ dw1, float* __restrict__ db1) {
   __shared__ float dn[64];           // this row's output gradient per sample
   const int row = blockIdx.x, tid = threadIdx.x;
@@ -263,12 +276,17 @@ __global__ __launch_bounds__(256) void temb_bwd_outer_kernel(int N, int half, in
     dst = blk.dw[b] + (long)o * hid; bdst = blk.db[b] + o;
   } else if (row < P + hid) {
     const int o = row - P;
-    if (tid < N) dn[tid] = scratch[(long)tid * 2 * hid + o];
+    if (tid < N) dn[tid] = scratch[(long)tid * hid + o];
     cols = hid; act_off = ed + hid;
     dst = dw1 + (long)o * hid; bdst = db1 + o;
   } else {
     const int o = row - P - hid;
-    if (tid < N) dn[tid] = scratch[(long)tid * 2 * hid + hid + o];
+    if (tid < N) {                   // dz1 = swish'(z1) * sum over the w1 row chunks, in chunk order
+      const float* p2 = scratch + (long)N * hid * (1 + nch1) + (long)tid * nch2 * hid + o;
+      float dh = 0.f;
+      for (int c = 0; c < nch2; ++c) dh += p2[(long)c * hid];
+      dn[tid] = dh * tg_dswish(saved[(long)tid * sstride + ed + o]);
+    }
     cols = ed; act_off = 0;
     dst = dw0 + (long)o * ed; bdst = db0 + o;
   }
@@ -483,11 +501,12 @@ int dua_temb_train_bwd(int N, int half_dim, int hidden, const float* w1, const d
   if (N <= 0 || N > 64 || half_dim <= 0 || 2 * half_dim > 1024 || hidden <= 0 || hidden % 256 || hidden > 512 || !w1 ||
       (((size_t)w1) & 15) || !dadd || !saved || !scratch || !dw0 || !db0 || !dw1 || !db1 || !temb_blocks_ok(blocks, hidden, true, &P))
     return DUA_ERR_ARG;
-  const size_t lds = (size_t)(dua::TB_WAVES * hidden + hidden + P) * sizeof(float);          // <= 32 + 2 + 16 KB
-  hipLaunchKernelGGL(dua::temb_bwd_chain_kernel, dim3(N), dim3(1024), lds, (hipStream_t)stream, N, half_dim, hidden, w1, *blocks, P,
-                     dadd, saved, scratch);
-  hipLaunchKernelGGL(dua::temb_bwd_outer_kernel, dim3(P + 2 * hidden), dim3(256), 0, (hipStream_t)stream, N, half_dim, hidden, *blocks,
-                     P, dadd, saved, (const float*)scratch, dw0, db0, dw1, db1);
+  const hipStream_t st = (hipStream_t)stream;
+  const int nch1 = (P + dua::TB_ROWS - 1) / dua::TB_ROWS, nch2 = hidden / dua::TB_ROWS;
+  hipLaunchKernelGGL(dua::temb_bwd_ds_kernel, dim3(nch1, N), dim3(256), 0, st, N, hidden, *blocks, P, dadd, scratch, nch1);
+  hipLaunchKernelGGL(dua::temb_bwd_dh_kernel, dim3(nch2, N), dim3(256), 0, st, N, half_dim, hidden, w1, saved, scratch, nch1, nch2);
+  hipLaunchKernelGGL(dua::temb_bwd_outer_kernel, dim3(P + 2 * hidden), dim3(256), 0, st, N, half_dim, hidden, *blocks, P, dadd, saved,
+                     (const float*)scratch, nch1, nch2, dw0, db0, dw1, db1);
   return (int)hipGetLastError();
 }
 

@@ -826,13 +826,14 @@ def temb_train_fwd(t, half, w0, b0, w1, b1, proj_w, proj_b):
 
 def temb_train_bwd(dadd, saved, half, w1, proj_w):
     """Every parameter gradient of temb_train_fwd from d add (block-major like add): returns (dw0, db0, dw1, db1, [dw_b], [db_b]),
-    views of one flat fp32 buffer, written (not accumulated) by two launches."""
+    views of one flat fp32 buffer, written (not accumulated) by three launches."""
     _f32c(dadd, "dadd"); _f32c(saved, "saved"); _f32c(w1, "w1")
     N, hid = saved.shape[0], w1.shape[0]
     ed = 2 * half
     P = sum(w.shape[0] for w in proj_w)
     assert dadd.numel() == N * P and saved.shape[1] == ed + 4 * hid
-    flat = torch.empty(hid * ed + hid + hid * hid + hid + P * hid + P + N * 2 * hid, dtype=torch.float32, device=saved.device)
+    nscratch = N * hid * (1 + -(-P // 64) + hid // 64)
+    flat = torch.empty(hid * ed + hid + hid * hid + hid + P * hid + P + nscratch, dtype=torch.float32, device=saved.device)
     pos = [0]
 
     def take(*shape):
@@ -846,7 +847,7 @@ def temb_train_bwd(dadd, saved, half, w1, proj_w):
     dw0, db0, dw1, db1 = take(hid, ed), take(hid), take(hid, hid), take(hid)
     dws = [take(w.shape[0], hid) for w in proj_w]
     dbs = [take(w.shape[0]) for w in proj_w]
-    scratch = take(N, 2 * hid)
+    scratch = take(nscratch)
     blk = _temb_blocks(proj_w, dws=dws, dbs=dbs)
     nv.check(nv.lib().dua_temb_train_bwd(N, half, hid, nv.ptr(w1), C.byref(blk), nv.ptr(dadd), nv.ptr(saved), nv.ptr(scratch),
                                          nv.ptr(dw0), nv.ptr(db0), nv.ptr(dw1), nv.ptr(db1), nv.stream_ptr()), "dua_temb_train_bwd")

@@ -219,9 +219,9 @@ int dua_q_sample_affine(int N, long per_sample, const float* src, float a, float
  * for every TwoConv block b (its temb_proj).  ``add`` / ``dadd`` are BLOCK-MAJOR: block b's [N][cout_b] rows are contiguous
  * at float offset N * (cout_0 + .. + cout_{b-1}) -- each block reads / writes an ordinary dense [N][cout] tensor.
  * fwd: writes add and saved = fp32 [N][2*half + 4*hidden] (e, z1, h1, z2, s).
- * bwd: from dadd and saved, every parameter gradient in two launches: dw0 [hidden][2*half], db0, dw1 [hidden][hidden], db1 and
+ * bwd: from dadd and saved, every parameter gradient in three launches: dw0 [hidden][2*half], db0, dw1 [hidden][hidden], db1 and
  *      blocks->dw[b] [cout_b][hidden], blocks->db[b] [cout_b] (all WRITTEN, summed over the samples in a fixed order);
- *      scratch = fp32 [N][2*hidden].  hidden: 256 or 512; 2*half <= 1024; N <= 64; sum of cout <= 4096; weights 16-byte aligned. */
+ *      scratch = fp32 [N * hidden * (1 + ceil(P / 64) + hidden / 64)], P = sum of cout.  hidden: 256 or 512; 2*half <= 1024; N <= 64; sum of cout <= 4096; weights 16-byte aligned. */
 #define DUA_TEMB_MAX_BLOCKS 16
 typedef struct {
   int nblocks;

@@ -76,15 +76,27 @@ __global__ __launch_bounds__(256) void q_sample_affine_kernel(long per, const fl
     const f32x4* s4 = (const f32x4*)(src + base);
     const f32x4* e4 = (const f32x4*)(eps + base);
     f32x4* o4 = (f32x4*)(out + base);
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < per / 4; i += (long)gridDim.x * 256) {
-      const f32x4 s = s4[i], e = e4[i];
-      f32x4 o;
+    const long n4 = per / 4;
+    // four pieces of each stream per thread, requested before anything waits (the coefficient lookup t -> sched in front of a
+    // single piece per thread made every workgroup three dependent round trips: 83 us for 340 MB)
+    for (long i0 = blockIdx.x * 1024L + threadIdx.x; i0 < n4; i0 += (long)gridDim.x * 1024) {
+      f32x4 s[4], e[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float x0 = a * s[k] + b;          // rounded to fp32 like the tensor torch would have materialised (-ffp-contract=off)
-        o[k] = c0 * x0 + c1 * e[k];
+      for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * 256 < n4 ? i0 + u * 256 : n4 - 1;
+        s[u] = s4[i]; e[u] = e4[i];
       }
-      o4[i] = o;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + u * 256 >= n4) break;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float x0 = a * s[u][k] + b;          // rounded to fp32 like the tensor torch would have materialised (-ffp-contract=off)
+          o[k] = c0 * x0 + c1 * e[u][k];
+        }
+        o4[i0 + u * 256] = o;
+      }
     }
   } else {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
@@ -179,19 +191,30 @@ __device__ __forceinline__ f32x4 tb_partial(const dua_temb_blocks& blk, const fl
                                             const float* dl, int k0) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   int b = 0, off = 0;
-#pragma unroll 8
-  for (int r = r0; r < r1; r += rstep) {
-    const float* row;
-    if (BLOCKS) {
-      while (r >= off + blk.cout[b]) { off += blk.cout[b]; ++b; }
-      row = blk.w[b] + (long)(r - off) * hid;
-    } else {
-      row = w1 + (long)r * hid;
-    }
-    const f32x4 v = *(const f32x4*)(row + k0);
-    const float d = dl[r - r0];
+  // eight rows at a time: first their addresses (the walk over the blocks is scalar work), then eight independent 16-byte loads --
+  // with the walk inside the load loop the loads went out one per round trip (29 us for the 1 536 temb_proj rows)
+  for (int rb = r0; rb < r1; rb += 8 * rstep) {
+    const float* row[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = fmaf(v[q], d, acc[q]);
+    for (int u = 0; u < 8; ++u) {
+      const int r = min(rb + u * rstep, r1 - 1);          // clamped address, masked use
+      if (BLOCKS) {
+        while (r >= off + blk.cout[b]) { off += blk.cout[b]; ++b; }
+        row[u] = blk.w[b] + (long)(r - off) * hid + k0;
+      } else {
+        row[u] = w1 + (long)r * hid + k0;
+      }
+    }
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)row[u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = rb + u * rstep;
+      const float d = r < r1 ? dl[min(r, r1 - 1) - r0] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(v[u][q], d, acc[q]);
+    }
   }
   return acc;
 }
@@ -459,8 +482,8 @@ int dua_q_sample_affine(int N, long per_sample, const float* src, float a, float
                         const long long* t, float* out, void* stream) {
   if (N <= 0 || N > 65535 || per_sample <= 0 || !src || !eps || !sched || T <= 0 || !t || !out) return DUA_ERR_ARG;
   const int vec = per_sample % 4 == 0 && ((((size_t)src) | ((size_t)eps) | ((size_t)out)) & 15) == 0;
-  long blocks = ((vec ? per_sample / 4 : per_sample) + 255) / 256;          // one 16-byte piece per thread: a streaming pass wants
-  if (blocks > 65535) blocks = 65535;                                       // every CU full of independent requests (88 -> 59 us at 4 096 blocks per sample)
+  long blocks = vec ? (per_sample / 4 + 1023) / 1024 : (per_sample + 255) / 256;
+  if (blocks > 65535) blocks = 65535;
   hipLaunchKernelGGL(dua::q_sample_affine_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, per_sample, src, a, b,
                      eps, sched, T, t, out, vec);
   return (int)hipGetLastError();

@@ -333,17 +333,14 @@ class _ConvNormAct(torch.autograd.Function):
         ts = ctx.temb_state
         dadd_out = None
         if ts is not None:
-            if ts.dadd is None:
-                ts.dadd = torch.empty(ts.N * ts.P, dtype=torch.float32, device=raw.device)
+            if ts.dadd is None:           # zero-initialised: a block whose backward never runs (its output unused) contributes nothing
+                ts.dadd = ops.zeros((ts.N * ts.P,), torch.float32, raw.device)
             dadd_out = ts.rows(ts.dadd, ctx.temb_index)
         dgamma, dbeta, dadd = ops.instnorm_bwd(buf, off, raw, cout, norm, dY, want_add=ctx.has_add, dadd_out=dadd_out)
         if ts is not None:
             ts.written += 1
             # the evaluation's first block runs last in backward and hands the shared buffer on (see _TembState)
-            dadd = None
-            if ctx.temb_index == 0:
-                assert ts.written == len(ts.couts), "a TwoConv block's backward ran after the first block's"
-                dadd = ts.dadd
+            dadd = ts.dadd if ctx.temb_index == 0 else None
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1], ctx.packs)

@@ -617,8 +617,8 @@ class NativeConvTrainer:
 
     # ---- whole-step HIP graph (single process): the eager step issues ~3,000 launches and is host-bound once the kernels
     # take < 22 ms; one replay per step removes the host from the loop.  Everything a step decides stays on the device:
-    # the timestep -> (sqrt(a_bar), sqrt(1 - a_bar)) gather, the fp16 overflow check (found_inf feeds the fused AdamW,
-    # which skips the update itself) and the loss-scale update (torch._amp_update_scale_).
+    # the timestep -> (sqrt(a_bar), sqrt(1 - a_bar)) gather, the fp16 overflow check (the flag feeds NativeAdamW,
+    # which skips the update itself) and the loss-scale update (dua_adamw_advance: torch._amp_update_scale_'s rule).
     def _graph_fwd_bwd(self):
         from . import ops
         g = self._g

@@ -288,7 +288,7 @@ def test_native_trainer_two_ranks_equal_union_batch(overlap, graph):
     """Two processes (one GPU, gloo) each train on their own sample; the gradient averaging (DDP reducer buckets
     overlapped with backward, one flat all-reduce after it, or the flat all-reduce between the two HIP graphs of graph
     mode) must leave both with the parameters single-process training on the two-sample batch produces (oracle
-    autograd, CPU; graph mode uses the fused AdamW, whose arithmetic differs from the foreach one in the last bits)."""
+    autograd, CPU; the trainer's AdamW is the library's kernel, whose arithmetic differs from torch's foreach one in the last bits)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() + 177) % 2000
@@ -327,7 +327,7 @@ def test_native_trainer_two_ranks_equal_union_batch(overlap, graph):
 
 @pytest.mark.gpu
 def test_graph_replayed_training_step_equals_eager():
-    """The whole training step captured as one HIP graph (fused capturable AdamW, device-side overflow check and loss
+    """The whole training step captured as one HIP graph (the library's AdamW, device-side overflow check and loss
     scale) must walk the same parameters as the eager trainer on the same batches, timesteps and noise."""
     from diff_unet_amos_amd.training import NativeConvTrainer
     dev = torch.device("cuda:0")
@@ -337,7 +337,7 @@ def test_graph_replayed_training_step_equals_eager():
     torch.manual_seed(0)
     init = {k: v.detach().cpu().clone() for k, v in DiffUNet(**KW).state_dict().items()}
     runs = []
-    # eager with torch's default (foreach) AdamW, eager with the fused capturable AdamW, graph (always the fused one)
+    # eager with torch.optim.AdamW (foreach), eager with the library's AdamW (NativeAdamW), graph (always NativeAdamW)
     for mode, fused in ((False, False), (False, True), (True, True)):
         torch.manual_seed(0)
         net = DiffUNet(**KW).to(dev)
@@ -353,9 +353,9 @@ def test_graph_replayed_training_step_equals_eager():
         den = sum(float(((a[k] - init[k]).double() ** 2).sum()) for k in a)
         return (num / den) ** 0.5
 
-    opt_gap = rel_update_diff(runs[0][1], runs[1][1])      # foreach vs fused AdamW, both eager
+    opt_gap = rel_update_diff(runs[0][1], runs[1][1])      # torch.optim.AdamW vs NativeAdamW, both eager
     graph_gap = rel_update_diff(runs[1][1], runs[2][1])    # same optimizer kernel: eager vs graph replay
-    print(f"losses eager {runs[1][0]} graph {runs[2][0]}; relative 4-step update difference: foreach-vs-fused AdamW (eager) "
+    print(f"losses eager {runs[1][0]} graph {runs[2][0]}; relative 4-step update difference: torch-vs-library AdamW (eager) "
           f"{opt_gap:.3e}, eager-vs-graph with the same AdamW {graph_gap:.3e}")
     assert np.allclose(runs[1][0], runs[2][0], rtol=1e-6), (runs[1][0], runs[2][0])
     # same kernels, same order, same optimizer: the replayed step must reproduce the eager one (this also proves the

@@ -574,6 +574,7 @@ class NativeConvTrainer:
         self.lr, self.weight_decay, self.init_scale = lr, weight_decay, init_scale
         self.use_graph, self._graph, self._graph2 = graph, None, None
         self._qtab = None
+        self._amp = None
         self.module = _NativeModule(net, dtype)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.overlap = overlap and self.distributed and not graph        # the DDP reducer's hooks cannot be captured
@@ -718,6 +719,26 @@ class NativeConvTrainer:
             self._graph2.replay()
         return g["loss"]
 
+    def _amp_state(self):
+        """Device-resident loss-scaling state of eager fp16 steps on the library's AdamW: scale, growth counter, this step's
+        overflow flag and the flag the last completed step saw (``loss_scale()`` / ``last_step_overflowed()`` read them back)."""
+        if self._amp is None:
+            dev = self.params[0].device
+            self._amp = dict(scale=torch.full((), float(self.init_scale), device=dev), growth=torch.zeros((), dtype=torch.int32, device=dev),
+                             flag=torch.zeros((), device=dev), seen=torch.zeros((), device=dev))
+        return self._amp
+
+    def loss_scale(self):
+        """The current loss scale (a device read-back in the modes that keep it on the device)."""
+        if self.use_graph and self._graph is not None:
+            return float(self._g["scale"])
+        return float(self._amp["scale"]) if self._amp is not None else float(self.scale)
+
+    def last_step_overflowed(self):
+        if self.use_graph and self._graph is not None:
+            return bool(self._g["found_inf"].item())
+        return bool(self._amp["seen"].item()) if self._amp is not None else False
+
     def step(self, images, labels, noise=None, t=None):
         if self.use_graph:
             return self._graph_step(images, labels, noise, t)
@@ -742,32 +763,33 @@ class NativeConvTrainer:
         with (self.arena if self.arena is not None else contextlib.nullcontext()), torch.enable_grad():
             loss = _SegLoss.apply(self.module(images, x_t, t), labels.float().contiguous(), self.loss_names,
                                   self.loss_combine)
+            amp = self._amp_state() if (self.dtype == torch.float16 and self.native_opt) else None
             with _wgrad_side(self.wgrad_stream):
-                (loss * self.scale).backward()
+                (loss * (amp["scale"] if amp is not None else self.scale)).backward()
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         self._allreduce()
-        scale_dev = None
-        if self.dtype == torch.float16:
+        if amp is not None:
+            # dynamic loss scaling without a host decision (the eager step used to read found_inf back -- one synchronisation per
+            # step, which also kept the host from running ahead of the device under the DDP reducer): overflow flag, skipped update,
+            # scale and growth counter live on the device exactly as in the captured step
             from . import ops
+            ops.grads_nonfinite([p.grad for p in self.params], amp["flag"])
+            self.optimizer.step(grad_scale=amp["scale"], found_inf=amp["flag"], store_grad=True, advance=False)
+            ops.adamw_advance(self.optimizer._count, amp["flag"], amp["scale"], amp["growth"], 2.0, 0.5, 200, seen=amp["seen"])
+            return loss.detach()
+        if self.dtype == torch.float16:
             dev = self.params[0].device
             found_inf = torch.zeros(1, dtype=torch.float32, device=dev)
             grads = [p.grad for p in self.params]
-            if self.native_opt:          # read-only check; the update applies 1 / scale itself and stores the unscaled gradients
-                ops.grads_nonfinite(grads, found_inf)
-                scale_dev = torch.full((1,), self.scale, dtype=torch.float32, device=dev)
-            else:                        # torch's one multi-tensor kernel: grads *= 1/scale, found_inf = any non-finite
-                inv = torch.full((1,), 1.0 / self.scale, dtype=torch.float32, device=dev)
-                torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv)
+            inv = torch.full((1,), 1.0 / self.scale, dtype=torch.float32, device=dev)
+            torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv)      # torch.optim.AdamW path (fused_optimizer=False)
             if bool(found_inf.item()):                                           # overflow: skip, halve the scale
                 self.scale, self.good_steps = max(self.scale / 2, 2.0 ** -14), 0
                 return loss.detach()
             self.good_steps += 1
             if self.good_steps >= 200:
                 self.scale, self.good_steps = self.scale * 2, 0
-        if self.native_opt:
-            self.optimizer.step(grad_scale=scale_dev, store_grad=scale_dev is not None)
-        else:
-            self.optimizer.step()
+        self.optimizer.step()
         return loss.detach()

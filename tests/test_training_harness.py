@@ -409,22 +409,24 @@ def test_full_size_gradients_fp16_path_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_graph_trainer_fp16_dynamic_loss_scale():
-    """fp16 graph mode: an absurd initial loss scale must overflow, be halved on the device step by step (the fused
-    AdamW skipping those updates), and training must then proceed -- without any host decision inside the replay."""
+@pytest.mark.parametrize("graph", [True, False], ids=["graph", "eager"])
+def test_trainer_fp16_dynamic_loss_scale_stays_on_the_device(graph):
+    """fp16, captured or eager: an absurd initial loss scale must overflow, be halved on the device step by step (AdamW skipping
+    those updates), and training must then proceed -- without any host decision inside the step (the eager step used to read the
+    overflow flag back every step)."""
     from diff_unet_amos_amd.training import NativeConvTrainer
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     net = DiffUNet(**KW).to(dev)
     w0 = net.model.conv_0.conv_0.conv.weight.detach().clone()
-    tr = NativeConvTrainer(net, lr=2e-3, dtype=torch.float16, graph=True, init_scale=2.0 ** 40)
+    tr = NativeConvTrainer(net, lr=2e-3, dtype=torch.float16, graph=graph, init_scale=2.0 ** 40)
     image, labels, noise, t = _data(2, 11)
     image, labels, noise, t = image.to(dev), labels.to(dev), noise.to(dev), t.to(dev)
     first = float(tr.step(image, labels, noise=noise, t=t))
-    assert float(tr._g["found_inf"]) == 1.0 and float(tr._g["scale"]) == 2.0 ** 39       # overflow seen, scale halved
+    assert tr.last_step_overflowed() and tr.loss_scale() == 2.0 ** 39                      # overflow seen, scale halved
     assert torch.equal(net.model.conv_0.conv_0.conv.weight.detach(), w0)                   # and the update was skipped
     losses = [first] + [float(tr.step(image, labels, noise=noise, t=t)) for _ in range(40)]
-    assert float(tr._g["scale"]) < 2.0 ** 30 and all(np.isfinite(losses))
+    assert tr.loss_scale() < 2.0 ** 30 and all(np.isfinite(losses)) and not tr.last_step_overflowed()
     assert not torch.equal(net.model.conv_0.conv_0.conv.weight.detach(), w0)
     assert losses[-1] < losses[0], (losses[0], losses[-1])
 

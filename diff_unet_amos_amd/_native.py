@@ -125,7 +125,7 @@ class AdamWList(C.Structure):
                 ("g", C.c_void_p * ADAMW_MAX_TENSORS), ("m", C.c_void_p * ADAMW_MAX_TENSORS), ("v", C.c_void_p * ADAMW_MAX_TENSORS)]
 
 _P = C.c_void_p
-ABI_VERSION = 6          # DUA_ABI_VERSION of include/dua_hip.h this binding was written against
+ABI_VERSION = 7          # DUA_ABI_VERSION of include/dua_hip.h this binding was written against
 
 _SIGS = {
     "dua_abi_version": (C.c_int, []),
@@ -139,7 +139,7 @@ _SIGS = {
     "dua_final_conv_sampler": (C.c_int, [C.POINTER(TailDesc), _P, C.POINTER(InNorm)] + [_P] * 11),
     "dua_final_conv_sampler_res": (C.c_int, [C.POINTER(TailDesc), _P, C.POINTER(InNorm), C.POINTER(TailResidual)] + [_P] * 11),
     "dua_window_attention_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
-                                           _P, C.c_float, _P, _P]),
+                                           C.c_float, _P, _P]),
     "dua_patch_merge_norm": (C.c_int, [C.c_int] * 7 + [_P, _P, _P, _P, C.c_float, _P, _P]),
     "dua_residual_norm_act": (C.c_int, [C.c_int, C.c_int, C.c_long, C.c_int, _P, C.c_int, C.POINTER(InNorm), _P, C.c_int,
                                         C.POINTER(InNorm), _P, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_int,

@@ -23,12 +23,8 @@
 // keeps the 2197-entry column of its head in LDS (8.8 KB instead of 343 x 343 floats from L2) and looks up
 // table[off(q) - off(k) + centre].  Token -> coordinate uses the TABLE's grid (7, 7, 7) even for clipped windows: the
 // reference slices relative_position_index[:n, :n] of the 7^3 index (attention.py:104).
-// Alternative form (bias_tiles; kept for the kernel tests, NOT used by the launch plans -- it trades the LDS gathers for a global
-// round trip per key block and measured slower at the coarse stages): the same bias, gathered once per weight
-// version on the host side into the ACCUMULATOR's order --
-// [head][query block][key block][lane][16] fp32, pre-multiplied by log2 e -- so that a key block costs four 16-byte loads per
-// lane (4 KB contiguous per wave, shared by all windows of the image: 1.45 MB at 3 heads x 343 tokens, L2 resident) instead of
-// 16 per-lane LDS gathers and their address arithmetic (LDS instructions per launch 1.08 M -> 0.22 M, VALU 14.1 M -> 11.9 M).
+// A third form -- the bias gathered on the host side into the accumulator's order, four 16-byte global loads per key block instead
+// of the LDS lookups -- measured slower at the coarse stages and was removed in round 4 with its ABI parameter.
 // Bias and mask otherwise arrive TRANSPOSED ([head][key][query], [window][key][query], fp32) so that the 32 lanes of a half read
 // 128 contiguous bytes per key.  The shifted-window mask can instead be given as what compute_mask builds it from: one
 // region id per token of every window ([windows per image][tokens], uint8; attention.py:135-157) -- 343 bytes per window
@@ -47,14 +43,13 @@ constexpr int MAXTAB = 2208;    // (2*7-1)^3 = 2197 table entries per head, padd
 struct WinAttnArgs {
   const void* qkv; const float* bias_t; const float* mask_t; const unsigned char* region; void* out;
   const float* table;           // [heads][tab_len] or null (then bias_t)
-  const float* btile;           // [heads][nb][nb][64 lanes][16] bias in accumulator order, x log2 e; takes precedence
   int gd, gh, gw, tab_len;      // grid the relative-position index was built for
   int n, heads, nw;             // tokens per window, heads, windows per image (mask index = window % nw)
   float scale;
 };
 
-// BIAS: where the relative-position bias comes from -- 0 the reference's table (production), 1 accumulator-ordered tiles, 2 a dense
-// transposed matrix (both for the kernel tests).  A template parameter: as run-time branches the three forms left the score tile
+// BIAS: where the relative-position bias comes from -- 0 the reference's table (production), 2 a dense transposed matrix (the
+// kernel tests' independent form).  A template parameter: as run-time branches the forms left the score tile
 // "undefined on the other paths", which hipcc materialises as 16 register fills per key block.
 template <typename T, int BIAS>
 __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
@@ -102,12 +97,12 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) vp[e * 8] = v[e];
   }
-  constexpr bool has_tiles = BIAS == 1, has_table = BIAS == 0;
+  constexpr bool has_table = BIAS == 0;
   const int sh_ = 2 * a.gw - 1, sd_ = (2 * a.gh - 1) * sh_;         // strides of the (dd, dh, dw) difference grid
   // The score tile starts as the BIAS: the table lookups land in the accumulator registers and the MFMA adds q.k on top
   // (q carries the scale: head dimension 16 -> 0.25, exact in fp16), so a score costs no zero, no multiply-add of its own;
   // exp(z - m) is exp2(fma(z, log2 e, -m log2 e)).  koff holds BYTE offsets into the table: a lookup address is one subtraction.
-  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  constexpr float LOG2E = 1.4426950408889634f;
   if (has_table) {
     for (int i = tid; i < a.tab_len; i += 256) tab[i] = a.table[(long)head * a.tab_len + i];
     for (int i = tid; i < nb * 32; i += 256) {
@@ -160,11 +155,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
   auto scores = [&](int kb) {
     const f16x8 kf = *(const f16x8*)(Kl + (kb * 32 + r) * HD + hh * 8);  // A operand: K[key r][dims 8hh..]
     f32x16 z;
-    if constexpr (has_tiles) {
-      const f32x16 bt = *(const f32x16*)(a.btile + ((((long)head * nb + qb) * nb + kb) * 64 + lane) * 16);   // 4 x 16 B, L2 resident
-#pragma unroll
-      for (int i = 0; i < 16; ++i) z[i] = bt[i] * LN2;          // the tiles are stored x log2 e
-    } else if constexpr (has_table) {
+    if constexpr (has_table) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {               // register quad j = keys kb*32 + 8j + 4hh + (0..3): one 8-byte read of offsets
         typedef short short4v __attribute__((ext_vector_type(4)));
@@ -268,16 +259,15 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnArgs a) {
 extern "C" int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image,
                                         const void* qkv, const float* bias_t, const float* mask_t,
                                         const unsigned char* region_ids, const float* bias_table, int grid_d, int grid_h,
-                                        int grid_w, const float* bias_tiles, float scale, void* out, void* stream) {
+                                        int grid_w, float scale, void* out, void* stream) {
   using namespace dua;
-  if (!qkv || (!bias_t && !bias_table && !bias_tiles) || !out || windows <= 0 || heads <= 0 || tokens <= 0 || tokens > wa::MAXB * 32)
+  if (!qkv || (!bias_t && !bias_table) || !out || windows <= 0 || heads <= 0 || tokens <= 0 || tokens > wa::MAXB * 32)
     return DUA_ERR_ARG;
   if ((mask_t || region_ids) && (windows_per_image <= 0 || windows % windows_per_image)) return DUA_ERR_ARG;
   WinAttnArgs a;
-  a.btile = bias_tiles;
-  a.qkv = qkv; a.bias_t = (bias_table || bias_tiles) ? nullptr : bias_t; a.mask_t = mask_t; a.region = region_ids; a.out = out;
-  a.table = bias_tiles ? nullptr : bias_table; a.gd = grid_d; a.gh = grid_h; a.gw = grid_w; a.tab_len = 0;
-  if (bias_table && !bias_tiles) {
+  a.qkv = qkv; a.bias_t = bias_table ? nullptr : bias_t; a.mask_t = mask_t; a.region = region_ids; a.out = out;
+  a.table = bias_table; a.gd = grid_d; a.gh = grid_h; a.gw = grid_w; a.tab_len = 0;
+  if (bias_table) {
     if (grid_d <= 0 || grid_h <= 0 || grid_w <= 0 || tokens > grid_d * grid_h * grid_w) return DUA_ERR_ARG;
     a.tab_len = (2 * grid_d - 1) * (2 * grid_h - 1) * (2 * grid_w - 1);
     if (a.tab_len > wa::MAXTAB) return DUA_ERR_ARG;
@@ -288,12 +278,12 @@ extern "C" int dua_window_attention_fwd(int dtype, int windows, int tokens, int 
                   wa::MAXTAB * 4 + wa::MAXB * 32 * 2 + wa::MAXB * 32;                                        // table, offsets, regions
   dim3 grid(windows, heads, (long)windows * heads >= 1024 ? 1 : (nb + 3) / 4);
   if (dtype != DUA_F16 && dtype != DUA_F32) return DUA_ERR_ARG;
-  const int bias_mode = a.btile ? 1 : a.table ? 0 : 2;
+  const int bias_mode = a.table ? 0 : 2;
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, a); };
   if (dtype == DUA_F16) {
-    if (bias_mode == 0) go(window_attention_kernel<f16, 0>); else if (bias_mode == 1) go(window_attention_kernel<f16, 1>); else go(window_attention_kernel<f16, 2>);
+    if (bias_mode == 0) go(window_attention_kernel<f16, 0>); else go(window_attention_kernel<f16, 2>);
   } else {
-    if (bias_mode == 0) go(window_attention_kernel<float, 0>); else if (bias_mode == 1) go(window_attention_kernel<float, 1>); else go(window_attention_kernel<float, 2>);
+    if (bias_mode == 0) go(window_attention_kernel<float, 0>); else go(window_attention_kernel<float, 2>);
   }
   return (int)hipGetLastError();
 }

@@ -1030,24 +1030,8 @@ def denoiser_step(plan_struct):
     nv.check(nv.lib().dua_denoiser_step(C.byref(plan_struct), nv.stream_ptr()), "dua_denoiser_step")
 
 
-def attention_bias_tiles(bias):
-    """Dense relative-position bias [heads, n, n] (query, key) -> the tile form of dua_window_attention_fwd (kernel tests only; the plans use the table form): fp32
-    [heads, nb, nb, 64, 16] in the kernel's accumulator order, times log2(e), zero beyond n."""
-    import math
-    heads, n, _ = bias.shape
-    nb = -(-n // 32)
-    full = torch.zeros((heads, nb * 32, nb * 32), dtype=torch.float32, device=bias.device)
-    full[:, :n, :n] = bias.float() * math.log2(math.e)
-    lane = torch.arange(64, device=bias.device)
-    i = torch.arange(16, device=bias.device)
-    qrow = (lane & 31)[:, None].expand(64, 16)                                  # query within the block
-    krow = ((i & 3) + 8 * (i >> 2))[None, :] + 4 * (lane >> 5)[:, None]         # key within the block (accumulator row)
-    t = full.view(heads, nb, 32, nb, 32)[:, :, qrow, :, krow]                    # [64, 16, heads, nb, nb] (advanced indices first)
-    return t.permute(2, 3, 4, 0, 1).contiguous()
-
-
 def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1, region_ids=None, out=None, bias_table=None,
-                     table_grid=(7, 7, 7), bias_tiles=None):
+                     table_grid=(7, 7, 7)):
     """Softmax attention inside windows (models/swin_unetr/attention.py:97-120 between the qkv and proj Linear layers).
     qkv: [windows, tokens, 3 * heads * 16] (fp16 or fp32, contiguous); bias_t: fp32 [heads, tokens, tokens] = bias[h].T;
     the shifted-window mask either as mask_t: fp32 [windows_per_image, tokens, tokens] = mask[w].T, or as region_ids:
@@ -1057,11 +1041,7 @@ def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1, regio
     assert qkv.is_cuda and qkv.is_contiguous() and qkv.dim() == 3 and qkv.dtype in (torch.float16, torch.float32)
     Wn, n, c3 = qkv.shape
     assert c3 == 3 * heads * 16 and n <= 352, "head dimension 16, at most 352 tokens per window"
-    if bias_tiles is not None:
-        _f32c(bias_tiles, "bias_tiles")
-        nb_ = -(-n // 32)
-        assert bias_t is None and bias_table is None and tuple(bias_tiles.shape) == (heads, nb_, nb_, 64, 16)
-    elif bias_table is not None:
+    if bias_table is not None:
         _f32c(bias_table, "bias_table")
         gd, gh, gw = table_grid
         assert bias_t is None and tuple(bias_table.shape) == (heads, (2 * gd - 1) * (2 * gh - 1) * (2 * gw - 1)) and n <= gd * gh * gw
@@ -1080,7 +1060,7 @@ def window_attention(qkv, heads, bias_t, mask_t=None, windows_per_image=1, regio
     assert out.is_contiguous() and out.dtype == qkv.dtype and out.numel() == Wn * n * heads * 16
     nv.check(nv.lib().dua_window_attention_fwd(nv.dt_code(qkv.dtype), Wn, n, heads, windows_per_image, nv.ptr(qkv), nv.ptr(bias_t),
                                                nv.ptr(mask_t), nv.ptr(region_ids), nv.ptr(bias_table), table_grid[0], table_grid[1],
-                                               table_grid[2], nv.ptr(bias_tiles), 16 ** -0.5, nv.ptr(out), nv.stream_ptr()),
+                                               table_grid[2], 16 ** -0.5, nv.ptr(out), nv.stream_ptr()),
              "dua_window_attention_fwd")
     return out
 

@@ -273,7 +273,7 @@ int dua_adamw_advance(int* step, float* found_inf, float* scale, int* growth, fl
  * worker thread), call it once up front, on the device they will use, so that no such call happens inside a capture.
  * Thread-safe.  Returns 0, DUA_ERR_ARG (no current device) or a hipError_t.
  * dua_prepared_kernels(): how many kernels dua_prepare() configures (tests). */
-#define DUA_ABI_VERSION 6
+#define DUA_ABI_VERSION 7
 int dua_abi_version(void);
 int dua_prepare(void);
 int dua_prepared_kernels(void);
@@ -479,14 +479,11 @@ int dua_denoiser_step(const dua_denoiser_plan* plan, void* stream);
  * bias_table (or NULL): the relative-position bias in the form the reference stores it, transposed to
  * fp32 [heads][(2 grid_d - 1)(2 grid_h - 1)(2 grid_w - 1)] (attention.py:49-54 relative_position_bias_table; grid = the
  * window the index was built for, (7, 7, 7), also when the window itself is clipped); the kernel evaluates
- * relative_position_index (attention.py:56-73) from the token coordinates.  Takes precedence over bias_t.
- * bias_tiles (or NULL): the gathered bias in the kernel's accumulator order, fp32 [heads][nb][nb][64][16] with
- * nb = ceil(tokens / 32): element [h][qb][kb][lane][i] = log2(e) * bias[h][query qb*32 + (lane & 31)][key kb*32 + (i & 3) +
- * 8 (i >> 2) + 4 (lane >> 5)] (0 beyond `tokens`).  Built once per weight version; takes precedence over both other forms. */
+ * relative_position_index (attention.py:56-73) from the token coordinates.  Takes precedence over bias_t. */
 int dua_window_attention_fwd(int dtype, int windows, int tokens, int heads, int windows_per_image, const void* qkv,
                              const float* bias_t, const float* mask_t, const unsigned char* region_ids,
-                             const float* bias_table, int grid_d, int grid_h, int grid_w, const float* bias_tiles,
-                             float scale, void* out, void* stream);
+                             const float* bias_table, int grid_d, int grid_h, int grid_w, float scale, void* out,
+                             void* stream);
 
 /* PatchMerging.forward up to the reduction Linear (models/swin_unetr/patch.py:44-61; legacy != 0: the 3-D gather of
  * :70-91 with its duplicated corners): x [B][D][H][W][C] -> out [B][ceil(D/2)][ceil(H/2)][ceil(W/2)][8C] = LayerNorm_8C(gather),

@@ -73,13 +73,37 @@ __global__ __launch_bounds__(wf::NT) void conv3d_k3_wgrad_fo_kernel(wf::Args a) 
   const bool xchan = cs * 32 + 8 * g4 < a.Cin;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const long vox = (long)a.D * a.H * a.W;
-  auto issue_tile = [&](int tile, int buf) -> unsigned {
+  // tile -> (sample, tile coordinates) without a division per tile: the walk advances by P tiles, so the coordinates advance by
+  // P's own decomposition with carries (three runtime divisions per tile and wave were ~100 of the ~500 scalar instructions a
+  // wave spends per tile, profiles/r4_pmc_wgrad_fo.json: 3.2 SALU instructions per MFMA)
+  int nx_w, nx_h, nx_d, nx_n;                                  // coordinates of the NEXT tile to request (wave-uniform)
+  {
+    int t = part_id;
+    nx_w = t % a.tiles_w; t /= a.tiles_w;
+    nx_h = t % a.tiles_h; t /= a.tiles_h;
+    nx_d = t % a.tiles_d; nx_n = t / a.tiles_d;
+  }
+  int st_w, st_h, st_d, st_n;                                  // P in the same mixed radix
+  {
+    int t = a.P;
+    st_w = t % a.tiles_w; t /= a.tiles_w;
+    st_h = t % a.tiles_h; t /= a.tiles_h;
+    st_d = t % a.tiles_d; st_n = t / a.tiles_d;
+  }
+  auto advance = [&]() {
+    nx_w += st_w;
+    int c = nx_w >= a.tiles_w; nx_w -= c ? a.tiles_w : 0;
+    nx_h += st_h + c;
+    c = nx_h >= a.tiles_h; nx_h -= c ? a.tiles_h : 0;
+    nx_d += st_d + c;
+    c = nx_d >= a.tiles_d; nx_d -= c ? a.tiles_d : 0;
+    nx_n += st_n + c;
+  };
+  auto issue_tile = [&](int buf) -> unsigned {                 // requests tile (nx_n, nx_d, nx_h, nx_w) and advances the walk
     unsigned okbits = 0;
-    int t = tile;
-    const int tw_ = t % a.tiles_w; t /= a.tiles_w;
-    const int th_ = t % a.tiles_h; t /= a.tiles_h;
-    const int td_ = t % a.tiles_d; const int n = t / a.tiles_d;
-    const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
+    const int n = nx_n;
+    const int d0 = nx_d * TD, h0 = nx_h * TH, w0 = nx_w * TW;
+    advance();
     const T* xb = (const T*)a.x + n * vox * a.Cin_stride + a.Cin_off + cs * 32 + 8 * g4;
     const T* yb = (const T*)a.dy + n * vox * a.Cout_stride + a.Cout_off + ct * 64 + 8 * g4;
 #pragma unroll
@@ -193,13 +217,13 @@ __global__ __launch_bounds__(wf::NT) void conv3d_k3_wgrad_fo_kernel(wf::Args a) 
   // ---- tile loop: two buffers, one tile in flight ----
   int tile = part_id, cur = 0;
   unsigned okbits = 0;
-  if (tile < a.total_tiles) okbits = issue_tile(tile, 0);
+  if (tile < a.total_tiles) okbits = issue_tile(0);
   for (; tile < a.total_tiles; tile += a.P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile has landed ...
     fix_tile(cur, okbits);
     __syncthreads();                                           // ... for every wave, and the other buffer's readers are through
 #if !defined(WF_ABL) || WF_ABL != 1        // diagnostic builds: WF_ABL=1 no transfers, 2 no k loop
-    if (tile + a.P < a.total_tiles) okbits = issue_tile(tile + a.P, cur ^ 1);
+    if (tile + a.P < a.total_tiles) okbits = issue_tile(cur ^ 1);
 #endif
 #if !defined(WF_ABL) || WF_ABL != 2
     kloop(smem + cur * BUFB);

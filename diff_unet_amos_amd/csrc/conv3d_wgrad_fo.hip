@@ -160,8 +160,8 @@ __global__ __launch_bounds__(wf::NT) void conv3d_k3_wgrad_fo_kernel(wf::Args a) 
   const int i16 = lane & 15, qv = i16 >> 2, pch = i16 & 3, g1 = (lane >> 4) & 1;
   const int b_col = (16 * g1 + 4 * pch) * 2;
   // byte offsets inside a buffer: dy fragment (+ step * 16 * RSB), x fragment (+ step offset + tap offset)
-  const int ya0 = XIMG + coh * YIMG + (8 * hl + qv) * RSB + b_col, ya1 = ya0 + 4 * RSB;
-  const int xa0 = (hl * XW + qv) * RSB + b_col, xa1 = xa0 + 4 * RSB;
+  const int ya0 = XIMG + coh * YIMG + (8 * hl + qv) * RSB + b_col;      // (+ 4 * RSB: the second voxel quad)
+  const int xa0 = (hl * XW + qv) * RSB + b_col;
   int tap_off[NTAP];                                             // the tap's shift inside the x image (wave-uniform)
 #pragma unroll
   for (int j = 0; j < NTAP; ++j) {
@@ -170,36 +170,43 @@ __global__ __launch_bounds__(wf::NT) void conv3d_k3_wgrad_fo_kernel(wf::Args a) 
     tap_off[j] = ((kd * XH + kh) * XW + kw) * RSB;
   }
 
-  auto kloop = [&](const char* buf) {
+  typedef __attribute__((address_space(3))) h4* lds_h4p;
+  auto kloop = [&](int bufoff) {
+    // Every wave runs SEVEN taps per k-step: the two waves with six real taps (grp = 3) repeat their first tap into an accumulator
+    // nobody stores.  They finish a tile no later than the seven-tap waves they meet at the barrier, and the wave-uniform test
+    // "does my seventh tap exist" -- two branches per k-step in front of the fragment reads and the MFMAs -- is gone.
+    constexpr int NTW = NTAP;
     // k-step s: voxels 16 s + 8 hl + 4 r + q: d = s >> 2, h = 2 (s & 3) + hl, w = 4 r + q; the eight fragments of step s + 1 are
     // requested before the seven MFMAs of step s issue.  (One x-fragment set, each fragment re-requested right behind the MFMA
     // that consumed it, with the transfers issued from inside the loop for interior tiles, was built to shorten the head of
     // the tile: 476 -> 555 us on 96^3 64->64; not kept.)
+    // Fragment addresses: ONE vector register per tap (lane offset + the tap's shift + the buffer) and one for dy, made once per
+    // tile; the k-step's offset is a compile-time constant and rides in the instruction's offset field.  Written as
+    // buf + lane offset + step offset + tap_off[j] the compiler kept the 16 x 7 scalar sums (step, tap) live across the tile
+    // loop -- 92 scalar registers spilled into vector lanes (v_readlane per use) and a v_add in front of every fragment read.
+    const unsigned yv = lds0 + (unsigned)(bufoff + ya0);
+    unsigned xv[NTAP];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) xv[j] = lds0 + (unsigned)(bufoff + xa0 + tap_off[j]);
     auto rd = [&](int s, f16x8& pa, f16x8* pb) {
       const int yo = s * 16 * RSB, xo = ((s >> 2) * XH + 2 * (s & 3)) * XW * RSB;
       {
-        h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(buf + ya0 + yo));
-        h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(buf + ya1 + yo));
+        h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4p)(size_t)(yv + yo));
+        h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4p)(size_t)(yv + yo + 4 * RSB));
         pa = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int j = 0; j < NTAP; ++j) {
-        if (j == NTAP - 1 && ntap < NTAP) continue;              // wave-uniform
-        h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(buf + xa0 + xo + tap_off[j]));
-        h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(buf + xa1 + xo + tap_off[j]));
+      for (int j = 0; j < NTW; ++j) {
+        h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4p)(size_t)(xv[j] + xo));
+        h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4p)(size_t)(xv[j] + xo + 4 * RSB));
         pb[j] = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
       }
     };
     auto mm = [&](const f16x8& pa, const f16x8* pb) {
 #pragma unroll
-      for (int j = 0; j < NTAP; ++j) {
-        if (j == NTAP - 1 && ntap < NTAP) continue;
-        mma32(acc[j], pa, pb[j]);
-      }
+      for (int j = 0; j < NTW; ++j) mma32(acc[j], pa, pb[j]);
     };
     f16x8 A0, A1, B0[NTAP], B1[NTAP];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { B0[NTAP - 1][e] = (T)0.f; B1[NTAP - 1][e] = (T)0.f; }
     rd(0, A0, B0);
 #pragma unroll
     for (int s = 0; s < TV / 16; s += 2) {
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(wf::NT) void conv3d_k3_wgrad_fo_kernel(wf::Args a) 
     if (tile + a.P < a.total_tiles) okbits = issue_tile(cur ^ 1);
 #endif
 #if !defined(WF_ABL) || WF_ABL != 2
-    kloop(smem + cur * BUFB);
+    kloop(cur * BUFB);
 #endif
     cur ^= 1;
   }

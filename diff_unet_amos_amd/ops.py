@@ -223,7 +223,10 @@ class ConvPacks:
         return self.out.get(self._key(w, kind, packed))
 
 
-def pack_deconv_weights(w, bias, dtype):
+def pack_deconv_weights(w, bias, dtype, alias_bias=False):
+    """``alias_bias``: hand the fp32 bias tensor itself back when it already is a whole number of 64-channel tiles (the training
+    step, which repacks every layer every step, saves a fill and a copy launch that way); launch plans keep their own copy, so that
+    packed weights and bias always belong to the same weight version."""
     assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 5 and tuple(w.shape[2:]) == (2, 2, 2)
     w = w.contiguous()
     cin, cout = w.shape[:2]
@@ -235,7 +238,7 @@ def pack_deconv_weights(w, bias, dtype):
     if rc != nbytes:
         raise RuntimeError(f"dua_pack_deconv_weights failed ({rc})")
     cpad = -(-cout // 64) * 64
-    if bias is not None and cpad == cout and bias.dtype == torch.float32 and bias.is_contiguous():
+    if alias_bias and bias is not None and cpad == cout and bias.dtype == torch.float32 and bias.is_contiguous():
         return buf, bias.detach()                 # already a whole number of output tiles: no fill + copy per call
     b = torch.zeros(cpad, dtype=torch.float32, device=w.device)
     if bias is not None:

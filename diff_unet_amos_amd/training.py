@@ -255,7 +255,7 @@ class _UpCat(torch.autograd.Function):
             cat = torch.empty((N, D, H, W, cs + cout), dtype=skip.dtype, device=skip.device)
             cat[..., :cs].copy_(skip)
         w32 = weight.detach().float().contiguous()
-        wp, bp = ops.pack_deconv_weights(w32, bias.detach().float(), skip.dtype)
+        wp, bp = ops.pack_deconv_weights(w32, bias.detach().float(), skip.dtype, alias_bias=True)
         ops.deconv_k2s2(lo, cin, 0, wp, bp, cout, cat, cs)
         ctx.save_for_backward(lo, w32)
         ctx.cs = cs

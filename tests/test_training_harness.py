@@ -432,6 +432,34 @@ def test_trainer_fp16_dynamic_loss_scale_stays_on_the_device(graph):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("graph", [True, False], ids=["graph", "eager"])
+def test_scheduler_learning_rate_reaches_the_captured_step(graph):
+    """The reference steps LinearWarmupCosineAnnealingLR once per epoch (train.py:249): a learning rate changed on the optimizer's
+    param_groups must be the one the NEXT step uses -- also when the step is a replayed HIP graph, where a host float would have been
+    baked in at capture (NativeAdamW reads it from a device scalar there).  lr = 0 must leave every parameter untouched."""
+    from diff_unet_amos_amd.schedule import LinearWarmupCosineAnnealingLR
+    from diff_unet_amos_amd.training import NativeConvTrainer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = DiffUNet(**KW).to(dev)
+    tr = NativeConvTrainer(net, lr=1e-3, dtype=torch.float32, graph=graph)
+    sch = LinearWarmupCosineAnnealingLR(tr.optimizer, warmup_epochs=2, max_epochs=4)       # epoch 0: warm-up start lr = 0
+    assert tr.optimizer.param_groups[0]["lr"] == 0.0
+    image, labels, noise, t = _data(2, 5)
+    image, labels, noise, t = image.to(dev), labels.to(dev), noise.to(dev), t.to(dev)
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    tr.step(image, labels, noise=noise, t=t)
+    assert all(torch.equal(v, before[k]) for k, v in net.state_dict().items())              # lr = 0: nothing moves
+    sch.step()
+    assert tr.optimizer.param_groups[0]["lr"] > 0
+    tr.step(image, labels, noise=noise, t=t)
+    moved = sum(int(not torch.equal(v, before[k])) for k, v in net.state_dict().items())
+    assert moved > 0.9 * len(before), moved
+    sd = tr.optimizer.state_dict()                                                          # two steps counted, AdamW's state layout
+    assert float(sd["state"][0]["step"]) == 2.0 and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.gpu
 def test_native_trainer_other_loss_configuration():
     """A loss configuration other than the configs' default ("mse,dice" combined by "mean") runs on the same fused
     kernels (term weights + the combine's derivative through the gradient scale): one step must reproduce the oracle's

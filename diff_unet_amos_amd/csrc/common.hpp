@@ -123,8 +123,12 @@ struct InXform {
   const float* gamma;   // [C]
   const float* beta;    // [C]
   const float* add;     // [N][add_stride] or null
+  double inv_count;     // 1 / (voxels per sample), EXACT to double precision: make_xform recovers the integer count from the
+                        // boundary's float.  float(1 / 884736) is off by 3e-8, and mean^2 - that much of sum x^2 / n - mean^2 is
+                        // 0.3 % of the variance of a channel whose mean is 100 standard deviations (1.8e-3 on its normalised
+                        // values; volumes with a power-of-two voxel count never showed it)
   int add_stride, c_pad;
-  float inv_count, eps, slope;
+  float eps, slope;
 };
 
 // (sum x, sum x^2) of channel c of sample n: the replica rows are summed as integers (exact), then converted.
@@ -210,8 +214,8 @@ __device__ __forceinline__ void xform_preamble(const InXform& xf, int n, int C, 
     for (int u = 1; u < UN; ++u)
       if (part == u) { Sm = S[u]; Qm = Q[u]; gm = gam[u]; bm = bet[u]; am = add[u]; }
     const int c = c0 + part * nw * 16 + (lane & 15);
-    const double mean = Sm * (double)xf.inv_count;
-    double var = Qm * (double)xf.inv_count - mean * mean;
+    const double mean = Sm * xf.inv_count;
+    double var = Qm * xf.inv_count - mean * mean;
     var = var > 0 ? var : 0;
     const float g = gm * (float)(1.0 / sqrt(var + (double)xf.eps));
     if (c0 + part * nw * 16 < C && c < C) {
@@ -230,7 +234,8 @@ static inline InXform make_xform(const dua_in_norm* in, int C) {
   if (in && in->stats) {
     x.stats = in->stats; x.gamma = in->gamma; x.beta = in->beta; x.add = in->add;
     x.add_stride = in->add_stride > 0 ? in->add_stride : C;
-    x.c_pad = in->c_pad; x.inv_count = in->inv_count; x.eps = in->eps;
+    x.c_pad = in->c_pad; x.eps = in->eps;
+    x.inv_count = in->inv_count > 0.f ? 1.0 / rint(1.0 / (double)in->inv_count) : 0.0;      // counts up to 2^24 voxels come back exactly
   }
   x.slope = in ? in->slope : 0.f;
   return x;

@@ -187,8 +187,8 @@ __device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const 
       }
     }
     const int c = (wave + 4 * part) * 16 + (lane & 15);
-    const double mean = Sm * (double)a.xf.inv_count;
-    double var = Qm * (double)a.xf.inv_count - mean * mean;
+    const double mean = Sm * a.xf.inv_count;
+    double var = Qm * a.xf.inv_count - mean * mean;
     var = var > 0 ? var : 0;
     const float g = gm * (float)(1.0 / sqrt(var + (double)a.xf.eps));
     if (c < a.Cin) {

@@ -23,8 +23,8 @@ __device__ __forceinline__ void norm_preamble(const InXform& xf, int n, int C, f
     const float gam = xf.gamma[cc], bet = xf.beta[cc];
     double S, Q;
     stats_read_wave16(xf.stats, n, xf.c_pad, cc, S, Q);
-    const double mean = S * (double)xf.inv_count;
-    double var = Q * (double)xf.inv_count - mean * mean;
+    const double mean = S * xf.inv_count;
+    double var = Q * xf.inv_count - mean * mean;
     var = var > 0 ? var : 0;
     if (ok && lane < 16) {
       mu[c] = (float)mean;
@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
       const double* p = sums + (((long)n * STAT_REPLICAS + r) * xf.c_pad + c) * 4;
       a0 += p[0]; a1 += p[1]; a2 += p[2];
     }
-    k1[c] = (float)(a1 * (double)xf.inv_count);
-    k2[c] = (float)(a2 * (double)xf.inv_count);
+    k1[c] = (float)(a1 * xf.inv_count);
+    k2[c] = (float)(a2 * xf.inv_count);
     // parameter gradients of this layer, by the first block of every sample (consecutive lanes, consecutive channels):
     // d add[n][c] = sum dA, d beta[c] = sum_n sum dZ, d gamma[c] = sum_n sum dZ * zhat (buffers zeroed by the caller)
     if (blockIdx.x == 0) {

@@ -249,17 +249,26 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const T* __restrict
                                                              stat_t* __restrict__ stats, int c_pad) {
   constexpr int EPG = Elem<T>::EPG;
   using Frag = typename Elem<T>::Frag;
-  extern __shared__ float red[];                    // [vl][C][2]
+  // fp32 (parity) tensors: the thread's partial sums in double, like the convolution epilogues (a channel whose mean is many
+  // standard deviations loses digits of its variance to fp32 partial sums of x^2: a raw tensor of 100 +- 0.3 normalised 2e-3 ..
+  // 8e-3 off before, 5e-5 -- the consumer's own fp32 rounding -- after)
+  using part_t = typename std::conditional<sizeof(T) == 4, double, float>::type;
+  extern __shared__ __attribute__((aligned(8))) char red_raw[];
+  part_t* red = (part_t*)red_raw;                   // [vl][C][2]
   const int groups = C / EPG, vlanes = 256 / groups;
   const int n = blockIdx.y, g = threadIdx.x % groups, vl = threadIdx.x / groups;
-  float s[EPG], q[EPG];
+  part_t s[EPG], q[EPG];
 #pragma unroll
-  for (int e = 0; e < EPG; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  for (int e = 0; e < EPG; ++e) { s[e] = 0; q[e] = 0; }
   if (vl < vlanes) {
     for (long v = blockIdx.x * (long)vlanes + vl; v < vox; v += (long)gridDim.x * vlanes) {
       const Frag f = *(const Frag*)(x + ((long)n * vox + v) * x_stride + x_off + g * EPG);
 #pragma unroll
-      for (int e = 0; e < EPG; ++e) { const float a = (float)f[e]; s[e] += a; q[e] = fmaf(a, a, q[e]); }
+      for (int e = 0; e < EPG; ++e) {
+        const float a = (float)f[e];
+        s[e] += a;
+        if constexpr (sizeof(T) == 4) q[e] += (double)a * (double)a; else q[e] = fmaf(a, a, q[e]);
+      }
     }
 #pragma unroll
     for (int e = 0; e < EPG; ++e) {
@@ -395,7 +404,7 @@ int dua_instnorm_stats(int dtype, int N, long voxels, int C, const void* x, int 
   const int vlanes = 256 / groups;
   long b = (voxels + (long)vlanes * 8 - 1) / ((long)vlanes * 8);
   dim3 grid((unsigned)(b > 1024 ? 1024 : (b < 1 ? 1 : b)), N);
-  const size_t lds = (size_t)vlanes * C * 2 * sizeof(float);
+  const size_t lds = (size_t)vlanes * C * 2 * (dtype == DUA_F32 ? sizeof(double) : sizeof(float));
   if (dtype == DUA_F16)
     hipLaunchKernelGGL(instnorm_stats_kernel<f16>, grid, dim3(256), lds, (hipStream_t)stream, (const f16*)x, x_stride, x_off,
                        voxels, C, stats, c_pad);

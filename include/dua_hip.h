@@ -42,7 +42,8 @@ typedef struct {
   const float* add;          /* optional fp32 [N][add_stride] bias added after the activation, or NULL */
   int add_stride;            /* 0 = C */
   int c_pad;                 /* channel stride of stats */
-  float inv_count;           /* 1 / (D*H*W) of the producer's output */
+  float inv_count;           /* 1 / (D*H*W) of the producer's output; the kernels recover the integer count from it (exact up to
+                                2^24 voxels per sample) and divide in double: the float itself is 3e-8 off for 96^3 */
   float eps;                 /* 1e-5 */
   float slope;               /* LeakyReLU negative slope, 0 <= slope <= 1 (the fp16 kernels apply it as max(t, slope t)) */
 } dua_in_norm;

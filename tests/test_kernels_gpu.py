@@ -657,6 +657,35 @@ def test_fp16_weight_packing_through_lds_equals_the_elementwise_kernels(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("S,C_,split", [(16, 16, False), (6, 64, True)], ids=["epilogue", "splitk-finish"])
+def test_fp32_statistics_keep_the_variance_of_a_channel_far_from_zero(S, C_, split):
+    """fp32 (parity) convolutions keep a lane's partial sum x / sum x^2 in double: a channel whose mean is hundreds of standard
+    deviations (bias 100, output std ~0.2) must still normalise to 1e-4 -- with fp32 partials of x^2 its variance (sum x^2 / n -
+    mean^2) came out percent-level wrong, which InstanceNorm's backward amplified into 15 % errors on single channels of weight
+    gradients (found against an fp64 oracle).  Reference: InstanceNorm in double of the kernel's OWN raw output, so only
+    the statistics are under test; both producers of statistics words (convolution epilogue, split-K finish kernel)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(1, S, S, S, C_, generator=g).cuda()
+    w = (torch.randn(C_, C_, 3, 3, 3, generator=g) * 0.01).cuda()
+    bias = torch.full((C_,), 100.0).cuda()
+    wp, bp = ops.pack_conv3_weights(w, bias, torch.float32)
+    raw = torch.empty(1, S, S, S, C_, device="cuda")
+    stats = ops.stats_buffer(1, C_, "cuda")
+    ws = ops.splitk_ws(torch.float32, 1, S, S, S, C_, C_, "cuda") if split else None
+    ops.conv3d_k3(x, C_, 0, wp, bp, C_, raw, 0, stats, workspace=ws)
+    r64 = raw.double().cpu().flatten(0, 3)                                   # [voxels, C]
+    assert float((r64.mean(0).abs() / r64.std(0)).min()) > 100                # the regime under test
+    gamma, beta = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g)
+    want = (r64 - r64.mean(0)) / torch.sqrt(r64.var(0, unbiased=False) + 1e-5) * gamma.double() + beta.double()
+    want = torch.where(want > 0, want, 0.1 * want)
+    out = torch.empty_like(raw)
+    ops.materialize(raw, C_, ops.Norm(stats, gamma.cuda(), beta.cuda(), S ** 3), out, 0)
+    err = float((out.double().cpu().flatten(0, 3) - want).abs().max())
+    assert err < 2e-4, err
+
+
+@pytest.mark.gpu
 def test_batched_weight_packing_equals_the_per_layer_calls():
     """dua_pack_conv3_weights_batch (ops.ConvPacks): 70 tensors -- both layouts of 35 layers of mixed shapes, i.e. two by-value
     lists -- byte-equal to the per-layer packing calls; tensors the batch form does not take are refused, not mis-packed."""

@@ -227,23 +227,35 @@ def roofline_by_kernel(fl, by_launch, kern, peak, largest_name):
     all_tf = sum(fl) / (sum(by_launch) * 1e-3) / 1e12
     out["all_conv_launches"] = {"launches_per_step": len(fl), "avg_launch_ms": round(sum(by_launch) / len(by_launch), 4),
                                 "achieved": round(all_tf, 2), "frac": round(all_tf / peak, 4)}
+    if len(_BACK_TO_BACK_MS) == len(fl):
+        # the same figure with EVERY launch timed back to back (the only method of rounds 1-3; the in-step medians used above for
+        # launches >= 100 us read 5-8 % faster): the one to compare across rounds
+        b2b = sum(fl) / (sum(_BACK_TO_BACK_MS) * 1e-3) / 1e12
+        out["all_conv_launches"]["back_to_back"] = {"avg_launch_ms": round(sum(_BACK_TO_BACK_MS) / len(fl), 4),
+                                                    "achieved": round(b2b, 2), "frac": round(b2b / peak, 4)}
     return out
 
 
-def full_loop_config2(net, image, shape):
+def full_loop_config2(net, image, shape, D=None):
     """BASELINE config 2 as it is worded: the whole 1000-step DDPM loop through the public API,
     ``net.diffusion.p_sample_loop(net.model, shape, model_kwargs=...)`` (gaussian_diffusion.py:441-485 of the reference),
-    in-kernel noise, encoder pass included in neither figure.  The first call captures the step graph of this (plan, process)
-    pair; the second is what every later patch costs."""
+    in-kernel noise, the fp32 finishing steps of an fp16 plan included (engine.Plan.sample_loop: what the parity test of this
+    loop covers), encoder pass included in neither figure.  The first call captures the step graph of this (plan, process)
+    pair; the second is what every later patch costs -- bracketed by the ranks' barrier, maximum over the ranks."""
     out = {}
     with torch.no_grad():
         kw = {"image": image, "embeddings": net.embed_model(image)}
         for key in ("first_call_seconds", "seconds"):
+            if D is not None:
+                D.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             sample = net.diffusion.p_sample_loop(net.model, shape, model_kwargs=kw)
             torch.cuda.synchronize()
             out[key] = time.perf_counter() - t0
+            if D is not None:
+                out[key] = D.max_over_ranks(out[key])
+                D.barrier()
     T = net.diffusion.num_timesteps
     out.update(steps=T, ms_per_step=out["seconds"] / T * 1e3, voxel_steps_per_s=shape[0] * VOX * T / out["seconds"],
                finite=bool(torch.isfinite(sample).all()), api="net.diffusion.p_sample_loop(net.model, shape, model_kwargs)")
@@ -532,7 +544,7 @@ def run_config2(args, D):
     torch.manual_seed(0)
     net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES, compute_dtype=dtype).to(dev).eval()
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    B = args.batch
+    B = args.batch or 1
     image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     plan = net._rt.plan(B, (96, 96, 96), dev)
     diffusion = net.diffusion                      # 1000-step process; we time K of its steps
@@ -587,24 +599,35 @@ def run_config2(args, D):
             roof["measured_mfma_ceiling_clock_ghz"] = round(clock, 3)
             roof["frac_of_ceiling"] = round(roof["achieved"] / ceil_tf, 4)
             roof["largest_launch"]["frac_of_ceiling"] = round(roof["largest_launch"]["tflops"] / ceil_tf, 4)
+    # config 2 end to end, whatever --steps says: the 1000-step loop through the public sampler API, on every rank (replicas).
+    # THIS is the headline: the loop the parity test covers (test_thousand_step_p_sample_loop_matches_oracle), with the two
+    # exact-fp32 finishing steps of an fp16 plan inside the timed region; the K replayed steps above are kept beside it.
+    loop = None
+    if not args.no_graph and not args.no_full_loop:
+        loop = full_loop_config2(net, image, (B, CLASSES, 96, 96, 96), D)
     if rank == 0:
-        ms = dt / args.steps * 1e3
+        replayed_ms = dt / args.steps * 1e3
+        ms = loop["seconds"] / loop["steps"] * 1e3 if loop is not None else replayed_ms
         line = {
             "metric": "denoised voxel-steps/sec on 96^3 16-class AMOS patches",
-            "value": world * B * VOX * args.steps / dt, "unit": "voxel-steps/s", "n_gpus": world, "steps": args.steps,
+            "value": world * B * VOX / (ms * 1e-3), "unit": "voxel-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "DiffUNet 96^3 patch, 16 classes, DDPM p_sample steps of the 1000-step process "
-                                   "(BASELINE.json configs[1]); one patch per GPU, replicas only",
+            "config": {"workload": "DiffUNet 96^3 patch, 16 classes, 1000-step DDPM p_sample_loop (BASELINE.json configs[1]); "
+                                   "one patch per GPU, replicas only",
                        "patch": [96, 96, 96], "classes": CLASSES, "batch_per_gpu": B, "graph_replay": not args.no_graph,
                        "noise": "in-kernel Philox4x32-10", "weights": "torch.manual_seed(0) default init"},
+            "headline": ("full_loop: value / ms_per_step = the whole 1000-step net.diffusion.p_sample_loop through the API (second "
+                         "call; fp32 finishing steps included), max over ranks; replayed_step_ms = the --steps replays of the "
+                         "captured fp16 step after --warmup replays") if loop is not None else "replayed steps (--no-full-loop / --no-graph)",
+            "replayed_step_ms": replayed_ms, "replayed_value": world * B * VOX * args.steps / dt,
             "step_tflops": B * 1.0564e12 / (ms * 1e-3) / 1e12, "finite": finite,
         }
+        if loop is not None:
+            line["full_loop"] = loop
         if roof is not None:
             line["roofline"] = roof
         if world == 1 and not args.no_roofline and not args.no_graph and not args.no_full_loop:
-            # config 2 end to end, whatever --steps says: the 1000-step loop through the public sampler API
-            line["full_loop"] = full_loop_config2(net, image, (B, CLASSES, 96, 96, 96))
             if args.dtype == "f16" and not args.no_f32:
                 line["f32"] = f32_pass_config2(state, image, dev)
         if not args.no_cpu_baseline and world == 1:
@@ -620,7 +643,7 @@ def run_config3(args, D):
     torch.manual_seed(0)
     net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES, sample_steps=50).to(dev).eval()
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    vol = torch.rand(1, 1, 256, 256, 192, generator=torch.Generator().manual_seed(1)).to(dev)      # same volume on every rank
+    vol = torch.rand(1, 1, *args.volume, generator=torch.Generator().manual_seed(1)).to(dev)      # same volume on every rank
     nwin = len(inference._plan(vol, (96, 96, 96), 0.25)[4])
     swb = args.sw_batch
     timings = {}
@@ -635,7 +658,12 @@ def run_config3(args, D):
         return inference.binarise(out)
 
     with torch.no_grad():
-        net(vol[:, :, :96, :96, :96].contiguous().repeat(swb, 1, 1, 1, 1), pred_type="ddim_sample")   # packs weights, captures the graph
+        # pack weights and capture the step graph of every batch size this rank's sampler passes will have (sharded: the rank's
+        # windows in balanced calls, e.g. 6 windows at sw_batch_size 4 -> 3 + 3; single process: slices of sw_batch_size + tail)
+        mine = len(range(rank, nwin, world))
+        sizes = set(inference.balanced_batches(mine, swb)) if world > 1 else {min(swb, nwin), nwin % swb or min(swb, nwin)}
+        for b in sorted(sizes or {1}):
+            net(vol[:, :, :96, :96, :96].contiguous().repeat(b, 1, 1, 1, 1), pred_type="ddim_sample")
         for _ in range(args.warmup):
             one_volume()
         D.barrier()
@@ -657,7 +685,7 @@ def run_config3(args, D):
             "metric": "sliding-window DDIM inference: denoised voxel-steps/sec over a full volume", "value": nwin * VOX * 50 / per,
             "unit": "voxel-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "AMOS-sized volume 256x256x192, 96^3 windows (overlap 0.25 -> 48), 50-step DDIM, windows "
+            "config": {"workload": f"AMOS-sized volume {'x'.join(map(str, args.volume))}, 96^3 windows (overlap 0.25 -> {nwin}), 50-step DDIM, windows "
                                    "sharded over the ranks, one all_gather_into_tensor of the per-window sums (BASELINE.json configs[2])",
                        "windows": nwin, "sw_batch_size": swb, "gather_dtype": "f16" if args.gather_fp16 else "f32"},
             "seconds_per_volume": per, "all_gather_seconds": gather_s, "all_gather_share": gather_s / per if per > 0 else None,
@@ -678,7 +706,7 @@ def run_config4(args, D):
     torch.manual_seed(0)
     net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES).to(dev)
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    B = 2                                          # cfg/amos/train.yaml: batch 10 over 5 GPUs
+    B = args.batch or 2                            # default: cfg/amos/train.yaml, batch 10 over 5 GPUs; --batch 1 = BASELINE.md section 4
     tr = NativeConvTrainer(net, dtype=torch.float16, overlap=not args.flat_allreduce, graph=args.train_graph)
     g = torch.Generator(device=dev).manual_seed(10 + rank)
     image = torch.rand(B, 1, 96, 96, 96, device=dev, generator=g)
@@ -711,7 +739,7 @@ def run_config4(args, D):
             "metric": "DDP training samples/sec on synthetic 96^3 16-class batches", "value": world * B / per, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "q_sample + denoise + mse/bce/dice + backward + AdamW, 96^3, 16 classes, 2 samples per GPU "
+            "config": {"workload": f"q_sample + denoise + mse/bce/dice + backward + AdamW, 96^3, 16 classes, {B} sample(s) per GPU "
                                    "(BASELINE.json configs[3])", "batch_per_gpu": B,
                        "gradient_sync": "flat all-reduce after backward" if args.flat_allreduce else "DDP reducer, 32 MB buckets overlapped with backward",
                        "graph": bool(args.train_graph)},
@@ -735,7 +763,7 @@ def run_config5(args, D):
     torch.manual_seed(0)
     net = DiffSwinUNETR(in_channels=1, out_channels=CLASSES, feature_size=48, compute_dtype=dtype).to(dev).eval()
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    B = args.batch
+    B = args.batch or 1
     image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     plan = net._rt.plan(B, (96, 96, 96), dev)
     diffusion = net.diffusion
@@ -818,7 +846,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true", help="config 2: skip the 1000-step p_sample_loop pass (full_loop object)")
     ap.add_argument("--no-f32", action="store_true", help="config 2: skip the short fp32 pass (f32 object)")
-    ap.add_argument("--batch", type=int, default=1, help="config 2: patches per GPU (BASELINE config 2 is 1)")
+    ap.add_argument("--batch", type=int, default=None, help="configs 2 / 5: patches per GPU (default 1, BASELINE config 2); config 4: samples per GPU (default 2)")
+    ap.add_argument("--volume", type=int, nargs=3, default=[256, 256, 192], help="config 3: volume extents (BASELINE config 3: 256 256 192)")
     ap.add_argument("--sw-batch", type=int, default=4, help="config 3: windows per sampler pass (cfg/btcv/test.yaml:4 of the reference: 4)")
     ap.add_argument("--gather-fp16", action="store_true", help="config 3: all-gather the window sums in fp16")
     ap.add_argument("--flat-allreduce", action="store_true", help="config 4: one flat all-reduce instead of DDP buckets")

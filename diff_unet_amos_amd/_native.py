@@ -36,7 +36,7 @@ class Conv3Desc(C.Structure):
 
 class InNorm(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("add", C.c_void_p),
-                ("add_stride", C.c_int), ("c_pad", C.c_int), ("inv_count", C.c_float), ("eps", C.c_float),
+                ("add_stride", C.c_int), ("c_pad", C.c_int), ("count", C.c_longlong), ("eps", C.c_float),
                 ("slope", C.c_float)]
 
 
@@ -125,7 +125,7 @@ class AdamWList(C.Structure):
                 ("g", C.c_void_p * ADAMW_MAX_TENSORS), ("m", C.c_void_p * ADAMW_MAX_TENSORS), ("v", C.c_void_p * ADAMW_MAX_TENSORS)]
 
 _P = C.c_void_p
-ABI_VERSION = 7          # DUA_ABI_VERSION of include/dua_hip.h this binding was written against
+ABI_VERSION = 8          # DUA_ABI_VERSION of include/dua_hip.h this binding was written against
 
 _SIGS = {
     "dua_abi_version": (C.c_int, []),

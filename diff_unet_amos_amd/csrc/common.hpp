@@ -123,10 +123,10 @@ struct InXform {
   const float* gamma;   // [C]
   const float* beta;    // [C]
   const float* add;     // [N][add_stride] or null
-  double inv_count;     // 1 / (voxels per sample), EXACT to double precision: make_xform recovers the integer count from the
-                        // boundary's float.  float(1 / 884736) is off by 3e-8, and mean^2 - that much of sum x^2 / n - mean^2 is
-                        // 0.3 % of the variance of a channel whose mean is 100 standard deviations (1.8e-3 on its normalised
-                        // values; volumes with a power-of-two voxel count never showed it)
+  double inv_count;     // 1 / (voxels per sample) in double, from the boundary's integer count (dua_in_norm.count).  A float
+                        // 1 / 884736 is off by 3e-8, and mean^2 - that much of sum x^2 / n - mean^2 is 0.3 % of the variance
+                        // of a channel whose mean is 100 standard deviations (1.8e-3 on its normalised values; volumes with a
+                        // power-of-two voxel count never showed it)
   int add_stride, c_pad;
   float eps, slope;
 };
@@ -235,7 +235,7 @@ static inline InXform make_xform(const dua_in_norm* in, int C) {
     x.stats = in->stats; x.gamma = in->gamma; x.beta = in->beta; x.add = in->add;
     x.add_stride = in->add_stride > 0 ? in->add_stride : C;
     x.c_pad = in->c_pad; x.eps = in->eps;
-    x.inv_count = in->inv_count > 0.f ? 1.0 / rint(1.0 / (double)in->inv_count) : 0.0;      // counts up to 2^24 voxels come back exactly
+    x.inv_count = in->count > 0 ? 1.0 / (double)in->count : 0.0;
   }
   x.slope = in ? in->slope : 0.f;
   return x;
@@ -250,10 +250,14 @@ __device__ __forceinline__ void stats_add(stat_t* stats, int n, int c_pad, int r
   return;
 #endif
   // A non-finite or out-of-range contribution (an fp16 overflow upstream) must not turn into arbitrary finite words: it is
-  // replaced by a poison value far outside anything sums of fp16 data reach, so that every consumer derives an absurd variance
-  // (scale ~ 0 or NaN) instead of a plausible one.  The fp64 atomics this replaced propagated Inf / NaN by themselves.
+  // replaced by a poison value far outside anything sums of fp16 data reach (|sum x| <= 65504 * voxels < 2^41 up to 2^25 voxels),
+  // so that every consumer derives an absurd mean (>= 2^47 / voxels) and a negative variance: its outputs leave the fp16 range.
+  // The poison must survive being ADDED many times -- an overflow usually poisons many workgroups of a channel, and the words
+  // wrap modulo 2^64: 2^47 per contribution stays below 2^62 for 2^15 poisoned contributions summed over the 8 replica rows
+  // (a 96^3 layer at batch 16 makes 27 648 contributions per channel); the +-4e18 used before wrapped at the third.
   constexpr double LIM = 4.0e18;                       // < 2^62: the documented range of the fixed-point words
-  if (!(fabs(S) < LIM) || !(fabs(Q) < LIM)) { S = LIM; Q = -LIM; }      // (the comparison is false for NaN)
+  constexpr double POISON = 140737488355328.0;         // 2^47
+  if (!(fabs(S) < LIM) || !(fabs(Q) < LIM)) { S = POISON; Q = -POISON; }      // (the comparison is false for NaN)
   const double Si = rint(S), Qi = rint(Q);
   // two's-complement adds: negative parts wrap, the integer sum is exact either way.  System scope (sc1): the adds of all
   // eight XCDs must meet in one place; an agent-scope integer read-modify-write carries no sc bit on gfx950, and unlike the

@@ -1103,7 +1103,7 @@ int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_pack
   if (!d || !x || !w_packed || !bias_padded || !y || !out_stats) return DUA_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)
     return DUA_ERR_ARG;
-  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin || !(in->slope >= 0.f && in->slope <= 1.f))) return DUA_ERR_ARG;
+  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin || in->count <= 0 || !(in->slope >= 0.f && in->slope <= 1.f))) return DUA_ERR_ARG;
   if (d->dtype == DUA_F16)
     return dua::launch_conv3<dua::f16>(d, x, w_packed, bias_padded, in, y, out_stats, (float*)workspace, workspace_bytes, (hipStream_t)stream);
   if (d->dtype == DUA_F32)

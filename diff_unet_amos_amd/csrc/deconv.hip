@@ -536,7 +536,7 @@ extern "C" int dua_deconv_k2s2_kernel_kind(const dua_conv3_desc* d) {
 extern "C" int dua_deconv_k2s2_fwd(const dua_conv3_desc* d, const void* x, const void* w_packed,
                                    const float* bias_padded, const dua_in_norm* in, void* y, void* stream) {
   if (!d || !x || !w_packed || !bias_padded || !y) return DUA_ERR_ARG;
-  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin || !(in->slope >= 0.f && in->slope <= 1.f))) return DUA_ERR_ARG;
+  if (in && in->stats && (!in->gamma || !in->beta || in->c_pad < d->Cin || in->count <= 0 || !(in->slope >= 0.f && in->slope <= 1.f))) return DUA_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8)
     return DUA_ERR_ARG;
   if (d->dtype == DUA_F16) return dua::launch_deconv<dua::f16>(d, x, w_packed, bias_padded, in, y, (hipStream_t)stream);

@@ -427,7 +427,7 @@ class Plan:
             self.cur_add.data_ptr(), self.cur_coef.data_ptr(), self.step_word.data_ptr(), self.err_word.data_ptr(),
             self.den_stats.data_ptr(), self.den_stats.numel() * 8,
             self._step_ops, len(self._step_ops), self.splitk_ws.data_ptr(), self.splitk_ws.numel() * 4,
-            tail, self.uB[0].data_ptr(), nv.InNorm(tn.stats, tn.gamma, tn.beta, tn.add, tn.add_stride, tn.c_pad, tn.inv_count, tn.eps, tn.slope),
+            tail, self.uB[0].data_ptr(), nv.InNorm(tn.stats, tn.gamma, tn.beta, tn.add, tn.add_stride, tn.c_pad, tn.count, tn.eps, tn.slope),
             self.wf.data_ptr(), self.bf.data_ptr(), self.x_state.data_ptr(), ptr(noise),
             self.xin.data_ptr() if sampling else None, self.x_sum.data_ptr() if (use_sum and sampling) else None,
             ptr(logits), ptr(xstart))

@@ -43,7 +43,7 @@ def _norm_value(norm, N, Cc):
         return 0, nv.InNorm()
     norm.ref(N, Cc)
     c = norm.c
-    return 1, nv.InNorm(c.stats, c.gamma, c.beta, c.add, c.add_stride, c.c_pad, c.inv_count, c.eps, c.slope)
+    return 1, nv.InNorm(c.stats, c.gamma, c.beta, c.add, c.add_stride, c.c_pad, c.count, c.eps, c.slope)
 
 
 def _addr(t):
@@ -361,7 +361,7 @@ class Norm:
         self.keep = (stats, gamma, beta, add)
         self.N, self.C = stats.shape[0], gamma.numel()
         self.c = nv.InNorm(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), add.data_ptr() if add is not None else None,
-                           add_stride, stats.shape[3], 1.0 / count, eps, slope)
+                           add_stride, stats.shape[3], int(count), eps, slope)
 
     def ref(self, N, Cc):
         assert self.N == N and self.C >= Cc, "normalisation descriptor does not match the consumer's input"

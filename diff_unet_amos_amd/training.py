@@ -515,12 +515,6 @@ class NativeAdamW(torch.optim.Optimizer):
                     self._moments(p)
                     self._counter(p.device)
 
-    def reset_state(self):
-        for st in self.state.values():
-            st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["step"].zero_()
-        if self._count is not None:
-            self._count.zero_()
-
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None, found_inf=None, store_grad=False, advance=True):
         """``grad_scale`` / ``found_inf``: fp32 device scalars of a loss-scaled step (see ops.adamw_step); ``advance=False`` leaves
@@ -547,8 +541,40 @@ class NativeAdamW(torch.optim.Optimizer):
                 st["step"] = torch.tensor(k, dtype=torch.float32)
         return super().state_dict()
 
+    def snapshot_state(self):
+        """Copies of the moments and the update counter (``restore_state`` writes them back INTO the live tensors)."""
+        return ({p: (st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"].clone()) for p, st in self.state.items()
+                 if "exp_avg" in st}, None if self._count is None else self._count.clone())
+
+    def restore_state(self, snap):
+        moments, count = snap
+        for p, st in self.state.items():
+            if p in moments:
+                st["exp_avg"].copy_(moments[p][0]); st["exp_avg_sq"].copy_(moments[p][1]); st["step"] = moments[p][2].clone()
+            elif "exp_avg" in st:
+                st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["step"].zero_()
+        if self._count is not None:
+            if count is None:
+                self._count.zero_()
+            else:
+                self._count.copy_(count)
+
     def load_state_dict(self, state_dict):
+        # Moments that already exist keep their ADDRESSES: a captured step (NativeConvTrainer(graph=True)) updates those tensors
+        # on every replay, and the base class would rebind state[p] to fresh ones -- the graph would go on updating the old
+        # moments while state_dict() saved tensors that never move.  Loaded values are copied into the live tensors instead.
+        live = {p: (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items() if "exp_avg" in st}
         super().load_state_dict(state_dict)
+        with torch.no_grad():
+            for p, (m, v) in live.items():
+                st = self.state.get(p)
+                if st is None or "exp_avg" not in st:
+                    m.zero_(); v.zero_()
+                    self.state[p].update(step=torch.zeros((), dtype=torch.float32), exp_avg=m, exp_avg_sq=v)
+                    continue
+                if st["exp_avg"] is not m:
+                    m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                    st["exp_avg"], st["exp_avg_sq"] = m, v
         steps = [float(st["step"]) for st in self.state.values() if "step" in st]
         if steps:
             dev = next(iter(self.state)).device
@@ -664,6 +690,9 @@ class NativeConvTrainer:
                        growth=torch.zeros((), dtype=torch.int32, device=dev), found_inf=torch.zeros((), device=dev),
                        found_flag=torch.zeros((), device=dev))
         saved = [p.detach().clone() for p in self.params]
+        # ... and the optimizer state as it is NOW: a checkpoint loaded before the first step (load_checkpoint ->
+        # optimizer.load_state_dict) must survive the warm-up updates below
+        saved_opt = self.optimizer.snapshot_state()
         # Warm-up ON the capture stream: the per-(device, stream) scratch buffers of ops (split-K, weight-gradient partials)
         # are then allocated here, from the ordinary pool, and the capture finds them -- allocated inside the capture they
         # would live in this graph's private pool while the module-level cache hands them to every later capture.
@@ -692,7 +721,7 @@ class NativeConvTrainer:
         with torch.no_grad():
             for p, q in zip(self.params, saved):
                 p.copy_(q)
-            self.optimizer.reset_state()
+            self.optimizer.restore_state(saved_opt)
             self._g["found_inf"].zero_(); self._g["found_flag"].zero_()
             self._g["scale"].fill_(self.init_scale if self.dtype == torch.float16 else 1.0)
             self._g["growth"].zero_()

@@ -42,8 +42,9 @@ typedef struct {
   const float* add;          /* optional fp32 [N][add_stride] bias added after the activation, or NULL */
   int add_stride;            /* 0 = C */
   int c_pad;                 /* channel stride of stats */
-  float inv_count;           /* 1 / (D*H*W) of the producer's output; the kernels recover the integer count from it (exact up to
-                                2^24 voxels per sample) and divide in double: the float itself is 3e-8 off for 96^3 */
+  long long count;           /* D*H*W of the producer's output: voxels per (sample, channel), as an INTEGER -- the kernels divide
+                                the sums by it in double.  (Up to ABI 7 this was float 1/count: float(1/884736) is 3e-8 off, which
+                                is 0.3 % of the variance of a channel whose mean is 100 standard deviations.)  Must be > 0. */
   float eps;                 /* 1e-5 */
   float slope;               /* LeakyReLU negative slope, 0 <= slope <= 1 (the fp16 kernels apply it as max(t, slope t)) */
 } dua_in_norm;
@@ -274,7 +275,7 @@ int dua_adamw_advance(int* step, float* found_inf, float* scale, int* growth, fl
  * worker thread), call it once up front, on the device they will use, so that no such call happens inside a capture.
  * Thread-safe.  Returns 0, DUA_ERR_ARG (no current device) or a hipError_t.
  * dua_prepared_kernels(): how many kernels dua_prepare() configures (tests). */
-#define DUA_ABI_VERSION 7
+#define DUA_ABI_VERSION 8
 int dua_abi_version(void);
 int dua_prepare(void);
 int dua_prepared_kernels(void);

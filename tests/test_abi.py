@@ -58,9 +58,11 @@ def test_argument_validation_without_a_device(lib):
     assert lib.dua_conv3d_k3_fwd(C.byref(bad_policy), one, one, one, None, one, one, None, 0, None) == nv.ERR_ARG
     # LeakyReLU slope outside [0, 1]: the fp16 kernels apply the activation as max(t, slope * t)
     ok = nv.Conv3Desc(nv.F16, 1, 8, 8, 8, 16, 16, 0, 64, 64, 0)
-    bad = nv.InNorm(16, 16, 16, None, 0, 64, 1.0 / 512, 1e-5, 1.5)
+    bad = nv.InNorm(16, 16, 16, None, 0, 64, 512, 1e-5, 1.5)
     assert lib.dua_conv3d_k3_fwd(C.byref(ok), one, one, one, C.byref(bad), one, one, None, 0, None) == nv.ERR_ARG
     assert lib.dua_deconv_k2s2_fwd(C.byref(ok), one, one, one, C.byref(bad), one, None) == nv.ERR_ARG
+    no_count = nv.InNorm(16, 16, 16, None, 0, 64, 0, 1e-5, 0.1)       # the integer voxel count (ABI 8) must be positive
+    assert lib.dua_conv3d_k3_fwd(C.byref(ok), one, one, one, C.byref(no_count), one, one, None, 0, None) == nv.ERR_ARG
     assert lib.dua_pack_conv3_weights(nv.F16, 64, 17, 24, None, None, None, None) == 1 * 1 * 27 * 4 * 64 * 16
     # the training-step kernels (csrc/train_glue.hip)
     assert lib.dua_stats_channel_sums(1, 80, 64, one, one, None) == nv.ERR_ARG                  # more channels than the rows hold

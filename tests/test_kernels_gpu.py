@@ -686,6 +686,55 @@ def test_fp32_statistics_keep_the_variance_of_a_channel_far_from_zero(S, C_, spl
 
 
 @pytest.mark.gpu
+def test_non_finite_contributions_poison_the_statistics_however_many_there_are():
+    """An fp16 overflow upstream reaches many workgroups of a channel: each adds the poison (2^47, -2^47) to the fixed-point
+    words instead of its non-finite sums, and k of them must still read as an absurd total (k * 2^47) -- the +-4e18 of round 4
+    wrapped modulo 2^64 at the third contribution and could land on plausible finite words."""
+    ops = _ops()
+    x = torch.randn(1, 32, 32, 32, 16, device="cuda").half()
+    x[..., 3] = float("inf")                                   # every output voxel of every channel sees it
+    w = torch.randn(64, 16, 3, 3, 3, device="cuda") * 0.05
+    wp, bp = ops.pack_conv3_weights(w, torch.zeros(64, device="cuda"), torch.float16)
+    raw = torch.empty(1, 32, 32, 32, 64, device="cuda", dtype=torch.float16)
+    stats = ops.stats_buffer(1, 64, "cuda")
+    ops.conv3d_k3(x, 16, 0, wp, bp, 64, raw, 0, stats)
+    sums = ops.stats_decode(stats)[0, :64].cpu()              # [C, 2] float64
+    k = sums[:, 0] / 2.0 ** 47
+    assert bool((k >= 3).all()) and bool((k == k.round()).all()), k[:8]
+    assert torch.equal(sums[:, 1], -sums[:, 0])
+    out = torch.empty_like(raw)
+    ones = torch.ones(64, device="cuda")
+    ops.materialize(raw, 64, ops.Norm(stats, ones, torch.zeros(64, device="cuda"), 32 ** 3), out, 0)
+    assert not bool(torch.isfinite(out.float()).any())
+
+
+@pytest.mark.gpu
+def test_the_boundary_carries_the_voxel_count_as_an_integer_beyond_2_to_the_24():
+    """dua_in_norm.count (ABI 8) is an integer: a volume of 264 x 256 x 256 = 17 301 504 voxels (not a power of two, above
+    2^24 -- where the float 1/count of ABI <= 7 could no longer be inverted exactly) with a channel mean of 300 standard
+    deviations normalises to the consumer's own fp32 rounding.  Statistics by dua_instnorm_stats, consumer dua_materialize,
+    reference: InstanceNorm in double of the same tensor."""
+    ops = _ops()
+    D, H, W, C_ = 264, 256, 256, 8
+    g = torch.Generator(device="cuda").manual_seed(5)
+    raw = torch.randn(1, D, H, W, C_, generator=g, device="cuda") * 0.25 + 75.0
+    stats = ops.stats_buffer(1, C_, "cuda")
+    ops.instnorm_stats(raw, C_, stats)
+    gamma, beta = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda")
+    norm = ops.Norm(stats, gamma, beta, D * H * W)
+    assert norm.c.count == D * H * W > 2 ** 24
+    out = torch.empty_like(raw)
+    ops.materialize(raw, C_, norm, out, 0)
+    r64 = raw.double().flatten(0, 3)
+    mean, var = r64.mean(0), r64.var(0, unbiased=False)
+    assert float((mean.abs() / var.sqrt()).min()) > 250
+    want = (r64 - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+    want = torch.where(want > 0, want, 0.1 * want)
+    err = float((out.double().flatten(0, 3) - want).abs().max())
+    assert err < 2e-4, err
+
+
+@pytest.mark.gpu
 def test_batched_weight_packing_equals_the_per_layer_calls():
     """dua_pack_conv3_weights_batch (ops.ConvPacks): 70 tensors -- both layouts of 35 layers of mixed shapes, i.e. two by-value
     lists -- byte-equal to the per-layer packing calls; tensors the batch form does not take are refused, not mis-packed."""

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from diff_unet_amos_amd.inference import (_plan, binarise, dice_per_class, sharded_sliding_window_inference,
+from diff_unet_amos_amd.inference import (_plan, balanced_batches, binarise, dice_per_class, sharded_sliding_window_inference,
                                           sliding_window_inference)
 from oracle.sliding_window_ref import sliding_window_ref
 from oracle.unet_ref import dice_coeff
@@ -31,6 +31,18 @@ def test_window_count_of_config3():
     assert starts[0] == (0, 0, 0) and starts[1] == (0, 0, 72)         # last axis fastest
     with pytest.raises(ValueError):
         _plan(torch.zeros(1, 1, 8, 8, 8), (4, 4, 4), 1.0)
+
+
+def test_per_rank_batches_are_balanced():
+    """BASELINE config 3 on 8 GPUs: 6 windows per rank at sw_batch_size 4 run as 3 + 3, not 4 + 2; never more calls than
+    slicing by sw_batch_size would make, never a call above sw_batch_size or below half of it (when there are two or more)."""
+    assert balanced_batches(6, 4) == [3, 3]
+    assert balanced_batches(48, 4) == [4] * 12 and balanced_batches(0, 4) == [] and balanced_batches(3, 4) == [3]
+    for n in range(1, 60):
+        for b in range(1, 9):
+            sizes = balanced_batches(n, b)
+            assert sum(sizes) == n and len(sizes) == -(-n // b) and max(sizes) <= b
+            assert max(sizes) - min(sizes) <= 1 and (len(sizes) == 1 or 2 * min(sizes) >= b)
 
 
 DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]      # the scheduler also runs with device tensors under -m gpu
@@ -101,3 +113,40 @@ def test_binarise_and_dice_match_reference_formulas(device):
     for c in range(4):
         assert abs(float(got[c]) - dice_coeff(pred[:, c].cpu(), labels[:, c].cpu())) < 1e-12
     assert float(got[3]) == 0.0
+
+
+def _bench_line(args, timeout):
+    """Run bench.py as the driver does for N > 1 (its own torch.distributed.run launch, rendezvous on 127.0.0.1) with two
+    ranks sharing this box's one GPU over gloo; return the JSON line rank 0 printed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DUA_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-roofline", "--no-cpu-baseline"] + args,
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_config3_runs_end_to_end_on_two_ranks():
+    """The driver's first N > 1 run must not be the code's first: `bench.py --config 3 --gpus 2` (windows sharded over the
+    ranks, one all-gather, blend on every rank) on a 144 x 144 x 96 volume = 4 windows, two per rank in ONE balanced call."""
+    line = _bench_line(["--config", "3", "--steps", "1", "--warmup", "0", "--volume", "144", "144", "96"], 600)
+    assert line["n_gpus"] == 2 and line["config"]["windows"] == 4 and line["scaling"] == "strong"
+    assert line["all_gather_seconds"] > 0 and line["gathered_bytes"] == 2 * 2 * 16 * 96 ** 3 * 4
+    assert line["value"] > 0 and 0.0 <= line["foreground_fraction"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_bench_config4_runs_end_to_end_on_two_ranks():
+    """`bench.py --config 4 --gpus 2 --batch 1`: the DDP reducer's bucketed all-reduce under backward, two ranks."""
+    line = _bench_line(["--config", "4", "--steps", "2", "--warmup", "1", "--batch", "1"], 900)
+    assert line["n_gpus"] == 2 and line["config"]["batch_per_gpu"] == 1
+    assert np.isfinite(line["loss"]) and line["value"] > 0 and line["flat_allreduce_seconds"] > 0
+    assert line["gradient_bytes"] == 38405520 * 4

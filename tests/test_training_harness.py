@@ -364,6 +364,54 @@ def test_graph_replayed_training_step_equals_eager():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("when", ["before-capture", "after-capture"])
+def test_graph_trainer_resumes_from_a_checkpoint(when):
+    """NativeConvTrainer(graph=True) + load_state_dict: three captured steps, a checkpoint (model + optimizer), then a NEW
+    graph trainer that loads it -- before its first step (the capture's warm-up updates must not wipe the loaded moments
+    and update counter) or after it has already captured and stepped (the loaded moments must land in the tensors the
+    graph updates) -- takes step four exactly like the uninterrupted run."""
+    from diff_unet_amos_amd.training import NativeConvTrainer
+    dev = torch.device("cuda:0")
+    image, labels, noise, t = _data(2, 43)
+    image, labels, noise = image.to(dev), labels.to(dev), noise.to(dev)
+    ts = [torch.tensor([150 + 41 * k, 820 - 67 * k], device=dev) for k in range(4)]
+    torch.manual_seed(0)
+    net = DiffUNet(**KW).to(dev)
+    tr = NativeConvTrainer(net, lr=1e-3, dtype=torch.float32, graph=True)
+    for tk in ts[:3]:
+        tr.step(image, labels, noise=noise, t=tk)
+    ckpt = {"model": {k: v.detach().clone() for k, v in net.state_dict().items()},
+            "optimizer": {"state": {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                                    for i, st in tr.optimizer.state_dict()["state"].items()},
+                          "param_groups": tr.optimizer.state_dict()["param_groups"]}}
+    assert float(ckpt["optimizer"]["state"][0]["step"]) == 3.0
+    want_loss = float(tr.step(image, labels, noise=noise, t=ts[3]))
+    want = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+
+    torch.manual_seed(1)                                     # different initial weights: everything must come from the checkpoint
+    net2 = DiffUNet(**KW).to(dev)
+    tr2 = NativeConvTrainer(net2, lr=1e-3, dtype=torch.float32, graph=True)
+    if when == "after-capture":
+        tr2.step(image, labels, noise=noise, t=ts[0])        # captures; moments now live at the addresses the graph updates
+        held = {id(p): tr2.optimizer.state[p]["exp_avg"].data_ptr() for p in tr2.params}
+    net2.load_state_dict(ckpt["model"])
+    tr2.optimizer.load_state_dict(ckpt["optimizer"])
+    if when == "after-capture":
+        assert all(tr2.optimizer.state[p]["exp_avg"].data_ptr() == held[id(p)] for p in tr2.params)
+    got_loss = float(tr2.step(image, labels, noise=noise, t=ts[3]))
+    assert float(tr2.optimizer.state_dict()["state"][0]["step"]) == 4.0
+    assert abs(got_loss - want_loss) <= 1e-6 * abs(want_loss), (got_loss, want_loss)
+    # lost moments or a restarted update counter would move every element by O(lr) = 1e-3 (the first Adam step is sign-like)
+    for k, v in net2.state_dict().items():
+        assert float((v.detach().cpu() - want[k]).abs().max()) < 1e-6, k
+    m_a = tr.optimizer.state_dict()["state"]
+    m_b = tr2.optimizer.state_dict()["state"]
+    for i in m_a:
+        assert torch.allclose(m_a[i]["exp_avg"], m_b[i]["exp_avg"], rtol=1e-4, atol=1e-9), i
+        assert torch.allclose(m_a[i]["exp_avg_sq"], m_b[i]["exp_avg_sq"], rtol=1e-4, atol=1e-12), i
+
+
+@pytest.mark.gpu
 def test_full_size_gradients_fp16_path_vs_oracle():
     """Config-4 geometry (96^3 patch, 16 classes, full feature widths; batch 1 to bound the CPU oracle's time): parameter
     gradients of the fp16 HIP training path against the oracle network under torch autograd in fp32 on the host."""

@@ -1,0 +1,56 @@
+"""Per-tensor account of the two-rank training test (tests/test_training_harness.py): the averaged gradient of two ranks
+against the union-batch oracle's, tensor by tensor (relative L2), and -- after the one AdamW step -- which tensors hold the
+elements that moved differently, with the size of their gradients relative to Adam's eps and to the tensor's own scale.
+  python tools/two_rank_gradient_report.py [flat|ddp|graph]    (one GPU, two processes over gloo)"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import test_training_harness as T
+    mode = sys.argv[1] if len(sys.argv) > 1 else "flat"
+    overlap, graph = mode == "ddp", mode == "graph"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 311) % 2000
+    procs = [ctx.Process(target=T._native_ddp_worker, args=(r, 2, port, q, overlap, graph)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = {r: (l, sd, g) for r, l, sd, g in (q.get(timeout=600) for _ in range(2))}
+    for p in procs:
+        p.join(60)
+    want_sd, want_g = T._union_batch_reference(7)
+    _, sd, g = outs[0]
+    print(f"mode {mode}: per-tensor relative L2 of the averaged gradient against the union-batch oracle (sorted, worst first)")
+    rows = []
+    for k, v in want_g.items():
+        ref = v.double().numpy()
+        d = g[k].astype(np.float64) - ref
+        rows.append((float(np.sqrt((d ** 2).sum()) / max(np.sqrt((ref ** 2).sum()), 1e-300)), k, float(np.sqrt((ref ** 2).mean())),
+                     float(np.abs(d).max())))
+    for rel, k, rms, dmax in sorted(rows, reverse=True)[:40]:
+        print(f"  {rel:10.3e}  rms|g_ref| {rms:10.3e}  max|dg| {dmax:10.3e}  {k}")
+    print("parameters after one AdamW step (lr 1e-3): elements whose gap to the oracle exceeds 2e-4, by tensor")
+    tot = 0
+    for k, v in want_sd.items():
+        gap = np.abs(sd[k] - v.detach().numpy())
+        n = int((gap > 2e-4).sum())
+        if n and k in want_g:
+            ref = np.abs(want_g[k].double().numpy())
+            sel = ref[gap > 2e-4]
+            print(f"  {n:7d} of {gap.size:8d}  {k}: |g_ref| of those elements median {np.median(sel):.2e} max {sel.max():.2e} "
+                  f"(tensor rms {np.sqrt((ref ** 2).mean()):.2e}; Adam eps 1e-8)")
+        tot += n
+    print(f"  total {tot}")
+
+
+if __name__ == "__main__":
+    main()

@@ -74,10 +74,15 @@ CONV_KERNEL = "conv3d_k3_v2_kernel"          # the 4x8x8 / 2x8x8 / split-K forms
 WIDE_KERNEL = "conv3d_k3_wide_kernel"        # round 4: the 8x8x8-tile form of the fp16 96^3 layers, 70 % of a step's FLOPs
 
 
+UPCONV_KERNEL = "upconv_k3_kernel"            # round 5: UpCat's transposed convolution folded into its first convolution
+
+
 def conv_kernel_of(call):
     """Which kernel the launcher picks for a recorded ops.conv3d_k3 call (dua_conv3d_k3_kernel_kind: the launcher's own rule)."""
     from diff_unet_amos_amd import ops
     a, k = call
+    if k.get("__upconv__"):
+        return UPCONV_KERNEL
     x, cin, cout = a[0], a[1], a[5]
     N, D, H, W = x.shape[:4]
     kind = ops.conv3_kernel_kind(x.dtype, N, D, H, W, cin, x.shape[-1], cout, fused=k.get("norm") is not None,
@@ -95,8 +100,15 @@ def conv3_flops(plan):
             out.append(2.0 * c.cin * c.cout * 27 * v * plan.N)
     for l in (3, 2, 1, 0):
         v = plan.S[l][0] * plan.S[l][1] * plan.S[l][2]
-        for c in plan.dec[l]:
-            out.append(2.0 * c.cin * c.cout * 27 * v * plan.N)
+        for i, c in enumerate(plan.dec[l]):
+            fl = 2.0 * c.cin * c.cout * 27 * v * plan.N
+            if i == 0 and plan._fold_level(l):
+                # the folded launch also does the transposed convolution's work (2 * Cin * Cout * 8 * coarse voxels
+                # ... * 8 children = 2 * Cin * Cout * fine voxels); ALGORITHMIC figures of the reference's two layers, not the
+                # 3.4x fewer multiply-adds the regrouped upsampled half executes
+                d = plan.deconv[l]
+                fl += 2.0 * d.weight.shape[0] * d.weight.shape[1] * v * plan.N
+            out.append(fl)
     return out
 
 
@@ -112,21 +124,29 @@ def time_conv_launches(plan, reps):
     rocprofv3 summary lists it.  Returns (avg ms per launch, launches/step, ms by launch)."""
     from diff_unet_amos_amd import _native as nv
     from diff_unet_amos_amd import ops
-    real = ops.conv3d_k3
+    real_conv, real_up = ops.conv3d_k3, ops.upconv_k3
     calls = []
     global _LAST_CONV_CALLS
     _LAST_CONV_CALLS = calls
 
+    def real(*a, **k):
+        k = dict(k)
+        return (real_up if k.pop("__upconv__", False) else real_conv)(*a, **k)
+
     def wrapped(*a, **k):
         calls.append((a, k))
-        return real(*a, **k)
+        return real_conv(*a, **k)
 
-    ops.conv3d_k3 = wrapped
+    def wrapped_up(*a, **k):
+        calls.append((a, dict(k, __upconv__=True)))
+        return real_up(*a, **k)
+
+    ops.conv3d_k3, ops.upconv_k3 = wrapped, wrapped_up
     try:
         plan.denoiser_body()
         torch.cuda.synchronize()
     finally:
-        ops.conv3d_k3 = real
+        ops.conv3d_k3, ops.upconv_k3 = real_conv, real_up
     by_launch = []
     ops.CONV_POLICY |= nv.POLICY_NO_FINISH
     try:
@@ -153,26 +173,28 @@ def time_conv_launches(plan, reps):
         pairs = {i: [] for i in big}
         idx = [0]
 
-        def timed(*a, **k):
-            i = idx[0]
-            idx[0] += 1
-            if i in pairs:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                real(*a, **k)
-                e1.record()
-                pairs[i].append((e0, e1))
-            else:
-                real(*a, **k)
+        def timed_with(fn):
+            def timed(*a, **k):
+                i = idx[0]
+                idx[0] += 1
+                if i in pairs:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn(*a, **k)
+                    e1.record()
+                    pairs[i].append((e0, e1))
+                else:
+                    fn(*a, **k)
+            return timed
 
-        ops.conv3d_k3 = timed
+        ops.conv3d_k3, ops.upconv_k3 = timed_with(real_conv), timed_with(real_up)
         try:
             for _ in range(1 + max(3, reps // 4)):
                 idx[0] = 0
                 plan.denoiser_body()
             torch.cuda.synchronize()
         finally:
-            ops.conv3d_k3 = real
+            ops.conv3d_k3, ops.upconv_k3 = real_conv, real_up
         for i in big:
             ts = sorted(e0.elapsed_time(e1) for e0, e1 in pairs[i][1:])
             by_launch[i] = ts[len(ts) // 2]
@@ -219,7 +241,7 @@ def roofline_by_kernel(fl, by_launch, kern, peak, largest_name):
            "by_launch_us": [round(x * 1e3, 1) for x in by_launch],
            "by_launch_back_to_back_us": [round(x * 1e3, 1) for x in _BACK_TO_BACK_MS],
            "by_launch_tflops": [round(f / (x * 1e-3) / 1e12) for f, x in zip(fl, by_launch)],
-           "by_launch_kernel": [{"conv3d_k3_first_kernel": "first", WIDE_KERNEL: "wide", CONV_KERNEL: "v2"}[k_] for k_ in kern],
+           "by_launch_kernel": [{"conv3d_k3_first_kernel": "first", WIDE_KERNEL: "wide", CONV_KERNEL: "v2", UPCONV_KERNEL: "upconv"}[k_] for k_ in kern],
            "largest_launch": {"layer": largest_name, "kernel": kern[big],
                               "tflops": round(max(fl) / (by_launch[big] * 1e-3) / 1e12, 2)},
            "other_kernels": {n_: summary(g) for n_, g in groups.items() if n_ != main}}

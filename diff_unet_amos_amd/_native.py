@@ -40,6 +40,12 @@ class InNorm(C.Structure):
                 ("slope", C.c_float)]
 
 
+class UpConvDesc(C.Structure):
+    """dua_upconv_desc."""
+    _fields_ = [(n, C.c_int) for n in ("dtype", "N", "D", "H", "W", "Cskip", "Cskip_stride", "Cskip_off", "Cu", "Cu_stride", "Cu_off",
+                                       "Cout", "Cout_stride", "Cout_off", "layout")]
+
+
 class MaterializeDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
                 ("raw_stride", C.c_int), ("emb_stride", C.c_int), ("out_stride", C.c_int), ("out_off", C.c_int),
@@ -66,13 +72,13 @@ class TailResidual(C.Structure):
 IN_BLOCKED, OUT_BLOCKED = 1, 2            # dua_conv3_desc.layout bits
 POLICY_NO_FINISH = 256                    # dua_conv3_desc.policy bit: skip the split-K finish kernel (timing only)
 MODE_LOGITS, MODE_DDPM, MODE_DDIM = 0, 1, 2
-OP_CONV3, OP_MATERIALIZE, OP_DECONV = 1, 2, 3
+OP_CONV3, OP_MATERIALIZE, OP_DECONV, OP_UPCONV = 1, 2, 3, 4
 
 
 class StepOp(C.Structure):
     _fields_ = [("kind", C.c_int), ("has_norm", C.c_int), ("conv", Conv3Desc), ("mat", MaterializeDesc), ("norm", InNorm),
                 ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("stats", C.c_void_p),
-                ("emb", C.c_void_p), ("pooled", C.c_void_p)]
+                ("emb", C.c_void_p), ("pooled", C.c_void_p), ("up", UpConvDesc), ("u", C.c_void_p), ("wu", C.c_void_p)]
 
 
 class DenoiserPlan(C.Structure):
@@ -162,6 +168,9 @@ _SIGS = {
     "dua_conv3d_k3_kernel_kind": (C.c_int, [C.POINTER(Conv3Desc), C.c_int, C.c_int]),
     "dua_deconv_k2s2_kernel_kind": (C.c_int, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P, _P, C.c_long, _P]),
+    "dua_upconv_k3_supported": (C.c_int, [C.POINTER(UpConvDesc)]),
+    "dua_pack_upconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_upconv_k3_fwd": (C.c_int, [C.POINTER(UpConvDesc), _P, _P, C.POINTER(InNorm), _P, _P, _P, _P, _P, _P]),
     "dua_conv3d_k3_wgrad_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_wgrad": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.c_int, _P, _P, C.c_long, _P]),
     "dua_pack_conv3_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -29,6 +29,9 @@ extern "C" int dua_denoiser_step(const dua_denoiser_plan* p, void* stream) {
       case DUA_OP_DECONV:
         rc = dua_deconv_k2s2_fwd(&o.conv, o.x, o.w, o.bias, in, o.y, stream);
         break;
+      case DUA_OP_UPCONV:
+        rc = dua_upconv_k3_fwd(&o.up, o.x, o.u, in, o.w, o.wu, o.bias, o.y, o.stats, stream);
+        break;
       default:
         return DUA_ERR_ARG;
     }

@@ -1,0 +1,584 @@
+// UpCat's first convolution with the transposed convolution in front of it folded in (round 5).
+//
+// models/basic_unet/denoiser.py:172-194 (UpCat.forward):   x_0 = upsample(x)            ConvTranspose3d(k2, s2) + bias
+//                                                           y   = conv(cat([x_e, x_0]))  Conv3d(k3, p1) + bias   (TwoConv.conv_0)
+// Nothing non-linear sits between the two, so for an output voxel o = 2 m + phi (phi in {0,1}^3 its parity, m its parent cell)
+//   y[o] = b'(o) + sum_{taps t} Wc_skip[t] x_e[o + t - 1]  +  sum_{delta in {0,1}^3} W'[phi][delta] u[m + delta - 1 + phi]
+// with W'[phi][delta] = sum over the taps t whose input voxel o + t - 1 is a child of parent m + delta - 1 + phi of
+// Wc_up[t] Wd[child] (1, 2, 4 or 8 products), and b'(o) = bc + sum_{t inside the volume} Wc_up[t] bd (27 border classes).
+// The upsampled half of the convolution therefore contracts 8 parents x Cu channels instead of 27 taps x Cmid channels:
+// at 96^3 (Cu = Cmid = 64) 58 GFLOP instead of 195.7 + 7.2 for the transposed convolution itself, whose launch, output
+// write (113 MB) and re-read disappear -- the same function of the same parameters, regrouped (composed weights in fp32,
+// rounded once to fp16; dua_pack_upconv_weights below).
+//
+// Kernel = the wide-tile form of conv3d_wide.hip (8x8x8 output voxels x 64 channels per workgroup, 8 accumulators per wave,
+// 16-channel half chunks, kd planes of weights by LDS-DMA) with PHASE-MAJOR accumulators: an MFMA block applies ONE weight
+// matrix to its 32 rows, so the rows of a block must share their parity.  Wave w = (pd, ph) = (w >> 1, w & 1) owns the voxels
+// of the tile with d, h parity (pd, ph); its four blocks are (cz_hi, pw): 32 cells (cz_lo 2 x cy 4 x cx 4) of w-parity pw.
+//   part 1 (skip half): as the wide kernel, A fragments gathered with doubled strides from a halo laid out for exactly that
+//     (rows of 336 B, 16-byte halves swapped by (plane >> 1) & 1: every ds_read_b128 conflict-free, checked by emulation);
+//   part 2 (upsampled half): the 6x6x6 parent cells of 64 coarse channels (30 KB, normalised + activated on the way in) are
+//     staged where the weight ring was; per (delta_d, delta_h, half chunk, pw) a wave multiplies 2 x 2 A fragments (x offsets,
+//     cz_hi) with the 2 x 2 B fragments (delta_w, cout half) of ITS OWN parities -- those weights are wave-private, so they
+//     come straight from L2 into registers (1 KB per load instruction, three iterations ahead), not through LDS.
+#include "common.hpp"
+#include "../../include/dua_hip.h"
+#include "stamp.hpp"
+
+namespace dua {
+
+namespace upc {
+constexpr int VS = 32, RS = 336, PS = 10 * RS;                 // skip halo: 32-byte voxels, 10 voxels + 16 B per row, 10 rows per plane
+constexpr int HALO = 10 * PS;                                  // 33600
+constexpr int WPLANE = 18 * 1024, RING = 2 * WPLANE;           // [9 taps][2 k-groups][64 couts][16 B] x 2
+constexpr int CR = 6 * VS, CP = 6 * CR + 128, CHC = 6 * CP;    // coarse halo per half chunk: rows 192 B, planes 1280 B, 7680 B
+constexpr int CGRP = 4 * CHC;                                  // 64 coarse channels: 30720 B (<= RING and <= HALO)
+constexpr int SLAB = 3 * 4 * 64 * 16;                          // one (kd, kh) slab of the packed skip weights (32-channel chunk)
+constexpr int BN = 64;
+constexpr int NPIECE = 7;                                      // coarse pieces per thread and group: 216 cells x 8 parts / 256
+static_assert(CGRP <= RING && CGRP <= HALO && 4 * 8192 <= HALO, "regions");
+}  // namespace upc
+
+struct UpConvArgs {
+  const void* xs; const void* u; const void* w; const void* wu; const float* btab; void* y;
+  stat_t* stats;
+  InXform xf;                          // producer of u
+  int N, D, H, W;                      // output (fine) extents
+  int Cs, Cs_stride, Cs_off, in_blk;
+  int Cu, Cu_stride, Cu_off;
+  int Cout, Cout_stride, Cout_off, out_blk, cout_pad;
+  int nchunks, ntiles, tiles_h, tiles_w;
+};
+
+__device__ __forceinline__ void upc_dma_piece(const char* src_lane, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src_lane), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
+  using namespace upc;
+  using T = f16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* ring = smem + HALO;
+  float* xsc = (float*)(smem + HALO + RING);
+  float* xsh = xsc + a.Cu;
+  float* xad = xsh + a.Cu;
+  float* ex = xad + a.Cu;                                      // [4 waves][64 couts][2]
+
+  const int per_slab = a.tiles_h * a.tiles_w;
+  const int tile = xcd_remap(blockIdx.x, a.ntiles);
+  const int td = tile / per_slab, rem = tile - td * per_slab, th = rem / a.tiles_w, tw = rem - th * a.tiles_w;
+  const int d0 = td * 8, h0 = th * 8, w0 = tw * 8, ct = blockIdx.y, n = blockIdx.z, replica = blockIdx.x & (STAT_REPLICAS - 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int pd = wave >> 1, ph = wave & 1;
+  const int nhc = a.Cs >> 4, U = nhc * 3, G = a.Cu >> 6;
+
+  // ---- skip halo pieces: thread = (position (hy, hx) in a halo plane, 16-byte half p), piece j = halo plane j ----
+  const int p_t = tid & 1, pos = tid >> 1;
+  const bool has_pos = pos < 100;
+  const int hy = pos / 10, hx = pos - hy * 10;
+  const int gh = h0 + hy - 1, gw = w0 + hx - 1;
+  const bool ok_hw = has_pos && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+  const int vstride = a.in_blk ? 16 : a.Cs_stride;
+  const long hcstride = a.in_blk ? (long)a.D * a.H * a.W * 16 : 16;
+  const T* xin = (const T*)a.xs + (long)n * a.D * a.H * a.W * a.Cs_stride +
+                 (a.in_blk ? (long)(a.Cs_off >> 4) * a.D * a.H * a.W * 16 : a.Cs_off) + p_t * 8;
+  const int voff = ok_hw ? (((d0 - 1) * a.H + gh) * a.W + gw) * vstride : 0;
+  const int pstep = a.H * a.W * vstride;
+  const int lbase = has_pos ? hy * RS + hx * VS : 0;
+  const int lsw0 = lbase + (p_t << 4), lsw1 = lbase + ((p_t ^ 1) << 4);       // planes with (j >> 1) & 1 = 0 / 1
+  f16x8 hreg[10];
+  auto load_halo = [&](int hc, int j0, int j1) {
+    const T* src = xin + hc * hcstride;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      if (j < j0 || j >= j1) continue;
+      const bool dok = (unsigned)(d0 + j - 1) < (unsigned)a.D;       // wave-uniform
+      hreg[j] = *(const f16x8*)(src + (ok_hw && dok ? voff + j * pstep : 0));
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const f32x4 raw = __builtin_bit_cast(f32x4, hreg[j]);
+      const bool ok = ok_hw && (unsigned)(d0 + j - 1) < (unsigned)a.D;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = ok ? raw[e] : 0.f;
+      if (has_pos) *(f32x4*)(halo + (((j >> 1) & 1) ? lsw1 : lsw0) + j * PS) = o;
+    }
+  };
+
+  // ---- skip weights: kd plane `kd` of half chunk `hc` -> ring slot (18 pieces of 1 KB; wave w takes pieces w, w + 4, ...) ----
+  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB + lane * 16;
+  const unsigned wlds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+  auto dma_plane = [&](int u, int slot) {
+    const int hc = u / 3, kd = u - hc * 3;
+    const char* src = wsrc + (long)((hc >> 1) * 3 + kd) * 3 * SLAB + (hc & 1) * 2048;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int p = wave + 4 * j;                              // piece = (tap p >> 1, k-group p & 1)
+      if (p < 18) upc_dma_piece(src + ((p >> 1) * 4 + (p & 1)) * 1024, wlds + slot * WPLANE + p * 1024);
+    }
+  };
+
+  // ---- coarse halo pieces of one 64-channel group: cell = (tid >> 3) + 32 j (6 x 6 x 6 parent cells), part = tid & 7 ----
+  const int part = tid & 7;
+  const int Dc = a.D >> 1, Hc = a.H >> 1, Wc = a.W >> 1;
+  const T* uin = (const T*)a.u + (long)n * Dc * Hc * Wc * a.Cu_stride + a.Cu_off + part * 8;
+  f16x8 creg[NPIECE];
+  auto load_coarse = [&](int g, int j0, int j1) {
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      if (j < j0 || j >= j1) continue;
+      const int cell = (tid >> 3) + 32 * j;
+      const int z = cell / 36, rm = cell - z * 36, y = rm / 6, x = rm - y * 6;
+      const int gz = (d0 >> 1) - 1 + z, gy = (h0 >> 1) - 1 + y, gx = (w0 >> 1) - 1 + x;
+      const bool ok = cell < 216 && (unsigned)gz < (unsigned)Dc && (unsigned)gy < (unsigned)Hc && (unsigned)gx < (unsigned)Wc;
+      creg[j] = *(const f16x8*)(uin + (ok ? (long)((gz * Hc + gy) * Wc + gx) * a.Cu_stride + g * 64 : 0));
+    }
+  };
+  auto store_coarse = [&](int g, char* dst) {
+    float sc[8], sh[8], ad[8], sn[8];
+    const int c0 = g * 64 + part * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+    xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int cell = (tid >> 3) + 32 * j;
+      const int z = cell / 36, rm = cell - z * 36, y = rm / 6, x = rm - y * 6;
+      const int gz = (d0 >> 1) - 1 + z, gy = (h0 >> 1) - 1 + y, gx = (w0 >> 1) - 1 + x;
+      const bool ok = (unsigned)gz < (unsigned)Dc && (unsigned)gy < (unsigned)Hc && (unsigned)gx < (unsigned)Wc;
+      const f16x8 v = xform_frag<T>(creg[j], sc, sh, ad, sn, a.xf.slope);
+      const f32x4 raw = __builtin_bit_cast(f32x4, v);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = ok ? raw[e] : 0.f;
+      if (cell < 216) *(f32x4*)(dst + (part >> 1) * CHC + z * CP + y * CR + x * VS + (((part & 1) ^ (y & 1)) << 4)) = o;
+    }
+  };
+
+  // ---- prologue: everything that must come from memory is requested before anything waits ----
+  const bool border = d0 == 0 || d0 + 8 == a.D || h0 == 0 || h0 + 8 == a.H || w0 == 0 || w0 + 8 == a.W;
+  float bias_q[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int bc = ct * BN + q * 32 + r;
+    bias_q[q] = bc >= a.Cout ? 0.f : a.btab[13 * a.cout_pad + bc];          // interior class (1, 1, 1)
+  }
+  constexpr int UN = 4;
+  stat_t sv[UN][2 * STAT_WORDS];
+  float gam[UN], bet[UN], addv[UN];
+  {
+    const int pr = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int c = (wave + 4 * u) * 16 + (lane & 15), cc = c < a.Cu ? c : a.Cu - 1;
+      gam[u] = a.xf.gamma[cc]; bet[u] = a.xf.beta[cc];
+      addv[u] = a.xf.add ? a.xf.add[(long)n * a.xf.add_stride + cc] : 0.f;
+      const stat_t* sp = a.xf.stats + ((long)n * STAT_REPLICAS + 2 * pr) * STAT_WORDS * a.xf.c_pad + cc;
+      if ((wave + 4 * u) * 16 < a.Cu) {
+#pragma unroll
+        for (int k = 0; k < 2 * STAT_WORDS; ++k) sv[u][k] = sp[(long)k * a.xf.c_pad];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 2 * STAT_WORDS; ++k) sv[u][k] = 0;
+      }
+    }
+  }
+  load_halo(0, 0, 10);
+  dma_plane(0, 0);
+  float btv[7];
+  if (border) {                                                // 27 classes x 64 channels of this cout tile -> ring slot 1
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int e = tid + 256 * j, cls = e >> 6, c = ct * BN + (e & 63);
+      btv[j] = (e < 27 * 64 && c < a.Cout) ? a.btab[cls * a.cout_pad + c] : 0.f;
+    }
+  }
+  {
+    const int pr = lane >> 4;
+    double Sm = 0, Qm = 0;
+    float gm = 0.f, bm = 0.f, am = 0.f;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      stat_t w[STAT_WORDS];
+#pragma unroll
+      for (int k = 0; k < STAT_WORDS; ++k) {
+        w[k] = sv[u][k] + sv[u][STAT_WORDS + k];
+        w[k] += __shfl_xor(w[k], 16);
+        w[k] += __shfl_xor(w[k], 32);
+      }
+      if (pr == u) {
+        Sm = (double)w[0] + (double)w[1] * (1.0 / STAT_FRAC);
+        Qm = (double)w[2] + (double)w[3] * (1.0 / STAT_FRAC);
+        gm = gam[u]; bm = bet[u]; am = addv[u];
+      }
+    }
+    const int c = (wave + 4 * pr) * 16 + (lane & 15);
+    const double mean = Sm * a.xf.inv_count;
+    double var = Qm * a.xf.inv_count - mean * mean;
+    var = var > 0 ? var : 0;
+    const float g = gm * (float)(1.0 / sqrt(var + (double)a.xf.eps));
+    if (c < a.Cu) {
+      xsc[c] = g;
+      xsh[c] = bm - (float)mean * g;
+      xad[c] = am;
+    }
+  }
+  float* btl = (float*)(ring + WPLANE);
+  if (border) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (tid + 256 * j < 27 * 64) btl[tid + 256 * j] = btv[j];
+  }
+  __syncthreads();
+  store_halo();
+
+  // ---- accumulators [block m = cz_hi * 2 + pw][cout half q]; register i of lane half hh = cell (cz_lo = i >> 3,
+  // cy = hh + 2 ((i >> 2) & 1), cx = i & 3); they start at the bias of their voxel's border class ----
+  f32x16 acc[4][2];
+  if (!border) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][q][i] = bias_q[q];
+  } else {
+    const bool lo_d = d0 == 0, hi_d = d0 + 8 == a.D, lo_h = h0 == 0, hi_h = h0 + 8 == a.H, lo_w = w0 == 0, hi_w = w0 + 8 == a.W;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ld = 2 * (2 * (m >> 1) + (i >> 3)) + pd, lh = 2 * (hh + 2 * ((i >> 2) & 1)) + ph, lw = 2 * (i & 3) + (m & 1);
+        const int cd = (lo_d && ld == 0) ? 0 : (hi_d && ld == 7) ? 2 : 1;
+        const int ch = (lo_h && lh == 0) ? 0 : (hi_h && lh == 7) ? 2 : 1;
+        const int cw = (lo_w && lw == 0) ? 0 : (hi_w && lw == 7) ? 2 : 1;
+        const int cls = cd * 9 + ch * 3 + cw;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[m][q][i] = btl[cls * 64 + q * 32 + r];
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's weight pieces (the compiler does not count them)
+  __syncthreads();
+
+  const int cz_lo = r >> 4, cy = (r >> 2) & 3, cx = r & 3;
+  const int La = 2 * cz_lo * PS + 2 * cy * RS + 2 * cx * VS + pd * PS + ph * RS;
+  const int A0 = La + ((hh ^ cz_lo) << 4), A1 = La + ((hh ^ cz_lo ^ 1) << 4);
+  const int b_base = (hh * BN + r) * 16;
+
+  // One phase = the 9 taps of kd plane `kd` of the current half chunk against ring slot `slot`: half-step h = (tap t = h / 2,
+  // sub = h % 2 = cz_hi) is 4 MFMAs on the A pair (pw = 0, 1) of (t, sub) and the B pair of t.
+  auto phase = [&](int kd, int slot) __attribute__((always_inline)) {
+    const char* hp = halo + kd * PS + (((pd + kd) >> 1) ? A1 : A0);
+    const char* wb = ring + slot * WPLANE + b_base;
+    f16x8 fa[2][2], fb[2][2];
+    auto ldA = [&](int t, int sub, int b) {
+      const int kh = t / 3, kw = t - kh * 3;
+      const char* ap = hp + sub * 4 * PS + kh * RS + kw * VS;
+      fa[b][0] = *(const f16x8*)ap;
+      fa[b][1] = *(const f16x8*)(ap + VS);
+    };
+    auto ldB = [&](int t, int b) {
+      fb[b][0] = *(const f16x8*)(wb + t * 2048);
+      fb[b][1] = *(const f16x8*)(wb + t * 2048 + 512);
+    };
+    ldB(0, 0);
+    ldA(0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < 18; ++h) {
+      const int t = h >> 1, sub = h & 1;
+      if (h + 1 < 18) {
+        const int t1 = (h + 1) >> 1, sub1 = (h + 1) & 1;
+        if (sub1 == 0) ldB(t1, t1 & 1);
+        ldA(t1, sub1, (h + 1) & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma32(acc[2 * sub][0], fa[h & 1][0], fb[t & 1][0]);
+      mma32(acc[2 * sub][1], fa[h & 1][0], fb[t & 1][1]);
+      mma32(acc[2 * sub + 1][0], fa[h & 1][1], fb[t & 1][0]);
+      mma32(acc[2 * sub + 1][1], fa[h & 1][1], fb[t & 1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- part 1: the skip half.  The next half chunk's halo -- or, under the last one, the first group of the coarse halo --
+  // is requested in three groups at the head of the three phases, behind that phase's weight pieces ----
+  for (int hc = 0; hc < nhc; ++hc) {
+    const bool more = hc + 1 < nhc;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int u = hc * 3 + kd, slot = u & 1;
+      if (u + 1 < U) dma_plane(u + 1, slot ^ 1);
+      if (more) load_halo(hc + 1, kd == 0 ? 0 : kd == 1 ? 4 : 7, kd == 0 ? 4 : kd == 1 ? 7 : 10);
+      else load_coarse(0, kd == 0 ? 0 : kd == 1 ? 3 : 5, kd == 0 ? 3 : kd == 1 ? 5 : NPIECE);
+      phase(kd, slot);
+      if (more) {
+        if (kd == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (kd == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (kd == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (kd == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      }
+      __syncthreads();
+    }
+    if (more) {
+      store_halo();
+      __syncthreads();
+    }
+  }
+
+  // ---- part 2: the upsampled half.  B fragments of iteration it = (delta_d, delta_h, half chunk, pw): 4 KB = (delta_w, q) ----
+  const char* wub = (const char*)a.wu + (long)(ct * 4 + wave) * G * (128 * 1024) + lane * 16;
+  const int Lc = cz_lo * CP + cy * CR + cx * VS + pd * CP + ph * CR;
+  const int C0 = Lc + ((hh ^ ((cy + ph) & 1)) << 4), C1 = Lc + ((hh ^ ((cy + ph) & 1) ^ 1) << 4);
+  f16x8 fb[3][4], fa[2][4];
+  auto ldBu = [&](const char* wg, int it, int b) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fb[b][k] = *(const f16x8*)(wg + (it * 4 + k) * 1024);
+  };
+  ldBu(wub, 0, 0); ldBu(wub, 1, 1); ldBu(wub, 2, 2);
+  store_coarse(0, ring);
+  if (G > 1) load_coarse(1, 0, NPIECE);
+  __syncthreads();
+  for (int g = 0; g < G; ++g) {
+    const char* cb = (g & 1) ? halo : ring;
+    const char* wg = wub + (long)g * (128 * 1024);
+    auto ldAu = [&](int it, int b) {
+      const int dd = it >> 4, dh = (it >> 3) & 1, hcl = (it >> 1) & 3, pw = it & 1;
+      const char* ap = cb + (dh ? C1 : C0) + hcl * CHC + dd * CP + dh * CR + pw * VS;
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw)
+#pragma unroll
+        for (int czh = 0; czh < 2; ++czh) fa[b][dw * 2 + czh] = *(const f16x8*)(ap + czh * 2 * CP + dw * VS);
+    };
+    if (g > 0) { ldBu(wg, 0, 0); ldBu(wg, 1, 1); ldBu(wg, 2, 2); }
+    ldAu(0, 0);
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int pw = it & 1;
+      if (it + 1 < 32) ldAu(it + 1, (it + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw)
+#pragma unroll
+        for (int czh = 0; czh < 2; ++czh) {
+          mma32(acc[czh * 2 + pw][0], fa[it & 1][dw * 2 + czh], fb[it % 3][dw * 2 + 0]);
+          mma32(acc[czh * 2 + pw][1], fa[it & 1][dw * 2 + czh], fb[it % 3][dw * 2 + 1]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 3 < 32) ldBu(wg, it + 3, it % 3);                 // into the buffer the MFMAs above have just read
+    }
+    if (g + 1 < G) {
+      store_coarse(g + 1, (g & 1) ? ring : halo);
+      if (g + 2 < G) load_coarse(g + 2, 0, NPIECE);
+      __syncthreads();
+    }
+  }
+  if (!(G & 1)) __syncthreads();                                 // the last group was read from the region the epilogue stages in
+
+  // ---- epilogue: statistics from the fp32 accumulators; each wave stages the two blocks (pw = 0, 1) of one cz_hi at a
+  // time as 64 voxel rows [cz_lo][cy][w = 2 cx + pw] x 128 B in rows of its own, whole voxel lines leave in 16-byte stores ----
+  char* ot = halo + wave * 8192;
+  const long nvox = (long)a.D * a.H * a.W;
+  T* yout = (T*)a.y + (long)n * nvox * a.Cout_stride;
+  float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+#pragma unroll
+  for (int czh = 0; czh < 2; ++czh) {
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[czh * 2 + pw][q][i];
+          s[q] += v;
+          ss[q] = fmaf(v, v, ss[q]);
+          const int row = (i >> 3) * 32 + (hh + 2 * ((i >> 2) & 1)) * 8 + (i & 3) * 2 + pw;
+          *(T*)(ot + row * 128 + (q * 32 + r) * 2) = (T)v;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int v = it * 8 + (lane >> 3), cg = lane & 7;         // v = staged row: cz_lo = v >> 5, cy = (v >> 3) & 3, w = v & 7
+      const int gd = d0 + 2 * (2 * czh + (v >> 5)) + pd, ghh = h0 + 2 * ((v >> 3) & 3) + ph, gww = w0 + (v & 7);
+      if (ct * BN + cg * 8 < a.Cout)
+        *(f16x8*)(yout + chan_off(a.out_blk, ((long)gd * a.H + ghh) * a.W + gww, a.Cout_off + ct * BN + cg * 8, a.Cout_stride, nvox)) =
+            *(const f16x8*)(ot + v * 128 + cg * 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    s[q] += __shfl_xor(s[q], 32);
+    ss[q] += __shfl_xor(ss[q], 32);
+    if (hh == 0) { ex[(wave * BN + q * 32 + r) * 2] = s[q]; ex[(wave * BN + q * 32 + r) * 2 + 1] = ss[q]; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double S = 0, Q = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
+    if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, replica, ct * BN + lane, S, Q);
+  }
+}
+
+static const LdsAttr kUpconvLdsAttrs[] = {{(const void*)upconv_k3_kernel, 80 * 1024}};
+static const LdsAttrs kUpconvLdsReg(kUpconvLdsAttrs);
+
+// ---- weights.  wc: Conv3d weight fp32 [Cout][Cskip + Cmid][27]; wd: ConvTranspose3d weight fp32 [Cu][Cmid][8].
+// Composed element (co, ci, phi, delta): sum over the taps of (phi, delta) (per dimension: phi 0, delta 0 -> {k = 0, child 1};
+// phi 0, delta 1 -> {k = 1, child 0; k = 2, child 1}; phi 1, delta 0 -> {k = 0, child 0; k = 1, child 1}; phi 1, delta 1 ->
+// {k = 2, child 0}) and over cm, in a fixed order, fp32; stored as fp16 in the order the kernel streams it:
+// [cout tile][wave = (pd, ph)][group g][delta_d][delta_h][half chunk][pw][delta_w][q][k-group hh][r][8 channels]. ----
+__device__ __forceinline__ int upc_taps(int phi, int delta, int* k, int* child) {
+  if (phi == 0 && delta == 0) { k[0] = 0; child[0] = 1; return 1; }
+  if (phi == 0) { k[0] = 1; child[0] = 0; k[1] = 2; child[1] = 1; return 2; }
+  if (delta == 0) { k[0] = 0; child[0] = 0; k[1] = 1; child[1] = 1; return 2; }
+  k[0] = 2; child[0] = 0; return 1;
+}
+
+__global__ void upconv_pack_kernel(int Cout, int Cskip, int Cmid, int Cu, const float* __restrict__ wc,
+                                   const float* __restrict__ wd, f16* __restrict__ out, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  // idx = position in the packed order
+  long t = idx;
+  const int e = t & 7; t >>= 3;
+  const int r = t & 31; t >>= 5;
+  const int hh = t & 1; t >>= 1;
+  const int q = t & 1; t >>= 1;
+  const int dw = t & 1; t >>= 1;
+  const int pw = t & 1; t >>= 1;
+  const int hcl = t & 3; t >>= 2;
+  const int dh = t & 1; t >>= 1;
+  const int dd = t & 1; t >>= 1;
+  const int G = Cu >> 6;
+  const int g = t % G; t /= G;
+  const int wave = t & 3; t >>= 2;
+  const int ct = (int)t;
+  const int pd = wave >> 1, ph = wave & 1;
+  const int co = ct * 64 + q * 32 + r, ci = g * 64 + hcl * 16 + hh * 8 + e;
+  float accv = 0.f;
+  if (co < Cout && ci < Cu) {
+    int kd[2], ad[2], kh[2], ah[2], kw[2], aw[2];
+    const int nd = upc_taps(pd, dd, kd, ad), nh = upc_taps(ph, dh, kh, ah), nw = upc_taps(pw, dw, kw, aw);
+    const int Cin = Cskip + Cmid;
+    for (int x = 0; x < nd; ++x)
+      for (int y = 0; y < nh; ++y)
+        for (int z = 0; z < nw; ++z) {
+          const int tap = (kd[x] * 3 + kh[y]) * 3 + kw[z], child = (ad[x] * 2 + ah[y]) * 2 + aw[z];
+          const float* wcp = wc + ((long)co * Cin + Cskip) * 27 + tap;
+          const float* wdp = wd + (long)ci * Cmid * 8 + child;
+          float sacc = 0.f;
+          for (int cm = 0; cm < Cmid; ++cm) sacc = fmaf(wcp[(long)cm * 27], wdp[(long)cm * 8], sacc);
+          accv += sacc;
+        }
+  }
+  out[idx] = (f16)accv;
+}
+
+// bias table [27 classes = (cd, ch, cw), 0 = low border, 1 = interior, 2 = high border][cout_pad]
+__global__ void upconv_bias_kernel(int Cout, int Cskip, int Cmid, int cout_pad, const float* __restrict__ wc,
+                                   const float* __restrict__ bc, const float* __restrict__ bd, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 27 * cout_pad) return;
+  const int cls = idx / cout_pad, co = idx - cls * cout_pad;
+  float v = 0.f;
+  if (co < Cout) {
+    const int cd = cls / 9, ch = (cls / 3) % 3, cw = cls % 3;
+    const int Cin = Cskip + Cmid;
+    v = bc ? bc[co] : 0.f;
+    if (bd) {
+      for (int kd = 0; kd < 3; ++kd) {
+        if ((cd == 0 && kd == 0) || (cd == 2 && kd == 2)) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+          if ((ch == 0 && kh == 0) || (ch == 2 && kh == 2)) continue;
+          for (int kw = 0; kw < 3; ++kw) {
+            if ((cw == 0 && kw == 0) || (cw == 2 && kw == 2)) continue;
+            const float* wcp = wc + ((long)co * Cin + Cskip) * 27 + (kd * 3 + kh) * 3 + kw;
+            float sacc = 0.f;
+            for (int cm = 0; cm < Cmid; ++cm) sacc = fmaf(wcp[(long)cm * 27], bd[cm], sacc);
+            v += sacc;
+          }
+        }
+      }
+    }
+  }
+  out[idx] = v;
+}
+
+static bool upconv_desc_ok(const dua_upconv_desc* d) {
+  if (!d || d->dtype != DUA_F16 || d->N <= 0) return false;
+  if (d->D <= 0 || d->H <= 0 || d->W <= 0 || d->D % 8 || d->H % 8 || d->W % 8) return false;
+  if (d->Cskip <= 0 || d->Cskip % 16 || d->Cskip_off % 8 || d->Cskip_off + d->Cskip > d->Cskip_stride) return false;
+  if (d->Cu <= 0 || d->Cu % 64 || d->Cu > 256 || d->Cu_off % 8 || d->Cu_off + d->Cu > d->Cu_stride || d->Cu_stride % 8) return false;
+  if (d->Cout <= 0 || d->Cout % 8 || d->Cout_off % 8 || d->Cout_off + d->Cout > d->Cout_stride) return false;
+  if (d->layout & ~(DUA_IN_BLOCKED | DUA_OUT_BLOCKED)) return false;
+  if ((d->layout & DUA_IN_BLOCKED) && (d->Cskip_off % 16 || d->Cskip_stride % 16)) return false;
+  if ((d->layout & DUA_OUT_BLOCKED) && (d->Cout_off % 16 || d->Cout_stride % 16)) return false;
+  if (!(d->layout & DUA_IN_BLOCKED) && d->Cskip_stride % 8) return false;
+  // index arithmetic of the kernel is 32-bit per sample
+  if ((long)d->D * d->H * d->W * (d->Cskip_stride > d->Cout_stride ? d->Cskip_stride : d->Cout_stride) >= (1L << 31)) return false;
+  return true;
+}
+
+}  // namespace dua
+
+extern "C" {
+
+int dua_upconv_k3_supported(const dua_upconv_desc* d) { return dua::upconv_desc_ok(d) ? 1 : 0; }
+
+long dua_pack_upconv_weights(int dtype, int Cout, int Cskip, int Cmid, int Cu, const float* wc, const float* bc, const float* wd,
+                             const float* bd, void* wu_packed, float* bias_table, void* stream) {
+  if (dtype != DUA_F16 || Cout <= 0 || Cskip < 0 || Cmid <= 0 || Cu <= 0 || Cu % 64) return DUA_ERR_ARG;
+  const int nct = (Cout + 63) / 64, G = Cu >> 6;
+  const long total = (long)nct * 4 * G * 128 * 512;             // fp16 elements
+  if (!wu_packed) return total * 2;
+  if (!wc || !wd || !bias_table) return DUA_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dua::upconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Cout, Cskip, Cmid, Cu, wc, wd,
+                     (dua::f16*)wu_packed, total);
+  const int cout_pad = nct * 64;
+  hipLaunchKernelGGL(dua::upconv_bias_kernel, dim3((27 * cout_pad + 255) / 256), dim3(256), 0, s, Cout, Cskip, Cmid, cout_pad, wc, bc, bd,
+                     bias_table);
+  const int e = (int)hipGetLastError();
+  return e ? -(long)e : total * 2;
+}
+
+int dua_upconv_k3_fwd(const dua_upconv_desc* d, const void* xskip, const void* u, const dua_in_norm* u_in, const void* w_skip_packed,
+                      const void* wu_packed, const float* bias_table, void* y, dua_stat_word* out_stats, void* stream) {
+  using namespace dua;
+  if (!upconv_desc_ok(d) || !xskip || !u || !w_skip_packed || !wu_packed || !bias_table || !y || !out_stats) return DUA_ERR_ARG;
+  if (!u_in || !u_in->stats || !u_in->gamma || !u_in->beta || u_in->c_pad < d->Cu || u_in->count <= 0 ||
+      !(u_in->slope >= 0.f && u_in->slope <= 1.f))
+    return DUA_ERR_ARG;
+  if (int e = ensure_prepared()) return e;
+  UpConvArgs a{};
+  a.xs = xskip; a.u = u; a.w = w_skip_packed; a.wu = wu_packed; a.btab = bias_table; a.y = y; a.stats = out_stats;
+  a.xf = make_xform(u_in, d->Cu);
+  a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
+  a.Cs = d->Cskip; a.Cs_stride = d->Cskip_stride; a.Cs_off = d->Cskip_off; a.in_blk = (d->layout & DUA_IN_BLOCKED) ? 1 : 0;
+  a.Cu = d->Cu; a.Cu_stride = d->Cu_stride; a.Cu_off = d->Cu_off;
+  a.Cout = d->Cout; a.Cout_stride = d->Cout_stride; a.Cout_off = d->Cout_off; a.out_blk = (d->layout & DUA_OUT_BLOCKED) ? 1 : 0;
+  a.cout_pad = (d->Cout + 63) / 64 * 64;
+  a.nchunks = (d->Cskip + 31) / 32;
+  a.tiles_h = d->H / 8; a.tiles_w = d->W / 8;
+  a.ntiles = (d->D / 8) * a.tiles_h * a.tiles_w;
+  const int lds = upc::HALO + upc::RING + 3 * 4 * d->Cu + 4 * 64 * 2 * 4;
+  if (lds > 80 * 1024) return DUA_ERR_ARG;
+  hipLaunchKernelGGL(upconv_k3_kernel, dim3(a.ntiles, a.cout_pad / 64, a.N), dim3(256), lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -169,6 +169,7 @@ class Plan:
         self.dec = [(self._mk(f"u{l}a", ups[l].convs.conv_0), self._mk(f"u{l}b", ups[l].convs.conv_1)) for l in range(4)]
         self.deconv = [ups[l].upsample.deconv for l in range(4)]
         self.deconv_packed = [None] * 4
+        self.upconv_packed = [None] * 4
         # timestep-embedding blocks in table order, with their offsets
         blocks = [den.conv_0, den.down_1.convs, den.down_2.convs, den.down_3.convs, den.down_4.convs,
                   den.upcat_4.convs, den.upcat_3.convs, den.upcat_2.convs, den.upcat_1.convs]
@@ -202,7 +203,15 @@ class Plan:
                     c.norm = c.norm_add = None       # rebuilt lazily against the new gamma/beta
             for l in range(4):
                 d = self.deconv[l]
-                self.deconv_packed[l] = ops.pack_deconv_weights(d.weight.detach().float().contiguous(), d.bias.detach(), dt)
+                if self._fold_level(l):
+                    # UpCat's first convolution with the transposed convolution folded in (csrc/upconv.hip): composed weights
+                    a = self.dec[l][0]
+                    self.upconv_packed[l] = ops.pack_upconv_weights(a.w.detach().float().contiguous(), a.b.detach(),
+                                                                    d.weight.detach().float().contiguous(), d.bias.detach(), self.f[l])
+                    self.deconv_packed[l] = None
+                else:
+                    self.upconv_packed[l] = None
+                    self.deconv_packed[l] = ops.pack_deconv_weights(d.weight.detach().float().contiguous(), d.bias.detach(), dt)
             den = self.net.model
             self.wf = den.final_conv.weight.detach().float().reshape(self.C, -1).contiguous()
             self.bf = den.final_conv.bias.detach().float().contiguous()
@@ -239,6 +248,27 @@ class Plan:
         ops.conv3d_k3(x, cin, 0, c.wp, c.bp, c.cout, y, 0, c.stats, norm=norm, workspace=self.splitk_ws, tap_channel=c.tap,
                       in_blocked=in_blocked, out_blocked=out_blocked)
 
+    # Decoder levels whose transposed convolution is folded into the convolution behind it (dua_upconv_k3_fwd: one launch for
+    # upsample + cat + conv_0 of an UpCat block, 3.4x fewer multiply-adds on the upsampled half): fp16 plans, levels with at
+    # least this many 8x8x8 output tiles (x batch x output-channel tiles) -- below that the launch cannot fill the chip and the
+    # split forms of the plain convolution win.  ``net.fold_upconv = False`` keeps the two-launch form everywhere (A/B, tests).
+    UPCONV_MIN_TILES = 200
+
+    def _fold_level(self, l):
+        if getattr(self, "_fold", None) is None:
+            self._fold = [False] * 4
+            if self.dtype == torch.float16 and bool(getattr(self.net, "fold_upconv", True)):
+                for k in range(3):                       # level 3's source is the materialised bottom level (no producer descriptor)
+                    D, H, W = self.S[k]
+                    cat_c = self.f[k] + self.up[k]
+                    if D % 8 or H % 8 or W % 8:
+                        continue
+                    tiles = (D // 8) * (H // 8) * (W // 8) * self.N * (-(-self.dec_out[k] // 64))
+                    self._fold[k] = (tiles >= self.UPCONV_MIN_TILES and
+                                     ops.upconv_supported(self.dtype, self.N, D, H, W, self.f[k], cat_c, self.dec_out[k + 1],
+                                                          self.dec_out[k + 1], self.dec_out[k], self.dec_out[k]))
+        return self._fold[l]
+
     def _level0_layout(self):
         """Which level-0 buffers of the DENOISER are kept in 16-channel blocks (dua_conv3_desc.layout): those whose only
         consumer is the wide-tile convolution (it walks its input 16 channels at a time) and whose producer can write
@@ -253,11 +283,16 @@ class Plan:
             wide = ops.KIND_WIDE
             raw_a = (dt == torch.float16 and f[0] % 16 == 0 and kind(self.cin0, self.cin0, a0.cout, False, a0.tap) == ops.KIND_FIRST
                      and kind(a0.cout, f[0], b0.cout, True) == wide)
-            cat = (dt == torch.float16 and f[0] % 16 == 0 and (f[0] + self.up[0]) % 16 == 0
-                   and kind(f[0] + self.up[0], f[0] + self.up[0], u0a.cout, False) == wide
-                   and ops.deconv_kernel_kind(dt, N, *self.S[1], self.dec_out[1], self.up[0]) == ops.DECONV_ALLTAPS)
-            u_a = (dt == torch.float16 and self.dec_out[0] % 16 == 0 and kind(f[0] + self.up[0], f[0] + self.up[0], u0a.cout, False) == wide
-                   and kind(u0a.cout, self.dec_out[0], u0b.cout, True) == wide)
+            if self._fold_level(0):
+                # the folded up-convolution reads the skip half of cat[0] in blocks (written by materialise) and writes blocks
+                cat = f[0] % 16 == 0 and (f[0] + self.up[0]) % 16 == 0
+                u_a = self.dec_out[0] % 16 == 0 and kind(u0a.cout, self.dec_out[0], u0b.cout, True) == wide
+            else:
+                cat = (dt == torch.float16 and f[0] % 16 == 0 and (f[0] + self.up[0]) % 16 == 0
+                       and kind(f[0] + self.up[0], f[0] + self.up[0], u0a.cout, False) == wide
+                       and ops.deconv_kernel_kind(dt, N, *self.S[1], self.dec_out[1], self.up[0]) == ops.DECONV_ALLTAPS)
+                u_a = (dt == torch.float16 and self.dec_out[0] % 16 == 0 and kind(f[0] + self.up[0], f[0] + self.up[0], u0a.cout, False) == wide
+                       and kind(u0a.cout, self.dec_out[0], u0b.cout, True) == wide)
             self._l0 = (raw_a, cat, u_a)
         return self._l0
 
@@ -354,11 +389,17 @@ class Plan:
                 ops.materialize(self.rawB[4], b.cout, self._norm(b, 4), self.x4, 0, emb=self.emb[4])
         src, src_c, src_conv = self.x4, f[4], None
         for l in (3, 2, 1, 0):
-            wp, bp = self.deconv_packed[l]
             norm = self._norm(src_conv, l + 1) if src_conv is not None else None
-            ops.deconv_k2s2(src, src_c, 0, wp, bp, self.up[l], self.cat[l], f[l], norm=norm, out_blocked=blk_cat and l == 0)
             a, b = self.dec[l]
-            self._conv(a, self.cat[l], f[l] + self.up[l], self.uA[l], l, in_blocked=blk_cat and l == 0, out_blocked=blk_u and l == 0)
+            if self._fold_level(l):
+                # upsample + cat + conv_0 in one launch: the skip half of cat[l] on the fine grid, the coarse raw tensor behind it
+                w_skip, wu, btab = self.upconv_packed[l]
+                ops.upconv_k3(self.cat[l], f[l], 0, src, src_c, 0, norm, w_skip, wu, btab, a.cout, self.uA[l], 0, a.stats,
+                              in_blocked=blk_cat and l == 0, out_blocked=blk_u and l == 0)
+            else:
+                wp, bp = self.deconv_packed[l]
+                ops.deconv_k2s2(src, src_c, 0, wp, bp, self.up[l], self.cat[l], f[l], norm=norm, out_blocked=blk_cat and l == 0)
+                self._conv(a, self.cat[l], f[l] + self.up[l], self.uA[l], l, in_blocked=blk_cat and l == 0, out_blocked=blk_u and l == 0)
             self._conv(b, self.uA[l], a.cout, self.uB[l], l, xform_from=a, add_key=f"u{l}", in_blocked=blk_u and l == 0)
             src, src_c, src_conv = self.uB[l], b.cout, b
         return self.dec[0][1]

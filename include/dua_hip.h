@@ -109,6 +109,39 @@ int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_pack
                       const dua_in_norm* in, void* y, dua_stat_word* out_stats, void* workspace, long workspace_bytes,
                       void* stream);
 
+/* ---- UpCat's first convolution with the transposed convolution folded in ------------------------------------
+ * Replaces, in ONE launch, UpCat.forward up to the first convolution (models/basic_unet/denoiser.py:172-194, 56-59):
+ *     x_0 = ConvTranspose3d(k2, s2)(act(norm(u)))      (MONAI UpSample "deconv", denoiser.py:161-170)
+ *     y   = Conv3d(k3, p1)(cat([x_e, x_0], 1))          (TwoConv.conv_0.conv)
+ * Nothing non-linear sits between the two layers, so the upsampled half of the convolution is a 2x2x2-parent contraction
+ * per output parity with composed weights W'[phi][delta] = sum over taps of Wc_up[tap] Wd[child] (8 parents x Cu channels
+ * instead of 27 taps x Cmid channels: 3.4x fewer multiply-adds on that half, and the transposed convolution's launch, its
+ * output write and the re-read of it are gone); the transposed convolution's bias becomes one of 27 per-border-class bias
+ * vectors (taps that fall outside the volume see no bias).  Same function of the same parameters; the composed weights are
+ * formed in fp32 and rounded once to fp16.  D, H, W: OUTPUT extents (multiples of 8); u is the coarse tensor
+ * [N][D/2][H/2][W/2][Cu_stride] (channels-last, a RAW convolution output whose producer descriptor u_in is mandatory);
+ * xskip holds x_e on the fine grid (channels-last or 16-channel blocks).  DUA_F16 only; Cskip % 16 == 0, Cu % 64 == 0,
+ * Cu <= 256.  dua_upconv_k3_supported: 1 when the descriptor can be launched (callers fall back to
+ * dua_deconv_k2s2_fwd + dua_conv3d_k3_fwd otherwise). */
+typedef struct {
+  int dtype;
+  int N, D, H, W;                       /* output extents */
+  int Cskip, Cskip_stride, Cskip_off;   /* x_e: channels [Cskip_off, Cskip_off + Cskip) of the fine-grid buffer */
+  int Cu, Cu_stride, Cu_off;            /* u: channels of the coarse buffer */
+  int Cout, Cout_stride, Cout_off;
+  int layout;                           /* DUA_IN_BLOCKED: xskip in 16-channel blocks; DUA_OUT_BLOCKED: y in 16-channel blocks */
+} dua_upconv_desc;
+int dua_upconv_k3_supported(const dua_upconv_desc* d);
+/* wc: Conv3d weight fp32 [Cout][Cskip + Cmid][3][3][3] (input channels [Cskip, Cskip + Cmid) are the upsampled half), bc its
+ * bias [Cout] or NULL; wd: ConvTranspose3d weight fp32 [Cu][Cmid][2][2][2], bd its bias [Cmid] or NULL.  Writes the composed
+ * weights (fp16, the order the kernel streams them) and bias_table fp32 [27][ceil(Cout/64)*64] (class = (cd*3 + ch)*3 + cw,
+ * 0 = low border, 1 = interior, 2 = high border).  Returns the bytes of wu_packed (query with wu_packed == NULL).  The skip
+ * half's weights are packed by dua_pack_conv3_weights(dtype, Cout, Cskip + Cmid, Cskip, wc, NULL, ...). */
+long dua_pack_upconv_weights(int dtype, int Cout, int Cskip, int Cmid, int Cu, const float* wc, const float* bc, const float* wd,
+                             const float* bd, void* wu_packed, float* bias_table, void* stream);
+int dua_upconv_k3_fwd(const dua_upconv_desc* d, const void* xskip, const void* u, const dua_in_norm* u_in, const void* w_skip_packed,
+                      const void* wu_packed, const float* bias_table, void* y, dua_stat_word* out_stats, void* stream);
+
 /* Weight gradient of the same convolution (backward of train.py:258-268 through denoiser.py:56-59):
  *   dw[co][ci][kd][kh][kw] += sum over (n, voxel) of dy[n, v, co] * x[n, v + tap - 1, ci]
  * d describes the FORWARD convolution (x: Cin channels at Cin_off of a Cin_stride buffer; dy: Cout channels at
@@ -434,6 +467,7 @@ int dua_step_begin_clear(int N, int P, const float* table, int table_rows, const
 #define DUA_OP_CONV3 1        /* dua_conv3d_k3_fwd(conv, x, w, bias, norm?, y, stats, workspace) */
 #define DUA_OP_MATERIALIZE 2  /* dua_materialize(mat, raw = x, norm, emb, out = y, pooled) */
 #define DUA_OP_DECONV 3       /* dua_deconv_k2s2_fwd(conv, x, w, bias, norm?, y) */
+#define DUA_OP_UPCONV 4       /* dua_upconv_k3_fwd(up, xskip = x, u, norm, w, wu, bias (= bias_table), y, stats) */
 typedef struct {
   int kind;                /* DUA_OP_* */
   int has_norm;            /* norm below describes the producer of x (fused InstanceNorm + LeakyReLU + add) */
@@ -447,6 +481,9 @@ typedef struct {
   dua_stat_word* stats;    /* CONV3: this layer's statistics rows inside the arena */
   const void* emb;         /* MATERIALIZE: encoder feature map added after the activation, or NULL */
   void* pooled;            /* MATERIALIZE: MaxPool3d(2) output, or NULL */
+  dua_upconv_desc up;      /* UPCONV */
+  const void* u;           /* UPCONV: coarse input (norm describes ITS producer) */
+  const void* wu;          /* UPCONV: composed weights of the upsampled half */
 } dua_step_op;
 
 typedef struct {

@@ -263,7 +263,17 @@ def test_native_conv_trainer_learns():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
-def _native_ddp_worker(rank, world, port, q, overlap=True, graph=False):
+# Data seed of the two-rank test.  At 32^3 with eight channels a LeakyReLU input lands within fp32 rounding of the kink (slope
+# 0.1 | 1) in about every other seed, on the native path or on the CPU oracle's own fp32 path, and a flipped activation at a
+# 4^3 or 2^3 level moves every gradient that flows through it by 1e-3 .. 4e-2 of its scale: tools/gradient_seed_scan.py
+# compares both fp32 paths with an fp64 evaluation of the oracle, seed by seed (seeds 7 .. 16, profiles/r5_gradient_seed_scan.txt):
+# seed 7, which this test used before, has such a crossing on the native side (worst tensor 3.6e-2, the oracle's fp32 path
+# 1e-5), seeds 9 and 11 have one on the ORACLE's fp32 side (2e-2, native 4e-6 / 4e-3); with seeds 8, 10 and 15 both paths agree with
+# fp64 to 1e-5 on every tensor.  The test needs an arbiter-free comparison of two fp32 paths, so it uses a seed without a crossing.
+DDP_DATA_SEED = 8
+
+
+def _native_ddp_worker(rank, world, port, q, overlap=True, graph=False, seed=DDP_DATA_SEED):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share cuda:0; gloo moves CUDA tensors via the host
     try:
@@ -272,57 +282,67 @@ def _native_ddp_worker(rank, world, port, q, overlap=True, graph=False):
         torch.manual_seed(0)
         net = DiffUNet(**KW).to(dev)
         tr = NativeConvTrainer(net, lr=1e-3, dtype=torch.float32, overlap=overlap, graph=graph)
-        image, labels, noise, t = _data(2, 7)
+        image, labels, noise, t = _data(2, seed)
         sl = slice(rank, rank + 1)
         loss = tr.step(image[sl].to(dev), labels[sl].to(dev), noise=noise[sl].to(dev), t=t[sl].to(dev))
         grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}          # averaged over the ranks
-        q.put((rank, float(loss), {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}, grads))
+        moments = {k: tr.optimizer.state[p]["exp_avg"].detach().cpu().numpy() for k, p in net.named_parameters()}
+        q.put((rank, float(loss), {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}, grads, moments))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
+def _zero_gradient_bias(k):
+    """The bias of a convolution that InstanceNorm follows: its true gradient is zero (the norm subtracts the mean), what either
+    path computes for it is rounding noise.  (`final_conv.bias` and the transposed convolutions' biases are NOT of that kind.)"""
+    return k.endswith(".conv.bias")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("overlap,graph", [(True, False), (False, False), (False, True)], ids=["ddp-buckets", "flat", "flat-graph"])
 def test_native_trainer_two_ranks_equal_union_batch(overlap, graph):
-    """Two processes (one GPU, gloo) each train on their own sample; the gradient averaging (DDP reducer buckets
-    overlapped with backward, one flat all-reduce after it, or the flat all-reduce between the two HIP graphs of graph
-    mode) must leave both with the parameters single-process training on the two-sample batch produces (oracle
-    autograd, CPU; the trainer's AdamW is the library's kernel, whose arithmetic differs from torch's foreach one in the last bits)."""
+    """Two processes (one GPU, gloo) each train on their own sample; the gradient averaging (DDP reducer buckets overlapped with
+    backward, one flat all-reduce after it, or the flat all-reduce between the two HIP graphs of graph mode) must hand the
+    optimizer the gradient of single-process training on the two-sample batch (oracle autograd, CPU fp32; train.py:258-268).
+    Every check is LINEAR in the gradient -- the parameters after a first Adam step are lr * g / (|g| + eps), sign-like wherever
+    |g| is of the order of eps = 1e-8, which is where the deep levels' gradients of this small network live (the 7 463 elements
+    the round-4 form of this test had to tolerate: tools/two_rank_gradient_report.py, profiles/r5_two_rank_gradient_report.txt)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() + 177) % 2000
     procs = [ctx.Process(target=_native_ddp_worker, args=(r, 2, port + int(overlap) + 2 * int(graph), q, overlap, graph)) for r in range(2)]
     for p in procs:
         p.start()
-    outs = {r: (l, sd, g) for r, l, sd, g in (q.get(timeout=300) for _ in range(2))}
+    outs = {r: (l, sd, g, m) for r, l, sd, g, m in (q.get(timeout=300) for _ in range(2))}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    # (0) both ranks hold bit-identical parameters, gradients and moments
     for k in outs[0][1]:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
-    want_sd, want_g = _union_batch_reference(7)
-    # (1) the averaged gradient IS the union batch's gradient.  Whole-gradient relative L2: a single activation that lands on the
-    # other side of LeakyReLU's kink than on the CPU (|z| ~ 1e-7: the slope there jumps between 0.1 and 1) changes one channel of
-    # one coarse layer's gradient by ~15 % of that tensor's (tiny) scale -- an fp64 oracle showed exactly that for
-    # upcat_4.convs.conv_1, channel 26, under this seed, with torch's own fp32 CPU path on the fp64 side of the kink.
-    num = sum(float(((outs[0][2][k].astype(np.float64) - v.double().numpy()) ** 2).sum()) for k, v in want_g.items())
-    den = sum(float((v.double().numpy() ** 2).sum()) for v in want_g.values())
-    assert (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5        # measured 2.2e-4 with that one kink crossing (a wrong or missing
-                                                                # average is an error of order 1)
-    # (2) the parameters after the AdamW step.  The first Adam step is lr * g / (|g| + eps): sign-like, so an element whose
-    # gradient is rounding noise (the convolution biases in front of InstanceNorm: true gradient zero) or sits in the channel
-    # described above moves by +-lr on either side; everything else must agree closely, and nothing may differ by more than 2 lr.
-    bad = total = 0
-    worst = 0.0
-    for k, v in want_sd.items():
-        if k.endswith("conv.bias"):       # zero true gradient: Adam turns rounding noise into +-lr steps on both sides
+    for k in outs[0][2]:
+        assert np.array_equal(outs[0][2][k], outs[1][2][k]) and np.array_equal(outs[0][3][k], outs[1][3][k]), k
+    _, want_g = _union_batch_reference(DDP_DATA_SEED)
+    got_g, got_m = outs[0][2], outs[0][3]
+    worst = ("", 0.0)
+    for k, v in want_g.items():
+        ref = v.double().numpy()
+        if _zero_gradient_bias(k):
+            # (1a) rounding noise on both sides: small against the same convolution's weight gradient
+            wk = k[:-len("bias")] + "weight"
+            assert float(np.abs(got_g[k]).max()) <= 1e-3 * float(np.abs(want_g[wk].numpy()).max()), k
             continue
-        gap = np.abs(outs[0][1][k] - v.detach().numpy())
-        worst = max(worst, float(gap.max()))
-        bad += int((gap > (2e-4 if not graph else 5e-4)).sum())
-        total += gap.size
-    assert worst < 2.1e-3 and bad <= 0.02 * total, (worst, bad, total)          # measured: 0.74 % of the elements
+        # (1b) per tensor: the averaged gradient IS the union batch's gradient (a missing or doubled average is an error of order 1,
+        # a wrong kernel in one layer an error of order 1 in that tensor; measured <= 1e-5 for every tensor in all three modes)
+        scale = max(float(np.sqrt((ref ** 2).sum())), 1e-30)
+        rel = float(np.sqrt(((got_g[k].astype(np.float64) - ref) ** 2).sum())) / scale
+        worst = max(worst, (k, rel), key=lambda t: t[1])
+        assert rel < 1e-4, (k, rel)
+        # (2) the optimizer consumed THAT gradient: Adam's first moment after one step is (1 - beta1) g
+        relm = float(np.sqrt(((got_m[k].astype(np.float64) - 0.1 * ref) ** 2).sum())) / (0.1 * scale)
+        assert relm < 1e-4, (k, relm)
+    print(f"worst per-tensor relative L2 of the averaged gradient: {worst[1]:.2e} ({worst[0]})")
 
 
 @pytest.mark.gpu

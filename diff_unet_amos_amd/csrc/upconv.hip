@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "../../include/dua_hip.h"
 #include "stamp.hpp"
+#include "named_acc.hpp"
 
 namespace dua {
 
@@ -56,7 +57,10 @@ __device__ __forceinline__ void upc_dma_piece(const char* src_lane, unsigned lds
                : "=&s"(keep) : "v"(src_lane), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
+// GG = groups of 64 coarse channels (1 or 2): compile-time, so that the registers of a second group's prefetch and of the
+// statistics words of channels that do not exist are not allocated
+template <int GG>
+__global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(UpConvArgs a) {
   using namespace upc;
   using T = f16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,7 +78,8 @@ __global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
   const int pd = wave >> 1, ph = wave & 1;
-  const int nhc = a.Cs >> 4, U = nhc * 3, G = a.Cu >> 6;
+  const int nhc = a.Cs >> 4, U = nhc * 3;
+  constexpr int G = GG;
 
   // ---- skip halo pieces: thread = (position (hy, hx) in a halo plane, 16-byte half p), piece j = halo plane j ----
   const int p_t = tid & 1, pos = tid >> 1;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
     const int bc = ct * BN + q * 32 + r;
     bias_q[q] = bc >= a.Cout ? 0.f : a.btab[13 * a.cout_pad + bc];          // interior class (1, 1, 1)
   }
-  constexpr int UN = 4;
+  constexpr int UN = GG;                                       // 16 channels per (wave, group): 64 channels per group
   stat_t sv[UN][2 * STAT_WORDS];
   float gam[UN], bet[UN], addv[UN];
   {
@@ -239,31 +244,38 @@ __global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
   __syncthreads();
   store_halo();
 
-  // ---- accumulators [block m = cz_hi * 2 + pw][cout half q]; register i of lane half hh = cell (cz_lo = i >> 3,
-  // cy = hh + 2 ((i >> 2) & 1), cx = i & 3); they start at the bias of their voxel's border class ----
-  f32x16 acc[4][2];
+  // ---- accumulators: tuple (m * 2 + q) = a[16 (2 m + q) ..] for block m = cz_hi * 2 + pw and cout half q, held in
+  // v[128:255] by name (named_acc.hpp); register i of lane half hh = cell (cz_lo = i >> 3, cy = hh + 2 ((i >> 2) & 1),
+  // cx = i & 3); they start at the bias of their voxel's border class ----
   if (!border) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+      float v[16];
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int i = 0; i < 16; ++i) v[i] = bias_q[q];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][q][i] = bias_q[q];
+      for (int m = 0; m < 4; ++m) named_write16_sel(m * 2 + q, v);
+    }
   } else {
     const bool lo_d = d0 == 0, hi_d = d0 + 8 == a.D, lo_h = h0 == 0, hi_h = h0 + 8 == a.H, lo_w = w0 == 0, hi_w = w0 + 8 == a.W;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ld = 2 * (2 * (m >> 1) + (i >> 3)) + pd, lh = 2 * (hh + 2 * ((i >> 2) & 1)) + ph, lw = 2 * (i & 3) + (m & 1);
-        const int cd = (lo_d && ld == 0) ? 0 : (hi_d && ld == 7) ? 2 : 1;
-        const int ch = (lo_h && lh == 0) ? 0 : (hi_h && lh == 7) ? 2 : 1;
-        const int cw = (lo_w && lw == 0) ? 0 : (hi_w && lw == 7) ? 2 : 1;
-        const int cls = cd * 9 + ch * 3 + cw;
+      for (int q = 0; q < 2; ++q) {
+        float v[16];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) acc[m][q][i] = btl[cls * 64 + q * 32 + r];
+        for (int i = 0; i < 16; ++i) {
+          const int ld = 2 * (2 * (m >> 1) + (i >> 3)) + pd, lh = 2 * (hh + 2 * ((i >> 2) & 1)) + ph, lw = 2 * (i & 3) + (m & 1);
+          const int cd = (lo_d && ld == 0) ? 0 : (hi_d && ld == 7) ? 2 : 1;
+          const int ch = (lo_h && lh == 0) ? 0 : (hi_h && lh == 7) ? 2 : 1;
+          const int cw = (lo_w && lw == 0) ? 0 : (hi_w && lw == 7) ? 2 : 1;
+          v[i] = btl[(cd * 9 + ch * 3 + cw) * 64 + q * 32 + r];
+        }
+        named_write16_sel(m * 2 + q, v);
+        __builtin_amdgcn_sched_barrier(0);
       }
   }
+  named_acc_fence_init();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's weight pieces (the compiler does not count them)
   __syncthreads();
 
@@ -299,10 +311,10 @@ __global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
         ldA(t1, sub1, (h + 1) & 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mma32(acc[2 * sub][0], fa[h & 1][0], fb[t & 1][0]);
-      mma32(acc[2 * sub][1], fa[h & 1][0], fb[t & 1][1]);
-      mma32(acc[2 * sub + 1][0], fa[h & 1][1], fb[t & 1][0]);
-      mma32(acc[2 * sub + 1][1], fa[h & 1][1], fb[t & 1][1]);
+      named_mfma_sel(4 * sub + 0, fa[h & 1][0], fb[t & 1][0]);
+      named_mfma_sel(4 * sub + 1, fa[h & 1][0], fb[t & 1][1]);
+      named_mfma_sel(4 * sub + 2, fa[h & 1][1], fb[t & 1][0]);
+      named_mfma_sel(4 * sub + 3, fa[h & 1][1], fb[t & 1][1]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -338,14 +350,16 @@ __global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
   const char* wub = (const char*)a.wu + (long)(ct * 4 + wave) * G * (128 * 1024) + lane * 16;
   const int Lc = cz_lo * CP + cy * CR + cx * VS + pd * CP + ph * CR;
   const int C0 = Lc + ((hh ^ ((cy + ph) & 1)) << 4), C1 = Lc + ((hh ^ ((cy + ph) & 1) ^ 1) << 4);
-  f16x8 fb[3][4], fa[2][4];
+  constexpr int RB = GG == 1 ? 3 : 2;                          // iterations of B fragments in flight
+  f16x8 fb[RB][4], fa[2][4];
   auto ldBu = [&](const char* wg, int it, int b) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) fb[b][k] = *(const f16x8*)(wg + (it * 4 + k) * 1024);
   };
-  ldBu(wub, 0, 0); ldBu(wub, 1, 1); ldBu(wub, 2, 2);
   store_coarse(0, ring);
   if (G > 1) load_coarse(1, 0, NPIECE);
+#pragma unroll
+  for (int b = 0; b < RB; ++b) ldBu(wub, b, b);
   __syncthreads();
   for (int g = 0; g < G; ++g) {
     const char* cb = (g & 1) ? halo : ring;
@@ -358,7 +372,10 @@ __global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
 #pragma unroll
         for (int czh = 0; czh < 2; ++czh) fa[b][dw * 2 + czh] = *(const f16x8*)(ap + czh * 2 * CP + dw * VS);
     };
-    if (g > 0) { ldBu(wg, 0, 0); ldBu(wg, 1, 1); ldBu(wg, 2, 2); }
+    if (g > 0) {
+#pragma unroll
+      for (int b = 0; b < RB; ++b) ldBu(wg, b, b);
+    }
     ldAu(0, 0);
 #pragma unroll
     for (int it = 0; it < 32; ++it) {
@@ -369,11 +386,11 @@ __global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
       for (int dw = 0; dw < 2; ++dw)
 #pragma unroll
         for (int czh = 0; czh < 2; ++czh) {
-          mma32(acc[czh * 2 + pw][0], fa[it & 1][dw * 2 + czh], fb[it % 3][dw * 2 + 0]);
-          mma32(acc[czh * 2 + pw][1], fa[it & 1][dw * 2 + czh], fb[it % 3][dw * 2 + 1]);
+          named_mfma_sel((czh * 2 + pw) * 2 + 0, fa[it & 1][dw * 2 + czh], fb[it % RB][dw * 2 + 0]);
+          named_mfma_sel((czh * 2 + pw) * 2 + 1, fa[it & 1][dw * 2 + czh], fb[it % RB][dw * 2 + 1]);
         }
       __builtin_amdgcn_sched_barrier(0);
-      if (it + 3 < 32) ldBu(wg, it + 3, it % 3);                 // into the buffer the MFMAs above have just read
+      if (it + RB < 32) ldBu(wg, it + RB, it % RB);                 // into the buffer the MFMAs above have just read
     }
     if (g + 1 < G) {
       store_coarse(g + 1, (g & 1) ? ring : halo);
@@ -389,20 +406,25 @@ __global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
   const long nvox = (long)a.D * a.H * a.W;
   T* yout = (T*)a.y + (long)n * nvox * a.Cout_stride;
   float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+  named_acc_fence_read();
 #pragma unroll
   for (int czh = 0; czh < 2; ++czh) {
 #pragma unroll
     for (int pw = 0; pw < 2; ++pw)
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < 2; ++q) {
+        float av[16];
+        named_read16_sel((czh * 2 + pw) * 2 + q, av);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float v = acc[czh * 2 + pw][q][i];
+          const float v = av[i];
           s[q] += v;
           ss[q] = fmaf(v, v, ss[q]);
           const int row = (i >> 3) * 32 + (hh + 2 * ((i >> 2) & 1)) * 8 + (i & 3) * 2 + pw;
           *(T*)(ot + row * 128 + (q * 32 + r) * 2) = (T)v;
         }
+        __builtin_amdgcn_sched_barrier(0);                       // one tuple at a time: the reads are not hoisted over the stores
+      }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -433,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void upconv_k3_kernel(UpConvArgs a) {
   }
 }
 
-static const LdsAttr kUpconvLdsAttrs[] = {{(const void*)upconv_k3_kernel, 80 * 1024}};
+static const LdsAttr kUpconvLdsAttrs[] = {{(const void*)upconv_k3_kernel<1>, 80 * 1024}, {(const void*)upconv_k3_kernel<2>, 80 * 1024}};
 static const LdsAttrs kUpconvLdsReg(kUpconvLdsAttrs);
 
 // ---- weights.  wc: Conv3d weight fp32 [Cout][Cskip + Cmid][27]; wd: ConvTranspose3d weight fp32 [Cu][Cmid][8].
@@ -522,7 +544,7 @@ static bool upconv_desc_ok(const dua_upconv_desc* d) {
   if (!d || d->dtype != DUA_F16 || d->N <= 0) return false;
   if (d->D <= 0 || d->H <= 0 || d->W <= 0 || d->D % 8 || d->H % 8 || d->W % 8) return false;
   if (d->Cskip <= 0 || d->Cskip % 16 || d->Cskip_off % 8 || d->Cskip_off + d->Cskip > d->Cskip_stride) return false;
-  if (d->Cu <= 0 || d->Cu % 64 || d->Cu > 256 || d->Cu_off % 8 || d->Cu_off + d->Cu > d->Cu_stride || d->Cu_stride % 8) return false;
+  if (d->Cu <= 0 || d->Cu % 64 || d->Cu > 128 || d->Cu_off % 8 || d->Cu_off + d->Cu > d->Cu_stride || d->Cu_stride % 8) return false;
   if (d->Cout <= 0 || d->Cout % 8 || d->Cout_off % 8 || d->Cout_off + d->Cout > d->Cout_stride) return false;
   if (d->layout & ~(DUA_IN_BLOCKED | DUA_OUT_BLOCKED)) return false;
   if ((d->layout & DUA_IN_BLOCKED) && (d->Cskip_off % 16 || d->Cskip_stride % 16)) return false;
@@ -577,7 +599,8 @@ int dua_upconv_k3_fwd(const dua_upconv_desc* d, const void* xskip, const void* u
   a.ntiles = (d->D / 8) * a.tiles_h * a.tiles_w;
   const int lds = upc::HALO + upc::RING + 3 * 4 * d->Cu + 4 * 64 * 2 * 4;
   if (lds > 80 * 1024) return DUA_ERR_ARG;
-  hipLaunchKernelGGL(upconv_k3_kernel, dim3(a.ntiles, a.cout_pad / 64, a.N), dim3(256), lds, (hipStream_t)stream, a);
+  if (d->Cu == 64) hipLaunchKernelGGL(upconv_k3_kernel<1>, dim3(a.ntiles, a.cout_pad / 64, a.N), dim3(256), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(upconv_k3_kernel<2>, dim3(a.ntiles, a.cout_pad / 64, a.N), dim3(256), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

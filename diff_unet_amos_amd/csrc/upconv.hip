@@ -131,30 +131,34 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   };
 
   // ---- coarse halo pieces of one 64-channel group: cell = (tid >> 3) + 32 j (6 x 6 x 6 parent cells), part = tid & 7 ----
-  const int part = tid & 7;
+  // (lane-dependent values of the later sections are derived from a thread id made opaque at the head of each section:
+  // otherwise hipcc computes them all in the prologue, keeps them through the K loops of a 128-register kernel in scratch, and the
+  // reloads in the epilogue wait -- vmcnt retires in order -- for the output stores in front of them: 23 000 cycles of epilogue)
+  int tid2 = tid;
   const int Dc = a.D >> 1, Hc = a.H >> 1, Wc = a.W >> 1;
-  const T* uin = (const T*)a.u + (long)n * Dc * Hc * Wc * a.Cu_stride + a.Cu_off + part * 8;
   f16x8 creg[NPIECE];
   auto load_coarse = [&](int g, int j0, int j1) {
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       if (j < j0 || j >= j1) continue;
-      const int cell = (tid >> 3) + 32 * j;
+      const int cell = (tid2 >> 3) + 32 * j;
       const int z = cell / 36, rm = cell - z * 36, y = rm / 6, x = rm - y * 6;
       const int gz = (d0 >> 1) - 1 + z, gy = (h0 >> 1) - 1 + y, gx = (w0 >> 1) - 1 + x;
       const bool ok = cell < 216 && (unsigned)gz < (unsigned)Dc && (unsigned)gy < (unsigned)Hc && (unsigned)gx < (unsigned)Wc;
+      const T* uin = (const T*)a.u + (long)n * Dc * Hc * Wc * a.Cu_stride + a.Cu_off + (tid2 & 7) * 8;
       creg[j] = *(const f16x8*)(uin + (ok ? (long)((gz * Hc + gy) * Wc + gx) * a.Cu_stride + g * 64 : 0));
     }
   };
   auto store_coarse = [&](int g, char* dst) {
     float sc[8], sh[8], ad[8], sn[8];
+    const int part = tid2 & 7;
     const int c0 = g * 64 + part * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
     xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
-      const int cell = (tid >> 3) + 32 * j;
+      const int cell = (tid2 >> 3) + 32 * j;
       const int z = cell / 36, rm = cell - z * 36, y = rm / 6, x = rm - y * 6;
       const int gz = (d0 >> 1) - 1 + z, gy = (h0 >> 1) - 1 + y, gx = (w0 >> 1) - 1 + x;
       const bool ok = (unsigned)gz < (unsigned)Dc && (unsigned)gy < (unsigned)Hc && (unsigned)gx < (unsigned)Wc;
@@ -168,6 +172,8 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   };
 
   // ---- prologue: everything that must come from memory is requested before anything waits ----
+  DUA_STAMP_AT(0, true);
+  DUA_STAMP_AT(2, false);
   const bool border = d0 == 0 || d0 + 8 == a.D || h0 == 0 || h0 + 8 == a.H || w0 == 0 || w0 + 8 == a.W;
   float bias_q[2];
 #pragma unroll
@@ -278,11 +284,14 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   named_acc_fence_init();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's weight pieces (the compiler does not count them)
   __syncthreads();
+  DUA_STAMP_AT(3, false);
 
-  const int cz_lo = r >> 4, cy = (r >> 2) & 3, cx = r & 3;
+  asm volatile("" : "+v"(tid2));
+  const int lane1 = tid2 & 63, r1 = lane1 & 31, hh1 = lane1 >> 5;
+  const int cz_lo = r1 >> 4, cy = (r1 >> 2) & 3, cx = r1 & 3;
   const int La = 2 * cz_lo * PS + 2 * cy * RS + 2 * cx * VS + pd * PS + ph * RS;
-  const int A0 = La + ((hh ^ cz_lo) << 4), A1 = La + ((hh ^ cz_lo ^ 1) << 4);
-  const int b_base = (hh * BN + r) * 16;
+  const int A0 = La + ((hh1 ^ cz_lo) << 4), A1 = La + ((hh1 ^ cz_lo ^ 1) << 4);
+  const int b_base = (hh1 * BN + r1) * 16;
 
   // One phase = the 9 taps of kd plane `kd` of the current half chunk against ring slot `slot`: half-step h = (tap t = h / 2,
   // sub = h % 2 = cz_hi) is 4 MFMAs on the A pair (pw = 0, 1) of (t, sub) and the B pair of t.
@@ -339,6 +348,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
         else if (kd == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       }
       __syncthreads();
+      if (u < 24) DUA_STAMP_AT(4 + u, false);
     }
     if (more) {
       store_halo();
@@ -347,9 +357,12 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   }
 
   // ---- part 2: the upsampled half.  B fragments of iteration it = (delta_d, delta_h, half chunk, pw): 4 KB = (delta_w, q) ----
-  const char* wub = (const char*)a.wu + (long)(ct * 4 + wave) * G * (128 * 1024) + lane * 16;
-  const int Lc = cz_lo * CP + cy * CR + cx * VS + pd * CP + ph * CR;
-  const int C0 = Lc + ((hh ^ ((cy + ph) & 1)) << 4), C1 = Lc + ((hh ^ ((cy + ph) & 1) ^ 1) << 4);
+  asm volatile("" : "+v"(tid2));
+  const int lane2 = tid2 & 63, r2 = lane2 & 31, hh2 = lane2 >> 5;
+  const int cz2 = r2 >> 4, cy2 = (r2 >> 2) & 3, cx2 = r2 & 3;
+  const char* wub = (const char*)a.wu + (long)(ct * 4 + wave) * G * (128 * 1024) + lane2 * 16;
+  const int Lc = cz2 * CP + cy2 * CR + cx2 * VS + pd * CP + ph * CR;
+  const int C0 = Lc + ((hh2 ^ ((cy2 + ph) & 1)) << 4), C1 = Lc + ((hh2 ^ ((cy2 + ph) & 1) ^ 1) << 4);
   constexpr int RB = GG == 1 ? 3 : 2;                          // iterations of B fragments in flight
   f16x8 fb[RB][4], fa[2][4];
   auto ldBu = [&](const char* wg, int it, int b) {
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
 #pragma unroll
   for (int b = 0; b < RB; ++b) ldBu(wub, b, b);
   __syncthreads();
+  DUA_STAMP_AT(30, false);
   for (int g = 0; g < G; ++g) {
     const char* cb = (g & 1) ? halo : ring;
     const char* wg = wub + (long)g * (128 * 1024);
@@ -392,6 +406,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
       __builtin_amdgcn_sched_barrier(0);
       if (it + RB < 32) ldBu(wg, it + RB, it % RB);                 // into the buffer the MFMAs above have just read
     }
+    DUA_STAMP_AT(31 + g, false);
     if (g + 1 < G) {
       store_coarse(g + 1, (g & 1) ? ring : halo);
       if (g + 2 < G) load_coarse(g + 2, 0, NPIECE);
@@ -402,6 +417,9 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
 
   // ---- epilogue: statistics from the fp32 accumulators; each wave stages the two blocks (pw = 0, 1) of one cz_hi at a
   // time as 64 voxel rows [cz_lo][cy][w = 2 cx + pw] x 128 B in rows of its own, whole voxel lines leave in 16-byte stores ----
+  DUA_STAMP_AT(62, false);
+  asm volatile("" : "+v"(tid2));
+  const int lane3 = tid2 & 63, r3 = lane3 & 31, hh3 = lane3 >> 5;
   char* ot = halo + wave * 8192;
   const long nvox = (long)a.D * a.H * a.W;
   T* yout = (T*)a.y + (long)n * nvox * a.Cout_stride;
@@ -420,17 +438,20 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
           const float v = av[i];
           s[q] += v;
           ss[q] = fmaf(v, v, ss[q]);
-          const int row = (i >> 3) * 32 + (hh + 2 * ((i >> 2) & 1)) * 8 + (i & 3) * 2 + pw;
-          *(T*)(ot + row * 128 + (q * 32 + r) * 2) = (T)v;
+          const int row = (i >> 3) * 32 + (hh3 + 2 * ((i >> 2) & 1)) * 8 + (i & 3) * 2 + pw;
+          *(T*)(ot + row * 128 + (q * 32 + r3) * 2) = (T)v;
         }
-        __builtin_amdgcn_sched_barrier(0);                       // one tuple at a time: the reads are not hoisted over the stores
+        // one tuple at a time: the sums are made opaque here -- hipcc otherwise sinks the whole `s += v` chain of a tuple to the
+        // end of the kernel, keeps its sixteen values in scratch meanwhile, and reloads them behind the output stores
+        asm volatile("" : "+v"(s[q]), "+v"(ss[q]));
+        __builtin_amdgcn_sched_barrier(0);
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int v = it * 8 + (lane >> 3), cg = lane & 7;         // v = staged row: cz_lo = v >> 5, cy = (v >> 3) & 3, w = v & 7
+      const int v = it * 8 + (lane3 >> 3), cg = lane3 & 7;         // v = staged row: cz_lo = v >> 5, cy = (v >> 3) & 3, w = v & 7
       const int gd = d0 + 2 * (2 * czh + (v >> 5)) + pd, ghh = h0 + 2 * ((v >> 3) & 3) + ph, gww = w0 + (v & 7);
       if (ct * BN + cg * 8 < a.Cout)
         *(f16x8*)(yout + chan_off(a.out_blk, ((long)gd * a.H + ghh) * a.W + gww, a.Cout_off + ct * BN + cg * 8, a.Cout_stride, nvox)) =
@@ -444,16 +465,22 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   for (int q = 0; q < 2; ++q) {
     s[q] += __shfl_xor(s[q], 32);
     ss[q] += __shfl_xor(ss[q], 32);
-    if (hh == 0) { ex[(wave * BN + q * 32 + r) * 2] = s[q]; ex[(wave * BN + q * 32 + r) * 2 + 1] = ss[q]; }
+    if (hh3 == 0) { ex[(wave * BN + q * 32 + r3) * 2] = s[q]; ex[(wave * BN + q * 32 + r3) * 2 + 1] = ss[q]; }
   }
   __syncthreads();
   if (wave == 0) {
     double S = 0, Q = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
-    if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, replica, ct * BN + lane, S, Q);
+    for (int w = 0; w < 4; ++w) { S += (double)ex[(w * BN + lane3) * 2]; Q += (double)ex[(w * BN + lane3) * 2 + 1]; }
+    if (ct * BN + lane3 < a.Cout) stats_add(a.stats, n, a.cout_pad, replica, ct * BN + lane3, S, Q);
   }
+  DUA_STAMP_AT(63, false);
+  DUA_STAMP_AT(1, true);
 }
+
+#ifdef DUA_STAMP
+extern "C" long dua_debug_stamps_upconv(void* host, long bytes) { return stamps_out(host, bytes); }
+#endif
 
 static const LdsAttr kUpconvLdsAttrs[] = {{(const void*)upconv_k3_kernel<1>, 80 * 1024}, {(const void*)upconv_k3_kernel<2>, 80 * 1024}};
 static const LdsAttrs kUpconvLdsReg(kUpconvLdsAttrs);

@@ -251,8 +251,10 @@ class Plan:
     # Decoder levels whose transposed convolution is folded into the convolution behind it (dua_upconv_k3_fwd: one launch for
     # upsample + cat + conv_0 of an UpCat block, 3.4x fewer multiply-adds on the upsampled half): fp16 plans, levels with at
     # least this many 8x8x8 output tiles (x batch x output-channel tiles) -- below that the launch cannot fill the chip and the
-    # split forms of the plain convolution win.  ``net.fold_upconv = False`` keeps the two-launch form everywhere (A/B, tests).
-    UPCONV_MIN_TILES = 200
+    # split forms of the plain convolution win (measured at 48^3, batch 1: 216 tiles, one lone workgroup on 216 of the 256 CUs,
+    # 57-70 us in the step against 54 + 15 for the two launches it replaces; profiles/r5_step_timeline_fold_level1.txt).
+    # ``net.fold_upconv = False`` keeps the two-launch form everywhere (A/B, tests).
+    UPCONV_MIN_TILES = 512
 
     def _fold_level(self, l):
         if getattr(self, "_fold", None) is None:

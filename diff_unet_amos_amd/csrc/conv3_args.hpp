@@ -20,6 +20,7 @@ struct Conv3Args {
 
 // conv3d_wide.hip: the 8-accumulator form (8x8x8 tiles) for fp16 layers with >= 1024 tiles of 4x8x8; D, H, W multiples of 8,
 // Cin a multiple of 16.
-int launch_conv3_wide(Conv3Args a, int D, hipStream_t s);
+// persistent (policies 8 / 9, A/B only): workgroups walk tiles (conv3d_k3_wide_pt_kernel); false = one tile per workgroup (shipped)
+int launch_conv3_wide(Conv3Args a, int D, hipStream_t s, bool persistent, int stagger = 0);
 
 }  // namespace dua

@@ -41,7 +41,7 @@ constexpr int BN = 64;                     // output channels per workgroup
 static inline int conv_variant_of(const dua_conv3_desc* d) { return d->policy & 0xff; }
 static inline bool conv_policy_ok(const dua_conv3_desc* d) {
   const int v = d->policy & 0xff;
-  return (d->policy & ~(0xff | DUA_POLICY_NO_FINISH)) == 0 && (v == 0 || v == 2 || v == 3 || v == 6 || v == 7);
+  return (d->policy & ~(0xff | DUA_POLICY_NO_FINISH)) == 0 && (v == 0 || v == 2 || v == 3 || v == 6 || v == 7 || v == 8 || v == 9);
 }
 
 #ifdef DUA_ABLATE
@@ -956,7 +956,7 @@ static int conv3_kernel_kind(const dua_conv3_desc* d, bool fused) {
   if (d->tap_channel_plus1 > 0) return (d->tap_channel_plus1 == 17 && g_conv_variant == 0) ? 1 : 0;
   const long tiles = (long)((d->D + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * ((d->Cout + c3::BN - 1) / c3::BN) * d->N;
   const long vox = (long)d->D * d->H * d->W;
-  if (g_conv_variant == 0 && !d->background && tiles >= 1024 && d->D % 8 == 0 && d->H % 8 == 0 && d->W % 8 == 0 &&
+  if ((g_conv_variant == 0 || g_conv_variant == 8 || g_conv_variant == 9) && !d->background && tiles >= 1024 && d->D % 8 == 0 && d->H % 8 == 0 && d->W % 8 == 0 &&
       d->Cin % 16 == 0 && d->Cin <= (fused ? 256 : 384) && vox * d->Cin_stride < 0x7fffffffL)
     return 2;
   return 0;
@@ -1016,10 +1016,13 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
   }
   // wide-tile form (conv3d_wide.hip): fp16 layers with tiles to spare (96^3); variant 7 keeps them on the 4x8x8 kernel (A/B)
   if constexpr (sizeof(T) == 2) {
-    if (kind == 2) return launch_conv3_wide(a, d->D, s);
+    // 8: persistent workgroups with the accumulators held by name (round 5, conv3d_k3_wide_pt_kernel), 9: the same with the
+    // odd-slot workgroup of a CU starting two sleeps late -- both measured 1.5-2.5 % SLOWER than one tile per workgroup
+    // (profiles/r5_conv_wide_persistent_named_acc_ab.txt) and kept for that A/B only
+    if (kind == 2) return launch_conv3_wide(a, d->D, s, g_conv_variant >= 8, g_conv_variant == 9 ? 2 : 0);
   }
-  const bool autop = g_conv_variant == 0 || g_conv_variant == 2 || g_conv_variant == 6 || g_conv_variant == 7;       // the automatic policy; 6 = without the kd-plane form, 7 = without the wide-tile form (A/B)
-  const bool big = g_conv_variant == 0 || g_conv_variant == 2 || g_conv_variant == 7;          // kd-plane form for the layers that cannot put two workgroups on every CU
+  const bool autop = g_conv_variant == 0 || g_conv_variant == 2 || g_conv_variant == 6 || g_conv_variant == 7 || g_conv_variant >= 8;       // the automatic policy; 6 = without the kd-plane form, 7 = without the wide-tile form (A/B)
+  const bool big = g_conv_variant == 0 || g_conv_variant == 2 || g_conv_variant == 7 || g_conv_variant >= 8;          // kd-plane form for the layers that cannot put two workgroups on every CU
   if (ws != nullptr && autop) {
     int ks, ups;
     if (g_conv_variant == 2) choose_split(a.ntiles * nct * d->N, a.nchunks * 3, &ks, &ups, 512, 256);    // A/B: K split up to 256 base workgroups

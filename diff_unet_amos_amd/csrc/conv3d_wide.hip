@@ -28,6 +28,7 @@
 #include "../../include/dua_hip.h"
 #include "conv3_args.hpp"
 #include "stamp.hpp"
+#include "named_acc.hpp"
 
 namespace dua {
 
@@ -348,14 +349,285 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wide_kernel(Conv3Args a) {
   wide_tile<4>(a, smem, td * 8, th * 8, tw * 8, blockIdx.y, blockIdx.z, blockIdx.x & (STAT_REPLICAS - 1));
 }
 
-static const LdsAttr kWideLdsAttrs[] = {{(const void*)conv3d_k3_wide_kernel, 80 * 1024}};
+
+// ---- round 5: the same tile with PERSISTENT workgroups and the accumulators in v[128:255] by name (named_acc.hpp) ----
+// A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its (cout tile, sample): bias, the statistics -> scale / shift
+// tables of a fused input and the kernel's set-up are paid once per workgroup; the NEXT tile's first half-chunk halo and first
+// weight plane are requested under the last three phases of the current tile exactly like a next half chunk (they land while
+// the matrix pipes run), so a tile boundary costs an epilogue + a halo transform/store instead of an epilogue + a cold prologue
+// (round 4 measured that at -3 ... -8 % per launch with the tile loop in plain C++, and lost it again to 190-230 spilled
+// registers: hipcc copied the eight accumulator tuples around the loop -- profiles/r4_conv_wide_persistent_tiles_ab.txt.  With
+// the tuples held by name they are not values of the program and the allocator sees a ~110-register kernel).
+// InstanceNorm sums: a lane adds its tile sums into double accumulators and the workgroup issues ONE set of atomics at the end.
+__global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void conv3d_k3_wide_pt_kernel(Conv3Args a) {
+  using namespace c3w;
+  using T = f16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + HALO_MAX;
+  float* xsc = (float*)(smem + LDS_FIXED);
+  float* xsh = xsc + a.Cin;
+  float* xad = xsh + a.Cin;
+  float* ex = xad + (a.xf.stats ? a.Cin : 0) - (a.xf.stats ? 0 : 2 * a.Cin);          // behind the tables (or at LDS_FIXED)
+  constexpr int HD = 10;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int ct = blockIdx.y, n = blockIdx.z, replica = blockIdx.x & (STAT_REPLICAS - 1);
+  const bool fused = a.xf.stats != nullptr;
+  const int nhc = (a.Cin + 15) >> 4;
+  const int per_slab = a.tiles_h * a.tiles_w;
+
+  // ---- halo pieces of this thread (see wide_tile): position (hy, hx) x half p, piece j = halo plane j ----
+  const int p_t = tid & 1, pos = tid >> 1;
+  const int hy = pos / HW, hx = pos - hy * HW;
+  const int vstride = a.in_blk ? 16 : a.Cin_stride;
+  const long hcstride = a.in_blk ? (long)a.D * a.H * a.W * 16 : 16;
+  const T* xin = (const T*)a.x + (long)n * a.D * a.H * a.W * a.Cin_stride + (a.in_blk ? (long)(a.Cin_off >> 4) * a.D * a.H * a.W * 16 : a.Cin_off) + p_t * 8;
+  const int pstep = a.H * a.W * vstride;
+  const int loff = pos < HH * HW ? hy * RSF + hx * VSF + ((p_t ^ (hy & 1)) << 4) : HW * VSF + (p_t << 4);
+  f16x8 hreg[HD];
+  // tile geometry as the loads / stores of a halo need it: (d0, voff, ok_hw) -- `cur` for the tile being computed, `nxt` for
+  // the tile whose first halo is in flight
+  struct Geo { int d0, h0, w0, voff; bool ok_hw; };
+  auto geo_of = [&](int t) {
+    Geo g;
+    const int tile = xcd_remap(t, a.ntiles);
+    const int td = tile / per_slab, rem = tile - td * per_slab, th = rem / a.tiles_w, tw = rem - th * a.tiles_w;
+    g.d0 = td * 8; g.h0 = th * 8; g.w0 = tw * 8;
+    const int gh = g.h0 + hy - 1, gw = g.w0 + hx - 1;
+    g.ok_hw = pos < HH * HW && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+    g.voff = g.ok_hw ? (((g.d0 - 1) * a.H + gh) * a.W + gw) * vstride : 0;
+    return g;
+  };
+  auto load_halo = [&](const Geo& g, int hc, int j0, int j1) {
+    const T* src = xin + hc * hcstride;
+#pragma unroll
+    for (int j = 0; j < HD; ++j) {
+      if (j < j0 || j >= j1) continue;
+      const bool dok = (unsigned)(g.d0 + j - 1) < (unsigned)a.D;
+      hreg[j] = *(const f16x8*)(src + (g.ok_hw && dok ? g.voff + j * pstep : 0));
+    }
+  };
+  auto store_halo = [&](const Geo& g, int hc) {
+    float sc[8], sh[8], ad[8], sn[8];
+    if (fused) {
+      const int c0 = hc * 16 + p_t * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+      xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
+    }
+#pragma unroll
+    for (int j = 0; j < HD; ++j) {
+      f16x8 v = hreg[j];
+      if (fused) v = xform_frag<T>(v, sc, sh, ad, sn, a.xf.slope);
+      const f32x4 raw = __builtin_bit_cast(f32x4, v);
+      const bool ok = g.ok_hw && (unsigned)(g.d0 + j - 1) < (unsigned)a.D;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = ok ? raw[e] : 0.f;
+      *(f32x4*)(halo + loff + j * PSF) = o;
+    }
+  };
+
+  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB + lane * 16;
+  const unsigned wlds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wbuf;
+  auto dma_plane = [&](int hc, int kd, int slot) {
+    const char* src = wsrc + (long)((hc >> 1) * 3 + kd) * 3 * SLAB + (hc & 1) * 2048;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int p = wave + 4 * j;
+      if (p < 18) dma_piece(src + ((p >> 1) * 4 + (p & 1)) * 1024, wlds + slot * WPLANE + p * 1024);
+    }
+  };
+
+  // ---- once per workgroup: bias, statistics -> tables, first tile's halo and first weight plane ----
+  float bias_q[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int bc = ct * BN + q * 32 + r;
+    bias_q[q] = bc >= a.Cout ? 0.f : a.bias[bc];
+  }
+  int t = blockIdx.x;
+  Geo cur = geo_of(t);
+  if (fused) xform_preamble(a.xf, n, a.Cin, xsc, xsh, xad);
+  load_halo(cur, 0, 0, HD);
+  dma_plane(0, 0, 0);
+  int slot = 0;                                                  // ring slot of the plane the next phase reads
+  if (fused) __syncthreads();
+
+  const int sw = (r >> 3) & 1;
+  const int a_base = 2 * wave * PSF + (r >> 3) * RSF + (r & 7) * VSF;
+  const int a_even = a_base + ((hh ^ sw) << 4), a_odd = a_base + ((hh ^ sw ^ 1) << 4);
+  const int b_base = (hh * BN + r) * 16;
+
+  auto phase = [&](int kd, int sl) __attribute__((always_inline)) {
+    const char* hp = halo + kd * PSF;
+    const char* wb = wbuf + sl * WPLANE + b_base;
+    f16x8 fa[2][2], fb[2][2];
+    auto ldA = [&](int tp, int sub, int b) {
+      const int kh = tp / 3, kw = tp - kh * 3;
+      const char* ap = hp + ((kh & 1) ? a_odd : a_even) + sub * PSF + kh * RSF + kw * VSF;
+      fa[b][0] = *(const f16x8*)ap;
+      fa[b][1] = *(const f16x8*)(ap + 4 * RSF);
+    };
+    auto ldB = [&](int tp, int b) {
+      fb[b][0] = *(const f16x8*)(wb + tp * 2048);
+      fb[b][1] = *(const f16x8*)(wb + tp * 2048 + 512);
+    };
+    ldB(0, 0);
+    ldA(0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < 18; ++h) {
+      const int tp = h >> 1, sub = h & 1;
+      if (h + 1 < 18) {
+        const int t1 = (h + 1) >> 1, sub1 = (h + 1) & 1;
+        if (sub1 == 0) ldB(t1, t1 & 1);
+        ldA(t1, sub1, (h + 1) & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      named_mfma_sel(4 * sub + 0, fa[h & 1][0], fb[tp & 1][0]);          // tuple (2 sub + mm) * 2 + q
+      named_mfma_sel(4 * sub + 1, fa[h & 1][0], fb[tp & 1][1]);
+      named_mfma_sel(4 * sub + 2, fa[h & 1][1], fb[tp & 1][0]);
+      named_mfma_sel(4 * sub + 3, fa[h & 1][1], fb[tp & 1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const long nvox = (long)a.D * a.H * a.W;
+  T* yout = (T*)a.y + (long)n * nvox * a.Cout_stride;
+  double Sacc[2] = {0, 0}, Qacc[2] = {0, 0};
+  constexpr int J1 = 4, J2 = 7;
+
+  if (a.ksplit > 0) {
+    // The two workgroups of a CU start together and walk identical tiles: they would stay in step, both in their epilogues at
+    // once with the matrix pipes idle.  The one in the odd wave slot starts a fraction of a tile late (s_sleep 127 = 8 128 cycles);
+    // a.ksplit (unused by this form otherwise) carries the number of sleeps.
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if (hwid & 1)
+      for (int k = 0; k < a.ksplit; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the first tile's halo and weight plane
+  for (;;) {
+    const int tn = t + gridDim.x;
+    const bool has_next = tn < a.ntiles;
+    Geo nxt = cur;
+    if (has_next) nxt = geo_of(tn);
+    // (the halo in hreg and the weight plane have been waited for: before the loop for the first tile, at the end of the last
+    // phase for every later one -- a wait here would be a wait for the epilogue's output stores, vmcnt retires in order)
+    store_halo(cur, 0);
+    {
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = bias_q[q];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) named_write16_sel(m * 2 + q, v);
+      }
+    }
+    named_acc_fence_init();
+    __syncthreads();
+
+    for (int hc = 0; hc < nhc; ++hc) {
+      const bool more = hc + 1 < nhc;
+      const bool pre = more || has_next;                         // something to prefetch under this half chunk's phases
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        if (kd < 2) dma_plane(hc, kd + 1, slot ^ 1);
+        else if (more) dma_plane(hc + 1, 0, slot ^ 1);
+        else if (has_next) dma_plane(0, 0, slot ^ 1);
+        const int j0 = kd == 0 ? 0 : kd == 1 ? J1 : J2, j1 = kd == 0 ? J1 : kd == 1 ? J2 : HD;
+        if (more) load_halo(cur, hc + 1, j0, j1);
+        else if (has_next) load_halo(nxt, 0, j0, j1);
+        phase(kd, slot);
+        if (pre && kd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J1) : "memory");
+        else if (pre && kd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J2 - J1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        slot ^= 1;
+      }
+      if (more) {
+        store_halo(cur, hc + 1);
+        __syncthreads();
+      }
+    }
+
+    // ---- epilogue of this tile (the K loop ended with a workgroup barrier: the halo is free); hreg holds the next tile's halo ----
+    {
+      char* ot = halo + wave * 8192;
+      float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+      named_acc_fence_read();
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float av[16];
+            named_read16_sel((2 * pr + mm) * 2 + q, av);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float v = av[i];
+              s[q] += v;
+              ss[q] = fmaf(v, v, ss[q]);
+              *(T*)(ot + mm * 4096 + acc_row(i, hh) * 128 + (q * 32 + r) * 2) = (T)v;
+            }
+            asm volatile("" : "+v"(s[q]), "+v"(ss[q]));          // keeps the sum chain here (hipcc sinks it behind the stores)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int gd = cur.d0 + 2 * wave + pr;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int v = it * 8 + (lane >> 3), cg = lane & 7;
+          const int gh = cur.h0 + (v >> 3), gw = cur.w0 + (v & 7);
+          if (ct * BN + cg * 8 < a.Cout)
+            *(f16x8*)(yout + chan_off(a.out_blk, ((long)gd * a.H + gh) * a.W + gw, a.Cout_off + ct * BN + cg * 8, a.Cout_stride, nvox)) =
+                *(const f16x8*)(ot + v * 128 + cg * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { Sacc[q] += (double)s[q]; Qacc[q] += (double)ss[q]; }
+    }
+    if (!has_next) break;
+    __syncthreads();                                            // every wave is done with its staging rows: the halo may be overwritten
+    t = tn;
+    cur = nxt;
+  }
+
+  // ---- the workgroup's InstanceNorm sums: lane halves, then waves, in a fixed order; one set of atomics ----
+  double* exd = (double*)(smem);                                 // [4 waves][64 couts][2] doubles = 4 KB of the (finished) halo
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const double S = Sacc[q] + __shfl_xor(Sacc[q], 32), Q = Qacc[q] + __shfl_xor(Qacc[q], 32);
+    if (hh == 0) { exd[(wave * BN + q * 32 + r) * 2] = S; exd[(wave * BN + q * 32 + r) * 2 + 1] = Q; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double S = 0, Q = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { S += exd[(w * BN + lane) * 2]; Q += exd[(w * BN + lane) * 2 + 1]; }
+    if (ct * BN + lane < a.Cout) stats_add(a.stats, n, a.cout_pad, replica, ct * BN + lane, S, Q);
+  }
+  (void)ex;
+}
+
+static const LdsAttr kWideLdsAttrs[] = {{(const void*)conv3d_k3_wide_kernel, 80 * 1024}, {(const void*)conv3d_k3_wide_pt_kernel, 80 * 1024}};
 static const LdsAttrs kWideLdsReg(kWideLdsAttrs);
 
 #ifdef DUA_STAMP
 extern "C" long dua_debug_stamps_wide(void* host, long bytes) { return stamps_out(host, bytes); }
 #endif
 
-int launch_conv3_wide(Conv3Args a, int D, hipStream_t s) {
+int launch_conv3_wide(Conv3Args a, int D, hipStream_t s, bool persistent, int stagger) {
   using namespace c3w;
   if (int e = ensure_prepared()) return e;
   if (D % 8 || a.H % 8 || a.W % 8 || a.Cin % 16 || (a.xf.stats && a.Cin > 256)) return DUA_ERR_ARG;
@@ -365,6 +637,18 @@ int launch_conv3_wide(Conv3Args a, int D, hipStream_t s) {
   a.ntiles = (D / 8) * a.tiles_h * a.tiles_w;
   const int lds = LDS_FIXED + (a.xf.stats ? 3 * 4 * a.Cin : 0);
   if (lds > 80 * 1024) return DUA_ERR_ARG;
+  if (persistent) {
+    // two workgroups per CU over the whole launch, shared by the (cout tile, sample) pairs; each walks its tiles with stride grid.x
+    const int cus = device_cus();
+    if (cus <= 0) return DUA_ERR_ARG;
+    const int pairs = (a.cout_pad / BN) * a.N;
+    int gx = (2 * cus + pairs - 1) / pairs;
+    gx = (gx + 7) & ~7;                                          // whole XCD rounds: tile t and t + grid.x stay on one XCD
+    if (gx > a.ntiles) gx = a.ntiles;
+    a.ksplit = stagger;
+    hipLaunchKernelGGL(conv3d_k3_wide_pt_kernel, dim3(gx, a.cout_pad / BN, a.N), dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(conv3d_k3_wide_kernel, dim3(a.ntiles, a.cout_pad / BN, a.N), dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }

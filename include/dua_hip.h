@@ -77,7 +77,8 @@ typedef struct {
                                       for the kernel tests (every form is exercised on shapes the automatic choice would not
                                       give it) and same-process A/B timing; results are the same.  dua_conv3d_k3_fwd: low byte
                                       2 = 4x8x8 tiles without split-K, 3 = 2x8x8 tiles (slab form), 6 = automatic without the
-                                      kd-plane / LDS-DMA form of the small layers, 7 = automatic without the wide-tile form;
+                                      kd-plane / LDS-DMA form of the small layers, 7 = automatic without the wide-tile form, 8 / 9 = the wide-tile
+                                      form with persistent workgroups (9: staggered start; both measured slower, kept for A/B);
                                       bit 8 (DUA_POLICY_NO_FINISH) = skip the split-K finish kernel (timing the main kernel alone:
                                       outputs are then NOT valid).  dua_deconv_k2s2_fwd: 6 = the one-tap-per-workgroup kernel
                                       for every shape that has it, 256-voxel all-taps tiles.  dua_conv3d_k3_wgrad: bit 0 = plain

@@ -151,7 +151,7 @@ def conv_variant_any(request):
 
 
 @pytest.mark.parametrize("conv_variant_any,layout", [(0, (False, False)), (0, (True, False)), (0, (False, True)), (0, (True, True)),
-                                                     (7, (False, False))], indirect=["conv_variant_any"])
+                                                     (7, (False, False)), (8, (False, False)), (8, (True, True))], indirect=["conv_variant_any"])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("shape", [
     # N, Cin, Cout, D, H, W, input channel offset / stride, output channel offset / stride: layers with >= 1024 tiles of 4x8x8
@@ -162,7 +162,8 @@ def conv_variant_any(request):
 ])
 def test_conv3_wide_tile_form(shape, fused, conv_variant_any, layout):
     """The 8-accumulator form (conv3d_wide.hip) that fp16 layers with >= 1024 tiles take: against torch conv3d on the
-    fp16-rounded operands (0), like the 4x8x8 kernel it replaces (7); statistics against the exact convolution.  ``layout``:
+    fp16-rounded operands (0: one tile per workgroup; 8: persistent workgroups with the accumulators in v[128:255] by name, the
+    round-5 form that measured slower and stays for the A/B), like the 4x8x8 kernel it replaces (7); statistics against the exact convolution.  ``layout``:
     input / output buffer in 16-channel blocks (dua_conv3_desc.layout) instead of channels-last rows."""
     ops = _ops()
     dtype = torch.float16

@@ -89,20 +89,24 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   const bool ok_hw = has_pos && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
   const int vstride = a.in_blk ? 16 : a.Cs_stride;
   const long hcstride = a.in_blk ? (long)a.D * a.H * a.W * 16 : 16;
+  // (wave-uniform base pointers stay in scalar registers; what depends on the lane is a 32-bit element offset)
   const T* xin = (const T*)a.xs + (long)n * a.D * a.H * a.W * a.Cs_stride +
-                 (a.in_blk ? (long)(a.Cs_off >> 4) * a.D * a.H * a.W * 16 : a.Cs_off) + p_t * 8;
-  const int voff = ok_hw ? (((d0 - 1) * a.H + gh) * a.W + gw) * vstride : 0;
+                 (a.in_blk ? (long)(a.Cs_off >> 4) * a.D * a.H * a.W * 16 : a.Cs_off);
+  const int voff = (ok_hw ? (((d0 - 1) * a.H + gh) * a.W + gw) * vstride : 0) + p_t * 8;
   const int pstep = a.H * a.W * vstride;
   const int lbase = has_pos ? hy * RS + hx * VS : 0;
-  const int lsw0 = lbase + (p_t << 4), lsw1 = lbase + ((p_t ^ 1) << 4);       // planes with (j >> 1) & 1 = 0 / 1
+  const int lsw0 = lbase + (p_t << 4), lswd = 16 - (p_t << 5);                 // planes with (j >> 1) & 1 = 1: the other half
   f16x8 hreg[10];
   auto load_halo = [&](int hc, int j0, int j1) {
     const T* src = xin + hc * hcstride;
+    int vo = voff;
+    asm volatile("" : "+v"(vo));      // 64-bit addresses are formed per call (kept across the loop they cost 16 registers of scratch
+                                      // and a reload -- behind the weight pieces, vmcnt retires in order -- at the head of every phase)
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
       if (j < j0 || j >= j1) continue;
       const bool dok = (unsigned)(d0 + j - 1) < (unsigned)a.D;       // wave-uniform
-      hreg[j] = *(const f16x8*)(src + (ok_hw && dok ? voff + j * pstep : 0));
+      hreg[j] = *(const f16x8*)(src + (ok_hw && dok ? vo + j * pstep : p_t * 8));
     }
   };
   auto store_halo = [&]() {
@@ -113,12 +117,13 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = ok ? raw[e] : 0.f;
-      if (has_pos) *(f32x4*)(halo + (((j >> 1) & 1) ? lsw1 : lsw0) + j * PS) = o;
+      if (has_pos) *(f32x4*)(halo + lsw0 + (((j >> 1) & 1) ? lswd : 0) + j * PS) = o;
     }
   };
 
   // ---- skip weights: kd plane `kd` of half chunk `hc` -> ring slot (18 pieces of 1 KB; wave w takes pieces w, w + 4, ...) ----
-  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB + lane * 16;
+  const char* wsrc = (const char*)a.w + (long)ct * a.nchunks * 9 * SLAB;
+  const int wlane = lane * 16;
   const unsigned wlds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
   auto dma_plane = [&](int u, int slot) {
     const int hc = u / 3, kd = u - hc * 3;
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int p = wave + 4 * j;                              // piece = (tap p >> 1, k-group p & 1)
-      if (p < 18) upc_dma_piece(src + ((p >> 1) * 4 + (p & 1)) * 1024, wlds + slot * WPLANE + p * 1024);
+      if (p < 18) upc_dma_piece(src + ((p >> 1) * 4 + (p & 1)) * 1024 + wlane, wlds + slot * WPLANE + p * 1024);
     }
   };
 
@@ -138,14 +143,16 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   const int Dc = a.D >> 1, Hc = a.H >> 1, Wc = a.W >> 1;
   f16x8 creg[NPIECE];
   auto load_coarse = [&](int g, int j0, int j1) {
+    int tl = tid2;
+    asm volatile("" : "+v"(tl));      // addresses are formed HERE: hoisted out of the half-chunk loop they sat in scratch through part 1
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       if (j < j0 || j >= j1) continue;
-      const int cell = (tid2 >> 3) + 32 * j;
+      const int cell = (tl >> 3) + 32 * j;
       const int z = cell / 36, rm = cell - z * 36, y = rm / 6, x = rm - y * 6;
       const int gz = (d0 >> 1) - 1 + z, gy = (h0 >> 1) - 1 + y, gx = (w0 >> 1) - 1 + x;
       const bool ok = cell < 216 && (unsigned)gz < (unsigned)Dc && (unsigned)gy < (unsigned)Hc && (unsigned)gx < (unsigned)Wc;
-      const T* uin = (const T*)a.u + (long)n * Dc * Hc * Wc * a.Cu_stride + a.Cu_off + (tid2 & 7) * 8;
+      const T* uin = (const T*)a.u + (long)n * Dc * Hc * Wc * a.Cu_stride + a.Cu_off + (tl & 7) * 8;
       creg[j] = *(const f16x8*)(uin + (ok ? (long)((gz * Hc + gy) * Wc + gx) * a.Cu_stride + g * 64 : 0));
     }
   };

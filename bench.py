@@ -565,6 +565,8 @@ def run_config2(args, D):
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
     torch.manual_seed(0)
     net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES, compute_dtype=dtype).to(dev).eval()
+    if args.fold_min_tiles is not None:
+        net.upconv_min_tiles = args.fold_min_tiles
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     B = args.batch or 1
     image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
@@ -874,6 +876,7 @@ def main():
     ap.add_argument("--gather-fp16", action="store_true", help="config 3: all-gather the window sums in fp16")
     ap.add_argument("--flat-allreduce", action="store_true", help="config 4: one flat all-reduce instead of DDP buckets")
     ap.add_argument("--train-graph", action="store_true", help="config 4: whole step as one HIP graph")
+    ap.add_argument("--fold-min-tiles", type=int, default=None, help="diagnostics: engine.Plan.UPCONV_MIN_TILES for this run (0 = fold every level that can; a huge value = never)")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostics: dua_conv3_desc.policy of every convolution launch (same-box A/B of launch forms)")
     args = ap.parse_args()
     defaults = {2: (200, 20), 3: (1, 0), 4: (5, 2), 5: (100, 10)}[args.config]

@@ -250,11 +250,11 @@ class Plan:
 
     # Decoder levels whose transposed convolution is folded into the convolution behind it (dua_upconv_k3_fwd: one launch for
     # upsample + cat + conv_0 of an UpCat block, 3.4x fewer multiply-adds on the upsampled half): fp16 plans, levels with at
-    # least this many 8x8x8 output tiles (x batch x output-channel tiles) -- below that the launch cannot fill the chip and the
-    # split forms of the plain convolution win (measured at 48^3, batch 1: 216 tiles, one lone workgroup on 216 of the 256 CUs,
-    # 57-70 us in the step against 54 + 15 for the two launches it replaces; profiles/r5_step_timeline_fold_level1.txt).
-    # ``net.fold_upconv = False`` keeps the two-launch form everywhere (A/B, tests).
-    UPCONV_MIN_TILES = 512
+    # least this many 8x8x8 output tiles (x batch x output-channel tiles): the launch must fill the chip.  Same-box A/B of the
+    # whole 1000-step loop (profiles/r5_fold_threshold_ab.txt): no fold 1.469 ms/step, level 0 only 1.325, levels 0 and 1 (216 tiles
+    # at 48^3) 1.316; the 24^3 level (27 tiles) stays on the split forms of the plain convolution.
+    # ``net.fold_upconv = False`` keeps the two-launch form everywhere, ``net.upconv_min_tiles`` overrides the bound (A/B, tests).
+    UPCONV_MIN_TILES = 200
 
     def _fold_level(self, l):
         if getattr(self, "_fold", None) is None:
@@ -266,7 +266,7 @@ class Plan:
                     if D % 8 or H % 8 or W % 8:
                         continue
                     tiles = (D // 8) * (H // 8) * (W // 8) * self.N * (-(-self.dec_out[k] // 64))
-                    self._fold[k] = (tiles >= self.UPCONV_MIN_TILES and
+                    self._fold[k] = (tiles >= int(getattr(self.net, "upconv_min_tiles", self.UPCONV_MIN_TILES)) and
                                      ops.upconv_supported(self.dtype, self.N, D, H, W, self.f[k], cat_c, self.dec_out[k + 1],
                                                           self.dec_out[k + 1], self.dec_out[k], self.dec_out[k]))
         return self._fold[l]

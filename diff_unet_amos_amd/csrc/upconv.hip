@@ -370,7 +370,10 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   const char* wub = (const char*)a.wu + (long)(ct * 4 + wave) * G * (128 * 1024) + lane2 * 16;
   const int Lc = cz2 * CP + cy2 * CR + cx2 * VS + pd * CP + ph * CR;
   const int C0 = Lc + ((hh2 ^ ((cy2 + ph) & 1)) << 4), C1 = Lc + ((hh2 ^ ((cy2 + ph) & 1) ^ 1) << 4);
-  constexpr int RB = GG == 1 ? 3 : 2;                          // iterations of B fragments in flight
+#ifndef UPC_RB1
+#define UPC_RB1 3
+#endif
+  constexpr int RB = GG == 1 ? UPC_RB1 : 2;                    // iterations of B fragments in flight
   f16x8 fb[RB][4], fa[2][4];
   auto ldBu = [&](const char* wg, int it, int b) {
 #pragma unroll

@@ -464,7 +464,7 @@ def cpu_training_baseline(net_state, threads):
                       f"ONE 96^3 x 16-class sample, {dt:.2f} s/sample"}
 
 
-def measure_traffic(dtype_flag, kernel=None):
+def measure_traffic(dtype_flag, kernel=None, config=2, extra=()):
     """HBM bytes per conv launch from the PMC counters, as MI355X_MICROARCH.md (HBM / rocprofv3 sections) prescribes:
     FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes over a short eager run of this script (a child
     process: the profiler must start the program itself), FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request),
@@ -481,7 +481,7 @@ def measure_traffic(dtype_flag, kernel=None):
         try:
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-graph",
-                   "--no-cpu-baseline", "--no-roofline", "--dtype", dtype_flag]
+                   "--no-cpu-baseline", "--no-roofline", "--dtype", dtype_flag, "--config", str(config)] + list(extra)
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -804,6 +804,7 @@ def run_config4(args, D):
             "gradient_bytes": sum(p.numel() for p in net.parameters()) * 4, "loss": float(loss),
             "step_tflops": B * 3 * (1.0564e12 + 0.2798e12) / per / 1e12}
         if roof is not None:
+            roof["traffic"] = getattr(args, "traffic", None)       # HBM bytes per launch of conv3d_k3_wgrad_fo_kernel (PMC child passes)
             line["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_training_baseline(state, host_threads())
@@ -884,6 +885,10 @@ def run_config5(args, D):
                        "noise": "in-kernel Philox4x32-10", "weights": "torch.manual_seed(0) default init"},
             "finite": finite}
         if roof is not None:
+            if roof.get("kernel") == CONV_KERNEL:
+                roof["traffic"] = getattr(args, "traffic", None)
+            else:
+                roof["other_kernels"].get(CONV_KERNEL, {})["traffic"] = getattr(args, "traffic", None)
             line["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(state, host_threads(), swin=True)
@@ -919,9 +924,15 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
-    if args.config == 2 and args.gpus == 1 and not (args.no_roofline or args.no_traffic):
-        # two short child runs of this script under rocprofv3 --pmc, started before this process initialises the GPU
-        args.traffic = measure_traffic(args.dtype, WIDE_KERNEL if (args.dtype == "f16" and not args.conv_variant) else CONV_KERNEL)
+    if args.gpus == 1 and not (args.no_roofline or args.no_traffic) and args.config in (2, 4, 5):
+        # two short child runs of this script under rocprofv3 --pmc, started before this process initialises the GPU; the kernel
+        # is the one the roofline object of that config describes
+        if args.config == 2:
+            args.traffic = measure_traffic(args.dtype, WIDE_KERNEL if (args.dtype == "f16" and not args.conv_variant) else CONV_KERNEL)
+        elif args.config == 4:
+            args.traffic = measure_traffic("f16", "conv3d_k3_wgrad_fo_kernel", 4, ["--flat-allreduce"] + (["--batch", str(args.batch)] if args.batch else []))
+        else:
+            args.traffic = measure_traffic(args.dtype, CONV_KERNEL, 5)
     D = Dist(args)
     if args.conv_variant:
         from diff_unet_amos_amd import ops

@@ -73,6 +73,33 @@ def test_denoise_matches_oracle(dtype, mx, mean, kw):
     assert d.max() < mx and d.mean() < mean
 
 
+@pytest.mark.parametrize("min_tiles", [200, 0], ids=["shipped-bound", "every-level-that-can"])
+def test_folded_upconvolution_equals_the_two_launch_form_and_the_oracle(min_tiles):
+    """fp16 plans fold UpCat's transposed convolution into the convolution behind it (dua_upconv_k3_fwd) where a
+    level has enough tiles.  Default widths at 64^3: level 0 (512 tiles, 64 coarse channels) folds under the shipped bound;
+    with the bound at 0 level 1 folds too (128 coarse channels = two groups; level 2's 256 are refused and stay on two launches).
+    Against the oracle within the fp16 tolerance, and against the SAME network with the fold switched off: the two forms round
+    differently (composed weights rounded once; no fp16 upsampled tensor), nothing more."""
+    kw = dict(in_channels=1, out_channels=2)
+    net, ref = _pair(kw, torch.float16)
+    net.upconv_min_tiles = min_tiles
+    g = torch.Generator().manual_seed(5)
+    image, x, t = torch.rand(1, 1, 64, 64, 64, generator=g), torch.randn(1, 2, 64, 64, 64, generator=g), torch.tensor([321])
+    with torch.no_grad():
+        want = ref(image=image, x=x, step=t, pred_type="denoise")
+        got = net(image=image.cuda(), x=x.cuda(), step=t.cuda(), pred_type="denoise").cpu()
+    plan = net._rt.plan(1, (64, 64, 64), torch.device("cuda", 0))
+    assert [plan._fold_level(l) for l in range(4)] == ([True, False, False, False] if min_tiles else [True, True, False, False])
+    d = (got - want).abs()
+    assert float(d.max()) < 1e-2 and float(d.mean()) < 1e-3, (float(d.max()), float(d.mean()))
+    net2, _ = _pair(kw, torch.float16)
+    net2.fold_upconv = False
+    with torch.no_grad():
+        plain = net2(image=image.cuda(), x=x.cuda(), step=t.cuda(), pred_type="denoise").cpu()
+    assert not any(net2._rt.plan(1, (64, 64, 64), torch.device("cuda", 0))._fold_level(l) for l in range(4))
+    assert float((got - plain).abs().max()) < 5e-3, float((got - plain).abs().max())
+
+
 def test_q_sample_api():
     net, ref = _pair(TINY, torch.float32)
     x0 = (torch.rand(3, 2, 32, 32, 32) > 0.5).float() * 2 - 1

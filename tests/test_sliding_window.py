@@ -150,3 +150,14 @@ def test_bench_config4_runs_end_to_end_on_two_ranks():
     assert line["n_gpus"] == 2 and line["config"]["batch_per_gpu"] == 1
     assert np.isfinite(line["loss"]) and line["value"] > 0 and line["flat_allreduce_seconds"] > 0
     assert line["gradient_bytes"] == 38405520 * 4
+
+
+@pytest.mark.gpu
+def test_bench_config2_runs_end_to_end_on_two_ranks():
+    """`bench.py --gpus 2` (the headline config: replicas only, no data-path collective): both ranks run the 1000-step loop
+    between barriers, rank 0 prints the contract line with the aggregate of the two replicas."""
+    line = _bench_line(["--steps", "5", "--warmup", "2"], 900)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["finite"] is True
+    assert line["full_loop"]["steps"] == 1000 and abs(line["ms_per_step"] * 1000 - line["full_loop"]["seconds"] * 1e3) < 1e-6
+    assert abs(line["value"] - 2 * 96 ** 3 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    assert line["replayed_step_ms"] > 0 and "roofline" not in line

@@ -21,7 +21,8 @@ class _FusedAdapter:
         out = self.plan.sample_loop(diffusion, kind, noise=noise, eta=eta, step_noise=step_noise)
         # One tensor that already is the sum over steps: summing ``all_samples`` as
         # models/diffusion/diffusion.py:94-98 does gives the reference's result without keeping T tensors.
-        out["all_samples"] = [out["sum_pred_xstart"]]
+        if out["sum_pred_xstart"] is not None:       # DDIM loops; a DDPM loop returns its final sample alone, like the reference's
+            out["all_samples"] = [out["sum_pred_xstart"]]
         return out
 
 

@@ -498,12 +498,16 @@ class Plan:
         return out
 
     def sample_loop(self, diffusion, kind, noise=None, step_noise=None, eta=0.0, use_graph=True, seed=None,
-                    want_final_xstart=False, snapshots=None):
+                    want_final_xstart=False, snapshots=None, want_sum=None):
         """T reverse steps (T = diffusion.num_timesteps) starting from ``noise`` (x_T, NCDHW) or a fresh
         draw.  ``step_noise``: optional list of per-step NCDHW draws (parity runs); otherwise the
         tail kernel generates eps in-kernel (Philox, keyed per call: ``seed`` or a draw from torch's generator).
         ``snapshots``: optional dict {step count k: None}; after k steps the state x is stored there (NCDHW copy;
-        eager mode) -- drift-versus-step measurements.  Returns dict(sample, sum_pred_xstart)."""
+        eager mode) -- drift-versus-step measurements.  ``want_sum``: accumulate the sum of the per-step x0 predictions (what
+        models/diffusion/diffusion.py:94-98 sums from ``all_samples``); default: DDIM loops only -- the reference's p_sample_loop
+        (gaussian_diffusion.py:441-485) returns the final sample alone, and the sum is 113 MB of HBM traffic per step at 96^3 x 16.
+        Returns dict(sample, sum_pred_xstart (None without the sum))."""
+        want_sum = (kind == "ddim") if want_sum is None else bool(want_sum)
         self.refresh_weights()
         N, T = self.N, diffusion.num_timesteps
         shape = (N, self.C, *self.dims)
@@ -516,6 +520,7 @@ class Plan:
         self.x_sum.zero_()
         mode = nv.MODE_DDPM if kind == "ddpm" else nv.MODE_DDIM
         tkey = (diffusion, kind, float(eta))          # the object itself: the table keeps it alive, no id() reuse after GC
+        gkey = tkey + (want_sum,)
         if tkey not in self.tables:
             order = list(range(T))[::-1]
             tt = torch.tensor(order)
@@ -533,7 +538,7 @@ class Plan:
             use_graph = False
 
         def one_step(eps):
-            self.native_step(mode, row_of_step=row_of_step, coef_table=coef_table, noise=eps, use_sum=True)
+            self.native_step(mode, row_of_step=row_of_step, coef_table=coef_table, noise=eps, use_sum=want_sum)
 
         # DDPM in an fp16 plan: the LAST steps run on the exact-fp32 path (see finish_fp32_steps in __init__)
         finish = min(T, self.finish_fp32_steps) if (kind == "ddpm" and self.dtype == torch.float16) else 0
@@ -549,7 +554,7 @@ class Plan:
             hi.seed_word.copy_(self.seed_word)
             for k in range(first_step, T):
                 eps = None if step_noise is None else step_noise[k].detach().to(self.dev).float().contiguous()
-                hi.native_step(mode, row_of_step=row_of_step, coef_table=coef_table, noise=eps, use_sum=True)
+                hi.native_step(mode, row_of_step=row_of_step, coef_table=coef_table, noise=eps, use_sum=want_sum)
                 if snapshots and (k + 1) in snapshots:
                     snapshots[k + 1] = ops.from_channels_last(hi.x_state, self.C)
             self.x_state.copy_(hi.x_state)
@@ -562,7 +567,7 @@ class Plan:
                 if snapshots and (k + 1) in snapshots:
                     snapshots[k + 1] = ops.from_channels_last(self.x_state, self.C)
         else:
-            key = tkey
+            key = gkey
             g = self.graphs.get(key)
             if g is None:
                 # warm-up outside capture (sets kernel attributes, fills caches); state is reset below
@@ -581,5 +586,5 @@ class Plan:
         if finish:
             finish_hi(lo_steps)
         out = {"sample": ops.from_channels_last(self.x_state, self.C),
-               "sum_pred_xstart": ops.from_channels_last(self.x_sum, self.C)}
+               "sum_pred_xstart": ops.from_channels_last(self.x_sum, self.C) if want_sum else None}
         return out

@@ -621,10 +621,12 @@ class SwinPlan:
             raise ValueError(f"timestep out of range: the model was built for 0 <= t < {T}")
         return out
 
-    def sample_loop(self, diffusion, kind, noise=None, step_noise=None, eta=0.0, use_graph=True, seed=None):
+    def sample_loop(self, diffusion, kind, noise=None, step_noise=None, eta=0.0, use_graph=True, seed=None, want_sum=None):
         """T reverse steps from ``noise`` (x_T, NCDHW) or a fresh draw: the loop bodies of p_sample_loop_progressive /
         ddim_sample_loop_progressive (gaussian_diffusion.py:487-535, 667-716) around SwinUNETRDenoiser.forward, one
-        captured HIP graph replayed per step.  Returns dict(sample, sum_pred_xstart)."""
+        captured HIP graph replayed per step.  ``want_sum`` (default: DDIM loops only, see engine.Plan.sample_loop): keep the sum of
+        the x0 predictions.  Returns dict(sample, sum_pred_xstart (None without the sum))."""
+        want_sum = (kind == "ddim") if want_sum is None else bool(want_sum)
         self.refresh_weights()
         N, T = self.N, diffusion.num_timesteps
         shape = (N, self.C, *self.dims)
@@ -660,17 +662,17 @@ class SwinPlan:
                            coef_table=coef_table, cur_coef=self.cur_coef, step_word=self.step_word, err_word=self.err_word,
                            clear=self.den_stats)
             self.denoiser_body(zero_stats=False)
-            self.tail(mode, noise=eps, use_sum=True)
+            self.tail(mode, noise=eps, use_sum=want_sum)
 
         if not use_graph:
             for k in range(T):
                 one_step(None if step_noise is None else step_noise[k].detach().to(self.dev).float().contiguous())
         else:
-            g = self.graphs.get(tkey)
+            g = self.graphs.get(tkey + (want_sum,))
             if g is None:
                 g = self.capture_step(lambda: one_step(None))
-                self.graphs[tkey] = g
+                self.graphs[tkey + (want_sum,)] = g
                 reset()
             g.replay(T)
         return {"sample": ops.from_channels_last(self.x_state, self.C),
-                "sum_pred_xstart": ops.from_channels_last(self.x_sum, self.C)}
+                "sum_pred_xstart": ops.from_channels_last(self.x_sum, self.C) if want_sum else None}

@@ -227,7 +227,7 @@ def test_full_size_config2_evaluation_matches_oracle():
     with torch.no_grad():
         net.embed_model(image.cuda())
         xT = x.cuda()
-        a = plan.sample_loop(net.sample_diffusion, "ddpm", noise=xT, seed=11)
+        a = plan.sample_loop(net.sample_diffusion, "ddpm", noise=xT, seed=11, want_sum=True)
         s1, x1 = a["sample"].clone(), a["sum_pred_xstart"].clone()
         b = plan.sample_loop(net.sample_diffusion, "ddpm", noise=xT, seed=11)
         c = plan.sample_loop(net.sample_diffusion, "ddpm", noise=xT)            # key drawn from torch's generator

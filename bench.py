@@ -599,6 +599,7 @@ def run_config2(args, D):
     net = DiffUNet(in_channels=1, out_channels=CLASSES, features=FEATURES, compute_dtype=dtype).to(dev).eval()
     if args.fold_min_tiles is not None:
         net.upconv_min_tiles = args.fold_min_tiles
+    net.fold_upconv = not args.no_fold
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     B = args.batch or 1
     image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
@@ -820,6 +821,7 @@ def run_config5(args, D):
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
     torch.manual_seed(0)
     net = DiffSwinUNETR(in_channels=1, out_channels=CLASSES, feature_size=48, compute_dtype=dtype).to(dev).eval()
+    net.fold_upconv = not args.no_fold
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     B = args.batch or 1
     image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
@@ -868,7 +870,9 @@ def run_config5(args, D):
             # config 2 (every launch replayed alone, back to back); useful FLOPs = 2 * 27 * Cin * Cout * voxels, so the 48-wide
             # layers are charged for their padding to 32-channel chunks and 64-output tiles
             avg_ms, per_step, by_launch = time_conv_launches(plan, 20)
-            fl = [2.0 * 27 * a[1] * a[5] * a[0].shape[0] * a[0].shape[1] * a[0].shape[2] * a[0].shape[3] for a, _ in _LAST_CONV_CALLS]
+            # (a folded call's arguments are (cat, skip channels, ...): the algorithmic figure is conv1 over the whole 2 x cout concat)
+            fl = [2.0 * 27 * (2 * a[1] if k.get("__upconv__") else a[1]) * (a[10] if k.get("__upconv__") else a[5]) *
+                  a[0].shape[0] * a[0].shape[1] * a[0].shape[2] * a[0].shape[3] for a, k in _LAST_CONV_CALLS]
             peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_F32_TFLOPS
             roof = roofline_by_kernel(fl, by_launch, [conv_kernel_of(c) for c in _LAST_CONV_CALLS], peak,
                                       "decoder1 conv1 96->48 @96^3")
@@ -915,6 +919,7 @@ def main():
     ap.add_argument("--flat-allreduce", action="store_true", help="config 4: one flat all-reduce instead of DDP buckets")
     ap.add_argument("--train-graph", action="store_true", help="config 4: whole step as one HIP graph")
     ap.add_argument("--fold-min-tiles", type=int, default=None, help="diagnostics: engine.Plan.UPCONV_MIN_TILES for this run (0 = fold every level that can; a huge value = never)")
+    ap.add_argument("--no-fold", action="store_true", help="diagnostics: keep every transposed convolution + convolution on two launches (net.fold_upconv = False; A/B)")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostics: dua_conv3_desc.policy of every convolution launch (same-box A/B of launch forms)")
     args = ap.parse_args()
     defaults = {2: (200, 20), 3: (1, 0), 4: (5, 2), 5: (100, 10)}[args.config]

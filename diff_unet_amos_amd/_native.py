@@ -169,7 +169,7 @@ _SIGS = {
     "dua_deconv_k2s2_kernel_kind": (C.c_int, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P, _P, C.c_long, _P]),
     "dua_upconv_k3_supported": (C.c_int, [C.POINTER(UpConvDesc)]),
-    "dua_pack_upconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "dua_pack_upconv_weights": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dua_upconv_k3_fwd": (C.c_int, [C.POINTER(UpConvDesc), _P, _P, C.POINTER(InNorm), _P, _P, _P, _P, _P, _P]),
     "dua_conv3d_k3_wgrad_workspace": (C.c_long, [C.POINTER(Conv3Desc)]),
     "dua_conv3d_k3_wgrad": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.c_int, _P, _P, C.c_long, _P]),

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   const int pd = wave >> 1, ph = wave & 1;
   const int nhc = a.Cs >> 4, U = nhc * 3;
   constexpr int G = GG;
+  const bool fused = a.xf.stats != nullptr;                   // u is a raw convolution output (else: already materialised)
 
   // ---- skip halo pieces: thread = (position (hy, hx) in a halo plane, 16-byte half p), piece j = halo plane j ----
   const int p_t = tid & 1, pos = tid >> 1;
@@ -160,16 +161,19 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
     float sc[8], sh[8], ad[8], sn[8];
     const int part = tid2 & 7;
     const int c0 = g * 64 + part * 8;
+    if (fused) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
-    xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
+      for (int e = 0; e < 8; ++e) { sc[e] = xsc[c0 + e]; sh[e] = xsh[c0 + e]; ad[e] = xad[c0 + e]; }
+      xform_prep<T>(sc, sh, ad, sn, a.xf.slope);
+    }
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int cell = (tid2 >> 3) + 32 * j;
       const int z = cell / 36, rm = cell - z * 36, y = rm / 6, x = rm - y * 6;
       const int gz = (d0 >> 1) - 1 + z, gy = (h0 >> 1) - 1 + y, gx = (w0 >> 1) - 1 + x;
       const bool ok = (unsigned)gz < (unsigned)Dc && (unsigned)gy < (unsigned)Hc && (unsigned)gx < (unsigned)Wc;
-      const f16x8 v = xform_frag<T>(creg[j], sc, sh, ad, sn, a.xf.slope);
+      f16x8 v = creg[j];
+      if (fused) v = xform_frag<T>(v, sc, sh, ad, sn, a.xf.slope);
       const f32x4 raw = __builtin_bit_cast(f32x4, v);
       f32x4 o;
 #pragma unroll
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   constexpr int UN = GG;                                       // 16 channels per (wave, group): 64 channels per group
   stat_t sv[UN][2 * STAT_WORDS];
   float gam[UN], bet[UN], addv[UN];
-  {
+  if (fused) {
     const int pr = lane >> 4;
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
       btv[j] = (e < 27 * 64 && c < a.Cout) ? a.btab[cls * a.cout_pad + c] : 0.f;
     }
   }
-  {
+  if (fused) {
     const int pr = lane >> 4;
     double Sm = 0, Qm = 0;
     float gm = 0.f, bm = 0.f, am = 0.f;
@@ -507,7 +511,7 @@ __device__ __forceinline__ int upc_taps(int phi, int delta, int* k, int* child) 
   k[0] = 2; child[0] = 0; return 1;
 }
 
-__global__ void upconv_pack_kernel(int Cout, int Cskip, int Cmid, int Cu, const float* __restrict__ wc,
+__global__ void upconv_pack_kernel(int Cout, int Cskip, int Cmid, int Cu, int up_off, const float* __restrict__ wc,
                                    const float* __restrict__ wd, f16* __restrict__ out, long total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -537,7 +541,7 @@ __global__ void upconv_pack_kernel(int Cout, int Cskip, int Cmid, int Cu, const 
       for (int y = 0; y < nh; ++y)
         for (int z = 0; z < nw; ++z) {
           const int tap = (kd[x] * 3 + kh[y]) * 3 + kw[z], child = (ad[x] * 2 + ah[y]) * 2 + aw[z];
-          const float* wcp = wc + ((long)co * Cin + Cskip) * 27 + tap;
+          const float* wcp = wc + ((long)co * Cin + up_off) * 27 + tap;
           const float* wdp = wd + (long)ci * Cmid * 8 + child;
           float sacc = 0.f;
           for (int cm = 0; cm < Cmid; ++cm) sacc = fmaf(wcp[(long)cm * 27], wdp[(long)cm * 8], sacc);
@@ -548,7 +552,7 @@ __global__ void upconv_pack_kernel(int Cout, int Cskip, int Cmid, int Cu, const 
 }
 
 // bias table [27 classes = (cd, ch, cw), 0 = low border, 1 = interior, 2 = high border][cout_pad]
-__global__ void upconv_bias_kernel(int Cout, int Cskip, int Cmid, int cout_pad, const float* __restrict__ wc,
+__global__ void upconv_bias_kernel(int Cout, int Cskip, int Cmid, int up_off, int cout_pad, const float* __restrict__ wc,
                                    const float* __restrict__ bc, const float* __restrict__ bd, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= 27 * cout_pad) return;
@@ -565,7 +569,7 @@ __global__ void upconv_bias_kernel(int Cout, int Cskip, int Cmid, int cout_pad, 
           if ((ch == 0 && kh == 0) || (ch == 2 && kh == 2)) continue;
           for (int kw = 0; kw < 3; ++kw) {
             if ((cw == 0 && kw == 0) || (cw == 2 && kw == 2)) continue;
-            const float* wcp = wc + ((long)co * Cin + Cskip) * 27 + (kd * 3 + kh) * 3 + kw;
+            const float* wcp = wc + ((long)co * Cin + up_off) * 27 + (kd * 3 + kh) * 3 + kw;
             float sacc = 0.f;
             for (int cm = 0; cm < Cmid; ++cm) sacc = fmaf(wcp[(long)cm * 27], bd[cm], sacc);
             v += sacc;
@@ -598,18 +602,19 @@ extern "C" {
 
 int dua_upconv_k3_supported(const dua_upconv_desc* d) { return dua::upconv_desc_ok(d) ? 1 : 0; }
 
-long dua_pack_upconv_weights(int dtype, int Cout, int Cskip, int Cmid, int Cu, const float* wc, const float* bc, const float* wd,
-                             const float* bd, void* wu_packed, float* bias_table, void* stream) {
+long dua_pack_upconv_weights(int dtype, int Cout, int Cskip, int Cmid, int Cu, int up_first, const float* wc, const float* bc,
+                             const float* wd, const float* bd, void* wu_packed, float* bias_table, void* stream) {
   if (dtype != DUA_F16 || Cout <= 0 || Cskip < 0 || Cmid <= 0 || Cu <= 0 || Cu % 64) return DUA_ERR_ARG;
+  const int up_off = up_first ? 0 : Cskip;                     // first input channel of the upsampled half in wc
   const int nct = (Cout + 63) / 64, G = Cu >> 6;
   const long total = (long)nct * 4 * G * 128 * 512;             // fp16 elements
   if (!wu_packed) return total * 2;
   if (!wc || !wd || !bias_table) return DUA_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(dua::upconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Cout, Cskip, Cmid, Cu, wc, wd,
+  hipLaunchKernelGGL(dua::upconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Cout, Cskip, Cmid, Cu, up_off, wc, wd,
                      (dua::f16*)wu_packed, total);
   const int cout_pad = nct * 64;
-  hipLaunchKernelGGL(dua::upconv_bias_kernel, dim3((27 * cout_pad + 255) / 256), dim3(256), 0, s, Cout, Cskip, Cmid, cout_pad, wc, bc, bd,
+  hipLaunchKernelGGL(dua::upconv_bias_kernel, dim3((27 * cout_pad + 255) / 256), dim3(256), 0, s, Cout, Cskip, Cmid, up_off, cout_pad, wc, bc, bd,
                      bias_table);
   const int e = (int)hipGetLastError();
   return e ? -(long)e : total * 2;
@@ -619,8 +624,8 @@ int dua_upconv_k3_fwd(const dua_upconv_desc* d, const void* xskip, const void* u
                       const void* wu_packed, const float* bias_table, void* y, dua_stat_word* out_stats, void* stream) {
   using namespace dua;
   if (!upconv_desc_ok(d) || !xskip || !u || !w_skip_packed || !wu_packed || !bias_table || !y || !out_stats) return DUA_ERR_ARG;
-  if (!u_in || !u_in->stats || !u_in->gamma || !u_in->beta || u_in->c_pad < d->Cu || u_in->count <= 0 ||
-      !(u_in->slope >= 0.f && u_in->slope <= 1.f))
+  if (u_in && u_in->stats && (!u_in->gamma || !u_in->beta || u_in->c_pad < d->Cu || u_in->count <= 0 ||
+                             !(u_in->slope >= 0.f && u_in->slope <= 1.f)))
     return DUA_ERR_ARG;
   if (int e = ensure_prepared()) return e;
   UpConvArgs a{};

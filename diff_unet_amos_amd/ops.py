@@ -728,30 +728,37 @@ def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=Non
                                           nv.ptr(y), nv.stream_ptr()), "dua_deconv_k2s2_fwd")
 
 
-def pack_upconv_weights(wc, bc, wd, bd, cskip, dtype=torch.float16):
+def pack_upconv_weights(wc, bc, wd, bd, cskip, dtype=torch.float16, up_first=False, cu_packed=None):
     """UpCat's first convolution with the transposed convolution folded in (dua_upconv_k3_fwd): ``wc`` / ``bc`` = Conv3d
-    [Cout, Cskip + Cmid, 3,3,3] parameters, ``wd`` / ``bd`` = ConvTranspose3d [Cu, Cmid, 2,2,2] parameters.  Returns
-    (packed skip-half weights, composed weights of the upsampled half, bias table fp32 [27, ceil(Cout/64)*64])."""
+    [Cout, Cskip + Cmid, 3,3,3] parameters, ``wd`` / ``bd`` = ConvTranspose3d [Cu, Cmid, 2,2,2] parameters.  ``up_first``: the
+    upsampled half is the FIRST Cmid input channels of ``wc`` (torch.cat((up, skip)): the Swin-UNETR decoder), else the last.
+    ``cu_packed`` (a multiple of 64, >= Cu): channel count of the coarse BUFFER the kernel will read (channels behind Cu are zero
+    padding; their weight rows are zeros).  Returns (packed skip-half weights, composed weights of the upsampled half, bias table
+    fp32 [27, ceil(Cout/64)*64])."""
     assert wc.is_cuda and wc.dtype == torch.float32 and wc.dim() == 5 and tuple(wc.shape[2:]) == (3, 3, 3)
     assert wd.is_cuda and wd.dtype == torch.float32 and wd.dim() == 5 and tuple(wd.shape[2:]) == (2, 2, 2)
     wc, wd = wc.contiguous(), wd.contiguous()
     cout, cin = wc.shape[:2]
     cu, cmid = wd.shape[:2]
-    assert cin == cskip + cmid and cskip % 16 == 0 and cu % 64 == 0 and dtype == torch.float16
+    cu_packed = cu if cu_packed is None else cu_packed
+    assert cin == cskip + cmid and cskip % 16 == 0 and cu_packed % 64 == 0 and cu_packed >= cu and dtype == torch.float16
+    if cu_packed > cu:
+        wd = torch.cat([wd, torch.zeros(cu_packed - cu, *wd.shape[1:], dtype=wd.dtype, device=wd.device)], 0).contiguous()
     L = nv.lib()
     code = nv.dt_code(dtype)
+    perm = torch.arange(cmid, cmid + cskip, dtype=torch.int32, device=wc.device) if up_first else None
     nb = L.dua_pack_conv3_weights(code, cout, cin, cskip, None, None, None, None)
     w_skip = torch.empty(nb, dtype=torch.uint8, device=wc.device)
-    if L.dua_pack_conv3_weights(code, cout, cin, cskip, nv.ptr(wc), None, nv.ptr(w_skip), nv.stream_ptr()) != nb:
+    if L.dua_pack_conv3_weights(code, cout, cin, cskip, nv.ptr(wc), nv.ptr(perm), nv.ptr(w_skip), nv.stream_ptr()) != nb:
         raise RuntimeError("dua_pack_conv3_weights failed")
-    nb = L.dua_pack_upconv_weights(code, cout, cskip, cmid, cu, None, None, None, None, None, None, None)
+    nb = L.dua_pack_upconv_weights(code, cout, cskip, cmid, cu_packed, 0, None, None, None, None, None, None, None)
     assert nb > 0
     wu = torch.empty(nb, dtype=torch.uint8, device=wc.device)
     btab = torch.empty((27, -(-cout // 64) * 64), dtype=torch.float32, device=wc.device)
     bc_ = None if bc is None else bc.detach().float().contiguous()
     bd_ = None if bd is None else bd.detach().float().contiguous()
-    rc = L.dua_pack_upconv_weights(code, cout, cskip, cmid, cu, nv.ptr(wc), nv.ptr(bc_), nv.ptr(wd), nv.ptr(bd_), nv.ptr(wu),
-                                   nv.ptr(btab), nv.stream_ptr())
+    rc = L.dua_pack_upconv_weights(code, cout, cskip, cmid, cu_packed, 1 if up_first else 0, nv.ptr(wc), nv.ptr(bc_), nv.ptr(wd), nv.ptr(bd_),
+                                   nv.ptr(wu), nv.ptr(btab), nv.stream_ptr())
     if rc != nb:
         raise RuntimeError(f"dua_pack_upconv_weights failed ({rc})")
     return w_skip, wu, btab
@@ -773,13 +780,14 @@ def upconv_supported(dtype, N, D, H, W, cskip, cskip_stride, cu, cu_stride, cout
 def upconv_k3(xs, cskip, cskip_off, u, cu, cu_off, norm, w_skip, wu, btab, cout, y, cout_off, out_stats, in_blocked=False,
               out_blocked=False):
     """conv3x3x3(cat([x_e, ConvTranspose3d_k2s2(act(norm(u)))])) in one launch (dua_upconv_k3_fwd): ``xs`` holds x_e on the fine
-    grid, ``u`` is the RAW coarse tensor whose producer ``norm`` describes; accumulates this layer's InstanceNorm sums."""
+    grid, ``u`` is the RAW coarse tensor whose producer ``norm`` describes (``norm`` None: ``u`` already is an activation);
+    accumulates this layer's InstanceNorm sums."""
     _cl_check(xs, "xs"); _cl_check(u, "u"); _cl_check(y, "y")
     N, D, H, W, _ = xs.shape
     assert xs.dtype == u.dtype == y.dtype == torch.float16 and tuple(y.shape[:4]) == (N, D, H, W)
     assert tuple(u.shape[:4]) == (N, D // 2, H // 2, W // 2) and D % 8 == 0 and H % 8 == 0 and W % 8 == 0
     assert cskip % 16 == 0 and cskip_off + cskip <= xs.shape[-1] and cu % 64 == 0 and cu_off + cu <= u.shape[-1]
-    assert cout % 8 == 0 and cout_off + cout <= y.shape[-1] and norm is not None
+    assert cout % 8 == 0 and cout_off + cout <= y.shape[-1]
     nct = -(-cout // 64)
     assert w_skip.numel() == nct * (-(-cskip // 32)) * 27 * 4 * 64 * 16 and wu.numel() == nct * 4 * (cu // 64) * 128 * 1024
     assert btab.dtype == torch.float32 and btab.is_contiguous() and tuple(btab.shape) == (27, nct * 64)
@@ -790,7 +798,7 @@ def upconv_k3(xs, cskip, cskip_off, u, cu, cu_off, norm, w_skip, wu, btab, cout,
         _RECORD.append(nv.StepOp(nv.OP_UPCONV, has, nv.Conv3Desc(), nv.MaterializeDesc(), nval, _addr(xs), _addr(w_skip), _addr(btab),
                                  _addr(y), _addr(out_stats), None, None, d, _addr(u), _addr(wu)))
         return
-    nv.check(nv.lib().dua_upconv_k3_fwd(C.byref(d), nv.ptr(xs), nv.ptr(u), norm.ref(N, cu), nv.ptr(w_skip), nv.ptr(wu), nv.ptr(btab),
+    nv.check(nv.lib().dua_upconv_k3_fwd(C.byref(d), nv.ptr(xs), nv.ptr(u), _norm_ref(norm, N, cu), nv.ptr(w_skip), nv.ptr(wu), nv.ptr(btab),
                                         nv.ptr(y), nv.ptr(out_stats), nv.stream_ptr()), "dua_upconv_k3_fwd")
 
 

@@ -134,7 +134,22 @@ class SwinPlan:
         self.hs = [z(1, f), z(2, 2 * f), z(3, 4 * f), None, z(5, 16 * f)]      # hs[3] lives in cat[4]
         self.cat = [z(0, 2 * f), z(1, 2 * f), z(2, 4 * f), z(3, 8 * f), z(4, 16 * f)]   # (up | skip) of decoder1..5
         self.tail_k = -(-f // 32) * 32                      # decoder1's output keeps a 64-channel stride (48 real, the rest zero)
-        self.dec = [z(0, self.tail_k), z(1, f), z(2, 2 * f), z(3, 4 * f), z(4, 8 * f), z(5, 16 * f)]   # out, dec0..dec4
+        # Decoder levels whose 3x3x3 convolution over torch.cat((up, skip)) takes the folded form (dua_upconv_k3_fwd, DESIGN 6: the
+        # upsampled half contracted as 8 parents x the coarse channels instead of 27 taps): fp16, >= 200 tiles of 8x8x8 -- decoder1
+        # (96^3) and decoder2 (48^3) at 96^3 patches.  The coarse tensor of such a level is kept at a 64-channel multiple (zero
+        # padding behind its 48 / 96 channels); the transposed convolution itself still runs, for the block's 1x1x1 residual branch.
+        self.dec_c = [self.tail_k, f, 2 * f, 4 * f, 8 * f, 16 * f]              # real channels of out, dec0..dec4
+        self.fold_up = [False] * 5
+        if dtype == torch.float16 and bool(getattr(net, "fold_upconv", True)):
+            for k in range(2):
+                Dk, Hk, Wk = S[k]
+                cu_p = -(-self.dec_c[k + 1] // 64) * 64
+                tiles = (Dk // 8) * (Hk // 8) * (Wk // 8) * N if (Dk % 8 == 0 and Hk % 8 == 0 and Wk % 8 == 0) else 0
+                cout = self.cat[k].shape[-1] // 2
+                self.fold_up[k] = (tiles >= int(getattr(net, "upconv_min_tiles", 200)) and cout % 16 == 0 and
+                                   ops.upconv_supported(dtype, N, Dk, Hk, Wk, cout, 2 * cout, cu_p, cu_p, cout, cout))
+        dec_stride = [c if not (1 <= i <= 2 and self.fold_up[i - 1]) else -(-c // 64) * 64 for i, c in enumerate(self.dec_c)]
+        self.dec = [z(i if i else 0, dec_stride[i]) for i in range(6)]            # out, dec0..dec4 (levels 0, 1, 2, 3, 4, 5)
                                                             # so that the fused head + sampler tail runs its MFMA form
         # ---- shared scratch (the two networks never run concurrently)
         big = max(N * S[l][0] * S[l][1] * S[l][2] * c for l, c in ((0, f), (1, f), (2, 2 * f), (3, 4 * f), (4, 8 * f), (5, 16 * f)))
@@ -300,6 +315,13 @@ class SwinPlan:
                 r.norms = None
             self.up_packed = [ops.pack_deconv_weights(u.transp_conv.conv.weight.detach().float().contiguous(), None, dt)
                               for u in self.ups]
+            for k in range(5):
+                r = self.u_res[k]
+                r.fold = None
+                if self.fold_up[k]:
+                    wd = self.ups[k].transp_conv.conv.weight.detach().float().contiguous()
+                    r.fold = ops.pack_upconv_weights(r.block.conv1.conv.weight.detach().float().contiguous(), None, wd, None,
+                                                     r.cout, up_first=True, cu_packed=self.dec[k + 1].shape[-1])
             enc, den = self.net.embed_model, self.net.model
             self.e_vit = self._pack_vit(enc.swinViT, 8)
             self.d_vit = self._pack_vit(den.swinViT, self.cin0, self.perm0)
@@ -334,7 +356,7 @@ class SwinPlan:
     def _tadd(self, off, c):
         return None if off is None else self.cur_add[:, off:off + c]
 
-    def _res_block(self, r, x, cin, out, out_off=0, post_add=None, ra=None, ra_off=0, side=False, defer=False):
+    def _res_block(self, r, x, cin, out, out_off=0, post_add=None, ra=None, ra_off=0, side=False, defer=False, up_src=None):
         """UnetResBlock.forward (blocks.py:298-316) on channels [0, cin) of ``x`` -> channels [out_off, ...) of ``out``.
         ``side``: use the second set of scratch buffers (blocks running on the side stream, see denoiser_body).
         ``defer``: do not materialise the output; return (raw2, norm2, res, norm3) for a consumer that assembles it (tail)."""
@@ -353,7 +375,12 @@ class SwinPlan:
         assert r.has3 or not defer
 
         def convs():
-            ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws, background=bg, tap_channel=r.tap)
+            if up_src is not None:
+                # conv1 over cat((up, skip)) with the transposed convolution folded in: the skip half of x, the coarse activation
+                w_skip, wu, btab = r.fold
+                ops.upconv_k3(x, cin - r.cout, r.cout, up_src, up_src.shape[-1], 0, None, w_skip, wu, btab, r.cout, raw1, 0, r.st[0])
+            else:
+                ops.conv3d_k3(x, cin, 0, r.w1, r.b1, r.cout, raw1, 0, r.st[0], workspace=ws, background=bg, tap_channel=r.tap)
             ops.conv3d_k3(raw1, r.cout, 0, r.w2, r.b2, r.cout, raw2, 0, r.st[1], norm=n1, workspace=ws, background=bg)
 
         # conv3 reads the block's input only, so on the side stream it could go first and land under the Swin chain's small GEMMs
@@ -536,16 +563,17 @@ class SwinPlan:
         for k in (4, 3, 2, 1, 0):                                                  # decoder5 .. decoder1
             cout = cat[k].shape[-1] // 2
             wp, bp = self.up_packed[k]
-            ops.deconv_k2s2(src, src.shape[-1], 0, wp, bp, cout, cat[k], 0)
+            ops.deconv_k2s2(src, self.dec_c[k + 1], 0, wp, bp, cout, cat[k], 0)
             if two and k < 4:
                 main.wait_event(self.enc_done[k])                                  # the skip half of cat[k]
             ra = cat[k] if k < 4 else None                                         # + r_k (not for decoder5: skip = hs[3])
             if k == 0 and self.fused_tail:
                 # decoder1's output is consumed by the `out` convolution only: the tail assembles it from the block's two
                 # branches instead of reading it back (saves writing and re-reading 2 x 113 MB at 96^3)
-                self._tail_src = self._res_block(self.u_res[0], cat[0], 2 * cout, dec[0], 0, defer=True) + (cat[0], cout, cout)
+                self._tail_src = self._res_block(self.u_res[0], cat[0], 2 * cout, dec[0], 0, defer=True,
+                                                 up_src=src if self.fold_up[0] else None) + (cat[0], cout, cout)
                 break
-            self._res_block(self.u_res[k], cat[k], 2 * cout, dec[k], 0, ra=ra, ra_off=cout)
+            self._res_block(self.u_res[k], cat[k], 2 * cout, dec[k], 0, ra=ra, ra_off=cout, up_src=src if self.fold_up[k] else None)
             src = dec[k]
 
     def _gemm_scratch(self, nbytes, which=0):

@@ -120,7 +120,8 @@ int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_pack
  * output write and the re-read of it are gone); the transposed convolution's bias becomes one of 27 per-border-class bias
  * vectors (taps that fall outside the volume see no bias).  Same function of the same parameters; the composed weights are
  * formed in fp32 and rounded once to fp16.  D, H, W: OUTPUT extents (multiples of 8); u is the coarse tensor
- * [N][D/2][H/2][W/2][Cu_stride] (channels-last, a RAW convolution output whose producer descriptor u_in is mandatory);
+ * [N][D/2][H/2][W/2][Cu_stride] (channels-last; u_in = the producer descriptor of a RAW convolution output, or NULL when u is already
+ * an activation);
  * xskip holds x_e on the fine grid (channels-last or 16-channel blocks).  DUA_F16 only; Cskip % 16 == 0, Cu % 64 == 0,
  * Cu <= 256.  dua_upconv_k3_supported: 1 when the descriptor can be launched (callers fall back to
  * dua_deconv_k2s2_fwd + dua_conv3d_k3_fwd otherwise). */
@@ -133,13 +134,16 @@ typedef struct {
   int layout;                           /* DUA_IN_BLOCKED: xskip in 16-channel blocks; DUA_OUT_BLOCKED: y in 16-channel blocks */
 } dua_upconv_desc;
 int dua_upconv_k3_supported(const dua_upconv_desc* d);
-/* wc: Conv3d weight fp32 [Cout][Cskip + Cmid][3][3][3] (input channels [Cskip, Cskip + Cmid) are the upsampled half), bc its
- * bias [Cout] or NULL; wd: ConvTranspose3d weight fp32 [Cu][Cmid][2][2][2], bd its bias [Cmid] or NULL.  Writes the composed
- * weights (fp16, the order the kernel streams them) and bias_table fp32 [27][ceil(Cout/64)*64] (class = (cd*3 + ch)*3 + cw,
- * 0 = low border, 1 = interior, 2 = high border).  Returns the bytes of wu_packed (query with wu_packed == NULL).  The skip
- * half's weights are packed by dua_pack_conv3_weights(dtype, Cout, Cskip + Cmid, Cskip, wc, NULL, ...). */
-long dua_pack_upconv_weights(int dtype, int Cout, int Cskip, int Cmid, int Cu, const float* wc, const float* bc, const float* wd,
-                             const float* bd, void* wu_packed, float* bias_table, void* stream);
+/* wc: Conv3d weight fp32 [Cout][Cskip + Cmid][3][3][3]; up_first = 0: input channels [0, Cskip) are x_e and [Cskip, Cskip + Cmid)
+ * the upsampled half (torch.cat([x_e, x_0]), models/basic_unet/denoiser.py:190); up_first = 1: the upsampled half comes first
+ * (torch.cat((out, skip)), MONAI UnetrUpBlock as used by models/swin_unetr/denoiser.py:388-397).  bc: its bias [Cout] or NULL.
+ * wd: ConvTranspose3d weight fp32 [Cu][Cmid][2][2][2] (rows of zero-padding channels of u: zeros), bd its bias [Cmid] or NULL.
+ * Writes the composed weights (fp16, the order the kernel streams them) and bias_table fp32 [27][ceil(Cout/64)*64] (class =
+ * (cd*3 + ch)*3 + cw, 0 = low border, 1 = interior, 2 = high border).  Returns the bytes of wu_packed (query with wu_packed ==
+ * NULL).  The skip half's weights are packed by dua_pack_conv3_weights(dtype, Cout, Cskip + Cmid, Cskip, wc, in_perm, ...) with
+ * in_perm = NULL (up_first = 0) or the channels [Cmid, Cmid + Cskip) (up_first = 1). */
+long dua_pack_upconv_weights(int dtype, int Cout, int Cskip, int Cmid, int Cu, int up_first, const float* wc, const float* bc,
+                             const float* wd, const float* bd, void* wu_packed, float* bias_table, void* stream);
 int dua_upconv_k3_fwd(const dua_upconv_desc* d, const void* xskip, const void* u, const dua_in_norm* u_in, const void* w_skip_packed,
                       const void* wu_packed, const float* bias_table, void* y, dua_stat_word* out_stats, void* stream);
 

@@ -177,3 +177,38 @@ def test_upconv_refuses_what_it_cannot_run():
     assert not ops.upconv_supported(torch.float16, 1, 12, 96, 96, 64, 128, 64, 64, 64, 64)        # depth not a multiple of 8
     assert not ops.upconv_supported(torch.float16, 1, 96, 96, 96, 24, 128, 64, 64, 64, 64)        # skip half not in 16-channel half chunks
     assert not ops.upconv_supported(torch.float16, 1, 96, 96, 96, 64, 128, 96, 96, 64, 64)        # coarse channels not in groups of 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 48, 48, 48, 48, 32, 32, 32), (2, 48, 96, 48, 48, 16, 16, 24)])
+def test_upconv_swin_decoder_form(shape):
+    """The Swin-UNETR decoder's shape of the same fold (MONAI UnetrUpBlock under models/swin_unetr/denoiser.py:388-397):
+    torch.cat((up, skip)) -- the upsampled half FIRST --, 48-channel widths (the coarse buffer padded to a 64-channel stride with
+    zeros, the skip half at channel offset 48 of the 96-channel concat buffer, 48 outputs on a 64-wide tile), a transposed
+    convolution without bias, and a coarse input that already is an activation (no producer descriptor)."""
+    ops = _ops()
+    dt = torch.float16
+    N, Cs, Cu, Cmid, Cout, D, H, W = shape
+    cu_packed = -(-Cu // 64) * 64
+    g = torch.Generator().manual_seed(sum(shape))
+    skip = torch.randn(N, Cs, D, H, W, generator=g)
+    u = torch.randn(N, Cu, D // 2, H // 2, W // 2, generator=g)
+    wc = torch.randn(Cout, Cmid + Cs, 3, 3, 3, generator=g) / (27 * (Cs + Cmid)) ** 0.5
+    bc = torch.randn(Cout, generator=g)
+    wd = torch.randn(Cu, Cmid, 2, 2, 2, generator=g) / Cu ** 0.5
+    up = F.conv_transpose3d(u.to(dt).float(), wd, None, stride=2)
+    ref = F.conv3d(torch.cat([up, skip.to(dt).float()], 1), wc, bc, padding=1)
+    cat = torch.full((N, D, H, W, Cmid + Cs), 3.0, dtype=dt, device="cuda")
+    ops.to_channels_last(skip.cuda(), cat, Cmid, Cs)
+    ubuf = torch.zeros((N, D // 2, H // 2, W // 2, cu_packed), dtype=dt, device="cuda")
+    ops.to_channels_last(u.cuda(), ubuf, 0, Cu)
+    y = torch.full((N, D, H, W, Cout), -5.0, dtype=dt, device="cuda")
+    w_skip, wu, btab = ops.pack_upconv_weights(wc.cuda(), bc.cuda(), wd.cuda(), None, Cs, up_first=True, cu_packed=cu_packed)
+    stats = ops.stats_buffer(N, Cout, "cuda")
+    ops.upconv_k3(cat, Cs, Cmid, ubuf, cu_packed, 0, None, w_skip, wu, btab, Cout, y, 0, stats)
+    got = ops.from_channels_last(y, Cout, 0).cpu()
+    err = (got - ref).abs()
+    assert torch.allclose(got, ref, **TOL16), (float(err.max()), [int(v) for v in torch.nonzero(err == err.max())[0]])
+    st = ops.stats_decode(stats).cpu()[:, :Cout]
+    gd = got.double().flatten(2)
+    assert bool(((st[..., 0] - gd.sum(-1)).abs() <= 1e-3 * gd.abs().sum(-1) + 0.5).all())

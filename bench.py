@@ -643,8 +643,17 @@ def run_config2(args, D):
         D.barrier()
         finite = bool(torch.isfinite(plan.x_state).all())
 
+    # config 2 end to end, whatever --steps says: the 1000-step loop through the public sampler API, on every rank (replicas).
+    # THIS is the headline: the loop the parity test covers (test_thousand_step_p_sample_loop_matches_oracle), with the two
+    # exact-fp32 finishing steps of an fp16 plan inside the timed region; the K replayed steps above are kept beside it.  It runs
+    # BEFORE rank 0's per-kernel measurements (the bare-MFMA probe holds the chip at its power cap for two seconds).
+    loop = None
+    if not args.no_graph and not args.no_full_loop:
+        loop = full_loop_config2(net, image, (B, CLASSES, 96, 96, 96), D)
+    with torch.no_grad():
         roof = None
         if rank == 0 and not args.no_roofline:
+            ops.to_channels_last(x_T, plan.xin, 0, plan.C)       # a defined input for the per-launch timings
             roof = conv_roofline(plan, args.dtype)
     if rank == 0 and roof is not None:
         roof["traffic"] = getattr(args, "traffic", None)   # measured by main() before this process touched the GPU
@@ -657,12 +666,6 @@ def run_config2(args, D):
             roof["frac_of_ceiling"] = round(roof["achieved"] / ceil_tf, 4)
             # the matrix pipes run what is EXECUTED: the folded launch is priced by its executed figure against the ceiling
             roof["largest_launch"]["frac_of_ceiling"] = round(roof["largest_launch"].get("executed_tflops", roof["largest_launch"]["tflops"]) / ceil_tf, 4)
-    # config 2 end to end, whatever --steps says: the 1000-step loop through the public sampler API, on every rank (replicas).
-    # THIS is the headline: the loop the parity test covers (test_thousand_step_p_sample_loop_matches_oracle), with the two
-    # exact-fp32 finishing steps of an fp16 plan inside the timed region; the K replayed steps above are kept beside it.
-    loop = None
-    if not args.no_graph and not args.no_full_loop:
-        loop = full_loop_config2(net, image, (B, CLASSES, 96, 96, 96), D)
     if rank == 0:
         replayed_ms = dt / args.steps * 1e3
         ms = loop["seconds"] / loop["steps"] * 1e3 if loop is not None else replayed_ms

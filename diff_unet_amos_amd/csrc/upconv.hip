@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  DUA_STAMP_AT(60, false);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     s[q] += __shfl_xor(s[q], 32);
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
     if (hh3 == 0) { ex[(wave * BN + q * 32 + r3) * 2] = s[q]; ex[(wave * BN + q * 32 + r3) * 2 + 1] = ss[q]; }
   }
   __syncthreads();
+  DUA_STAMP_AT(61, false);
   if (wave == 0) {
     double S = 0, Q = 0;
 #pragma unroll

@@ -73,6 +73,8 @@ def main():
           " + ".join(str(med(st[:, 31 + g] - (st[:, 30 + g]))) for g in range(G)) + f" (MFMA 8192 per group) | "
           f"epilogue {med(st[:, 63] - st[:, 62])}")
     print("    phases:", " ".join(str(p) for p in ph))
+    print(f"    epilogue split: read + stage + store (wave 0) {med(st[:, 60] - st[:, 62])} | sums to LDS + workgroup barrier {med(st[:, 61] - st[:, 60])} | "
+          f"final reduction + atomics {med(st[:, 63] - st[:, 61])}")
     border = st[:, 3] - st[:, 2]
     print(f"    prologue: quartiles {int(np.percentile(border, 25))} / {int(np.percentile(border, 75))} / max {int(border.max())}")
 

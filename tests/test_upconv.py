@@ -212,3 +212,67 @@ def test_upconv_swin_decoder_form(shape):
     st = ops.stats_decode(stats).cpu()[:, :Cout]
     gd = got.double().flatten(2)
     assert bool(((st[..., 0] - gd.sum(-1)).abs() <= 1e-3 * gd.abs().sum(-1) + 0.5).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_upconv_random_shapes(seed):
+    """Seeded random draws over everything the descriptor lets vary: batch, ragged extents (multiples of 8), skip / coarse / middle /
+    output channel counts, channel offsets and strides of all three buffers, blocked or channels-last buffers, with and without a
+    producer descriptor, either channel order of the concat."""
+    import random
+    ops = _ops()
+    dt = torch.float16
+    rnd = random.Random(1000 + seed)
+    N = rnd.choice([1, 1, 2])
+    D, H, W = (8 * rnd.randint(1, 3) for _ in range(3))
+    Cs, Cu, Cmid = 16 * rnd.randint(1, 4), 64 * rnd.randint(1, 2), 8 * rnd.randint(1, 9)
+    Cout = 8 * rnd.randint(1, 17)
+    up_first = rnd.random() < 0.4
+    with_norm = rnd.random() < 0.6
+    blocked = rnd.random() < 0.4 and not up_first
+    soff = (Cmid if up_first else 16 * rnd.randint(0, 1))
+    if blocked:
+        soff = 16 * rnd.randint(0, 1)
+    sstride = soff + Cs + 16 * rnd.randint(0, 1)
+    if blocked:
+        sstride = -(-sstride // 16) * 16
+    uoff, ooff = 8 * rnd.randint(0, 2), 16 * rnd.randint(0, 1)
+    ustride, ostride = uoff + Cu + 8 * rnd.randint(0, 1), -(-(ooff + Cout + 16 * rnd.randint(0, 1)) // 16) * 16
+    g = torch.Generator().manual_seed(seed)
+    skip = torch.randn(N, Cs, D, H, W, generator=g)
+    raw_u = torch.randn(N, Cu, D // 2, H // 2, W // 2, generator=g) * 1.5 + 0.25
+    cin = Cs + Cmid
+    wc = torch.randn(Cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    bc = torch.randn(Cout, generator=g) if rnd.random() < 0.7 else None
+    wd = torch.randn(Cu, Cmid, 2, 2, 2, generator=g) / Cu ** 0.5
+    bd = torch.randn(Cmid, generator=g) if rnd.random() < 0.7 else None
+    if with_norm:
+        from test_kernels_gpu import _producer
+        norm, act = _producer(raw_u, dt, g, add=torch.randn(N, Cu, generator=g))
+        act = act.to(dt).float()
+    else:
+        norm, act = None, raw_u.to(dt).float()
+    up = F.conv_transpose3d(act, wd, bd, stride=2)
+    parts = [up, skip.to(dt).float()] if up_first else [skip.to(dt).float(), up]
+    ref = F.conv3d(torch.cat(parts, 1), wc, bc, padding=1)
+    xbuf = torch.full((N, D, H, W, sstride), 3.0, dtype=dt, device="cuda")
+    ops.to_channels_last(skip.cuda(), xbuf, soff, Cs)
+    if blocked:
+        xbuf = ops.to_blocked(xbuf)
+    ubuf = torch.full((N, D // 2, H // 2, W // 2, ustride), 2.0, dtype=dt, device="cuda")
+    ops.to_channels_last(raw_u.cuda(), ubuf, uoff, Cu)
+    ybuf = torch.full((N, D, H, W, ostride), -5.0, dtype=dt, device="cuda")
+    w_skip, wu, btab = ops.pack_upconv_weights(wc.cuda(), None if bc is None else bc.cuda(), wd.cuda(), None if bd is None else bd.cuda(),
+                                               Cs, up_first=up_first)
+    stats = ops.stats_buffer(N, Cout, "cuda")
+    ops.upconv_k3(xbuf, Cs, soff, ubuf, Cu, uoff, norm, w_skip, wu, btab, Cout, ybuf, ooff, stats, in_blocked=blocked, out_blocked=blocked)
+    ycl = ops.from_blocked(ybuf) if blocked else ybuf
+    got = ops.from_channels_last(ycl, Cout, ooff).cpu()
+    desc = dict(N=N, dims=(D, H, W), Cs=Cs, Cu=Cu, Cmid=Cmid, Cout=Cout, up_first=up_first, norm=with_norm, blocked=blocked,
+                soff=soff, sstride=sstride, uoff=uoff, ustride=ustride, ooff=ooff, ostride=ostride)
+    assert torch.allclose(got, ref, **TOL16), (float((got - ref).abs().max()), desc)
+    if ooff:
+        assert float((ycl[..., :ooff].float() + 5).abs().max()) == 0, desc
+    if ooff + Cout < ostride:
+        assert float((ycl[..., ooff + Cout:].float() + 5).abs().max()) == 0, desc

@@ -739,6 +739,7 @@ def run_config3(args, D):
         if rank == 0 and not args.no_roofline:      # the conv kernel over one denoiser evaluation of the sampler's own plan
             roof = conv_roofline(net._rt.plan(swb, (96, 96, 96), dev), "f16")
             roof["note"] = f"one denoiser evaluation at batch {swb} (the windows of one sampler pass)"
+            roof["traffic"] = getattr(args, "traffic", None)       # bytes per launch of the wide kernel at that batch (PMC child passes)
     if rank == 0:
         per = dt / args.steps
         gather_s = timings.get("all_gather_s", 0.0) / max(1, args.steps)
@@ -932,11 +933,16 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
-    if args.gpus == 1 and not (args.no_roofline or args.no_traffic) and args.config in (2, 4, 5):
+    if args.gpus == 1 and not (args.no_roofline or args.no_traffic) and args.config in (2, 3, 4, 5):
         # two short child runs of this script under rocprofv3 --pmc, started before this process initialises the GPU; the kernel
         # is the one the roofline object of that config describes
         if args.config == 2:
             args.traffic = measure_traffic(args.dtype, WIDE_KERNEL if (args.dtype == "f16" and not args.conv_variant) else CONV_KERNEL)
+        elif args.config == 3:
+            # one sampler pass of sw_batch windows (a 168 x 168 x 96 volume = 2 x 2 x 1 windows at sw_batch_size 4): the same launches
+            # as the benchmarked volume's passes
+            v = ["168", "168", "96"] if args.sw_batch == 4 else [str(96 + 72 * (args.sw_batch - 1)), "96", "96"]
+            args.traffic = measure_traffic("f16", WIDE_KERNEL, 3, ["--volume"] + v + ["--sw-batch", str(args.sw_batch), "--steps", "1", "--warmup", "0"])
         elif args.config == 4:
             args.traffic = measure_traffic("f16", "conv3d_k3_wgrad_fo_kernel", 4, ["--flat-allreduce"] + (["--batch", str(args.batch)] if args.batch else []))
         else:

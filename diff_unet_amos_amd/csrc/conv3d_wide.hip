@@ -49,6 +49,9 @@ __device__ __forceinline__ void dma_piece(const char* src_lane, unsigned lds_dst
                : "=&s"(keep) : "v"(src_lane), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 
+#ifndef WIDE_LA
+#define WIDE_LA 1         // half-steps of A fragments in flight ahead of the MFMAs of the K loop
+#endif
 // MB = 32-voxel blocks per wave: 4 (8x8x8 tile, wave = depth slices 2w and 2w+1) or 2 (4x8x8 tile, wave = depth slice w)
 template <int MB>
 __device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const int d0, const int h0, const int w0,
@@ -227,7 +230,7 @@ __device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const 
   auto phase = [&](int kd, int slot) __attribute__((always_inline)) {
     const char* hp = halo + kd * PSF;
     const char* wb = wbuf + slot * WPLANE + b_base;
-    f16x8 fa[2][2], fb[2][2];                                    // [buffer][block of the pair] / [buffer][cout half]
+    f16x8 fa[WIDE_LA + 1][2], fb[2][2];                          // [buffer][block of the pair] / [buffer][cout half]
     auto ldA = [&](int t, int sub, int b) {
       const int kh = t / 3, kw = t - kh * 3;
       const char* ap = hp + ((kh & 1) ? a_odd : a_even) + sub * PSF + kh * RSF + kw * VSF;
@@ -239,20 +242,22 @@ __device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const 
       fb[b][1] = *(const f16x8*)(wb + t * 2048 + 512);
     };
     ldB(0, 0);
-    ldA(0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < WIDE_LA; ++h) ldA(h / NH, h % NH, h);
 #pragma unroll
     for (int h = 0; h < 9 * NH; ++h) {
       const int t = h / NH, sub = h % NH;
-      if (h + 1 < 9 * NH) {
-        const int t1 = (h + 1) / NH, sub1 = (h + 1) % NH;
-        if (sub1 == 0) ldB(t1, t1 & 1);
-        ldA(t1, sub1, (h + 1) & 1);
+      if (h + WIDE_LA < 9 * NH) {
+        const int t1 = (h + WIDE_LA) / NH, sub1 = (h + WIDE_LA) % NH;
+        if (WIDE_LA == 1 && sub1 == 0) ldB(t1, t1 & 1);
+        ldA(t1, sub1, (h + WIDE_LA) % (WIDE_LA + 1));
       }
+      if (WIDE_LA > 1 && sub == 0 && t + 1 < 9) ldB(t + 1, (t + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);                         // keep the requests ahead of the MFMAs (hipcc sinks them otherwise)
-      mma32(acc[2 * sub][0], fa[h & 1][0], fb[t & 1][0]);
-      mma32(acc[2 * sub][1], fa[h & 1][0], fb[t & 1][1]);
-      mma32(acc[2 * sub + 1][0], fa[h & 1][1], fb[t & 1][0]);
-      mma32(acc[2 * sub + 1][1], fa[h & 1][1], fb[t & 1][1]);
+      mma32(acc[2 * sub][0], fa[h % (WIDE_LA + 1)][0], fb[t & 1][0]);
+      mma32(acc[2 * sub][1], fa[h % (WIDE_LA + 1)][0], fb[t & 1][1]);
+      mma32(acc[2 * sub + 1][0], fa[h % (WIDE_LA + 1)][1], fb[t & 1][0]);
+      mma32(acc[2 * sub + 1][1], fa[h % (WIDE_LA + 1)][1], fb[t & 1][1]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };

@@ -59,6 +59,9 @@ __device__ __forceinline__ void upc_dma_piece(const char* src_lane, unsigned lds
 
 // GG = groups of 64 coarse channels (1 or 2): compile-time, so that the registers of a second group's prefetch and of the
 // statistics words of channels that do not exist are not allocated
+#ifndef UPC_LA
+#define UPC_LA 1          // half-steps of A fragments in flight ahead of the MFMAs of the skip half's K loop
+#endif
 template <int GG>
 __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(UpConvArgs a) {
   using namespace upc;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
   auto phase = [&](int kd, int slot) __attribute__((always_inline)) {
     const char* hp = halo + kd * PS + (((pd + kd) >> 1) ? A1 : A0);
     const char* wb = ring + slot * WPLANE + b_base;
-    f16x8 fa[2][2], fb[2][2];
+    f16x8 fa[UPC_LA + 1][2], fb[2][2];
     auto ldA = [&](int t, int sub, int b) {
       const int kh = t / 3, kw = t - kh * 3;
       const char* ap = hp + sub * 4 * PS + kh * RS + kw * VS;
@@ -320,21 +323,24 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void upconv_k3_kernel(
       fb[b][0] = *(const f16x8*)(wb + t * 2048);
       fb[b][1] = *(const f16x8*)(wb + t * 2048 + 512);
     };
+    // the fragments of half-step h + UPC_LA are requested before the MFMAs of half-step h issue (B pairs: one tap ahead)
     ldB(0, 0);
-    ldA(0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < UPC_LA; ++h) ldA(h >> 1, h & 1, h);
 #pragma unroll
     for (int h = 0; h < 18; ++h) {
       const int t = h >> 1, sub = h & 1;
-      if (h + 1 < 18) {
-        const int t1 = (h + 1) >> 1, sub1 = (h + 1) & 1;
-        if (sub1 == 0) ldB(t1, t1 & 1);
-        ldA(t1, sub1, (h + 1) & 1);
+      if (h + UPC_LA < 18) {
+        const int t1 = (h + UPC_LA) >> 1, sub1 = (h + UPC_LA) & 1;
+        if (UPC_LA == 1 && sub1 == 0) ldB(t1, t1 & 1);
+        ldA(t1, sub1, (h + UPC_LA) % (UPC_LA + 1));
       }
+      if (UPC_LA > 1 && sub == 0 && t + 1 < 9) ldB(t + 1, (t + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      named_mfma_sel(4 * sub + 0, fa[h & 1][0], fb[t & 1][0]);
-      named_mfma_sel(4 * sub + 1, fa[h & 1][0], fb[t & 1][1]);
-      named_mfma_sel(4 * sub + 2, fa[h & 1][1], fb[t & 1][0]);
-      named_mfma_sel(4 * sub + 3, fa[h & 1][1], fb[t & 1][1]);
+      named_mfma_sel(4 * sub + 0, fa[h % (UPC_LA + 1)][0], fb[t & 1][0]);
+      named_mfma_sel(4 * sub + 1, fa[h % (UPC_LA + 1)][0], fb[t & 1][1]);
+      named_mfma_sel(4 * sub + 2, fa[h % (UPC_LA + 1)][1], fb[t & 1][0]);
+      named_mfma_sel(4 * sub + 3, fa[h % (UPC_LA + 1)][1], fb[t & 1][1]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -513,74 +519,120 @@ __device__ __forceinline__ int upc_taps(int phi, int delta, int* k, int* child) 
   k[0] = 2; child[0] = 0; return 1;
 }
 
-__global__ void upconv_pack_kernel(int Cout, int Cskip, int Cmid, int Cu, int up_off, const float* __restrict__ wc,
-                                   const float* __restrict__ wd, f16* __restrict__ out, long total) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  // idx = position in the packed order
-  long t = idx;
-  const int e = t & 7; t >>= 3;
-  const int r = t & 31; t >>= 5;
-  const int hh = t & 1; t >>= 1;
-  const int q = t & 1; t >>= 1;
-  const int dw = t & 1; t >>= 1;
-  const int pw = t & 1; t >>= 1;
-  const int hcl = t & 3; t >>= 2;
-  const int dh = t & 1; t >>= 1;
-  const int dd = t & 1; t >>= 1;
-  const int G = Cu >> 6;
-  const int g = t % G; t /= G;
-  const int wave = t & 3; t >>= 2;
-  const int ct = (int)t;
-  const int pd = wave >> 1, ph = wave & 1;
-  const int co = ct * 64 + q * 32 + r, ci = g * 64 + hcl * 16 + hh * 8 + e;
-  float accv = 0.f;
+// One workgroup = one output channel co x 32 coarse channels: its Conv3d rows wc[co][up_off + cm][27] sit in LDS; thread = (ci, phi)
+// keeps the 27 (tap, child) sums of its phase -- per dimension the three pairs (k, child) of phi, every k once -- over cm and adds
+// them into its 8 deltas in the order (x, y, z) of upc_taps.  (Round 5's first form, one thread per packed element with two
+// strided 4-byte loads per multiply, took 104 us for the 96^3 level -- every training step packs.)
+__global__ __launch_bounds__(256) void upconv_pack_kernel(int Cout, int Cskip, int Cmid, int Cu, int up_off, const float* __restrict__ wc,
+                                                          const float* __restrict__ wd, f16* __restrict__ out, long total) {
+  extern __shared__ float arow[];                                // [Cmid][27]
+  const int nci = Cu >> 5;
+  const int co = blockIdx.x / nci, ci = (blockIdx.x - co * nci) * 32 + (threadIdx.x >> 3), phi = threadIdx.x & 7;
+  const int Cin = Cskip + Cmid;
+  const int cout_pad = (Cout + 63) / 64 * 64;
+  if (co < Cout)
+    for (int i = threadIdx.x; i < Cmid * 27; i += 256) arow[i] = wc[((long)co * Cin + up_off) * 27 + i];
+  __syncthreads();
+  const int pd = phi >> 2, ph = (phi >> 1) & 1, pw = phi & 1;
+  // per dimension: the pairs (k, child) of phase p in the order delta 0, delta 1 (upc_taps): p = 0: (0,1) | (1,0) (2,1);  p = 1: (0,0) (1,1) | (2,0)
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.f;
   if (co < Cout && ci < Cu) {
-    int kd[2], ad[2], kh[2], ah[2], kw[2], aw[2];
-    const int nd = upc_taps(pd, dd, kd, ad), nh = upc_taps(ph, dh, kh, ah), nw = upc_taps(pw, dw, kw, aw);
-    const int Cin = Cskip + Cmid;
-    for (int x = 0; x < nd; ++x)
-      for (int y = 0; y < nh; ++y)
-        for (int z = 0; z < nw; ++z) {
-          const int tap = (kd[x] * 3 + kh[y]) * 3 + kw[z], child = (ad[x] * 2 + ah[y]) * 2 + aw[z];
-          const float* wcp = wc + ((long)co * Cin + up_off) * 27 + tap;
-          const float* wdp = wd + (long)ci * Cmid * 8 + child;
-          float sacc = 0.f;
-          for (int cm = 0; cm < Cmid; ++cm) sacc = fmaf(wcp[(long)cm * 27], wdp[(long)cm * 8], sacc);
-          accv += sacc;
-        }
+    const float* wdp = wd + (long)ci * Cmid * 8;
+    for (int cm = 0; cm < Cmid; ++cm) {
+      const f32x4 w0 = *(const f32x4*)(wdp + cm * 8), w1 = *(const f32x4*)(wdp + cm * 8 + 4);
+      float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+      // child of tap k under phase p, per dimension: ((k + 1) & 1) ^ p -- the children are permuted by phi once (three conditional
+      // swaps), then every tap's child index is a constant
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const float x = wv[c], y = wv[c + 4]; wv[c] = pd ? y : x; wv[c + 4] = pd ? x : y; }
+#pragma unroll
+      for (int c = 0; c < 8; c += 4)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const float x = wv[c + j], y = wv[c + j + 2]; wv[c + j] = ph ? y : x; wv[c + j + 2] = ph ? x : y; }
+#pragma unroll
+      for (int c = 0; c < 8; c += 2) { const float x = wv[c], y = wv[c + 1]; wv[c] = pw ? y : x; wv[c + 1] = pw ? x : y; }
+      const float* ar = arow + cm * 27;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int child0 = (((kd + 1) & 1) * 2 + ((kh + 1) & 1)) * 2 + ((kw + 1) & 1);
+            acc[(kd * 3 + kh) * 3 + kw] = fmaf(ar[(kd * 3 + kh) * 3 + kw], wv[child0], acc[(kd * 3 + kh) * 3 + kw]);
+          }
+    }
   }
-  out[idx] = (f16)accv;
+  // delta of tap k under phase p: p = 0: k 0 -> delta 0, k 1, 2 -> delta 1;  p = 1: k 0, 1 -> delta 0, k 2 -> delta 1
+  const int ct = co >> 6, q = (co >> 5) & 1, r = co & 31;
+  const int G = Cu >> 6, g = ci >> 6, hcl = (ci >> 4) & 3, hh = (ci >> 3) & 1, e = ci & 7;
+  const int wave = pd * 2 + ph;
+  if (co >= cout_pad || ci >= Cu) return;
+#pragma unroll
+  for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        float v = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const bool in_d = (pd == 0 ? (kd == 0 ? 0 : 1) : (kd == 2 ? 1 : 0)) == dd;
+              const bool in_h = (ph == 0 ? (kh == 0 ? 0 : 1) : (kh == 2 ? 1 : 0)) == dh;
+              const bool in_w = (pw == 0 ? (kw == 0 ? 0 : 1) : (kw == 2 ? 1 : 0)) == dw;
+              if (in_d && in_h && in_w) v += acc[(kd * 3 + kh) * 3 + kw];
+            }
+        const long idx = (((((((((((long)ct * 4 + wave) * G + g) * 2 + dd) * 2 + dh) * 4 + hcl) * 2 + pw) * 2 + dw) * 2 + q) * 2 + hh) * 32 + r) * 8 + e;
+        if (idx < total) out[idx] = (f16)v;
+      }
 }
 
-// bias table [27 classes = (cd, ch, cw), 0 = low border, 1 = interior, 2 = high border][cout_pad]
-__global__ void upconv_bias_kernel(int Cout, int Cskip, int Cmid, int up_off, int cout_pad, const float* __restrict__ wc,
-                                   const float* __restrict__ bc, const float* __restrict__ bd, float* __restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 27 * cout_pad) return;
-  const int cls = idx / cout_pad, co = idx - cls * cout_pad;
-  float v = 0.f;
-  if (co < Cout) {
-    const int cd = cls / 9, ch = (cls / 3) % 3, cw = cls % 3;
-    const int Cin = Cskip + Cmid;
-    v = bc ? bc[co] : 0.f;
-    if (bd) {
+// bias table [27 classes = (cd, ch, cw), 0 = low border, 1 = interior, 2 = high border][cout_pad]: one workgroup per output
+// channel; T[tap] = sum_cm wc[co][up_off + cm][tap] * bd[cm] from coalesced reads (9 groups of 27 threads over cm), then one
+// thread per class adds the taps that stay inside the volume
+__global__ __launch_bounds__(256) void upconv_bias_kernel(int Cout, int Cskip, int Cmid, int up_off, int cout_pad, const float* __restrict__ wc,
+                                                          const float* __restrict__ bc, const float* __restrict__ bd, float* __restrict__ out) {
+  __shared__ float part[9][27];
+  __shared__ float T[27];
+  const int co = blockIdx.x, t = threadIdx.x;
+  const int Cin = Cskip + Cmid;
+  if (t < 243) {
+    const int grp = t / 27, tap = t - grp * 27;
+    float sacc = 0.f;
+    if (co < Cout && bd)
+      for (int cm = grp; cm < Cmid; cm += 9) sacc = fmaf(wc[((long)co * Cin + up_off + cm) * 27 + tap], bd[cm], sacc);
+    part[grp][tap] = sacc;
+  }
+  __syncthreads();
+  if (t < 27) {
+    float v = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 9; ++gq) v += part[gq][t];
+    T[t] = v;
+  }
+  __syncthreads();
+  if (t < 27) {
+    const int cd = t / 9, ch = (t / 3) % 3, cw = t % 3;
+    float v = (co < Cout && bc) ? bc[co] : 0.f;
+    if (co < Cout)
       for (int kd = 0; kd < 3; ++kd) {
         if ((cd == 0 && kd == 0) || (cd == 2 && kd == 2)) continue;
         for (int kh = 0; kh < 3; ++kh) {
           if ((ch == 0 && kh == 0) || (ch == 2 && kh == 2)) continue;
           for (int kw = 0; kw < 3; ++kw) {
             if ((cw == 0 && kw == 0) || (cw == 2 && kw == 2)) continue;
-            const float* wcp = wc + ((long)co * Cin + up_off) * 27 + (kd * 3 + kh) * 3 + kw;
-            float sacc = 0.f;
-            for (int cm = 0; cm < Cmid; ++cm) sacc = fmaf(wcp[(long)cm * 27], bd[cm], sacc);
-            v += sacc;
+            v += T[(kd * 3 + kh) * 3 + kw];
           }
         }
       }
-    }
+    out[t * cout_pad + co] = v;
   }
-  out[idx] = v;
 }
 
 static bool upconv_desc_ok(const dua_upconv_desc* d) {
@@ -613,11 +665,11 @@ long dua_pack_upconv_weights(int dtype, int Cout, int Cskip, int Cmid, int Cu, i
   if (!wu_packed) return total * 2;
   if (!wc || !wd || !bias_table) return DUA_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(dua::upconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Cout, Cskip, Cmid, Cu, up_off, wc, wd,
-                     (dua::f16*)wu_packed, total);
   const int cout_pad = nct * 64;
-  hipLaunchKernelGGL(dua::upconv_bias_kernel, dim3((27 * cout_pad + 255) / 256), dim3(256), 0, s, Cout, Cskip, Cmid, up_off, cout_pad, wc, bc, bd,
-                     bias_table);
+  if ((size_t)Cmid * 27 * sizeof(float) > 64 * 1024) return DUA_ERR_ARG;
+  hipLaunchKernelGGL(dua::upconv_pack_kernel, dim3((unsigned)(cout_pad * (Cu / 32))), dim3(256), (size_t)Cmid * 27 * sizeof(float), s, Cout, Cskip,
+                     Cmid, Cu, up_off, wc, wd, (dua::f16*)wu_packed, total);
+  hipLaunchKernelGGL(dua::upconv_bias_kernel, dim3(cout_pad), dim3(256), 0, s, Cout, Cskip, Cmid, up_off, cout_pad, wc, bc, bd, bias_table);
   const int e = (int)hipGetLastError();
   return e ? -(long)e : total * 2;
 }

@@ -506,6 +506,8 @@ def _wgrad_ws(nbytes, device):
 
 _SPLITK_WS = {}
 TRAIN_SPLITK = True          # tools/bench_train_ab.py switches it off for a same-process comparison
+TRAIN_FOLD_UPCONV = True     # training forward: UpCat's convolution over the concat as the folded launch (dua_upconv_k3_fwd)
+TRAIN_FOLD_MIN_TILES = 1024  # ... where the launch has at least this many 8x8x8 tiles (96^3: 1728 per sample)
 
 
 def splitk_ws(dtype, N, D, H, W, cin, cout, device):

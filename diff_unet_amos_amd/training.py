@@ -280,12 +280,16 @@ class _ConvNormAct(torch.autograd.Function):
     backward = norm/activation backward (reduce + apply) -> data gradient (conv kernel) + weight gradient kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False, cat_extra=0, temb_state=None, temb_index=0, packs=None):
+    def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False, cat_extra=0, temb_state=None, temb_index=0, packs=None,
+                fold=None):
         """``temb_state``: ``add`` is the block-major add buffer of the whole evaluation (_TembAdds) and this block uses rows
         ``temb_index`` of it (_TembState); otherwise ``add`` is this block's own [N, cout] tensor or None.
         ``cat_extra`` > 0: the activation is the skip of a decoder level -- it is written into channels [0, cout) of a buffer
         with ``cat_extra`` more channels (the half the transposed convolution fills later, _UpCat) and returned as that view:
-        torch.cat((x_e, upsampled)) (denoiser.py:190) costs no copy (226 MB moved per step at level 0 otherwise)."""
+        torch.cat((x_e, upsampled)) (denoiser.py:190) costs no copy (226 MB moved per step at level 0 otherwise).
+        ``fold`` = (lo, deconv weight, deconv bias, skip channels): ``x`` is the concat buffer _UpCat filled from ``lo``; the
+        FORWARD convolution then runs as the folded launch on (skip half of x, lo) with composed weights (dua_upconv_k3_fwd, 58
+        instead of 196 GFLOP per sample for the upsampled half at level 0); backward is unchanged and reads x as before."""
         from . import ops
         N, D, H, W, cs = x.shape
         cout = weight.shape[0]
@@ -299,7 +303,13 @@ class _ConvNormAct(torch.autograd.Function):
         ctx.packs = packs
         raw = torch.empty((N, D, H, W, cout), dtype=x.dtype, device=x.device)
         stats = ops.stats_buffer(N, cout, x.device)
-        ops.conv3d_k3(x, cs, 0, wp, bp, cout, raw, 0, stats, workspace=ops.splitk_ws(x.dtype, N, D, H, W, cs, cout, x.device))
+        if fold is not None:
+            lo, wd, bd, cskip = fold
+            w_skip, wu, btab = ops.pack_upconv_weights(weight.detach().float().contiguous(), bias.detach().float(),
+                                                       wd.detach().float().contiguous(), bd.detach().float(), cskip, x.dtype)
+            ops.upconv_k3(x, cskip, 0, lo, lo.shape[-1], 0, None, w_skip, wu, btab, cout, raw, 0, stats)
+        else:
+            ops.conv3d_k3(x, cs, 0, wp, bp, cout, raw, 0, stats, workspace=ops.splitk_ws(x.dtype, N, D, H, W, cs, cout, x.device))
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         if add is not None and temb_state is not None:
             a32 = temb_state.rows(add.detach(), temb_index)
@@ -348,10 +358,10 @@ class _ConvNormAct(torch.autograd.Function):
             dw = ops.zeros(tuple(weight.shape), torch.float32, x.device)
             _wgrad(x, dY, cout, dw)
         db = ops.zeros((cout,), torch.float32, x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
-        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None, None, None, None, None, None
 
 
-def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0, packs=None):
+def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0, packs=None, fold=None):
     """``temb``: None (the encoder's blocks) or (add, state): the evaluation's block-major add buffer (_TembAdds) and its
     _TembState; the blocks take their rows in call order."""
     add = state = None
@@ -362,7 +372,8 @@ def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0, packs=None):
         state.next += 1
         assert block.temb_proj.weight.shape[0] == state.couts[index]
     c0, c1 = block.conv_0, block.conv_1
-    h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None, False, 0, state, index, packs)
+    h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None, False, 0, state, index, packs,
+                           fold)
     return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb, pool, cat_extra, None, 0,
                               packs)
 
@@ -456,7 +467,16 @@ def native_logits_cl(net, image, x, step, dtype=torch.float16):
 
     def up(block, lo, skip):
         dc = block.upsample.deconv
-        return _two_conv_cl(block.convs, _UpCat.apply(lo, skip, dc.weight, dc.bias), temb, packs=packs)
+        cat = _UpCat.apply(lo, skip, dc.weight, dc.bias)
+        fold = None
+        N, D, H, W, cs = skip.shape
+        cout = block.convs.conv_0.conv.weight.shape[0]
+        # the forward convolution over the concat as ONE folded launch where the level has rounds of tiles to fill (level 0)
+        if (ops.TRAIN_FOLD_UPCONV and dtype == torch.float16 and N * (D // 8) * (H // 8) * (W // 8) >= ops.TRAIN_FOLD_MIN_TILES
+                and D % 8 == 0 and H % 8 == 0 and W % 8 == 0 and lo.is_contiguous()
+                and ops.upconv_supported(dtype, N, D, H, W, cs, cat.shape[-1], lo.shape[-1], lo.shape[-1], cout, cout)):
+            fold = (lo.detach(), dc.weight, dc.bias, cs)
+        return _two_conv_cl(block.convs, cat, temb, packs=packs, fold=fold)
 
     u4 = up(den.upcat_4, x4, x3)
     u3 = up(den.upcat_3, u4, x2)

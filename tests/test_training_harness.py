@@ -432,6 +432,49 @@ def test_graph_trainer_resumes_from_a_checkpoint(when):
 
 
 @pytest.mark.gpu
+def test_training_forward_fold_equals_the_unfolded_forward():
+    """ops.TRAIN_FOLD_UPCONV: UpCat's first convolution runs as the folded launch in the FORWARD of the training step (composed
+    weights, dua_upconv_k3_fwd) where a level has enough tiles; backward is the unfolded one either way.  At 32^3 with the tile
+    threshold lowered levels 0 and 1 fold: logits and every parameter gradient against the same network unfolded."""
+    from diff_unet_amos_amd import ops
+    from diff_unet_amos_amd.training import native_logits_cl, _SegLoss
+    kw = dict(in_channels=1, out_channels=16)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    nets = [DiffUNet(**kw).to(dev)]
+    nets.append(DiffUNet(**kw).to(dev))
+    nets[1].load_state_dict(nets[0].state_dict())
+    g = torch.Generator().manual_seed(43)
+    image = torch.rand(2, 1, 32, 32, 32, generator=g).to(dev)
+    labels = (torch.rand(2, 16, 32, 32, 32, generator=g) > 0.8).float().to(dev)
+    x_t = torch.randn(2, 16, 32, 32, 32, generator=g).to(dev)
+    t = torch.tensor([417, 83], device=dev)
+    seen = []
+    real = ops.upconv_k3
+    keep = (ops.TRAIN_FOLD_UPCONV, ops.TRAIN_FOLD_MIN_TILES)
+    try:
+        ops.TRAIN_FOLD_MIN_TILES = 1
+        ops.upconv_k3 = lambda *a, **k: (seen.append(tuple(a[0].shape)), real(*a, **k))[1]
+        outs = []
+        for net, fold in zip(nets, (True, False)):
+            ops.TRAIN_FOLD_UPCONV = fold
+            logits = native_logits_cl(net, image, x_t, t, torch.float16)
+            (_SegLoss.apply(logits, labels) * 4096.0).backward()
+            outs.append(logits.detach().float())
+    finally:
+        ops.upconv_k3 = real
+        ops.TRAIN_FOLD_UPCONV, ops.TRAIN_FOLD_MIN_TILES = keep
+    assert [s[1] for s in seen] == [16, 32], seen            # levels 1 and 0, in the order the decoder runs; never with the fold off
+    assert (outs[0] - outs[1]).abs().max().item() < 3e-2
+    num = den = 0.0
+    for (k, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        if k.endswith("conv.bias") or a.grad is None:
+            continue
+        num += float(((a.grad.double() - b.grad.double()) ** 2).sum()); den += float((b.grad.double() ** 2).sum())
+    assert (num / den) ** 0.5 < 3e-2, (num / den) ** 0.5
+
+
+@pytest.mark.gpu
 def test_full_size_gradients_fp16_path_vs_oracle():
     """Config-4 geometry (96^3 patch, 16 classes, full feature widths; batch 1 to bound the CPU oracle's time): parameter
     gradients of the fp16 HIP training path against the oracle network under torch autograd in fp32 on the host."""

@@ -14,17 +14,21 @@ from diff_unet_amos_amd.training import NativeConvTrainer         # noqa: E402
 
 
 def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    pos = [a for a in sys.argv[1:] if not a.startswith("-")]
+    rounds = int(pos[0]) if len(pos) > 0 else 5
+    steps = int(pos[1]) if len(pos) > 1 else 5
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     base = DiffUNet(in_channels=1, out_channels=16).to(dev)
     image = torch.rand(2, 1, 96, 96, 96, device=dev)
     labels = (torch.rand(2, 16, 96, 96, 96, device=dev) > 0.8).float()
     # constructor arguments; "_option": (1 | 4, value) = ops.CONV_POLICY / ops.WGRAD_POLICY in force while the trainer captures; "_ops": attributes of diff_unet_amos_amd.ops set while this trainer warms up and captures its graph
-    settings = {"default": {}, "weight gradients in line with the backward chain": {"wgrad_overlap": False},
-                "no split-K scratch for the training convolutions": {"_ops": {"TRAIN_SPLITK": False}},
-                "weight-gradient tiles through registers (ops.WGRAD_POLICY = 128)": {"_option": (4, 128)}}
+    settings = {"default": {},
+                "forward convolution over the level-0 concat unfolded": {"_ops": {"TRAIN_FOLD_UPCONV": False}}}
+    if "--all" in sys.argv:
+        settings.update({"weight gradients in line with the backward chain": {"wgrad_overlap": False},
+                         "no split-K scratch for the training convolutions": {"_ops": {"TRAIN_SPLITK": False}},
+                         "weight-gradient tiles through registers (ops.WGRAD_POLICY = 128)": {"_option": (4, 128)}})
     from diff_unet_amos_amd import ops, _native as nv
     trainers = {}
     for name, kv in settings.items():

@@ -75,6 +75,14 @@ def main():
     print("    phases:", " ".join(str(p) for p in ph))
     print(f"    epilogue split: read + stage + store (wave 0) {med(st[:, 60] - st[:, 62])} | sums to LDS + workgroup barrier {med(st[:, 61] - st[:, 60])} | "
           f"final reduction + atomics {med(st[:, 63] - st[:, 61])}")
+    t0, t1 = (st[:, 0] - st[:, 0].min()) * 0.01, (st[:, 1] - st[:, 0].min()) * 0.01       # us
+    edges = np.arange(0, span + 10, 10.0)
+    act = [int(((t0 < e + 5) & (t1 > e + 5)).sum()) for e in edges[:-1]]
+    print("    workgroups in flight at 5, 15, 25, ... us:", " ".join(str(a) for a in act))
+    order = np.argsort(t0)
+    life = (t1 - t0)[order]
+    q = len(life) // 8
+    print("    lifetime by start order (eighths, median us):", " ".join(f"{np.median(life[i * q:(i + 1) * q]):.1f}" for i in range(8)))
     border = st[:, 3] - st[:, 2]
     print(f"    prologue: quartiles {int(np.percentile(border, 25))} / {int(np.percentile(border, 75))} / max {int(border.max())}")
 

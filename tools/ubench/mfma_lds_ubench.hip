@@ -26,7 +26,7 @@ constexpr int BN = 64, KG = 4, SLAB = 3 * KG * BN * 16;    // 12 KB weight slab 
 // 16-wide k-steps of each tap (pairs of waves share a tile); BAR: 0 none, 1 one s_barrier per 12 KB slab;
 // STAGE: 1 = every thread also moves its share of the next weight slab global -> regs -> LDS per slab.
 template <int MA, int KSPLIT, int BAR, int STAGE, int NT, int S16 = 0>
-__global__ __launch_bounds__(NT) void loop_kernel(const char* __restrict__ src, const char* __restrict__ wsrc, float* out,
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void loop_kernel(const char* __restrict__ src, const char* __restrict__ wsrc, float* out,
                                                   int nslabs, int halo_bytes, unsigned long long* clk) {
   constexpr int RS = Geo<S16>::RS, PS = Geo<S16>::PS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -45,10 +45,10 @@ __global__ __launch_bounds__(NT) void loop_kernel(const char* __restrict__ src, 
   for (int m = 0; m < NA; ++m) {
     if (S16) {
       const int c = mq * NA + m, row = lane & 15;
-      a_base[m] = (c >> 2) * PS + ((c & 3) * 2 + (row >> 3)) * RS + (row & 7) * VS + (lane >> 4) * 16;
+      a_base[m] = ((c >> 2) & 3) * PS + ((c & 3) * 2 + (row >> 3)) * RS + (row & 7) * VS + (lane >> 4) * 16;
     } else {
       const int b = mq * MA + m, r = lane & 31;
-      a_base[m] = (b >> 1) * PS + ((b & 1) * 4 + (r >> 3)) * RS + (r & 7) * VS + (lane >> 5) * 16;
+      a_base[m] = ((b >> 1) & 3) * PS + ((b & 1) * 4 + (r >> 3)) * RS + (r & 7) * VS + (lane >> 5) * 16;
     }
   }
   const int b_base = S16 ? ((lane >> 4) * BN + (lane & 15)) * 16 : ((lane >> 5) * BN + (lane & 31)) * 16;
@@ -178,6 +178,41 @@ __global__ __launch_bounds__(NT) void mfma16_only_kernel(const char* __restrict_
   if (tid == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
 }
 
+// legacy 16x16x16 shape (K = 16: 4 input elements per lane), operands in registers: cycles per instruction on gfx950
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+template <int NBLK, int NT>
+__global__ __launch_bounds__(NT) void mfma16k16_only_kernel(const char* __restrict__ src, float* out, int nslabs, unsigned long long* clk) {
+  const int tid = threadIdx.x;
+  f16x4 fa[NBLK / 4], fb[4];
+#pragma unroll
+  for (int m = 0; m < NBLK / 4; ++m) fa[m] = *(const f16x4*)(src + ((tid * 8 + m) * 16) % (1 << 20));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) fb[q] = *(const f16x4*)(src + 65536 * q + 4096 + tid * 16);
+  f32x4 acc[NBLK];
+#pragma unroll
+  for (int m = 0; m < NBLK; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[m][i] = 0.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int g = 0; g < nslabs; ++g) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int m = 0; m < NBLK; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x16f16(fa[m / 4], fb[m % 4], acc[m], 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < NBLK; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[m][i];
+  out[(long)blockIdx.x * NT + tid] = s;
+  if (tid == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
 // operands in registers: the MFMA-only ceiling at the clock the chip holds on random data
 template <int MA, int NT>
 __global__ __launch_bounds__(NT) void mfma_only_kernel(const char* __restrict__ src, float* out, int nslabs, unsigned long long* clk) {
@@ -293,6 +328,22 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL((mfma16_only_kernel<16, 256>), dim3(CUS * 2), dim3(256), 0, 0, c.src, c.out, nslabs, c.clk); });
     run("mfma16-only 64x64 nt=512", c, CUS, 512, (double)nslabs * 3 * 16 * 8 * 0.5, [&]() {
       hipLaunchKernelGGL((mfma16_only_kernel<16, 512>), dim3(CUS), dim3(512), 0, 0, c.src, c.out, nslabs, c.clk); });
+  }
+  if (argc > 3) {   // cycles of the legacy K = 16 instruction against the K = 32 one (same count of instructions per block)
+    run("mfma16x16x32-only nt=256 x2 (FLOP as printed)", c, CUS * 2, 256, (double)nslabs * 3 * 16 * 4 * 0.5, [&]() {
+      hipLaunchKernelGGL((mfma16_only_kernel<16, 256>), dim3(CUS * 2), dim3(256), 0, 0, c.src, c.out, nslabs, c.clk); });
+    run("mfma16x16x16-only nt=256 x2 (HALF the FLOP printed)", c, CUS * 2, 256, (double)nslabs * 3 * 16 * 4 * 0.5, [&]() {
+      hipLaunchKernelGGL((mfma16k16_only_kernel<16, 256>), dim3(CUS * 2), dim3(256), 0, 0, c.src, c.out, nslabs, c.clk); });
+    return 0;
+  }
+  if (argc > 2) {   // round 5: the wide kernel's shape -- 2 workgroups x 4 waves per CU, 128x64 wave tiles (depth slices alias planes 0..3)
+    LAUNCH_LOOP(4, 0, 1, 2, 256, 0, CUS * 2, H6, H6 + 2 * SLAB)
+    LAUNCH_LOOP(4, 0, 1, 2, 256, 1, CUS * 2, G6, G6 + 2 * SLAB)
+    LAUNCH_LOOP(4, 0, 1, 0, 256, 0, CUS * 2, H6, H6 + 2 * SLAB)
+    LAUNCH_LOOP(4, 0, 1, 0, 256, 1, CUS * 2, G6, G6 + 2 * SLAB)
+    LAUNCH_LOOP(4, 0, 1, 2, 256, 0, CUS * 2, H6, H6 + 2 * SLAB)
+    LAUNCH_LOOP(4, 0, 1, 2, 256, 1, CUS * 2, G6, G6 + 2 * SLAB)
+    return 0;
   }
   // today's kernel shape: 2 workgroups x 4 waves per CU, 64x64 wave tiles
   LAUNCH_LOOP(2, 0, 1, 0, 256, 0, CUS * 2, H6, H6 + 2 * SLAB)

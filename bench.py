@@ -600,6 +600,7 @@ def run_config2(args, D):
     if args.fold_min_tiles is not None:
         net.upconv_min_tiles = args.fold_min_tiles
     net.fold_upconv = not args.no_fold
+    net.fold_residual = not args.no_fold_residual
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     B = args.batch or 1
     image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
@@ -826,6 +827,7 @@ def run_config5(args, D):
     torch.manual_seed(0)
     net = DiffSwinUNETR(in_channels=1, out_channels=CLASSES, feature_size=48, compute_dtype=dtype).to(dev).eval()
     net.fold_upconv = not args.no_fold
+    net.fold_residual = not args.no_fold_residual
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     B = args.batch or 1
     image = torch.rand(B, 1, 96, 96, 96, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
@@ -924,6 +926,7 @@ def main():
     ap.add_argument("--train-graph", action="store_true", help="config 4: whole step as one HIP graph")
     ap.add_argument("--fold-min-tiles", type=int, default=None, help="diagnostics: engine.Plan.UPCONV_MIN_TILES for this run (0 = fold every level that can; a huge value = never)")
     ap.add_argument("--no-fold", action="store_true", help="diagnostics: keep every transposed convolution + convolution on two launches (net.fold_upconv = False; A/B)")
+    ap.add_argument("--no-fold-residual", action="store_true", help="diagnostics (config 5): decoder1's 1x1x1 residual branch as transposed convolution + token GEMM (net.fold_residual = False; A/B)")
     ap.add_argument("--conv-variant", type=int, default=0, help="diagnostics: dua_conv3_desc.policy of every convolution launch (same-box A/B of launch forms)")
     args = ap.parse_args()
     defaults = {2: (200, 20), 3: (1, 0), 4: (5, 2), 5: (100, 10)}[args.config]

@@ -451,6 +451,218 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
   }
 }
 
+// ---- The 1x1x1 residual branch of a UnetResBlock over cat((ConvTranspose3d_k2s2(lo), skip)) in ONE launch (config 5, round 5) ----
+//   res[o] = W3_up . up[o] + W3_skip . skip[o],   up[2p + child] = Wd[child]^T lo[p]   (no bias in either layer: MONAI
+//   UnetrUpBlock / UnetResBlock as models/swin_unetr/denoiser.py:388-397 builds them)
+//          = (W3_up Wd[child]^T) lo[parent(o)] + W3_skip skip[o]
+// i.e. a transposed convolution with COMPOSED weights plus a pointwise term on the fine grid.  Once the block's 3x3x3 convolution
+// takes its upsampled half from lo directly (upconv.hip), nobody else reads `up`: this launch replaces the transposed
+// convolution (its 85 MB output write at 96^3) AND the token GEMM over the 96-channel concat (its re-read).  The all-taps
+// kernel above with, per tap pair, the 2 x 32 fine-grid rows of every wave staged next to the coarse tile (wave-private rows:
+// no workgroup barrier for them; requested before the previous pair's stores are issued) and NSK more 32-channel k-chunks
+// against the skip weights; the layer's InstanceNorm sums come out of the accumulators.  fp16, 128-voxel tiles, Cin <= 128.
+struct DeconvResArgs {
+  DeconvArgs base;
+  const void* xs; const void* ws; stat_t* stats;
+  int Cs, Cs_stride, Cs_off, cout_pad;
+};
+
+template <int NSK>
+__global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) {
+  using namespace dc;
+  using T = f16;
+  const DeconvArgs& a = ra.base;
+  constexpr int TM = 128, WR = 32, EPG = 8;
+  using Frag = f16x8;
+  constexpr int RB = 32 * 2 + 16;
+  constexpr int GPV = 4, VPI = 16, NST = 2 * WR / VPI;
+  constexpr int VSS = NSK * 64 + 16;                          // bytes per staged skip row (odd multiple of 16)
+  constexpr int GPM = 4 * NSK;                                // 16-byte pieces per skip row, padding included
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int VSA = a.nchunks * 64 + 16;
+  char* alds = smem;
+  char* wlds = alds + TM * VSA;                             // 2 pairs x 2 taps x nchunks x 4 KB
+  char* stg = wlds + 4 * a.nchunks * W_BYTES;               // 2 TM x RB
+  char* skw = stg + 2 * TM * RB;                            // NSK x 4 KB: the skip weights
+  char* skl = skw + NSK * W_BYTES;                          // [2 tk][TM] rows of VSS bytes
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const long vox = (long)a.D * a.H * a.W;
+  const long v0 = (long)blockIdx.x * TM;
+  const int ct = blockIdx.y, n = blockIdx.z;
+  const T* xin = (const T*)a.x + (long)n * vox * a.Cin_stride + a.Cin_off;
+  const int wtap = a.nchunks * W_BYTES;
+  const char* wsrc = (const char*)a.w + (long)ct * wtap;
+  const int kg_t = tid & 3;
+  const int H2 = 2 * a.H, W2 = 2 * a.W;
+  const T* xsk = (const T*)ra.xs + (long)n * vox * 8 * ra.Cs_stride + ra.Cs_off;
+  const int gp = ra.Cs >> 3;                                  // real pieces per skip row
+
+  constexpr int MCH = 4;
+  Frag f[MCH][TM / 64];
+#pragma unroll
+  for (int ch = 0; ch < MCH; ++ch) {
+    const int c0 = ch * 32 + kg_t * EPG;
+    const bool cok = ch < a.nchunks && c0 < a.Cin;
+#pragma unroll
+    for (int j = 0; j < TM / 64; ++j) {
+      const long v = v0 + (tid >> 2) + 64 * j;
+      f[ch][j] = *(const Frag*)(xin + (v < vox && cok ? v * a.Cin_stride + c0 : 0));
+    }
+  }
+  f32x4 wn[2][MCH];
+  auto load_pair = [&](int tp) {
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+      for (int j = 0; j < MCH; ++j)
+        wn[tk][j] = *(const f32x4*)(wsrc + (long)(2 * tp + tk) * a.nct * wtap + (j < a.nchunks ? (tid + 256 * j) * 16 : 0));
+  };
+  auto store_pair = [&](int tp) {
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+      for (int j = 0; j < MCH; ++j)
+        if (j < a.nchunks) *(f32x4*)(wlds + ((tp & 1) * 2 + tk) * wtap + (tid + 256 * j) * 16) = wn[tk][j];
+  };
+  // fine-grid rows of THIS wave for pair tp: piece = lane + 64 j -> (row = piece / GPM = 2 vl + tk, 16-byte group piece % GPM)
+  Frag skr[GPM];
+  auto load_skip = [&](int tp) {
+    const int ti = tp >> 1, tj = tp & 1;
+#pragma unroll
+    for (int j = 0; j < GPM; ++j) {
+      const int pid = lane + 64 * j, g = pid % GPM, row = pid / GPM;
+      const long v = v0 + wave * WR + (row >> 1);
+      const int vi = (int)(v < vox ? v : 0);
+      const int w = vi % a.W, t = vi / a.W, h = t % a.H, d = t / a.H;
+      const long ov = ((long)(2 * d + ti) * H2 + (2 * h + tj)) * W2 + 2 * w + (row & 1);
+      const bool ok = v < vox && g < gp;
+      skr[j] = *(const Frag*)(xsk + (ok ? ov * ra.Cs_stride + g * 8 : 0));
+      if (!ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) skr[j][e] = (T)0.f;
+      }
+    }
+  };
+  auto store_skip = [&]() {
+#pragma unroll
+    for (int j = 0; j < GPM; ++j) {
+      const int pid = lane + 64 * j, g = pid % GPM, row = pid / GPM;
+      *(Frag*)(skl + ((row & 1) * TM + wave * WR + (row >> 1)) * VSS + g * 16) = skr[j];
+    }
+  };
+  load_pair(0);
+  load_skip(0);
+  for (int i = tid; i < NSK * W_BYTES / 16; i += 256) *(f32x4*)(skw + i * 16) = *(const f32x4*)((const char*)ra.ws + (long)ct * NSK * W_BYTES + i * 16);
+#pragma unroll
+  for (int ch = 0; ch < MCH; ++ch) {
+    if (ch >= a.nchunks) break;
+    const int c0 = ch * 32 + kg_t * EPG;
+    const bool cok = c0 < a.Cin;
+#pragma unroll
+    for (int j = 0; j < TM / 64; ++j) {
+      const int vl = (tid >> 2) + 64 * j;
+      const bool ok = v0 + vl < vox && cok;
+      Frag g = f[ch][j];
+#pragma unroll
+      for (int e = 0; e < EPG; ++e) g[e] = ok ? g[e] : (T)0.f;
+      *(Frag*)(alds + vl * VSA + ch * 64 + kg_t * 16) = g;
+    }
+  }
+  store_pair(0);
+  store_skip();
+  __syncthreads();
+
+  T* yout = (T*)a.y + (long)n * vox * 8 * a.Cout_stride;
+  char* ot = stg + wave * 2 * WR * RB;
+  int ovb[NST];
+#pragma unroll
+  for (int it = 0; it < NST; ++it) {
+    const int j = it * VPI + lane / GPV;
+    const long v = v0 + wave * WR + (j >> 1);
+    const int vi = (int)(v < vox ? v : 0);
+    const int w = vi % a.W, t = vi / a.W, h = t % a.H, d = t / a.H;
+    ovb[it] = v < vox ? ((2 * d) * H2 + 2 * h) * W2 + 2 * w + (j & 1) : -1;
+  }
+  float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+  load_pair(1);
+  for (int tp = 0; tp < 4; ++tp) {
+    if (tp < 3) load_skip(tp + 1);                            // ahead of this pair's stores (vmcnt is in issue order)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc[tk][0][i] = 0.f; acc[tk][1][i] = 0.f; }
+      const char* wb = wlds + ((tp & 1) * 2 + tk) * wtap;
+      for (int ch = 0; ch < a.nchunks; ++ch) {
+#pragma unroll
+        for (int ks = 0; ks < KG / 2; ++ks) {
+          const Frag b0 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + r) * 16);
+          const Frag b1 = *(const Frag*)(wb + ch * W_BYTES + ((2 * ks + hh) * BN + 32 + r) * 16);
+          const Frag am = *(const Frag*)(alds + (wave * WR + r) * VSA + ch * 64 + (2 * ks + hh) * 16);
+          mma32(acc[tk][0], am, b0);
+          mma32(acc[tk][1], am, b1);
+        }
+      }
+#pragma unroll
+      for (int ch = 0; ch < NSK; ++ch) {
+#pragma unroll
+        for (int ks = 0; ks < KG / 2; ++ks) {
+          const Frag b0 = *(const Frag*)(skw + ch * W_BYTES + ((2 * ks + hh) * BN + r) * 16);
+          const Frag b1 = *(const Frag*)(skw + ch * W_BYTES + ((2 * ks + hh) * BN + 32 + r) * 16);
+          const Frag am = *(const Frag*)(skl + (tk * TM + wave * WR + r) * VSS + ch * 64 + (2 * ks + hh) * 16);
+          mma32(acc[tk][0], am, b0);
+          mma32(acc[tk][1], am, b1);
+        }
+      }
+    }
+    if (tp < 3) store_pair(tp + 1);
+    if (tp < 2) load_pair(tp + 2);
+    const int toff = ((tp >> 1) * H2 + (tp & 1)) * W2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = acc[tk][q][i];
+          s[q] += v;
+          ss[q] = fmaf(v, v, ss[q]);
+          *(T*)(ot + (2 * acc_row(i, hh) + tk) * RB + r * 2) = (T)v;
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < NST; ++it) {
+        const int j = it * VPI + lane / GPV, cg = lane % GPV;
+        if (ovb[it] >= 0 && ct * BN + q * 32 + cg * EPG < a.Cout)
+          *(Frag*)(yout + (long)(ovb[it] + toff) * a.Cout_stride + a.Cout_off + ct * BN + q * 32 + cg * EPG) = *(const Frag*)(ot + j * RB + cg * 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (tp < 3) store_skip();                                 // this wave's own rows: its reads of them are behind it
+    __syncthreads();      // the next pair's weights are in place, this pair's buffer is free
+  }
+  // ---- InstanceNorm sums of this layer: lane halves, waves (fixed order), one set of atomics ----
+  float* ex = (float*)stg;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    s[q] += __shfl_xor(s[q], 32);
+    ss[q] += __shfl_xor(ss[q], 32);
+    if (hh == 0) { ex[(wave * BN + q * 32 + r) * 2] = s[q]; ex[(wave * BN + q * 32 + r) * 2 + 1] = ss[q]; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double S = 0, Q = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { S += (double)ex[(w * BN + lane) * 2]; Q += (double)ex[(w * BN + lane) * 2 + 1]; }
+    if (ct * BN + lane < a.Cout) stats_add(ra.stats, n, ra.cout_pad, blockIdx.x & (STAT_REPLICAS - 1), ct * BN + lane, S, Q);
+  }
+}
+
+static inline int deconv_res_lds(int nchunks, int nsk) {
+  return 128 * (nchunks * 64 + 16) + 4 * nchunks * dc::W_BYTES + 2 * 128 * 80 + nsk * dc::W_BYTES + 2 * 128 * (nsk * 64 + 16);
+}
+
 // dynamic-LDS limits (raised once per device by ensure_prepared(), common.hpp)
 template <typename T> constexpr int deconv_plain_lds() {
   constexpr int OS = dc::BN * (int)sizeof(T) + 16;
@@ -463,6 +675,8 @@ static const LdsAttr kDeconvLdsAttrs[] = {
     {(const void*)deconv_k2s2_ksplit_kernel<float>, dcs::RED + 3 * 4 * 1024},
     {(const void*)deconv_k2s2_kernel<f16>, deconv_plain_lds<f16>()},
     {(const void*)deconv_k2s2_kernel<float>, deconv_plain_lds<float>()},
+    {(const void*)deconv_k2s2_res_kernel<1>, 160 * 1024}, {(const void*)deconv_k2s2_res_kernel<2>, 160 * 1024},
+    {(const void*)deconv_k2s2_res_kernel<3>, 160 * 1024}, {(const void*)deconv_k2s2_res_kernel<4>, 160 * 1024},
 };
 static const LdsAttrs kDeconvLdsReg(kDeconvLdsAttrs);
 
@@ -543,3 +757,48 @@ extern "C" int dua_deconv_k2s2_fwd(const dua_conv3_desc* d, const void* x, const
   if (d->dtype == DUA_F32) return dua::launch_deconv<float>(d, x, w_packed, bias_padded, in, y, (hipStream_t)stream);
   return DUA_ERR_ARG;
 }
+
+/* see include/dua_hip.h */
+extern "C" int dua_deconv_k2s2_res_supported(const dua_conv3_desc* d, int Cs) {
+  if (!d || d->dtype != DUA_F16 || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return 0;
+  if (d->Cin <= 0 || d->Cin % 8 || d->Cin > 128 || d->Cin_stride % 8 || d->Cin_off % 8 || d->Cin_off + d->Cin > d->Cin_stride) return 0;
+  if (d->Cout <= 0 || d->Cout % 8 || d->Cout_stride % 8 || d->Cout_off % 8 || d->Cout_off + d->Cout > d->Cout_stride) return 0;
+  if (Cs <= 0 || Cs % 8 || Cs > 128 || d->layout || d->policy) return 0;
+  const long vox = (long)d->D * d->H * d->W;
+  if (vox * 8 * (d->Cout_stride > 256 ? d->Cout_stride : 256) >= 0x7fffffffL) return 0;
+  return dua::deconv_res_lds((d->Cin + 31) / 32, (Cs + 31) / 32) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int dua_deconv_k2s2_res_fwd(const dua_conv3_desc* d, const void* lo, const void* w_packed, const void* xskip, int Cs,
+                                       int Cs_stride, int Cs_off, const void* ws_packed, void* y, dua_stat_word* stats, void* stream) {
+  using namespace dua;
+  if (!dua_deconv_k2s2_res_supported(d, Cs) || !lo || !w_packed || !xskip || !ws_packed || !y || !stats) return DUA_ERR_ARG;
+  if (Cs_stride % 8 || Cs_off % 8 || Cs_off + Cs > Cs_stride) return DUA_ERR_ARG;
+  if ((long)d->D * d->H * d->W * 8 * Cs_stride >= 0x7fffffffL) return DUA_ERR_ARG;
+  if (int e = ensure_prepared()) return e;
+  DeconvResArgs ra{};
+  DeconvArgs& a = ra.base;
+  a.x = lo; a.w = w_packed; a.bias = nullptr; a.y = y;
+  a.xf = make_xform(nullptr, d->Cin);
+  a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
+  a.Cin = d->Cin; a.Cin_stride = d->Cin_stride; a.Cin_off = d->Cin_off;
+  a.Cout = d->Cout; a.Cout_stride = d->Cout_stride; a.Cout_off = d->Cout_off;
+  a.nchunks = (d->Cin + 31) / 32;
+  a.nct = (d->Cout + dc::BN - 1) / dc::BN;
+  a.out_blk = 0;
+  ra.xs = xskip; ra.ws = ws_packed; ra.stats = (stat_t*)stats;
+  ra.Cs = Cs; ra.Cs_stride = Cs_stride; ra.Cs_off = Cs_off; ra.cout_pad = a.nct * dc::BN;
+  const int nsk = (Cs + 31) / 32;
+  const int lds = deconv_res_lds(a.nchunks, nsk);
+  const long vox = (long)d->D * d->H * d->W;
+  dim3 grid((unsigned)((vox + 127) / 128), a.nct, d->N);
+  hipStream_t s = (hipStream_t)stream;
+  switch (nsk) {
+    case 1: hipLaunchKernelGGL(deconv_k2s2_res_kernel<1>, grid, dim3(256), lds, s, ra); break;
+    case 2: hipLaunchKernelGGL(deconv_k2s2_res_kernel<2>, grid, dim3(256), lds, s, ra); break;
+    case 3: hipLaunchKernelGGL(deconv_k2s2_res_kernel<3>, grid, dim3(256), lds, s, ra); break;
+    default: hipLaunchKernelGGL(deconv_k2s2_res_kernel<4>, grid, dim3(256), lds, s, ra); break;
+  }
+  return (int)hipGetLastError();
+}
+

@@ -730,6 +730,46 @@ def deconv_k2s2(x, cin, cin_off, w_packed, bias_pad, cout, y, cout_off, norm=Non
                                           nv.ptr(y), nv.stream_ptr()), "dua_deconv_k2s2_fwd")
 
 
+def pack_deconv_res_weights(w3, wd, cskip, dtype=torch.float16, up_first=True, cu_packed=None):
+    """Weights of deconv_res (dua_deconv_k2s2_res_fwd): ``w3`` = the 1x1x1 convolution over cat((up, skip)) as a matrix
+    [Cout, Cmid + Cskip] (``up_first``: the upsampled half first, as torch.cat((up, skip)) of the Swin-UNETR decoder), ``wd`` =
+    ConvTranspose3d [Cu, Cmid, 2,2,2].  Returns (packed composed weights Cu -> Cout per tap, packed skip weights).  The
+    composition W3_up . Wd[child]^T is a handful of small matrix products at weight-load time (fp32)."""
+    assert w3.is_cuda and w3.dim() == 2 and wd.dim() == 5 and tuple(wd.shape[2:]) == (2, 2, 2)
+    cout = w3.shape[0]
+    cu, cmid = wd.shape[:2]
+    assert w3.shape[1] == cmid + cskip
+    w3 = w3.detach().float()
+    w3_up, w3_sk = (w3[:, :cmid], w3[:, cmid:]) if up_first else (w3[:, cskip:], w3[:, :cskip])
+    comp = torch.einsum("umk,om->uok", wd.detach().float().reshape(cu, cmid, 8), w3_up).contiguous()
+    if cu_packed is not None and cu_packed > cu:
+        comp = torch.cat([comp, torch.zeros(cu_packed - cu, cout, 8, dtype=comp.dtype, device=comp.device)], 0).contiguous()
+    wp, _ = pack_deconv_weights(comp.view(-1, cout, 2, 2, 2), None, dtype)
+    sk8 = w3_sk.t().contiguous()[:, :, None].expand(cskip, cout, 8).contiguous().view(cskip, cout, 2, 2, 2)
+    wsp, _ = pack_deconv_weights(sk8, None, dtype)
+    return wp, wsp
+
+
+def deconv_res_supported(dtype, N, D, H, W, cin, cin_stride, cout, cout_stride, cs):
+    """dua_deconv_k2s2_res_supported for COARSE extents D x H x W."""
+    d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, cin, cin_stride, 0, cout, cout_stride, 0)
+    return bool(nv.lib().dua_deconv_k2s2_res_supported(C.byref(d), cs))
+
+
+def deconv_res(lo, cin, cin_off, w_packed, xs, cs, cs_off, ws_packed, cout, y, cout_off, stats):
+    """res = conv1x1x1(cat((ConvTranspose3d_k2s2(lo), skip))) without the upsampled tensor (dua_deconv_k2s2_res_fwd): ``lo`` coarse
+    [N, D, H, W, *], ``xs`` / ``y`` on the 2x grid; accumulates the layer's InstanceNorm sums into ``stats``."""
+    _cl_check(lo, "lo"); _cl_check(xs, "xs"); _cl_check(y, "y")
+    N, D, H, W, cs_in = lo.shape
+    assert lo.dtype == xs.dtype == y.dtype == torch.float16
+    assert tuple(xs.shape[:4]) == tuple(y.shape[:4]) == (N, 2 * D, 2 * H, 2 * W)
+    assert cin_off + cin <= cs_in and cs_off + cs <= xs.shape[-1] and cout_off + cout <= y.shape[-1]
+    assert _RECORD is None, "not an op of dua_denoiser_step"
+    d = nv.Conv3Desc(nv.dt_code(lo.dtype), N, D, H, W, cin, cs_in, cin_off, cout, y.shape[-1], cout_off)
+    nv.check(nv.lib().dua_deconv_k2s2_res_fwd(C.byref(d), nv.ptr(lo), nv.ptr(w_packed), nv.ptr(xs), cs, xs.shape[-1], cs_off,
+                                              nv.ptr(ws_packed), nv.ptr(y), nv.ptr(stats), nv.stream_ptr()), "dua_deconv_k2s2_res_fwd")
+
+
 def pack_upconv_weights(wc, bc, wd, bd, cskip, dtype=torch.float16, up_first=False, cu_packed=None):
     """UpCat's first convolution with the transposed convolution folded in (dua_upconv_k3_fwd): ``wc`` / ``bc`` = Conv3d
     [Cout, Cskip + Cmid, 3,3,3] parameters, ``wd`` / ``bd`` = ConvTranspose3d [Cu, Cmid, 2,2,2] parameters.  ``up_first``: the

@@ -150,6 +150,16 @@ class SwinPlan:
                                    ops.upconv_supported(dtype, N, Dk, Hk, Wk, cout, 2 * cout, cu_p, cu_p, cout, cout))
         dec_stride = [c if not (1 <= i <= 2 and self.fold_up[i - 1]) else -(-c // 64) * 64 for i, c in enumerate(self.dec_c)]
         self.dec = [z(i if i else 0, dec_stride[i]) for i in range(6)]            # out, dec0..dec4 (levels 0, 1, 2, 3, 4, 5)
+        # ... and whose 1x1x1 residual branch (conv3 over the same concat) takes its upsampled half from the coarse tensor too
+        # (dua_deconv_k2s2_res_fwd: a transposed convolution with composed weights + a pointwise term on the skip half): then nobody
+        # reads the upsampled tensor and the transposed convolution is not launched at all -- decoder1 (<= 128 coarse channels)
+        self.res_up = [False] * 5
+        if bool(getattr(net, "fold_residual", True)):
+            for k in range(2):
+                if self.fold_up[k]:
+                    Dk, Hk, Wk = S[k + 1]
+                    cout = self.cat[k].shape[-1] // 2
+                    self.res_up[k] = ops.deconv_res_supported(dtype, N, Dk, Hk, Wk, self.dec_c[k + 1], dec_stride[k + 1], cout, cout, cout)
                                                             # so that the fused head + sampler tail runs its MFMA form
         # ---- shared scratch (the two networks never run concurrently)
         big = max(N * S[l][0] * S[l][1] * S[l][2] * c for l, c in ((0, f), (1, f), (2, 2 * f), (3, 4 * f), (4, 8 * f), (5, 16 * f)))
@@ -322,6 +332,10 @@ class SwinPlan:
                     wd = self.ups[k].transp_conv.conv.weight.detach().float().contiguous()
                     r.fold = ops.pack_upconv_weights(r.block.conv1.conv.weight.detach().float().contiguous(), None, wd, None,
                                                      r.cout, up_first=True, cu_packed=self.dec[k + 1].shape[-1])
+                    r.res_fold = None
+                    if self.res_up[k]:
+                        r.res_fold = ops.pack_deconv_res_weights(r.block.conv3.conv.weight.detach().reshape(r.cout, r.cin), wd, r.cout,
+                                                                 dt, up_first=True)
             enc, den = self.net.embed_model, self.net.model
             self.e_vit = self._pack_vit(enc.swinViT, 8)
             self.d_vit = self._pack_vit(den.swinViT, self.cin0, self.perm0)
@@ -392,7 +406,10 @@ class SwinPlan:
         if r.has3:
             res = self._view(b3, l, r.cout)
             x2 = x.view(-1, x.shape[-1])[:, :cin] if cin != x.shape[-1] else x.view(-1, cin)
-            if self.fused_linear and self.tl_conv3 and r.cout <= 64 and cin <= 384:
+            if up_src is not None and getattr(r, "res_fold", None) is not None:
+                wp3, ws3 = r.res_fold                # conv3 over cat((up, skip)) from the coarse tensor and the skip half: no `up`
+                ops.deconv_res(up_src, self.dec_c[l + 1], 0, wp3, x, cin - r.cout, r.cout, ws3, r.cout, res, 0, r.st[2])
+            elif self.fused_linear and self.tl_conv3 and r.cout <= 64 and cin <= 384:
                 ops.token_linear(x2, r.w3, None, "stats", out=res.view(-1, r.cout), stats=r.st[2], samples=N,
                                  background=self.background_conv3 if bg else 0)      # conv3 + norm3 sums
             elif self.wide_gemm:
@@ -562,8 +579,9 @@ class SwinPlan:
         src = dec[5]
         for k in (4, 3, 2, 1, 0):                                                  # decoder5 .. decoder1
             cout = cat[k].shape[-1] // 2
-            wp, bp = self.up_packed[k]
-            ops.deconv_k2s2(src, self.dec_c[k + 1], 0, wp, bp, cout, cat[k], 0)
+            if not self.res_up[k]:                                                  # (else: nobody reads the upsampled tensor)
+                wp, bp = self.up_packed[k]
+                ops.deconv_k2s2(src, self.dec_c[k + 1], 0, wp, bp, cout, cat[k], 0)
             if two and k < 4:
                 main.wait_event(self.enc_done[k])                                  # the skip half of cat[k]
             ra = cat[k] if k < 4 else None                                         # + r_k (not for decoder5: skip = hs[3])

@@ -186,6 +186,17 @@ int dua_instnorm_bwd_reduce(const dua_norm_bwd_desc* d, const void* dA, const vo
 int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
                            const double* sums, void* dY, float* dgamma, float* dbeta, float* dadd, void* stream);
 
+/* The 1x1x1 residual branch of MONAI's UnetResBlock over torch.cat((ConvTranspose3d_k2s2(lo), skip), 1) -- the decoder blocks of
+ * models/swin_unetr/denoiser.py:388-397 (UnetrUpBlock: transp_conv, cat, UnetResBlock whose conv3 is the 1x1x1 branch; no bias in
+ * either layer) -- as ONE launch:  res[o] = (W3_up Wd[child(o)]^T) lo[parent(o)] + W3_skip skip[o],  plus this layer's InstanceNorm
+ * sums.  d describes the transposed convolution as dua_deconv_k2s2_fwd does (N/D/H/W and Cin* of lo; Cout* of res on the 2D x 2H x 2W
+ * grid), with w_packed = dua_pack_deconv_weights of the COMPOSED weights [Cin][Cout][8]; xskip = Cs channels at Cs_off of a
+ * Cs_stride buffer on the fine grid; ws_packed = dua_pack_deconv_weights(Cs, Cout) of W3_skip^T repeated over the 8 taps (tap 0
+ * is read).  DUA_F16, channels-last, Cin <= 128, Cs <= 128.  dua_deconv_k2s2_res_supported: 1 when it can be launched. */
+int dua_deconv_k2s2_res_supported(const dua_conv3_desc* d, int Cs);
+int dua_deconv_k2s2_res_fwd(const dua_conv3_desc* d, const void* lo, const void* w_packed, const void* xskip, int Cs, int Cs_stride,
+                            int Cs_off, const void* ws_packed, void* y, dua_stat_word* stats, void* stream);
+
 /* Backward of nn.MaxPool3d(2) (denoiser.py:100,106) fused with the sum of x_l's two gradient paths:
  *   out[v] = dA[v] (or 0 when dA is NULL) + (v is the arg-max of its 2x2x2 window ? dP[window] : 0),
  * arg-max recomputed from the stored activation (first maximum in d,h,w scan order, as torch).  D, H, W = the

@@ -215,6 +215,43 @@ def test_upconv_swin_decoder_form(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 48, 96, 48, 48, 16, 16, 16), (2, 96, 64, 96, 96, 6, 10, 14), (1, 8, 32, 16, 24, 4, 6, 2),
+                                   (1, 48, 96, 48, 48, 48, 48, 48)])
+def test_deconv_res_matches_deconv_cat_pointwise(shape):
+    """dua_deconv_k2s2_res_fwd: the 1x1x1 residual branch of a UnetResBlock over torch.cat((ConvTranspose3d_k2s2(lo), skip)) without
+    the upsampled tensor -- against torch's three layers on the same fp16 operands; the coarse buffer padded to a 64-channel
+    stride, the skip half inside the concat buffer, ragged tile counts, one and two output-channel tiles; InstanceNorm sums."""
+    ops = _ops()
+    dt = torch.float16
+    N, Cs, Cu, Cmid, Cout, D, H, W = shape            # D, H, W: COARSE extents
+    cu_packed = -(-Cu // 64) * 64
+    g = torch.Generator().manual_seed(sum(shape))
+    skip = torch.randn(N, Cs, 2 * D, 2 * H, 2 * W, generator=g)
+    lo = torch.randn(N, Cu, D, H, W, generator=g)
+    w3 = torch.randn(Cout, Cmid + Cs, generator=g) / (Cmid + Cs) ** 0.5
+    wd = torch.randn(Cu, Cmid, 2, 2, 2, generator=g) / Cu ** 0.5
+    up = F.conv_transpose3d(lo.to(dt).float(), wd, None, stride=2)
+    ref = F.conv3d(torch.cat([up, skip.to(dt).float()], 1), w3[:, :, None, None, None])
+    cat = torch.full((N, 2 * D, 2 * H, 2 * W, Cmid + Cs), 3.0, dtype=dt, device="cuda")     # the upsampled half is never read
+    ops.to_channels_last(skip.cuda(), cat, Cmid, Cs)
+    lbuf = torch.zeros((N, D, H, W, cu_packed), dtype=dt, device="cuda")
+    ops.to_channels_last(lo.cuda(), lbuf, 0, Cu)
+    y = torch.full((N, 2 * D, 2 * H, 2 * W, Cout), -5.0, dtype=dt, device="cuda")
+    assert ops.deconv_res_supported(dt, N, D, H, W, Cu, cu_packed, Cout, Cout, Cs)
+    wp, wsp = ops.pack_deconv_res_weights(w3.cuda(), wd.cuda(), Cs, up_first=True)
+    stats = ops.stats_buffer(N, Cout, "cuda")
+    ops.deconv_res(lbuf, Cu, 0, wp, cat, Cs, Cmid, wsp, Cout, y, 0, stats)
+    got = ops.from_channels_last(y, Cout, 0).cpu()
+    err = (got - ref).abs()
+    assert torch.allclose(got, ref, **TOL16), (float(err.max()), [int(v) for v in torch.nonzero(err == err.max())[0]])
+    st = ops.stats_decode(stats).cpu()[:, :Cout]
+    gd = got.double().flatten(2)
+    assert bool(((st[..., 0] - gd.sum(-1)).abs() <= 1e-3 * gd.abs().sum(-1) + 0.5).all())
+    assert bool(((st[..., 1] - (gd * gd).sum(-1)).abs() <= 2e-3 * (gd * gd).sum(-1) + 0.5).all())
+    assert not ops.deconv_res_supported(dt, N, D, H, W, 192, 192, Cout, Cout, Cs)          # more than 128 coarse channels
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
 def test_upconv_random_shapes(seed):
     """Seeded random draws over everything the descriptor lets vary: batch, ragged extents (multiples of 8), skip / coarse / middle /

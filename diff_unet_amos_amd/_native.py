@@ -140,6 +140,8 @@ _SIGS = {
     "dua_mfma_probe": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
     "dua_chain_probe": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P]),
     "dua_deconv_k2s2_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.POINTER(InNorm), _P, _P]),
+    "dua_conv3d_k3_dgrad_reduce_supported": (C.c_int, [C.POINTER(Conv3Desc)]),
+    "dua_conv3d_k3_dgrad_reduce": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(InNorm), _P, _P]),
     "dua_deconv_k2s2_res_supported": (C.c_int, [C.POINTER(Conv3Desc), C.c_int]),
     "dua_deconv_k2s2_res_fwd": (C.c_int, [C.POINTER(Conv3Desc), _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "dua_q_sample": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P]),

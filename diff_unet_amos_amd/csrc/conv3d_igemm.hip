@@ -962,13 +962,21 @@ static int conv3_kernel_kind(const dua_conv3_desc* d, bool fused) {
   return 0;
 }
 
+// the owner of a data-gradient launch's output (dua_conv3d_k3_dgrad_reduce)
+struct BwdSums { const void* raw; int stride, off; const dua_in_norm* in; double* sums; };
+
 template <typename T>
 static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, const float* bias,
-                        const dua_in_norm* in, void* y, stat_t* stats, float* ws, long ws_bytes, hipStream_t s) {
+                        const dua_in_norm* in, void* y, stat_t* stats, float* ws, long ws_bytes, hipStream_t s,
+                        const BwdSums* bw = nullptr) {
   using namespace c3;
   constexpr int CK = KG * Elem<T>::EPG;
   Conv3Args a;
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
+  a.bw_raw = nullptr; a.bw_stride = a.bw_off = 0; a.bw_xf = make_xform(nullptr, d->Cout); a.bw_sums = nullptr;
+  if (bw) {
+    a.bw_raw = bw->raw; a.bw_stride = bw->stride; a.bw_off = bw->off; a.bw_xf = make_xform(bw->in, d->Cout); a.bw_sums = bw->sums;
+  }
   a.xf = make_xform(in, d->Cin);
   a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W;
   a.Cin = d->Cin; a.Cin_stride = d->Cin_stride; a.Cin_off = d->Cin_off;
@@ -1021,6 +1029,7 @@ static int launch_conv3(const dua_conv3_desc* d, const void* x, const void* w, c
     // (profiles/r5_conv_wide_persistent_named_acc_ab.txt) and kept for that A/B only
     if (kind == 2) return launch_conv3_wide(a, d->D, s, g_conv_variant >= 8, g_conv_variant == 9 ? 2 : 0);
   }
+  if (bw) return DUA_ERR_ARG;                                  // only the wide-tile form has the backward-sums epilogue
   const bool autop = g_conv_variant == 0 || g_conv_variant == 2 || g_conv_variant == 6 || g_conv_variant == 7 || g_conv_variant >= 8;       // the automatic policy; 6 = without the kd-plane form, 7 = without the wide-tile form (A/B)
   const bool big = g_conv_variant == 0 || g_conv_variant == 2 || g_conv_variant == 7 || g_conv_variant >= 8;          // kd-plane form for the layers that cannot put two workgroups on every CU
   if (ws != nullptr && autop) {
@@ -1112,6 +1121,22 @@ int dua_conv3d_k3_fwd(const dua_conv3_desc* d, const void* x, const void* w_pack
   if (d->dtype == DUA_F32)
     return dua::launch_conv3<float>(d, x, w_packed, bias_padded, in, y, out_stats, (float*)workspace, workspace_bytes, (hipStream_t)stream);
   return DUA_ERR_ARG;
+}
+
+int dua_conv3d_k3_dgrad_reduce_supported(const dua_conv3_desc* d) {
+  if (!d || d->dtype != DUA_F16 || d->layout || d->tap_channel_plus1 || d->background || dua::conv_variant_of(d) != 0) return 0;
+  return dua::conv3_kernel_kind(d, false) == 2 ? 1 : 0;
+}
+
+int dua_conv3d_k3_dgrad_reduce(const dua_conv3_desc* d, const void* dy, const void* w_packed, const float* bias_padded, void* dx,
+                               const void* raw, int raw_stride, int raw_off, const dua_in_norm* raw_in, double* sums, void* stream) {
+  if (!dua_conv3d_k3_dgrad_reduce_supported(d) || !dy || !w_packed || !bias_padded || !dx || !raw || !raw_in || !sums) return DUA_ERR_ARG;
+  if (d->Cin % 8 || d->Cout % 8 || d->Cin_stride % 8 || d->Cout_stride % 8 || d->Cin_off % 8 || d->Cout_off % 8) return DUA_ERR_ARG;
+  if (!raw_in->stats || !raw_in->gamma || !raw_in->beta || raw_in->c_pad < d->Cout || raw_in->count <= 0 ||
+      !(raw_in->slope >= 0.f && raw_in->slope <= 1.f) || raw_stride % 8 || raw_off % 8 || raw_off + d->Cout > raw_stride)
+    return DUA_ERR_ARG;
+  const dua::BwdSums bw{raw, raw_stride, raw_off, raw_in, sums};
+  return dua::launch_conv3<dua::f16>(d, dy, w_packed, bias_padded, nullptr, dx, nullptr, nullptr, 0, (hipStream_t)stream, &bw);
 }
 
 }  // extern "C"

@@ -53,7 +53,7 @@ __device__ __forceinline__ void dma_piece(const char* src_lane, unsigned lds_dst
 #define WIDE_LA 1         // half-steps of A fragments in flight ahead of the MFMAs of the K loop
 #endif
 // MB = 32-voxel blocks per wave: 4 (8x8x8 tile, wave = depth slices 2w and 2w+1) or 2 (4x8x8 tile, wave = depth slice w)
-template <int MB>
+template <int MB, bool BWD = false>
 __device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const int d0, const int h0, const int w0,
                                           const int ct, const int n, const int replica) {
   using namespace c3w;
@@ -166,6 +166,17 @@ __device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const 
       }
     }
   }
+  // backward-sums mode: mean / rstd / gamma / beta of the 64 channels this tile writes, from the forward statistics of the layer
+  // that owns them (wave w: channels 16 w ...), into 1 KB behind the transform tables
+  float* bwc = (float*)(smem + LDS_FIXED) + (fused ? 3 * a.Cin : 0);      // [4][64]: mean, rstd, gamma, beta
+  double bwS = 0, bwQ = 0;
+  float bwg = 0.f, bwb = 0.f;
+  constexpr bool bwd = BWD;                                     // its own kernel: in one kernel with the forward epilogue hipcc spilled 33 registers of BOTH
+  if (bwd) {
+    const int c = ct * BN + wave * 16 + (lane & 15), cc = c < a.Cout ? c : a.Cout - 1;
+    bwg = a.bw_xf.gamma[cc]; bwb = a.bw_xf.beta[cc];
+    stats_read_wave16(a.bw_xf.stats, n, a.bw_xf.c_pad, cc, bwS, bwQ);
+  }
   DUA_STAMP_AT(56, false);
   load_halo(0, 0, HD);
   DUA_STAMP_AT(57, false);
@@ -201,6 +212,16 @@ __device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const 
       xad[c] = am;
     }
     __syncthreads();
+  }
+  if (bwd && lane < 16) {
+    const double mean = bwS * a.bw_xf.inv_count;
+    double var = bwQ * a.bw_xf.inv_count - mean * mean;
+    var = var > 0 ? var : 0;
+    const int cl = wave * 16 + lane;
+    bwc[cl] = (float)mean;
+    bwc[64 + cl] = (float)(1.0 / sqrt(var + (double)a.bw_xf.eps));
+    bwc[128 + cl] = bwg;
+    bwc[192 + cl] = bwb;
   }
   DUA_STAMP_AT(60, false);
   DUA_STAMP_AT(61, false);
@@ -299,6 +320,91 @@ __device__ __forceinline__ void wide_tile(const Conv3Args& a, char* smem, const 
   const long nvox = (long)a.D * a.H * a.W;
   T* yout = (T*)a.y + (long)n * nvox * a.Cout_stride;
   float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+  if (bwd) {
+    // ---- backward-sums mode (training: this launch is a data gradient and its output the dA of the layer whose raw output is
+    // bw_raw).  The sums are taken where the rows leave: a lane of the store loop holds 8 channels of one voxel, so the layer's raw
+    // output arrives as one 16-byte load beside the 16-byte store, and the rounded dA it stores is what in_bwd_apply will read. ----
+    const int cg = lane & 7;
+    float m8[8], r8[8], g8[8], b8[8], s0[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      m8[e] = bwc[cg * 8 + e]; r8[e] = bwc[64 + cg * 8 + e]; g8[e] = bwc[128 + cg * 8 + e]; b8[e] = bwc[192 + cg * 8 + e];
+      s0[e] = s1[e] = s2[e] = 0.f;
+    }
+    const float slope = a.bw_xf.slope;
+    const T* rawn = (const T*)a.bw_raw + (long)n * nvox * a.bw_stride + a.bw_off + ct * BN + cg * 8;
+    const bool cok = ct * BN + cg * 8 < a.Cout;
+#pragma unroll
+    for (int pr = 0; pr < MB / 2; ++pr) {
+      const int gd = d0 + dsl + pr;
+      f16x8 yv[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int v = it * 8 + (lane >> 3);
+        const long vx = ((long)gd * a.H + h0 + (v >> 3)) * a.W + w0 + (v & 7);
+        yv[it] = *(const f16x8*)(rawn + (cok ? vx * a.bw_stride : 0));
+      }
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            *(T*)(ot + mm * 4096 + acc_row(i, hh) * 128 + (q * 32 + r) * 2) = (T)acc[2 * pr + mm][q][i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int v = it * 8 + (lane >> 3);
+        const int gh = h0 + (v >> 3), gw = w0 + (v & 7);
+        const f16x8 o = *(const f16x8*)(ot + v * 128 + cg * 16);
+        if (cok) {
+          *(f16x8*)(yout + chan_off(a.out_blk, ((long)gd * a.H + gh) * a.W + gw, a.Cout_off + ct * BN + cg * 8, a.Cout_stride, nvox)) = o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float zh = ((float)yv[it][e] - m8[e]) * r8[e];
+            const float z = fmaf(zh, g8[e], b8[e]);
+            const float dv = (float)o[e];
+            const float dz = z > 0.f ? dv : dv * slope;
+            s0[e] += dv; s1[e] += dz; s2[e] = fmaf(dz, zh, s2[e]);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // lanes with the same channel group (8 apart), then the four waves in a fixed order, then one double atomic per (sum, channel)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int sft = 8; sft < 64; sft <<= 1) {
+        s0[e] += __shfl_xor(s0[e], sft); s1[e] += __shfl_xor(s1[e], sft); s2[e] += __shfl_xor(s2[e], sft);
+      }
+    }
+    __syncthreads();                                             // every wave is past its staging rows and the tables
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ex[((wave * BN) + lane * 8 + e) * 3] = s0[e];
+        ex[((wave * BN) + lane * 8 + e) * 3 + 1] = s1[e];
+        ex[((wave * BN) + lane * 8 + e) * 3 + 2] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 3 * BN) {
+      const int which = tid / BN, c = tid - which * BN;
+      double acc_d = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc_d += (double)ex[(w * BN + c) * 3 + which];
+      if (ct * BN + c < a.Cout)
+        unsafeAtomicAdd(a.bw_sums + (((long)n * STAT_REPLICAS + replica) * a.bw_xf.c_pad + ct * BN + c) * 4 + which, acc_d);
+    }
+    DUA_STAMP_AT(63, false);
+    DUA_STAMP_AT(1, true);
+    return;
+  }
 #pragma unroll
   for (int pr = 0; pr < MB / 2; ++pr) {
 #pragma unroll
@@ -354,6 +460,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wide_kernel(Conv3Args a) {
   wide_tile<4>(a, smem, td * 8, th * 8, tw * 8, blockIdx.y, blockIdx.z, blockIdx.x & (STAT_REPLICAS - 1));
 }
 
+
+// the data-gradient launches of training whose output is another layer's dA (Conv3Args::bw_sums): backward-sums epilogue
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wide_bwd_kernel(Conv3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int per_slab = a.tiles_h * a.tiles_w;
+  const int tile = xcd_remap(blockIdx.x, a.ntiles);
+  const int td = tile / per_slab, rem = tile - td * per_slab, th = rem / a.tiles_w, tw = rem - th * a.tiles_w;
+  wide_tile<4, true>(a, smem, td * 8, th * 8, tw * 8, blockIdx.y, blockIdx.z, blockIdx.x & (STAT_REPLICAS - 1));
+}
 
 // ---- round 5: the same tile with PERSISTENT workgroups and the accumulators in v[128:255] by name (named_acc.hpp) ----
 // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its (cout tile, sample): bias, the statistics -> scale / shift
@@ -625,12 +740,18 @@ __global__ __launch_bounds__(256, 2) DUA_NAMED_ACC_KERNEL void conv3d_k3_wide_pt
   (void)ex;
 }
 
-static const LdsAttr kWideLdsAttrs[] = {{(const void*)conv3d_k3_wide_kernel, 80 * 1024}, {(const void*)conv3d_k3_wide_pt_kernel, 80 * 1024}};
+static const LdsAttr kWideLdsAttrs[] = {{(const void*)conv3d_k3_wide_kernel, 80 * 1024}, {(const void*)conv3d_k3_wide_pt_kernel, 80 * 1024},
+                                        {(const void*)conv3d_k3_wide_bwd_kernel, 80 * 1024}};
 static const LdsAttrs kWideLdsReg(kWideLdsAttrs);
 
 #ifdef DUA_STAMP
 extern "C" long dua_debug_stamps_wide(void* host, long bytes) { return stamps_out(host, bytes); }
 #endif
+
+bool conv3_wide_takes_bwd_sums(const Conv3Args& a) {
+  return a.bw_raw && a.bw_xf.stats && a.bw_xf.gamma && a.bw_xf.beta && a.bw_xf.c_pad >= a.Cout && a.bw_stride % 8 == 0 && a.bw_off % 8 == 0 &&
+         (long)a.D * a.H * a.W * a.bw_stride < 0x7fffffffL;
+}
 
 int launch_conv3_wide(Conv3Args a, int D, hipStream_t s, bool persistent, int stagger) {
   using namespace c3w;
@@ -640,8 +761,9 @@ int launch_conv3_wide(Conv3Args a, int D, hipStream_t s, bool persistent, int st
   if (a.out_blk && (a.Cout_off % 16 || a.Cout_stride % 16)) return DUA_ERR_ARG;
   a.tiles_h = a.H / 8; a.tiles_w = a.W / 8;
   a.ntiles = (D / 8) * a.tiles_h * a.tiles_w;
-  const int lds = LDS_FIXED + (a.xf.stats ? 3 * 4 * a.Cin : 0);
+  const int lds = LDS_FIXED + (a.xf.stats ? 3 * 4 * a.Cin : 0) + (a.bw_sums ? 1024 : 0);
   if (lds > 80 * 1024) return DUA_ERR_ARG;
+  if (a.bw_sums && (persistent || !conv3_wide_takes_bwd_sums(a))) return DUA_ERR_ARG;
   if (persistent) {
     // two workgroups per CU over the whole launch, shared by the (cout tile, sample) pairs; each walks its tiles with stride grid.x
     const int cus = device_cus();
@@ -654,7 +776,8 @@ int launch_conv3_wide(Conv3Args a, int D, hipStream_t s, bool persistent, int st
     hipLaunchKernelGGL(conv3d_k3_wide_pt_kernel, dim3(gx, a.cout_pad / BN, a.N), dim3(256), lds, s, a);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(conv3d_k3_wide_kernel, dim3(a.ntiles, a.cout_pad / BN, a.N), dim3(256), lds, s, a);
+  if (a.bw_sums) hipLaunchKernelGGL(conv3d_k3_wide_bwd_kernel, dim3(a.ntiles, a.cout_pad / BN, a.N), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(conv3d_k3_wide_kernel, dim3(a.ntiles, a.cout_pad / BN, a.N), dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }
 

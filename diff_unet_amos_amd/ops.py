@@ -372,6 +372,29 @@ def _norm_ref(norm, N, Cc):
     return None if norm is None else norm.ref(N, Cc)
 
 
+def conv3d_k3_dgrad_reduce_supported(dtype, N, D, H, W, cin, cout):
+    """The data-gradient launch of this shape (dense buffers) can take the norm-backward sums of its output's owner along."""
+    if dtype != torch.float16 or (CONV_POLICY & 0xff) != 0:
+        return False
+    d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, cin, cin, 0, cout, cout, 0)
+    return bool(nv.lib().dua_conv3d_k3_dgrad_reduce_supported(C.byref(d)))
+
+
+def conv3d_k3_dgrad_reduce(dy, cin, w_packed, bias_pad, cout, dx, raw, norm, sums):
+    """dx = conv3d_k3(dy) (the data gradient: dgrad-packed weights) where dx is the dA of the layer whose convolution output is
+    ``raw`` and whose forward statistics / affine parameters are ``norm``: the launch adds that layer's instnorm_bwd reduce sums
+    to ``sums`` (instnorm_bwd_sums) instead of statistics of dx (dua_conv3d_k3_dgrad_reduce)."""
+    _cl_check(dy, "dy"); _cl_check(dx, "dx"); _cl_check(raw, "raw")
+    N, D, H, W, cs_in = dy.shape
+    assert dy.dtype == dx.dtype == raw.dtype == torch.float16 and tuple(dx.shape[:4]) == tuple(raw.shape[:4]) == (N, D, H, W)
+    assert cin <= cs_in and cout <= dx.shape[-1] and cout <= raw.shape[-1] and _RECORD is None
+    assert sums.dtype == torch.float64 and sums.is_contiguous()
+    d = nv.Conv3Desc(nv.dt_code(dy.dtype), N, D, H, W, cin, cs_in, 0, cout, dx.shape[-1], 0)
+    nv.check(nv.lib().dua_conv3d_k3_dgrad_reduce(C.byref(d), nv.ptr(dy), nv.ptr(w_packed), nv.ptr(bias_pad), nv.ptr(dx), nv.ptr(raw),
+                                                 raw.shape[-1], 0, norm.ref(N, cout), nv.ptr(sums), nv.stream_ptr()),
+             "dua_conv3d_k3_dgrad_reduce")
+
+
 def conv3_workspace_bytes(dtype, N, D, H, W, cin, cout):
     d = nv.Conv3Desc(nv.dt_code(dtype), N, D, H, W, cin, cin, 0, cout, cout, 0)
     return int(nv.lib().dua_conv3d_k3_workspace(C.byref(d)))
@@ -506,6 +529,7 @@ def _wgrad_ws(nbytes, device):
 
 _SPLITK_WS = {}
 TRAIN_SPLITK = True          # tools/bench_train_ab.py switches it off for a same-process comparison
+TRAIN_DGRAD_REDUCE = True    # a data-gradient launch takes the norm-backward reduce sums of the layer its output belongs to (96^3 layers)
 TRAIN_FOLD_UPCONV = True     # training forward: UpCat's convolution over the concat as the folded launch (dua_upconv_k3_fwd)
 TRAIN_FOLD_MIN_TILES = 1024  # ... where the launch has at least this many 8x8x8 tiles (96^3: 1728 per sample)
 
@@ -538,21 +562,27 @@ def instnorm_finalize(norm, N, Cc):
     return scale, shift
 
 
-def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0, want_add=True, dadd_out=None):
+def instnorm_bwd_sums(raw, norm):
+    """Zeroed accumulator of instnorm_bwd's reduce pass (fp64 [N, replicas, c_pad, 4])."""
+    return zeros((raw.shape[0], STAT_REPLICAS, norm.keep[0].shape[3], 4), torch.float64, raw.device)
+
+
+def instnorm_bwd(dA, da_off, raw, Cc, norm, dY, dy_off=0, want_add=True, dadd_out=None, sums=None):
     """Backward of LeakyReLU(IN(raw)) [+ add] for channels [0, Cc) of ``raw``: writes d raw into ``dY`` and returns the
-    parameter gradients (dgamma [Cc], dbeta [Cc], dadd [N, Cc] or None), fp32, emitted by the apply launch itself."""
+    parameter gradients (dgamma [Cc], dbeta [Cc], dadd [N, Cc] or None), fp32, emitted by the apply launch itself.
+    ``sums``: the reduce pass's result when the launch that produced dA took it along (conv3d_k3_dgrad_reduce)."""
     _cl_check(dA, "dA"); _cl_check(raw, "raw"); _cl_check(dY, "dY")
     N = raw.shape[0]
     vox = raw.shape[1] * raw.shape[2] * raw.shape[3]
     assert dA.dtype == raw.dtype == dY.dtype and tuple(dA.shape[:4]) == tuple(raw.shape[:4]) == tuple(dY.shape[:4])
     assert Cc % 8 == 0 and Cc <= raw.shape[-1] and da_off % 8 == 0 and da_off + Cc <= dA.shape[-1]
     assert dy_off % 8 == 0 and dy_off + Cc <= dY.shape[-1]
-    cpad = norm.keep[0].shape[3]
-    sums = zeros((N, STAT_REPLICAS, cpad, 4), torch.float64, raw.device)
     d = nv.NormBwdDesc(nv.dt_code(raw.dtype), N, vox, Cc, dA.shape[-1], da_off, raw.shape[-1], 0, dY.shape[-1], dy_off)
     L = nv.lib()
-    nv.check(L.dua_instnorm_bwd_reduce(C.byref(d), nv.ptr(dA), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(sums), nv.stream_ptr()),
-             "dua_instnorm_bwd_reduce")
+    if sums is None:
+        sums = instnorm_bwd_sums(raw, norm)
+        nv.check(L.dua_instnorm_bwd_reduce(C.byref(d), nv.ptr(dA), nv.ptr(raw), norm.ref(N, Cc), nv.ptr(sums), nv.stream_ptr()),
+                 "dua_instnorm_bwd_reduce")
     pg = zeros((2, Cc), torch.float32, raw.device)              # dgamma, dbeta (accumulated over the samples)
     dadd = None
     if want_add:

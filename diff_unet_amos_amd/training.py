@@ -273,6 +273,17 @@ class _UpCat(torch.autograd.Function):
         return dx, (dcat[..., :cs] if ctx.needs_input_grad[1] else None), dw, db
 
 
+class _BwdLink:
+    """Hand-over between the two blocks of a TwoConv in backward: block b's data-gradient launch produces block a's dA and can take
+    the reduce pass of a's InstanceNorm backward along (ops.conv3d_k3_dgrad_reduce).  a.forward deposits what that needs; b.backward
+    (which runs first) leaves the sums and the address of the dA they belong to; a.backward uses them if that is the dA it gets."""
+
+    def __init__(self):
+        self.raw = self.stats = self.g32 = self.b32 = self.sums = None
+        self.count = 0
+        self.da_ptr = None
+
+
 class _ConvNormAct(torch.autograd.Function):
     """a = LeakyReLU(InstanceNorm(conv3d(x, w, b))) [+ add[n, c]] [+ emb] -- one MONAI Convolution block (+ the temb bias /
     the encoder embedding that follow it in TwoConv.forward / BasicUNetRDenoiser.forward), all on the HIP kernels:
@@ -281,7 +292,7 @@ class _ConvNormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, add, emb, pool=False, cat_extra=0, temb_state=None, temb_index=0, packs=None,
-                fold=None):
+                fold=None, link_out=None, link_in=None):
         """``temb_state``: ``add`` is the block-major add buffer of the whole evaluation (_TembAdds) and this block uses rows
         ``temb_index`` of it (_TembState); otherwise ``add`` is this block's own [N, cout] tensor or None.
         ``cat_extra`` > 0: the activation is the skip of a decoder level -- it is written into channels [0, cout) of a buffer
@@ -324,6 +335,9 @@ class _ConvNormAct(torch.autograd.Function):
         pooled = torch.empty((N, D // 2, H // 2, W // 2, cout), dtype=x.dtype, device=x.device) if pool else None
         ops.materialize(raw, cout, norm, cat, 0, emb=emb.detach() if emb is not None else None, pooled=pooled)
         ctx.save_for_backward(x, weight, raw, stats, g32, b32, act if pool else None)
+        ctx.link_out, ctx.link_in = link_out, link_in           # _BwdLink: this block's output feeds link_out's consumer / its input is link_in's
+        if link_out is not None:
+            link_out.raw, link_out.stats, link_out.g32, link_out.b32, link_out.count = raw, stats, g32, b32, D * H * W
         ctx.has_add, ctx.has_emb, ctx.pool = add is not None, emb is not None, pool
         ctx.temb_state, ctx.temb_index = (temb_state, temb_index) if add is not None else (None, 0)
         return (act, pooled) if pool else act
@@ -339,6 +353,10 @@ class _ConvNormAct(torch.autograd.Function):
             dA = buf = ops.maxpool2_bwd_add(abuf, aoff, cout, buf, off, dP.contiguous())
             off = 0
         norm = ops.Norm(stats, g32, b32, D * H * W)
+        sums = None
+        lo_ = ctx.link_out
+        if lo_ is not None and lo_.sums is not None and not (ctx.pool and dP is not None) and off == 0 and buf.data_ptr() == lo_.da_ptr:
+            sums = lo_.sums                 # the launch that produced dA already took this layer's reduce pass
         dY = torch.empty_like(raw)
         ts = ctx.temb_state
         dadd_out = None
@@ -346,19 +364,32 @@ class _ConvNormAct(torch.autograd.Function):
             if ts.dadd is None:           # zero-initialised: a block whose backward never runs (its output unused) contributes nothing
                 ts.dadd = ops.zeros((ts.N * ts.P,), torch.float32, raw.device)
             dadd_out = ts.rows(ts.dadd, ctx.temb_index)
-        dgamma, dbeta, dadd = ops.instnorm_bwd(buf, off, raw, cout, norm, dY, want_add=ctx.has_add, dadd_out=dadd_out)
+        dgamma, dbeta, dadd = ops.instnorm_bwd(buf, off, raw, cout, norm, dY, want_add=ctx.has_add, dadd_out=dadd_out, sums=sums)
         if ts is not None:
             ts.written += 1
             # the evaluation's first block runs last in backward and hands the shared buffer on (see _TembState)
             dadd = ts.dadd if ctx.temb_index == 0 else None
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1], ctx.packs)
+            li = ctx.link_in
+            if (li is not None and li.raw is not None and ops.TRAIN_DGRAD_REDUCE and x.shape[-1] == li.raw.shape[-1]
+                    and ops.conv3d_k3_dgrad_reduce_supported(dY.dtype, N, D, H, W, cout, x.shape[-1])):
+                # x is the activation of the block in front: dx is its dA, and this launch takes its norm-backward sums along
+                wp = ctx.packs.get(weight.detach(), "dgrad", cout) if ctx.packs is not None else None
+                if wp is None:
+                    wp, _ = ops.pack_conv3_weights_dgrad(weight.detach().float().contiguous(), dY.dtype, cout_packed=cout)
+                dx = torch.empty((N, D, H, W, x.shape[-1]), dtype=dY.dtype, device=dY.device)
+                pnorm = ops.Norm(li.stats, li.g32, li.b32, li.count)
+                li.sums = ops.instnorm_bwd_sums(li.raw, pnorm)
+                ops.conv3d_k3_dgrad_reduce(dY, cout, wp, ops.zero_bias(x.shape[-1], x.device), x.shape[-1], dx, li.raw, pnorm, li.sums)
+                li.da_ptr = dx.data_ptr()
+            else:
+                dx = _Conv3dK3._dgrad(dY, weight.detach().float().contiguous(), x.shape[-1], ctx.packs)
         if ctx.needs_input_grad[1]:
             dw = ops.zeros(tuple(weight.shape), torch.float32, x.device)
             _wgrad(x, dY, cout, dw)
         db = ops.zeros((cout,), torch.float32, x.device)      # bias before InstanceNorm: sum(dY) == 0 exactly
-        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, dadd, (dA if ctx.has_emb else None), None, None, None, None, None, None, None, None
 
 
 def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0, packs=None, fold=None):
@@ -372,10 +403,11 @@ def _two_conv_cl(block, x, temb, emb=None, pool=False, cat_extra=0, packs=None, 
         state.next += 1
         assert block.temb_proj.weight.shape[0] == state.couts[index]
     c0, c1 = block.conv_0, block.conv_1
+    link = _BwdLink() if torch.is_grad_enabled() else None       # conv_1's data gradient is conv_0's dA (see _BwdLink)
     h = _ConvNormAct.apply(x, c0.conv.weight, c0.conv.bias, c0.adn.N.weight, c0.adn.N.bias, add, None, False, 0, state, index, packs,
-                           fold)
+                           fold, link, None)
     return _ConvNormAct.apply(h, c1.conv.weight, c1.conv.bias, c1.adn.N.weight, c1.adn.N.bias, None, emb, pool, cat_extra, None, 0,
-                              packs)
+                              packs, None, None, link)
 
 
 class _Head(torch.autograd.Function):

@@ -186,6 +186,18 @@ int dua_instnorm_bwd_reduce(const dua_norm_bwd_desc* d, const void* dA, const vo
 int dua_instnorm_bwd_apply(const dua_norm_bwd_desc* d, const void* dA, const void* raw, const dua_in_norm* in,
                            const double* sums, void* dY, float* dgamma, float* dbeta, float* dadd, void* stream);
 
+/* Training: the data gradient of a Conv3d (dua_conv3d_k3_fwd on dy with the weights flipped and transposed -- d, dy, w_packed,
+ * bias_padded as there; dx = its output) whose input was a = LeakyReLU(InstanceNorm3d(raw)) of ANOTHER layer: dx is that layer's
+ * dA, and the launch adds the three sums of ITS InstanceNorm backward (dua_instnorm_bwd_reduce: sum dA, sum dZ, sum dZ * zhat per
+ * (n, c), on the rounded dA it stores) to `sums` (zeroed by the caller) instead of accumulating statistics of dx -- one pass
+ * over dA and raw less per layer pair (train.py:258-268 through denoiser.py:56-67).  raw: that layer's convolution output,
+ * channels [raw_off, raw_off + Cout) of a raw_stride buffer; raw_in: its forward statistics, gamma, beta, count, eps, slope.
+ * Only the wide-tile form has this epilogue: dua_conv3d_k3_dgrad_reduce_supported(d) == 1 (fp16, channels-last, >= 1024 tiles,
+ * extents multiples of 8), else DUA_ERR_ARG -- the caller keeps dua_conv3d_k3_fwd + dua_instnorm_bwd_reduce. */
+int dua_conv3d_k3_dgrad_reduce_supported(const dua_conv3_desc* d);
+int dua_conv3d_k3_dgrad_reduce(const dua_conv3_desc* d, const void* dy, const void* w_packed, const float* bias_padded, void* dx,
+                               const void* raw, int raw_stride, int raw_off, const dua_in_norm* raw_in, double* sums, void* stream);
+
 /* The 1x1x1 residual branch of MONAI's UnetResBlock over torch.cat((ConvTranspose3d_k2s2(lo), skip), 1) -- the decoder blocks of
  * models/swin_unetr/denoiser.py:388-397 (UnetrUpBlock: transp_conv, cat, UnetResBlock whose conv3 is the 1x1x1 branch; no bias in
  * either layer) -- as ONE launch:  res[o] = (W3_up Wd[child(o)]^T) lo[parent(o)] + W3_skip skip[o],  plus this layer's InstanceNorm

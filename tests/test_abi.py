@@ -100,7 +100,7 @@ def test_abi_version_and_prepare_registry(lib):
     src = open(HEADER).read()
     assert int(re.search(r"#define DUA_ABI_VERSION (\d+)", src).group(1)) == nv.ABI_VERSION == lib.dua_abi_version()
     # conv (12 + the wide-tile form + the folded up-convolution) + weight gradient (6 + the fetch-once form) + transposed conv (8) + its backward (4) + Swin token kernels (3 + 30)
-    assert lib.dua_prepared_kernels() == 72
+    assert lib.dua_prepared_kernels() == 73
 
 
 def test_no_launcher_sets_function_attributes_on_its_own():

@@ -837,6 +837,48 @@ def test_instnorm_lrelu_backward_matches_autograd(dtype, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 64, 64, 64, 64, 64), (2, 64, 32, 64, 128, 64)])
+def test_data_gradient_launch_takes_the_norm_backward_sums_along(shape):
+    """dua_conv3d_k3_dgrad_reduce (wide-tile form, training): the same dx as the plain launch, bit for bit, and the three sums of
+    the owner layer's InstanceNorm backward as the separate reduce launch computes them from that dx (fp32 partial sums over
+    different element subsets: 1e-5 relative); the apply pass on either agrees, parameter gradients included."""
+    ops = _ops()
+    N, D, H, W, Cin, Cout = shape                  # the launch: dy [.., Cin] -> dx [.., Cout]; Cout = the owner layer's channels
+    dev, dt = torch.device("cuda:0"), torch.float16
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    dy = (torch.randn(N, D, H, W, Cin, generator=g, device=dev) * 0.5).to(dt)
+    w = torch.randn(Cin, Cout, 3, 3, 3, generator=g, device=dev) / (27 * Cin) ** 0.5       # the forward layer's [cout_fwd = Cin, cin_fwd = Cout]
+    raw = (torch.randn(N, D, H, W, Cout, generator=g, device=dev) * 1.5 + 0.3).to(dt)
+    gamma = torch.rand(Cout, generator=g, device=dev) + 0.5
+    beta = torch.randn(Cout, generator=g, device=dev) * 0.2
+    rd = raw.double()
+    stats = ops.stats_encode(torch.stack([rd.sum((1, 2, 3)), (rd * rd).sum((1, 2, 3))], -1))
+    norm = ops.Norm(stats, gamma, beta, D * H * W)
+    assert ops.conv3d_k3_dgrad_reduce_supported(dt, N, D, H, W, Cin, Cout)
+    assert not ops.conv3d_k3_dgrad_reduce_supported(dt, 1, 16, 16, 16, Cin, Cout)          # too few tiles for the wide-tile form
+    wp, bp = ops.pack_conv3_weights_dgrad(w, dt, cout_packed=Cin)
+    dx0 = torch.empty(N, D, H, W, Cout, device=dev, dtype=dt)
+    ops.conv3d_k3(dy, Cin, 0, wp, bp, Cout, dx0, 0, ops.stats_buffer(N, Cout, dev), workspace=ops.splitk_ws(dt, N, D, H, W, Cin, Cout, dev))
+    dx1 = torch.empty_like(dx0)
+    sums = ops.instnorm_bwd_sums(raw, norm)
+    ops.conv3d_k3_dgrad_reduce(dy, Cin, wp, bp, Cout, dx1, raw, norm, sums)
+    assert torch.equal(dx0, dx1)
+    dY0, dY1 = torch.empty_like(raw), torch.empty_like(raw)
+    g0 = ops.instnorm_bwd(dx0, 0, raw, Cout, norm, dY0, want_add=True)
+    g1 = ops.instnorm_bwd(dx1, 0, raw, Cout, norm, dY1, want_add=True, sums=sums)
+    scale = max(1.0, dY0.abs().max().item())
+    assert (dY0.double() - dY1.double()).abs().max().item() <= 2e-3 * scale
+    for a_, b_ in zip(g0, g1):
+        assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-4 * (D * H * W) ** 0.5)
+    zh = (rd - rd.mean((1, 2, 3), keepdim=True)) / (rd.var((1, 2, 3), unbiased=False, keepdim=True) + 1e-5).sqrt()
+    z = zh * gamma.double() + beta.double()
+    dz = torch.where(z > 0, dx1.double(), dx1.double() * 0.1)
+    want = torch.stack([dx1.double().sum((1, 2, 3)), dz.sum((1, 2, 3)), (dz * zh).sum((1, 2, 3))], -1)
+    got = sums.sum(1)[:, :Cout, :3]
+    assert torch.allclose(got, want, rtol=2e-3, atol=2e-3 * (D * H * W) ** 0.5)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 16, 8, 8, 8), (1, 3, 5, 6, 7), (2, 13, 16, 8, 4), (1, 24, 9, 10, 11)])   # 16, 24: eight channels per read (fp16)
 def test_seg_loss_and_gradient_match_torch(dtype, shape):

@@ -24,7 +24,8 @@ def main():
     labels = (torch.rand(2, 16, 96, 96, 96, device=dev) > 0.8).float()
     # constructor arguments; "_option": (1 | 4, value) = ops.CONV_POLICY / ops.WGRAD_POLICY in force while the trainer captures; "_ops": attributes of diff_unet_amos_amd.ops set while this trainer warms up and captures its graph
     settings = {"default": {},
-                "forward convolution over the level-0 concat unfolded": {"_ops": {"TRAIN_FOLD_UPCONV": False}}}
+                "forward convolution over the level-0 concat unfolded": {"_ops": {"TRAIN_FOLD_UPCONV": False}},
+                "norm-backward reduce as its own pass at 96^3": {"_ops": {"TRAIN_DGRAD_REDUCE": False}}}
     if "--all" in sys.argv:
         settings.update({"weight gradients in line with the backward chain": {"wgrad_overlap": False},
                          "no split-K scratch for the training convolutions": {"_ops": {"TRAIN_SPLITK": False}},

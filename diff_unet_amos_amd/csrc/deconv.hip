@@ -458,9 +458,8 @@ __global__ __launch_bounds__(256) void deconv_k2s2_alltaps_kernel(DeconvArgs a) 
 // i.e. a transposed convolution with COMPOSED weights plus a pointwise term on the fine grid.  Once the block's 3x3x3 convolution
 // takes its upsampled half from lo directly (upconv.hip), nobody else reads `up`: this launch replaces the transposed
 // convolution (its 85 MB output write at 96^3) AND the token GEMM over the 96-channel concat (its re-read).  The all-taps
-// kernel above with, per tap pair, the 2 x 32 fine-grid rows of every wave staged next to the coarse tile (wave-private rows:
-// no workgroup barrier for them; requested before the previous pair's stores are issued) and NSK more 32-channel k-chunks
-// against the skip weights; the layer's InstanceNorm sums come out of the accumulators.  fp16, 128-voxel tiles, Cin <= 128.
+// kernel above with, per tap pair, NSK more 32-channel k-chunks against the skip weights whose A fragments every lane loads
+// straight from the fine-grid tensor (its own row: one 16-byte load per k-step and tap, requested a pair ahead); the layer's InstanceNorm sums come out of the accumulators.  fp16, 128-voxel tiles, Cin <= 128.
 struct DeconvResArgs {
   DeconvArgs base;
   const void* xs; const void* ws; stat_t* stats;
@@ -468,7 +467,7 @@ struct DeconvResArgs {
 };
 
 template <int NSK>
-__global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) {
+__global__ __launch_bounds__(256, 2) void deconv_k2s2_res_kernel(DeconvResArgs ra) {
   using namespace dc;
   using T = f16;
   const DeconvArgs& a = ra.base;
@@ -476,15 +475,12 @@ __global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) 
   using Frag = f16x8;
   constexpr int RB = 32 * 2 + 16;
   constexpr int GPV = 4, VPI = 16, NST = 2 * WR / VPI;
-  constexpr int VSS = NSK * 64 + 16;                          // bytes per staged skip row (odd multiple of 16)
-  constexpr int GPM = 4 * NSK;                                // 16-byte pieces per skip row, padding included
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int VSA = a.nchunks * 64 + 16;
   char* alds = smem;
   char* wlds = alds + TM * VSA;                             // 2 pairs x 2 taps x nchunks x 4 KB
   char* stg = wlds + 4 * a.nchunks * W_BYTES;               // 2 TM x RB
   char* skw = stg + 2 * TM * RB;                            // NSK x 4 KB: the skip weights
-  char* skl = skw + NSK * W_BYTES;                          // [2 tk][TM] rows of VSS bytes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const long vox = (long)a.D * a.H * a.W;
@@ -496,7 +492,6 @@ __global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) 
   const int kg_t = tid & 3;
   const int H2 = 2 * a.H, W2 = 2 * a.W;
   const T* xsk = (const T*)ra.xs + (long)n * vox * 8 * ra.Cs_stride + ra.Cs_off;
-  const int gp = ra.Cs >> 3;                                  // real pieces per skip row
 
   constexpr int MCH = 4;
   Frag f[MCH][TM / 64];
@@ -525,31 +520,33 @@ __global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) 
       for (int j = 0; j < MCH; ++j)
         if (j < a.nchunks) *(f32x4*)(wlds + ((tp & 1) * 2 + tk) * wtap + (tid + 256 * j) * 16) = wn[tk][j];
   };
-  // fine-grid rows of THIS wave for pair tp: piece = lane + 64 j -> (row = piece / GPM = 2 vl + tk, 16-byte group piece % GPM)
-  Frag skr[GPM];
+  // The skip operand needs no staging: an A fragment of the pointwise term is 8 channels of ONE fine voxel per lane -- the lane's own
+  // row of the pair (tile voxel wave * 32 + r, tap (ti, tj, tk)) -- i.e. one 16-byte global load per lane, k-step and tap; the
+  // fragments of pair tp + 1 are requested before pair tp's stores are issued.  (Staged through LDS like the coarse tile they cost
+  // 37 KB and left one workgroup per CU: 72 us at 96^3.)
+  const long vrow = v0 + wave * WR + r;
+  const bool vrok = vrow < vox;
+  long ovrow;
+  {
+    const int vi = (int)(vrok ? vrow : 0);
+    const int w = vi % a.W, t = vi / a.W, h = t % a.H, d = t / a.H;
+    ovrow = ((long)(2 * d) * H2 + 2 * h) * W2 + 2 * w;
+  }
+  Frag skf[2][2 * NSK];
   auto load_skip = [&](int tp) {
-    const int ti = tp >> 1, tj = tp & 1;
+    const long base = ovrow + ((long)(tp >> 1) * H2 + (tp & 1)) * W2;
 #pragma unroll
-    for (int j = 0; j < GPM; ++j) {
-      const int pid = lane + 64 * j, g = pid % GPM, row = pid / GPM;
-      const long v = v0 + wave * WR + (row >> 1);
-      const int vi = (int)(v < vox ? v : 0);
-      const int w = vi % a.W, t = vi / a.W, h = t % a.H, d = t / a.H;
-      const long ov = ((long)(2 * d + ti) * H2 + (2 * h + tj)) * W2 + 2 * w + (row & 1);
-      const bool ok = v < vox && g < gp;
-      skr[j] = *(const Frag*)(xsk + (ok ? ov * ra.Cs_stride + g * 8 : 0));
-      if (!ok) {
+    for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) skr[j][e] = (T)0.f;
+      for (int j = 0; j < 2 * NSK; ++j) {                       // j = (chunk, k-step): channels 32 (j >> 1) + 16 (j & 1) + 8 hh ...
+        const int c0 = (j >> 1) * 32 + (2 * (j & 1) + hh) * 8;
+        const bool ok = vrok && c0 < ra.Cs;
+        skf[tk][j] = *(const Frag*)(xsk + (ok ? (base + tk) * ra.Cs_stride + c0 : 0));
+        if (!ok) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) skf[tk][j][e] = (T)0.f;
+        }
       }
-    }
-  };
-  auto store_skip = [&]() {
-#pragma unroll
-    for (int j = 0; j < GPM; ++j) {
-      const int pid = lane + 64 * j, g = pid % GPM, row = pid / GPM;
-      *(Frag*)(skl + ((row & 1) * TM + wave * WR + (row >> 1)) * VSS + g * 16) = skr[j];
-    }
   };
   load_pair(0);
   load_skip(0);
@@ -570,7 +567,6 @@ __global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) 
     }
   }
   store_pair(0);
-  store_skip();
   __syncthreads();
 
   T* yout = (T*)a.y + (long)n * vox * 8 * a.Cout_stride;
@@ -587,7 +583,6 @@ __global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) 
   float s[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
   load_pair(1);
   for (int tp = 0; tp < 4; ++tp) {
-    if (tp < 3) load_skip(tp + 1);                            // ahead of this pair's stores (vmcnt is in issue order)
     f32x16 acc[2][2];
 #pragma unroll
     for (int tk = 0; tk < 2; ++tk) {
@@ -605,17 +600,14 @@ __global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) 
         }
       }
 #pragma unroll
-      for (int ch = 0; ch < NSK; ++ch) {
-#pragma unroll
-        for (int ks = 0; ks < KG / 2; ++ks) {
-          const Frag b0 = *(const Frag*)(skw + ch * W_BYTES + ((2 * ks + hh) * BN + r) * 16);
-          const Frag b1 = *(const Frag*)(skw + ch * W_BYTES + ((2 * ks + hh) * BN + 32 + r) * 16);
-          const Frag am = *(const Frag*)(skl + (tk * TM + wave * WR + r) * VSS + ch * 64 + (2 * ks + hh) * 16);
-          mma32(acc[tk][0], am, b0);
-          mma32(acc[tk][1], am, b1);
-        }
+      for (int j = 0; j < 2 * NSK; ++j) {
+        const Frag b0 = *(const Frag*)(skw + (j >> 1) * W_BYTES + ((2 * (j & 1) + hh) * BN + r) * 16);
+        const Frag b1 = *(const Frag*)(skw + (j >> 1) * W_BYTES + ((2 * (j & 1) + hh) * BN + 32 + r) * 16);
+        mma32(acc[tk][0], skf[tk][j], b0);
+        mma32(acc[tk][1], skf[tk][j], b1);
       }
     }
+    if (tp < 3) load_skip(tp + 1);                            // ahead of this pair's stores (vmcnt is in issue order)
     if (tp < 3) store_pair(tp + 1);
     if (tp < 2) load_pair(tp + 2);
     const int toff = ((tp >> 1) * H2 + (tp & 1)) * W2;
@@ -639,7 +631,6 @@ __global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) 
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (tp < 3) store_skip();                                 // this wave's own rows: its reads of them are behind it
     __syncthreads();      // the next pair's weights are in place, this pair's buffer is free
   }
   // ---- InstanceNorm sums of this layer: lane halves, waves (fixed order), one set of atomics ----
@@ -660,7 +651,7 @@ __global__ __launch_bounds__(256) void deconv_k2s2_res_kernel(DeconvResArgs ra) 
 }
 
 static inline int deconv_res_lds(int nchunks, int nsk) {
-  return 128 * (nchunks * 64 + 16) + 4 * nchunks * dc::W_BYTES + 2 * 128 * 80 + nsk * dc::W_BYTES + 2 * 128 * (nsk * 64 + 16);
+  return 128 * (nchunks * 64 + 16) + 4 * nchunks * dc::W_BYTES + 2 * 128 * 80 + nsk * dc::W_BYTES;
 }
 
 // dynamic-LDS limits (raised once per device by ensure_prepared(), common.hpp)

@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256) void upconv_pack_kernel(int Cout, int Cskip, i
   for (int i = 0; i < 27; ++i) acc[i] = 0.f;
   if (co < Cout && ci < Cu) {
     const float* wdp = wd + (long)ci * Cmid * 8;
+#pragma unroll 4                                                // four rows of the transposed-convolution weights in flight (the loop was one dependent load per k)
     for (int cm = 0; cm < Cmid; ++cm) {
       const f32x4 w0 = *(const f32x4*)(wdp + cm * 8), w1 = *(const f32x4*)(wdp + cm * 8 + 4);
       float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};

@@ -90,6 +90,13 @@ def main():
               f"{ph.max() if nph else 0:.0f} | post-loop {tailc:.0f} | epilogue {epi:.0f}")
         if nph:
             print("    phases: " + " ".join(f"{p:.0f}" for p in ph))
+        t0s, t1s = (st[:, 0] - st[:, 0].min()) * 0.01, (st[:, 1] - st[:, 0].min()) * 0.01       # us
+        act = [int(((t0s < e + 5) & (t1s > e + 5)).sum()) for e in np.arange(0, span, 10.0)]
+        print("    workgroups in flight at 5, 15, 25, ... us: " + " ".join(str(a_) for a_ in act))
+        order = np.argsort(t0s)
+        lifes = (t1s - t0s)[order]
+        q8 = max(1, len(lifes) // 8)
+        print("    lifetime by start order (eighths, median us): " + " ".join(f"{np.median(lifes[i * q8:(i + 1) * q8]):.1f}" for i in range(8)))
         if "--wide" in sys.argv and st[0, 56] != 0:
             print(f"    prologue issue: bias + statistics requests {np.median(st[:, 56] - st[:, 2]):.0f} | halo requests "
                   f"{np.median(st[:, 57] - st[:, 56]):.0f} | weight plane {np.median(st[:, 59] - st[:, 57]):.0f}")
